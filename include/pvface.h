@@ -1,0 +1,134 @@
+/*
+ * pvface.h -- C ABI of the MI355X-native face hot path (libpvface.so, built from pyannote-video_amd/csrc).
+ *
+ * This is the drop-in boundary: every entry point replaces one call the reference makes into dlib / scipy /
+ * munkres / pyannote.algorithms.  "ref:" lines cite the reference interface (file:line under /root/reference)
+ * the function stands in for.  INTEGRATION.md shows the reference-side ctypes binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; pvf_last_error() gives the thread-local message;
+ *     nothing throws or aborts across the boundary;
+ *   - handles are opaque uint64_t; the caller owns every host buffer, the library owns device memory;
+ *   - one HIP stream per context; a context is not re-entrant, different contexts (= different GPUs / ranks)
+ *     may be driven from different threads or processes;
+ *   - frames are uint8 RGB, HWC, C-contiguous (ref: pyannote/video/video.py:148-149,400-401);
+ *   - there is NO CPU fallback: without a gfx950 device pvf_ctx_create fails.
+ */
+#ifndef PVFACE_H
+#define PVFACE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t pvf_handle;
+typedef struct { int32_t left, top, right, bottom; } pvf_rect_i32;   /* dlib.rectangle (inclusive ints) */
+
+/* ---- context ------------------------------------------------------------------------------------- */
+const char* pvf_last_error(void);
+int32_t pvf_version(void);
+int32_t pvf_device_count(int32_t* n);
+int32_t pvf_ctx_create(int32_t device, pvf_handle* ctx);
+int32_t pvf_ctx_destroy(pvf_handle ctx);
+int32_t pvf_sync(pvf_handle ctx);
+
+/* ---- models --------------------------------------------------------------------------------------- */
+/* ref: face.py:54  dlib.get_frontal_face_detector()  (path == NULL: detector shipped with the package) */
+int32_t pvf_load_detector(pvf_handle ctx, const char* path);
+/* ref: face.py:58  dlib.shape_predictor(landmarks) */
+int32_t pvf_load_shape_predictor(pvf_handle ctx, const char* path);
+/* ref: face.py:62  dlib.face_recognition_model_v1(embedding) */
+int32_t pvf_load_embedder(pvf_handle ctx, const char* path);
+/* constant tables of dlib.correlation_tracker's default constructor (ref: tracking.py:250), computed once on the host:
+ * mask64[64*64], mask_scale[32], tw64[32*2] (cos,sin 2*pi*k/64), tw32[16*2] */
+int32_t pvf_set_tracker_tables(pvf_handle ctx, const double* mask64, const double* mask_scale, const double* tw64,
+                               const double* tw32, double alpha_pow_m16, double ln_alpha);
+
+/* ---- frames --------------------------------------------------------------------------------------- */
+/* stage a host frame into HBM once; detection, trackers, landmarks and embedding all reuse it
+ * (the reference re-reads the host array for every dlib call: tracking.py:203,251,426; pyannote-face.py:296-297) */
+int32_t pvf_frame_upload(pvf_handle ctx, const uint8_t* rgb, int32_t h, int32_t w, int64_t row_stride_bytes, pvf_handle* frame);
+/* wrap a frame that already lives in HBM (no copy; the caller keeps it alive until pvf_frame_release) */
+int32_t pvf_frame_wrap_device(pvf_handle ctx, const void* dev_rgb, int32_t h, int32_t w, pvf_handle* frame);
+int32_t pvf_frame_release(pvf_handle ctx, pvf_handle frame);
+
+/* ---- S1 detector ---------------------------------------------------------------------------------- */
+/* ref: face.py:64-67  for face in self.face_detector_(rgb, 1)  -> dlib.rectangle list, NMS order.
+ * scores (optional) receive dlib's detection_confidence (score - threshold). */
+int32_t pvf_detect(pvf_handle ctx, pvf_handle frame, int32_t upsample, double adjust_threshold,
+                   pvf_rect_i32* out, float* scores, int32_t cap, int32_t* n);
+/* same for many frames of identical size in one launch sequence; counts[i] = detections of frame i,
+ * written at out[i*cap_per_frame ...] */
+int32_t pvf_detect_batch(pvf_handle ctx, const pvf_handle* frames, int32_t n_frames, int32_t upsample,
+                         double adjust_threshold, pvf_rect_i32* out, float* scores, int32_t* counts,
+                         int32_t cap_per_frame);
+
+/* ---- S2 correlation tracker ------------------------------------------------------------------------ */
+/* ref: tracking.py:250  dlib.correlation_tracker() */
+int32_t pvf_tracker_create(pvf_handle ctx, pvf_handle* trk);
+int32_t pvf_tracker_destroy(pvf_handle ctx, pvf_handle trk);
+/* ref: tracking.py:251  tracker.start_track(frame, dlib.drectangle(*detection)) ; box = (l,t,r,b) doubles */
+int32_t pvf_tracker_start(pvf_handle ctx, pvf_handle trk, pvf_handle frame, const double box[4]);
+/* ref: tracking.py:203  confidence = tracker.update(frame)   (peak-to-sidelobe ratio) */
+int32_t pvf_tracker_update(pvf_handle ctx, pvf_handle trk, pvf_handle frame, double* psr);
+/* ref: tracking.py:165,231-237  tracker.get_position() -> drectangle */
+int32_t pvf_tracker_position(pvf_handle ctx, pvf_handle trk, double box[4]);
+/* batched forms (an addition; the per-object calls above keep working): tracker i runs on frames[i] */
+int32_t pvf_tracker_start_many(pvf_handle ctx, const pvf_handle* trks, const pvf_handle* frames,
+                               const double* boxes /* n*4 */, int32_t n);
+int32_t pvf_tracker_update_many(pvf_handle ctx, const pvf_handle* trks, const pvf_handle* frames, int32_t n,
+                                double* psr /* n */, double* boxes_out /* n*4, may be NULL */);
+
+/* ---- S3 rectangles + association (host; tiny, order-sensitive) --------------------------------------- */
+/* ref: tracking.py:129-134 _match on dlib.drectangle (width = r-l; empty -> area 0), :160-168 overlap matrix */
+int32_t pvf_overlap_matrix(const double* a, int32_t na, const double* b, int32_t nb, double ratio, double* out);
+/* ref: tracking.py:121,172  Munkres().compute(cost) on the square n x n matrix -> column of each row */
+int32_t pvf_munkres(const double* cost, int32_t n, int32_t* row_to_col);
+
+/* ---- S4 landmarks + embedding ---------------------------------------------------------------------- */
+/* ref: face.py:69-70  self.shape_predictor_(rgb, face) -> 68 integer points; face i lives on frames[i] */
+int32_t pvf_landmarks(pvf_handle ctx, const pvf_handle* frames, const pvf_rect_i32* boxes, int32_t n,
+                      int32_t* pts /* n*68*2 */);
+/* ref: face.py:73-76  face_recognition_.compute_face_descriptor(rgb, landmarks) -> 128 floats */
+int32_t pvf_embed(pvf_handle ctx, const pvf_handle* frames, const int32_t* pts /* n*68*2 */, int32_t n,
+                  float* out /* n*128 */);
+/* the network alone on ready-made 150x150x3 chips (host buffer), for testing K7 in isolation */
+int32_t pvf_embed_chips(pvf_handle ctx, const uint8_t* chips, int32_t n, float* out /* n*128 */);
+/* the aligned chips alone (get_face_chip_details + extract_image_chips), for testing K6 in isolation */
+int32_t pvf_face_chips(pvf_handle ctx, const pvf_handle* frames, const int32_t* pts, int32_t n, uint8_t* chips /* n*150*150*3 */);
+
+/* ---- S5 clustering --------------------------------------------------------------------------------- */
+/* ref: clustering.py:100-112  -squareform(pdist(X,'euclidean')) reduced to the T x T matrix of block means;
+ * X float64 [N][dim], rows grouped by track, row_start[T+1]; D float64 [T][T] (positive distances) */
+int32_t pvf_pair_mean_dist(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start,
+                           int32_t T, double* D);
+/* ref: clustering.py:116-119,138-148  FaceClustering(threshold)(starting_point, features): average-linkage HAC from the
+ * track partition, stop when the closest pair's mean distance exceeds `threshold`;
+ * labels[t] = smallest track index of t's cluster; merge_log optional [(T-1)*4] = (a, b, dist, new_size) */
+int32_t pvf_cluster_tracks(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start,
+                           int32_t T, double threshold, int32_t* labels, double* merge_log, int32_t* n_merges);
+
+/* ---- measurement ----------------------------------------------------------------------------------- */
+/* HIP-event timing of each kernel family on the context's stream ("pyramid","fhog","score","ert","chip","conv",
+ * "dsst","pdist","hac"); off by default */
+int32_t pvf_prof_enable(pvf_handle ctx, int32_t on);
+int32_t pvf_prof_reset(pvf_handle ctx);
+int32_t pvf_prof_get(pvf_handle ctx, const char* family, double* total_ms, int64_t* launches);
+
+/* ---- stage access used by the parity tests ------------------------------------------------------------ */
+int32_t pvf_debug_pyramid_level(pvf_handle ctx, pvf_handle frame, int32_t upsample, int32_t level,
+                                uint8_t* out, int32_t* h, int32_t* w);               /* out may be NULL: dims only */
+int32_t pvf_debug_fhog(pvf_handle ctx, const uint8_t* img, int32_t h, int32_t w, int32_t cell, int32_t pad_r,
+                       int32_t pad_c, float* out, int32_t* fh, int32_t* fw);          /* out [fh][fw][32] */
+int32_t pvf_debug_detect_raw(pvf_handle ctx, pvf_handle frame, int32_t upsample, double adjust, float* scores,
+                             int32_t* meta /* cap*8: filter,level,r,c,l,t,r,b */, int32_t cap, int32_t* n);
+int32_t pvf_debug_extract_chip(pvf_handle ctx, pvf_handle frame, const double rect[4], double cs, double sn,
+                               int32_t rows, int32_t cols, uint8_t* out);
+int32_t pvf_debug_tracker_state(pvf_handle ctx, pvf_handle trk, double* F, double* A, double* B);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -76,6 +76,9 @@ typedef struct {
     int32_t l, t, rr, b;       /* rectangle in input-image pixels */
 } pvo_det;
 
+/* OpenMP threads used by the row-parallel loops (results do not depend on it) */
+void pvo_set_threads(int n);
+int pvo_get_max_threads(void);
 int pvo_detector_levels(int h, int w, const pvo_detector* m);
 /* raw candidates (score >= thresh), before NMS, in canonical order (sorted) */
 int pvo_detect_raw(const uint8_t* rgb, int h, int w, int upsample, const pvo_detector* m,

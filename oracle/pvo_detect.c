@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 
 static inline long iround(double v) { return (long)floor(v + 0.5); }
 
@@ -91,6 +92,7 @@ void pvo_score_level(const float* feat, int fh, int fw, const pvo_detector* m, i
     /* [EXT spatially_filter_image]: only the non-border area is computed; window top-left = (r-fr/2, c-fc/2) */
     const int r0 = fr / 2, c0 = fc / 2;
     const int r1 = fh - (fr - fr / 2 - 1), c1 = fw - (fc - fc / 2 - 1);
+    #pragma omp parallel for schedule(static)
     for (int r = r0; r < r1; ++r)
         for (int c = c0; c < c1; ++c) {
             float acc = 0.0f;
@@ -217,3 +219,6 @@ int pvo_detect(const uint8_t* rgb, int h, int w, int upsample, const pvo_detecto
     free(raw);
     return k;
 }
+
+void pvo_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+int pvo_get_max_threads(void) { return omp_get_max_threads(); }

@@ -1,0 +1,414 @@
+// api.hip -- extern "C" entry points declared in include/pvface.h (context/model/frame calls live in ctx.hip).
+#include "pvf_internal.h"
+#include <algorithm>
+
+#define API_BEGIN try {
+#define API_END                                                        \
+    return 0;                                                          \
+    }                                                                  \
+    catch (const std::exception& e) { pvf_set_error(e.what()); return -1; } \
+    catch (...) { pvf_set_error("unknown error"); return -2; }
+
+static Ctx* enter(pvf_handle h)
+{
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    return c;
+}
+
+// ---- S1 -------------------------------------------------------------------------------------------
+extern "C" int32_t pvf_detect_batch(pvf_handle h, const pvf_handle* frames, int32_t n_frames, int32_t upsample, double adjust,
+                                    pvf_rect_i32* out, float* scores, int32_t* counts, int32_t cap)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    PVF_REQUIRE(n_frames > 0 && frames && out && counts && cap > 0, "pvf_detect_batch: bad arguments");
+    PVF_REQUIRE(upsample >= 0 && upsample <= 2, "pvf_detect_batch: upsample must be 0..2");
+    std::vector<Frame> fr(n_frames);
+    for (int i = 0; i < n_frames; ++i) fr[i] = c->frame(frames[i]);
+    std::vector<std::vector<RawDet>> raw;
+    det_run_batch(c, fr, upsample, adjust, raw);
+    std::vector<RawDet> kept;
+    for (int i = 0; i < n_frames; ++i) {
+        det_nms(c->det, raw[i], kept);
+        const int n = std::min<int>((int)kept.size(), cap);
+        counts[i] = n;
+        for (int k = 0; k < n; ++k) {
+            out[(size_t)i * cap + k] = pvf_rect_i32{kept[k].l, kept[k].t, kept[k].rr, kept[k].b};
+            if (scores) scores[(size_t)i * cap + k] = kept[k].score;
+        }
+    }
+    API_END
+}
+
+extern "C" int32_t pvf_detect(pvf_handle h, pvf_handle frame, int32_t upsample, double adjust, pvf_rect_i32* out, float* scores,
+                              int32_t cap, int32_t* n)
+{
+    int32_t cnt = 0;
+    const int32_t rc = pvf_detect_batch(h, &frame, 1, upsample, adjust, out, scores, &cnt, cap);
+    if (rc == 0 && n) *n = cnt;
+    return rc;
+}
+
+extern "C" int32_t pvf_debug_detect_raw(pvf_handle h, pvf_handle frame, int32_t upsample, double adjust, float* scores, int32_t* meta,
+                                        int32_t cap, int32_t* n)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    std::vector<Frame> fr{c->frame(frame)};
+    std::vector<std::vector<RawDet>> raw;
+    det_run_batch(c, fr, upsample, adjust, raw);
+    const int k = std::min<int>((int)raw[0].size(), cap);
+    *n = (int)raw[0].size();
+    for (int i = 0; i < k; ++i) {
+        const RawDet& d = raw[0][i];
+        scores[i] = d.score;
+        int32_t* m = meta + (size_t)i * 8;
+        m[0] = d.filter; m[1] = d.level; m[2] = d.r; m[3] = d.c; m[4] = d.l; m[5] = d.t; m[6] = d.rr; m[7] = d.b;
+    }
+    API_END
+}
+
+extern "C" int32_t pvf_debug_pyramid_level(pvf_handle h, pvf_handle frame, int32_t upsample, int32_t level, uint8_t* out, int32_t* oh,
+                                           int32_t* ow)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    std::vector<uint8_t> buf;
+    int hh = 0, ww = 0;
+    det_pyramid_level(c, c->frame(frame), upsample, level, out ? &buf : nullptr, &hh, &ww);
+    *oh = hh; *ow = ww;
+    if (out) memcpy(out, buf.data(), buf.size());
+    API_END
+}
+
+extern "C" int32_t pvf_debug_fhog(pvf_handle h, const uint8_t* img, int32_t ih, int32_t iw, int32_t cell, int32_t pad_r, int32_t pad_c,
+                                  float* out, int32_t* fh, int32_t* fw)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    int a = 0, b = 0;
+    if (!out) { fhog_dims(ih, iw, cell, pad_r, pad_c, &a, &b); *fh = a; *fw = b; return 0; }
+    std::vector<float> buf;
+    fhog_debug(c, img, ih, iw, cell, pad_r, pad_c, buf, &a, &b);
+    *fh = a; *fw = b;
+    memcpy(out, buf.data(), buf.size() * sizeof(float));
+    API_END
+}
+
+// ---- S2 -------------------------------------------------------------------------------------------
+extern "C" int32_t pvf_tracker_create(pvf_handle h, pvf_handle* trk)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    std::unique_ptr<Tracker> t(new Tracker());
+    if (!c->tracker_pool.empty()) { t->d_state = c->tracker_pool.back(); c->tracker_pool.pop_back(); }
+    else HIP_CHECK(hipMalloc((void**)&t->d_state, TRK_DOUBLES * sizeof(double)));
+    const uint64_t id = c->next_id++;
+    c->trackers[id] = std::move(t);
+    *trk = id;
+    API_END
+}
+extern "C" int32_t pvf_tracker_destroy(pvf_handle h, pvf_handle trk)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    auto it = c->trackers.find(trk);
+    PVF_REQUIRE(it != c->trackers.end(), "unknown tracker handle");
+    c->tracker_pool.push_back(it->second->d_state);
+    c->trackers.erase(it);
+    API_END
+}
+extern "C" int32_t pvf_tracker_start_many(pvf_handle h, const pvf_handle* trks, const pvf_handle* frames, const double* boxes, int32_t n)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    std::vector<Tracker*> t(n);
+    std::vector<Frame> f(n);
+    for (int i = 0; i < n; ++i) { t[i] = &c->tracker(trks[i]); f[i] = c->frame(frames[i]); }
+    dsst_start_many(c, t, f, boxes);
+    API_END
+}
+extern "C" int32_t pvf_tracker_update_many(pvf_handle h, const pvf_handle* trks, const pvf_handle* frames, int32_t n, double* psr,
+                                           double* boxes_out)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    std::vector<Tracker*> t(n);
+    std::vector<Frame> f(n);
+    for (int i = 0; i < n; ++i) { t[i] = &c->tracker(trks[i]); f[i] = c->frame(frames[i]); }
+    dsst_update_many(c, t, f, psr, boxes_out);
+    API_END
+}
+extern "C" int32_t pvf_tracker_start(pvf_handle h, pvf_handle trk, pvf_handle frame, const double box[4])
+{
+    return pvf_tracker_start_many(h, &trk, &frame, box, 1);
+}
+extern "C" int32_t pvf_tracker_update(pvf_handle h, pvf_handle trk, pvf_handle frame, double* psr)
+{
+    return pvf_tracker_update_many(h, &trk, &frame, 1, psr, nullptr);
+}
+extern "C" int32_t pvf_tracker_position(pvf_handle h, pvf_handle trk, double box[4])
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    memcpy(box, c->tracker(trk).pos, 4 * sizeof(double));
+    API_END
+}
+extern "C" int32_t pvf_debug_tracker_state(pvf_handle h, pvf_handle trk, double* F, double* A, double* B)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    Tracker& t = c->tracker(trk);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (F && c->s_trk1.p) HIP_CHECK(hipMemcpy(F, c->s_trk1.p, (size_t)32 * 64 * 64 * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    if (A) HIP_CHECK(hipMemcpy(A, t.d_state + TRK_A, (size_t)32 * 64 * 64 * 2 * sizeof(double), hipMemcpyDeviceToHost));
+    if (B) HIP_CHECK(hipMemcpy(B, t.d_state + TRK_B, (size_t)64 * 64 * sizeof(double), hipMemcpyDeviceToHost));
+    API_END
+}
+
+// ---- S3 (host) --------------------------------------------------------------------------------------
+static double darea(double l, double t, double r, double b) { return (l > r || t > b) ? 0.0 : (r - l) * (b - t); }
+
+void overlap_matrix_host(const double* a, int na, const double* b, int nb, double ratio, double* out)
+{
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) {
+            const double* p = a + 4 * i;
+            const double* q = b + 4 * j;
+            const double il = std::max(p[0], q[0]), it = std::max(p[1], q[1]);
+            const double ir = std::min(p[2], q[2]), ib = std::min(p[3], q[3]);
+            double ov = darea(il, it, ir, ib);
+            if (ov < ratio * darea(p[0], p[1], p[2], p[3]) || ov < ratio * darea(q[0], q[1], q[2], q[3])) ov = 0.0;
+            out[(size_t)i * nb + j] = ov;
+        }
+}
+
+// Kuhn-Munkres in the six-step formulation the `munkres` package uses (row-major search for uncovered zeros),
+// so that ties between equally good assignments resolve the way the reference's host code resolves them.
+namespace {
+struct Hungarian {
+    int n;
+    std::vector<double> C;
+    std::vector<char> mark, rowc, colc;
+    std::vector<int> path;
+    int z0r = 0, z0c = 0;
+    explicit Hungarian(const double* cost, int n_) : n(n_), C(cost, cost + (size_t)n_ * n_), mark((size_t)n_ * n_, 0), rowc(n_, 0), colc(n_, 0), path(4 * n_ + 8, 0) {}
+    void clear_covers() { std::fill(rowc.begin(), rowc.end(), 0); std::fill(colc.begin(), colc.end(), 0); }
+    int reduce_rows()
+    {
+        for (int i = 0; i < n; ++i) {
+            double mn = C[(size_t)i * n];
+            for (int j = 1; j < n; ++j) mn = std::min(mn, C[(size_t)i * n + j]);
+            for (int j = 0; j < n; ++j) C[(size_t)i * n + j] -= mn;
+        }
+        return 2;
+    }
+    int star_initial()
+    {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                if (C[(size_t)i * n + j] == 0 && !colc[j] && !rowc[i]) { mark[(size_t)i * n + j] = 1; colc[j] = 1; rowc[i] = 1; break; }
+        clear_covers();
+        return 3;
+    }
+    int cover_starred()
+    {
+        int count = 0;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                if (mark[(size_t)i * n + j] == 1 && !colc[j]) { colc[j] = 1; ++count; }
+        return count >= n ? 7 : 4;
+    }
+    int prime_zeros()
+    {
+        for (;;) {
+            int row = -1, col = -1;
+            for (int i = 0; i < n && row < 0; ++i) {
+                if (rowc[i]) continue;
+                for (int j = 0; j < n; ++j)
+                    if (!colc[j] && C[(size_t)i * n + j] == 0) { row = i; col = j; break; }
+            }
+            if (row < 0) return 6;
+            mark[(size_t)row * n + col] = 2;
+            int star = -1;
+            for (int j = 0; j < n; ++j) if (mark[(size_t)row * n + j] == 1) { star = j; break; }
+            if (star < 0) { z0r = row; z0c = col; return 5; }
+            rowc[row] = 1; colc[star] = 0;
+        }
+    }
+    int augment()
+    {
+        int count = 0;
+        path[0] = z0r; path[1] = z0c;
+        for (;;) {
+            int row = -1;
+            for (int i = 0; i < n; ++i) if (mark[(size_t)i * n + path[2 * count + 1]] == 1) { row = i; break; }
+            if (row < 0) break;
+            ++count; path[2 * count] = row; path[2 * count + 1] = path[2 * (count - 1) + 1];
+            int col = -1;
+            for (int j = 0; j < n; ++j) if (mark[(size_t)path[2 * count] * n + j] == 2) { col = j; break; }
+            ++count; path[2 * count] = path[2 * (count - 1)]; path[2 * count + 1] = col;
+        }
+        for (int k = 0; k <= count; ++k) {
+            char& m = mark[(size_t)path[2 * k] * n + path[2 * k + 1]];
+            m = (m == 1) ? 0 : 1;
+        }
+        clear_covers();
+        for (auto& m : mark) if (m == 2) m = 0;
+        return 3;
+    }
+    int shift_costs()
+    {
+        double mn = 0; bool have = false;
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                if (!rowc[i] && !colc[j] && (!have || C[(size_t)i * n + j] < mn)) { mn = C[(size_t)i * n + j]; have = true; }
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                if (rowc[i]) C[(size_t)i * n + j] += mn;
+                if (!colc[j]) C[(size_t)i * n + j] -= mn;
+            }
+        return 4;
+    }
+    void solve(int32_t* row_to_col)
+    {
+        int step = 1;
+        while (step != 7) {
+            switch (step) {
+                case 1: step = reduce_rows(); break;
+                case 2: step = star_initial(); break;
+                case 3: step = cover_starred(); break;
+                case 4: step = prime_zeros(); break;
+                case 5: step = augment(); break;
+                default: step = shift_costs(); break;
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            row_to_col[i] = -1;
+            for (int j = 0; j < n; ++j) if (mark[(size_t)i * n + j] == 1) { row_to_col[i] = j; break; }
+        }
+    }
+};
+} // namespace
+
+void munkres_host(const double* cost, int n, int32_t* row_to_col)
+{
+    Hungarian hg(cost, n);
+    hg.solve(row_to_col);
+}
+
+extern "C" int32_t pvf_overlap_matrix(const double* a, int32_t na, const double* b, int32_t nb, double ratio, double* out)
+{
+    API_BEGIN
+    overlap_matrix_host(a, na, b, nb, ratio, out);
+    API_END
+}
+extern "C" int32_t pvf_munkres(const double* cost, int32_t n, int32_t* row_to_col)
+{
+    API_BEGIN
+    PVF_REQUIRE(n > 0 && cost && row_to_col, "pvf_munkres: bad arguments");
+    munkres_host(cost, n, row_to_col);
+    API_END
+}
+
+// ---- S4 -------------------------------------------------------------------------------------------
+extern "C" int32_t pvf_landmarks(pvf_handle h, const pvf_handle* frames, const pvf_rect_i32* boxes, int32_t n, int32_t* pts)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    if (n == 0) return 0;
+    std::vector<Frame> f(n);
+    for (int i = 0; i < n; ++i) f[i] = c->frame(frames[i]);
+    ert_run(c, f, boxes, n, pts);
+    API_END
+}
+
+static uint8_t* make_face_chips(Ctx* c, const pvf_handle* frames, const int32_t* pts, int n)
+{
+    const EmbedModel& e = c->emb;
+    PVF_REQUIRE(e.loaded, "embedder not loaded");
+    std::vector<ChipJob> jobs(n);
+    for (int i = 0; i < n; ++i) {
+        ChipDetails d;
+        face_chip_details(e, pts + (size_t)i * 68 * 2, &d);
+        jobs[i] = chip_plan(c->frame(frames[i]), d);
+    }
+    const size_t bytes = (size_t)n * e.chip_size * e.chip_size * 3;
+    c->s_trk0.ensure(bytes);
+    chip_extract_batch(c, jobs, c->s_trk0.as<uint8_t>());
+    return c->s_trk0.as<uint8_t>();
+}
+
+extern "C" int32_t pvf_face_chips(pvf_handle h, const pvf_handle* frames, const int32_t* pts, int32_t n, uint8_t* chips)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    if (n == 0) return 0;
+    uint8_t* d = make_face_chips(c, frames, pts, n);
+    HIP_CHECK(hipMemcpyAsync(chips, d, (size_t)n * 150 * 150 * 3, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    API_END
+}
+
+extern "C" int32_t pvf_embed(pvf_handle h, const pvf_handle* frames, const int32_t* pts, int32_t n, float* out)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    if (n == 0) return 0;
+    const int CH = 1024; // faces per chip-extraction round
+    for (int i0 = 0; i0 < n; i0 += CH) {
+        const int m = std::min(CH, n - i0);
+        uint8_t* d = make_face_chips(c, frames + i0, pts + (size_t)i0 * 136, m);
+        resnet_forward(c, d, m, out + (size_t)i0 * 128);
+    }
+    API_END
+}
+
+extern "C" int32_t pvf_embed_chips(pvf_handle h, const uint8_t* chips, int32_t n, float* out)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    if (n == 0) return 0;
+    const size_t bytes = (size_t)n * 150 * 150 * 3;
+    c->s_trk0.ensure(bytes);
+    HIP_CHECK(hipMemcpyAsync(c->s_trk0.p, chips, bytes, hipMemcpyHostToDevice, c->stream));
+    resnet_forward(c, c->s_trk0.as<uint8_t>(), n, out);
+    API_END
+}
+
+extern "C" int32_t pvf_debug_extract_chip(pvf_handle h, pvf_handle frame, const double rect[4], double cs, double sn, int32_t rows,
+                                          int32_t cols, uint8_t* out)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    ChipDetails d{rect[0], rect[1], rect[2], rect[3], cs, sn, rows, cols};
+    std::vector<ChipJob> jobs{chip_plan(c->frame(frame), d)};
+    const size_t bytes = (size_t)rows * cols * 3;
+    c->s_trk0.ensure(bytes);
+    chip_extract_batch(c, jobs, c->s_trk0.as<uint8_t>());
+    HIP_CHECK(hipMemcpyAsync(out, c->s_trk0.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    API_END
+}
+
+// ---- S5 -------------------------------------------------------------------------------------------
+extern "C" int32_t pvf_pair_mean_dist(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T, double* D)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    pair_mean_dist_dev(c, X, N, dim, row_start, T, D, nullptr);
+    API_END
+}
+
+extern "C" int32_t pvf_cluster_tracks(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
+                                      double threshold, int32_t* labels, double* merge_log, int32_t* n_merges)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    double* dD = nullptr;
+    pair_mean_dist_dev(c, X, N, dim, row_start, T, nullptr, &dD);
+    const int n = hac_dev(c, dD, row_start, T, threshold, labels, merge_log);
+    if (n_merges) *n_merges = n;
+    API_END
+}

@@ -1,0 +1,389 @@
+// ctx.hip -- context, model containers, frames, HIP-event profiling.
+#include "pvf_internal.h"
+#include <fstream>
+#include <mutex>
+
+static thread_local std::string g_err;
+void pvf_set_error(const char* msg) { g_err = msg ? msg : ""; }
+extern "C" const char* pvf_last_error(void) { return g_err.c_str(); }
+
+static std::mutex g_ctx_mu;
+static std::unordered_map<uint64_t, std::unique_ptr<Ctx>> g_ctxs;
+static uint64_t g_next_ctx = 0x1000;
+
+Ctx* pvf_ctx(pvf_handle h)
+{
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto it = g_ctxs.find(h);
+    if (it == g_ctxs.end()) throw PvfError("unknown context handle");
+    return it->second.get();
+}
+
+// ---------------------------------------------------------------------------------------------------
+std::map<std::string, Tensor> pvf_read_container(const char* path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw PvfError(std::string("cannot open model file: ") + path);
+    char magic[8];
+    f.read(magic, 8);
+    if (!f || memcmp(magic, "PVFMODEL", 8) != 0) throw PvfError(std::string("not a PVFMODEL container: ") + path);
+    uint32_t ver = 0, n = 0;
+    f.read((char*)&ver, 4); f.read((char*)&n, 4);
+    std::map<std::string, Tensor> out;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t ln = 0;
+        f.read((char*)&ln, 4);
+        std::string name(ln, '\0');
+        f.read(&name[0], ln);
+        uint32_t dt = 0, nd = 0;
+        f.read((char*)&dt, 4); f.read((char*)&nd, 4);
+        Tensor t;
+        t.name = name; t.dtype = (int)dt;
+        for (uint32_t d = 0; d < nd; ++d) { uint64_t v; f.read((char*)&v, 8); t.dims.push_back((int64_t)v); }
+        uint64_t nbytes = 0;
+        f.read((char*)&nbytes, 8);
+        std::streamoff pos = f.tellg();
+        std::streamoff pad = (8 - (pos % 8)) % 8;
+        f.seekg(pad, std::ios::cur);
+        t.data.resize(nbytes);
+        f.read((char*)t.data.data(), (std::streamsize)nbytes);
+        if (!f) throw PvfError(std::string("truncated model file: ") + path);
+        out[name] = std::move(t);
+    }
+    return out;
+}
+
+static const Tensor& need(const std::map<std::string, Tensor>& m, const char* k)
+{
+    auto it = m.find(k);
+    if (it == m.end()) throw PvfError(std::string("model file lacks tensor ") + k);
+    return it->second;
+}
+
+template <class T>
+static T* upload(const void* src, size_t count)
+{
+    T* d = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d, count * sizeof(T)));
+    HIP_CHECK(hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+static void load_detector(Ctx* c, const char* path)
+{
+    auto m = pvf_read_container(path);
+    const Tensor& meta = need(m, "det.meta");
+    PVF_REQUIRE(meta.numel() >= 10, "det.meta too short");
+    const int32_t* q = meta.i32();
+    DetectorModel& d = c->det;
+    d.n_filters = q[0]; d.frows = q[1]; d.fcols = q[2]; d.cell = q[3]; d.padding = q[4];
+    d.win_w = q[5]; d.win_h = q[6]; d.min_w = q[7]; d.min_h = q[8]; d.max_levels = q[9];
+    PVF_REQUIRE(d.n_filters >= 1 && d.n_filters <= 8, "detector: 1..8 filters supported");
+    PVF_REQUIRE(d.frows == 10 && d.fcols == 10 && d.cell == 8, "detector: 10x10 cells of 8 px supported");
+    const Tensor& nms = need(m, "det.nms");
+    d.nms_iou = nms.f64()[0]; d.nms_covered = nms.f64()[1];
+    const Tensor& w = need(m, "det.w");
+    PVF_REQUIRE(w.numel() == (size_t)d.n_filters * d.frows * d.fcols * 32, "det.w shape");
+    const Tensor& th = need(m, "det.thresh");
+    d.thresh.assign(th.f32(), th.f32() + d.n_filters);
+    if (d.d_w) (void)hipFree(d.d_w);
+    if (d.d_wt) (void)hipFree(d.d_wt);
+    d.d_w = upload<float>(w.f32(), w.numel());
+    // filter-minor copy [m][n][p][8]
+    std::vector<float> wt((size_t)d.frows * d.fcols * 32 * 8, 0.0f);
+    for (int f = 0; f < d.n_filters; ++f)
+        for (int i = 0; i < d.frows * d.fcols * 32; ++i) wt[(size_t)i * 8 + f] = w.f32()[(size_t)f * d.frows * d.fcols * 32 + i];
+    d.d_wt = upload<float>(wt.data(), wt.size());
+    d.loaded = true;
+}
+
+static void load_shape(Ctx* c, const char* path)
+{
+    auto m = pvf_read_container(path);
+    const int32_t* q = need(m, "sp.meta").i32();
+    ShapeModel& s = c->shape;
+    s.n_cascades = q[0]; s.n_trees = q[1]; s.n_parts = q[2]; s.n_pix = q[3]; s.depth = q[4];
+    PVF_REQUIRE(s.n_parts == 68, "shape predictor: 68 parts expected");
+    PVF_REQUIRE(s.depth >= 1 && s.depth <= 6, "shape predictor: tree depth 1..6");
+    PVF_REQUIRE(s.n_pix <= 1024, "shape predictor: at most 1024 feature pixels per cascade");
+    auto up_f = [&](const char* k) { const Tensor& t = need(m, k); return upload<float>(t.f32(), t.numel()); };
+    auto up_i = [&](const char* k) { const Tensor& t = need(m, k); return upload<int32_t>(t.i32(), t.numel()); };
+    s.d_initial = up_f("sp.initial_shape");
+    s.d_anchor = up_i("sp.anchor_idx");
+    s.d_deltas = up_f("sp.deltas");
+    s.d_idx1 = up_i("sp.split_idx1");
+    s.d_idx2 = up_i("sp.split_idx2");
+    s.d_thresh = up_f("sp.split_thresh");
+    s.d_leaves = up_f("sp.leaves");
+    s.loaded = true;
+}
+
+static const int UNITS[14][3] = {{32, 32, 0}, {32, 32, 0}, {32, 32, 0}, {32, 64, 1}, {64, 64, 0}, {64, 64, 0}, {64, 64, 0},
+                                 {64, 128, 1}, {128, 128, 0}, {128, 128, 0}, {128, 256, 1}, {256, 256, 0}, {256, 256, 0}, {256, 256, 1}};
+
+static void load_embedder(Ctx* c, const char* path)
+{
+    auto m = pvf_read_container(path);
+    EmbedModel& e = c->emb;
+    e.chip_size = need(m, "emb.meta").i32()[0];
+    e.chip_padding = need(m, "emb.padding").f64()[0];
+    PVF_REQUIRE(e.chip_size == 150, "embedder: 150x150 chips expected");
+    const Tensor& ms = need(m, "emb.mean_shape");
+    PVF_REQUIRE(ms.numel() == 102, "emb.mean_shape must be 51x2");
+    e.mean_shape.assign(ms.f32(), ms.f32() + 102);
+    const Tensor& blob = need(m, "emb.blob");
+    const float* p = blob.f32();
+    const float* end = p + blob.numel();
+    e.convs.clear();
+    auto add_conv = [&](int cin, int cout, int k, int stride, int pad) {
+        ConvLayer L{cin, cout, k, stride, pad, nullptr, nullptr, nullptr, nullptr};
+        const size_t nw = (size_t)cout * cin * k * k;
+        PVF_REQUIRE(p + nw + 3 * (size_t)cout <= end, "emb.blob too short");
+        std::vector<float> wt(nw);
+        // [cout][cin][r][s] -> [(r*k+s)*cin + c][cout]
+        for (int o = 0; o < cout; ++o)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int r = 0; r < k; ++r)
+                    for (int s = 0; s < k; ++s)
+                        wt[((size_t)(r * k + s) * cin + ci) * cout + o] = p[(((size_t)o * cin + ci) * k + r) * k + s];
+        L.d_w = upload<float>(wt.data(), nw);
+        p += nw;
+        L.d_bias = upload<float>(p, cout); p += cout;
+        L.d_gamma = upload<float>(p, cout); p += cout;
+        L.d_beta = upload<float>(p, cout); p += cout;
+        e.convs.push_back(L);
+    };
+    add_conv(3, 32, 7, 2, 0);
+    for (int u = 0; u < 14; ++u) {
+        const int cin = UNITS[u][0], n = UNITS[u][1], down = UNITS[u][2];
+        add_conv(cin, n, 3, down ? 2 : 1, down ? 0 : 1);
+        add_conv(n, n, 3, 1, 1);
+    }
+    PVF_REQUIRE(p + 256 * 128 == end, "emb.blob size mismatch");
+    e.d_fc = upload<float>(p, 256 * 128);
+    e.loaded = true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+ProfScope::ProfScope(Ctx* ctx, const char* family) : c(ctx)
+{
+    if (!c->prof_on) return;
+    f = &c->prof[family];
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+        else HIP_CHECK(hipEventCreate(&e));
+        return e;
+    };
+    a = get(); b = get();
+    HIP_CHECK(hipEventRecord(a, c->stream));
+}
+ProfScope::~ProfScope()
+{
+    if (!f) return;
+    (void)hipEventRecord(b, c->stream);
+    f->pending.emplace_back(a, b);
+    f->launches += 1;
+}
+
+static void prof_drain(Ctx* c)
+{
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (auto& kv : c->prof) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) kv.second.total_ms += ms;
+            c->event_pool.push_back(pr.first);
+            c->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+#define API_BEGIN try {
+#define API_END                                                        \
+    return 0;                                                          \
+    }                                                                  \
+    catch (const std::exception& e) { pvf_set_error(e.what()); return -1; } \
+    catch (...) { pvf_set_error("unknown error"); return -2; }
+
+extern "C" int32_t pvf_version(void) { return 100; }
+
+extern "C" int32_t pvf_device_count(int32_t* n)
+{
+    API_BEGIN
+    int k = 0;
+    hipError_t e = hipGetDeviceCount(&k);
+    if (e != hipSuccess) k = 0;
+    *n = k;
+    API_END
+}
+
+extern "C" int32_t pvf_ctx_create(int32_t device, pvf_handle* out)
+{
+    API_BEGIN
+    int k = 0;
+    if (hipGetDeviceCount(&k) != hipSuccess || k <= 0) throw PvfError("no HIP device visible: libpvface has no CPU fallback");
+    PVF_REQUIRE(device >= 0 && device < k, "device index out of range");
+    HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        throw PvfError(std::string("libpvface is built for gfx950 (MI355X) only; device is ") + prop.gcnArchName);
+    std::unique_ptr<Ctx> c(new Ctx());
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    uint64_t id = g_next_ctx++;
+    g_ctxs[id] = std::move(c);
+    *out = id;
+    API_END
+}
+
+extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->frames) if (kv.second.owned) (void)hipFree((void*)kv.second.d);
+    for (auto& kv : c->trackers) if (kv.second->d_state) (void)hipFree(kv.second->d_state);
+    for (auto p : c->tracker_pool) (void)hipFree(p);
+    (void)hipStreamDestroy(c->stream);
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_ctxs.erase(h);
+    API_END
+}
+
+extern "C" int32_t pvf_sync(pvf_handle h)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    API_END
+}
+
+extern "C" int32_t pvf_load_detector(pvf_handle h, const char* path)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    PVF_REQUIRE(path != nullptr, "pvf_load_detector: path is NULL (the Python layer passes the packaged default)");
+    load_detector(c, path);
+    API_END
+}
+extern "C" int32_t pvf_load_shape_predictor(pvf_handle h, const char* path)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    PVF_REQUIRE(path != nullptr, "path is NULL");
+    load_shape(c, path);
+    API_END
+}
+extern "C" int32_t pvf_load_embedder(pvf_handle h, const char* path)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    PVF_REQUIRE(path != nullptr, "path is NULL");
+    load_embedder(c, path);
+    API_END
+}
+
+extern "C" int32_t pvf_set_tracker_tables(pvf_handle h, const double* mask64, const double* mask_scale, const double* tw64,
+                                          const double* tw32, double alpha_pow_m16, double ln_alpha)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    TrackerTables& t = c->ttab;
+    if (!t.d_mask64) {
+        HIP_CHECK(hipMalloc((void**)&t.d_mask64, 64 * 64 * 8));
+        HIP_CHECK(hipMalloc((void**)&t.d_mask_scale, 32 * 8));
+        HIP_CHECK(hipMalloc((void**)&t.d_tw64, 64 * 8));
+        HIP_CHECK(hipMalloc((void**)&t.d_tw32, 32 * 8));
+    }
+    HIP_CHECK(hipMemcpy(t.d_mask64, mask64, 64 * 64 * 8, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(t.d_mask_scale, mask_scale, 32 * 8, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(t.d_tw64, tw64, 64 * 8, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(t.d_tw32, tw32, 32 * 8, hipMemcpyHostToDevice));
+    t.alpha_pow_m16 = alpha_pow_m16; t.ln_alpha = ln_alpha;
+    t.set = true;
+    API_END
+}
+
+extern "C" int32_t pvf_frame_upload(pvf_handle h, const uint8_t* rgb, int32_t fh, int32_t fw, int64_t stride, pvf_handle* out)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    PVF_REQUIRE(rgb && fh > 0 && fw > 0, "pvf_frame_upload: bad frame");
+    if (stride == 0) stride = (int64_t)fw * 3;
+    PVF_REQUIRE(stride >= (int64_t)fw * 3, "pvf_frame_upload: row stride smaller than a row");
+    uint8_t* d = nullptr;
+    HIP_CHECK(hipMalloc((void**)&d, (size_t)fh * fw * 3));
+    HIP_CHECK(hipMemcpy2DAsync(d, (size_t)fw * 3, rgb, (size_t)stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    Frame f; f.d = d; f.h = fh; f.w = fw; f.owned = true;
+    uint64_t id = c->next_id++;
+    c->frames[id] = f;
+    *out = id;
+    API_END
+}
+
+extern "C" int32_t pvf_frame_wrap_device(pvf_handle h, const void* dev, int32_t fh, int32_t fw, pvf_handle* out)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    PVF_REQUIRE(dev && fh > 0 && fw > 0, "pvf_frame_wrap_device: bad frame");
+    Frame f; f.d = (const uint8_t*)dev; f.h = fh; f.w = fw; f.owned = false;
+    uint64_t id = c->next_id++;
+    c->frames[id] = f;
+    *out = id;
+    API_END
+}
+
+extern "C" int32_t pvf_frame_release(pvf_handle h, pvf_handle frame)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    auto it = c->frames.find(frame);
+    PVF_REQUIRE(it != c->frames.end(), "unknown frame handle");
+    if (it->second.owned) {
+        HIP_CHECK(hipSetDevice(c->device));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        HIP_CHECK(hipFree((void*)it->second.d));
+    }
+    c->frames.erase(it);
+    API_END
+}
+
+extern "C" int32_t pvf_prof_enable(pvf_handle h, int32_t on)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    if (!on && c->prof_on) prof_drain(c);
+    c->prof_on = on != 0;
+    API_END
+}
+extern "C" int32_t pvf_prof_reset(pvf_handle h)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    prof_drain(c);
+    for (auto& kv : c->prof) { kv.second.total_ms = 0; kv.second.launches = 0; }
+    API_END
+}
+extern "C" int32_t pvf_prof_get(pvf_handle h, const char* family, double* total_ms, int64_t* launches)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    prof_drain(c);
+    auto it = c->prof.find(family);
+    if (it == c->prof.end()) { *total_ms = 0; *launches = 0; }
+    else { *total_ms = it->second.total_ms; *launches = it->second.launches; }
+    API_END
+}

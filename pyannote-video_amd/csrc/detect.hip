@@ -1,0 +1,638 @@
+// detect.hip -- K1..K4: image pyramid, FHOG, filter scoring, NMS  (replaces dlib.get_frontal_face_detector()(rgb, 1);
+// reference pyannote/video/face/face.py:54,66).  All arithmetic follows the orders stated in oracle/pvo_fhog.c and
+// oracle/pvo_detect.c so that boxes are bit-identical; the code itself is written for gfx950 (wave64, LDS tiles).
+#include "pvf_internal.h"
+#include <algorithm>
+#include <cmath>
+
+// =====================================================================================================
+// K1: bilinear resize (pyramid_up / pyramid_down<6>), uint8 RGB HWC, double coordinates, (v + 0.5) truncation
+// =====================================================================================================
+__global__ void __launch_bounds__(256) resize_bilinear_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
+                                                         size_t in_stride, int ih, int iw, uint8_t* __restrict__ out, size_t out_stride,
+                                                         int oh, int ow, double x_scale, double y_scale)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    const int b = blockIdx.z;
+    if (c >= ow) return;
+    const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
+    const double y = r * y_scale;
+    const int top = (int)floor(y);
+    const int bottom = min(top + 1, ih - 1);
+    const double tb = y - top;
+    const double x = c * x_scale;
+    const int left = (int)floor(x);
+    const int right = min(left + 1, iw - 1);
+    const double lr = x - left;
+    const uint8_t* ptl = in + ((size_t)top * iw + left) * 3;
+    const uint8_t* ptr = in + ((size_t)top * iw + right) * 3;
+    const uint8_t* pbl = in + ((size_t)bottom * iw + left) * 3;
+    const uint8_t* pbr = in + ((size_t)bottom * iw + right) * 3;
+    uint8_t* o = out + (size_t)b * out_stride + ((size_t)r * ow + c) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double tl = ptl[k], tr = ptr[k], bl = pbl[k], br = pbr[k];
+        const double v = (1 - tb) * ((1 - lr) * tl + lr * tr) + tb * ((1 - lr) * bl + lr * br);
+        o[k] = (uint8_t)(v + 0.5);
+    }
+}
+
+static void launch_resize(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* in_base, size_t in_stride, int ih, int iw,
+                          uint8_t* out, size_t out_stride, int oh, int ow, int batch)
+{
+    const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
+    const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
+    dim3 grid((ow + 255) / 256, oh, batch);
+    hipLaunchKernelGGL(resize_bilinear_k, grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
+                       x_scale, y_scale);
+}
+
+static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
+{
+    const double right = ((iw - 1) + 1.25) * 2.0;
+    const double bottom = ((ih - 1) + 0.75) * 2.0;
+    *ow = (int)std::floor(right + 0.5) + 1;
+    *oh = (int)std::floor(bottom + 0.5) + 1;
+}
+
+// =====================================================================================================
+// K2: FHOG.  gradient -> (orientation bin, magnitude) per pixel; histogram cells gather their 2C x 2C window in
+// row-major pixel order (== the order dlib's scatter loop adds in); 4-way block normalisation -> 31 features.
+// =====================================================================================================
+__constant__ float c_dirx[9] = {1.0000f, 0.9397f, 0.7660f, 0.500f, 0.1736f, -0.1736f, -0.5000f, -0.7660f, -0.9397f};
+__constant__ float c_diry[9] = {0.0000f, 0.3420f, 0.6428f, 0.8660f, 0.9848f, 0.9848f, 0.8660f, 0.6428f, 0.3420f};
+
+__device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, const uint8_t* __restrict__ row_c,
+                                           const uint8_t* __restrict__ row_d, int x3, float* v2, int* bo)
+{
+    // row_* point at the byte rows; x3 = 3*x (pixel x of the centre row)
+    int bx = (int)row_c[x3 + 3] - (int)row_c[x3 - 3], by = (int)row_d[x3] - (int)row_u[x3];
+    int bv = bx * bx + by * by;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+        const int cx = (int)row_c[x3 + 3 + k] - (int)row_c[x3 - 3 + k], cy = (int)row_d[x3 + k] - (int)row_u[x3 + k];
+        const int cv = cx * cx + cy * cy;
+        if (cv > bv) { bv = cv; bx = cx; by = cy; }
+    }
+    const float gx = (float)bx, gy = (float)by;
+    float best_dot = 0.0f;
+    int best_o = 0;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+        const float dot = gx * c_dirx[o] + gy * c_diry[o];
+        if (dot > best_dot) { best_dot = dot; best_o = o; }
+        else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
+    }
+    *v2 = (float)bv;
+    *bo = best_o;
+}
+
+// one block = TxT histogram cells; LDS holds the (T+1)C x (T+1)C pixel window (+1 px halo) and its (bin, magnitude)
+template <int C, int T>
+__global__ void __launch_bounds__(384) fhog_hist_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
+                                                   int visible_nc, float* __restrict__ hist, size_t hist_stride, int hr, int hc)
+{
+    constexpr int R = (T + 1) * C;      // window side in pixels
+    constexpr int RH = R + 2;           // with halo
+    __shared__ uint8_t s_img[RH][RH * 3 + 2];
+    __shared__ float s_v[R][R + 1];
+    __shared__ uint8_t s_o[R][R + 4];
+    const int b = blockIdx.z;
+    const int hy0 = blockIdx.y * T, hx0 = blockIdx.x * T;
+    const uint8_t* im = img + (size_t)b * img_stride;
+    const int py0 = C * hy0 - 3 * C / 2, px0 = C * hx0 - 3 * C / 2; // image coords of window pixel (0,0)
+    // stage bytes (zero outside the image)
+    for (int i = threadIdx.x; i < RH * RH * 3; i += blockDim.x) {
+        const int ry = i / (RH * 3), rb = i % (RH * 3);
+        const int y = py0 - 1 + ry, xb = (px0 - 1) * 3 + rb;
+        uint8_t v = 0;
+        if (y >= 0 && y < ih && xb >= 0 && xb < iw * 3) v = im[(size_t)y * iw * 3 + xb];
+        s_img[ry][rb] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < R * R; i += blockDim.x) {
+        const int ly = i / R, lx = i % R;
+        const int y = py0 + ly, x = px0 + lx;
+        float v = 0.0f;
+        int o = 0;
+        if (y >= 1 && y < visible_nr && x >= 1 && x < visible_nc) {
+            float v2;
+            pixel_grad(&s_img[ly][0], &s_img[ly + 1][0], &s_img[ly + 2][0], (lx + 1) * 3, &v2, &o);
+            v = sqrtf(v2);
+        }
+        s_v[ly][lx] = v;
+        s_o[ly][lx] = (uint8_t)o;
+    }
+    __syncthreads();
+    // gather: work item = (cell, bin)
+    for (int item = threadIdx.x; item < T * T * 18; item += blockDim.x) {
+        const int cell = item / 18, bin = item % 18;
+        const int cy = cell / T, cx = cell % T;
+        const int hy = hy0 + cy, hx = hx0 + cx;
+        if (hy >= hr || hx >= hc) continue;
+        float acc = 0.0f;
+        for (int wy = 0; wy < 2 * C; ++wy) {
+            const int i = wy % C;
+            const float fy = ((float)i + 0.5f) / (float)C;
+            const float wyv = (wy < C) ? fy : 1.0f - fy;
+            const int ly = cy * C + wy;
+#pragma unroll 4
+            for (int wx = 0; wx < 2 * C; ++wx) {
+                const int j = wx % C;
+                const float fx = ((float)j + 0.5f) / (float)C;
+                const float wxv = (wx < C) ? fx : 1.0f - fx;
+                const int lx = cx * C + wx;
+                const float contrib = (wyv * wxv) * s_v[ly][lx];
+                acc += (s_o[ly][lx] == bin) ? contrib : 0.0f;
+            }
+        }
+        hist[(size_t)b * hist_stride + ((size_t)hy * hc + hx) * 18 + bin] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) fhog_norm_k(const float* __restrict__ hist, size_t hist_stride, int hc, float* __restrict__ norm,
+                                                   size_t norm_stride, int cells_nr, int cells_nc)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y, b = blockIdx.z;
+    if (c >= cells_nc) return;
+    const float* h = hist + (size_t)b * hist_stride + ((size_t)(r + 1) * hc + (c + 1)) * 18;
+    float acc = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) { const float s = h[o] + h[o + 9]; acc = acc + s * s; }
+    norm[(size_t)b * norm_stride + (size_t)r * cells_nc + c] = acc;
+}
+
+__device__ __forceinline__ void cell_features(const float* h, const float* n, float* o)
+{
+    const float eps = 0.0001f;
+    const float z1[4] = {n[4], n[1], n[3], n[0]};
+    const float z2[4] = {n[5], n[2], n[4], n[1]};
+    const float z3[4] = {n[7], n[4], n[6], n[3]};
+    const float z4[4] = {n[8], n[5], n[7], n[4]};
+    float nn[4], nv[4], t[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        nn[k] = 0.2f * sqrtf((((z1[k] + z2[k]) + z3[k]) + z4[k]) + eps);
+        nv[k] = 0.1f / nn[k];
+    }
+#pragma unroll
+    for (int g = 0; g < 18; g += 3) {
+        float hh[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hh[j][k] = fminf(h[g + j], nn[k]) * nv[k];
+            o[g + j] = (hh[j][0] + hh[j][1]) + (hh[j][2] + hh[j][3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = t[k] + ((hh[0][k] + hh[1][k]) + hh[2][k]);
+    }
+    const float tscale = (float)(2 * 0.2357);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = t[k] * tscale;
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        const float s = h[g] + h[g + 9];
+        float hh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hh[k] = fminf(s, nn[k]) * nv[k];
+        o[18 + g] = (hh[0] + hh[1]) + (hh[2] + hh[3]);
+    }
+    o[27] = t[0]; o[28] = t[1]; o[29] = t[2]; o[30] = t[3];
+    o[31] = 0.0f;
+}
+
+__global__ void __launch_bounds__(256) fhog_feat_k(const float* __restrict__ hist, size_t hist_stride, int hc, const float* __restrict__ norm,
+                                                   size_t norm_stride, int cells_nc, float* __restrict__ feat, size_t feat_stride, int fw,
+                                                   int hog_nr, int hog_nc, int oy, int ox)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= hog_nc) return;
+    float n[9], h[18], o[32];
+    const float* nb = norm + (size_t)b * norm_stride;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) n[i * 3 + j] = nb[(size_t)(y + i) * cells_nc + (x + j)];
+    const float* hp = hist + (size_t)b * hist_stride + ((size_t)(y + 2) * hc + (x + 2)) * 18;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) h[k] = hp[k];
+    cell_features(h, n, o);
+    float4* dst = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)(y + oy) * fw + (x + ox)) * PVF_FHOG_STRIDE);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+// cell size 1 (correlation tracker translation chip): every pixel is a cell
+__global__ void __launch_bounds__(256) fhog1_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw,
+                                                    float* __restrict__ norm, uint8_t* __restrict__ angle, size_t px_stride)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= iw) return;
+    float v = 0.0f;
+    int o = 0;
+    if (y >= 1 && y < ih - 1 && x >= 1 && x < iw - 1) {
+        const uint8_t* im = img + (size_t)b * img_stride;
+        pixel_grad(im + (size_t)(y - 1) * iw * 3, im + (size_t)y * iw * 3, im + (size_t)(y + 1) * iw * 3, x * 3, &v, &o);
+    }
+    norm[(size_t)b * px_stride + (size_t)y * iw + x] = v;
+    angle[(size_t)b * px_stride + (size_t)y * iw + x] = (uint8_t)o;
+}
+
+__global__ void __launch_bounds__(256) fhog1_feat_k(const float* __restrict__ norm, const uint8_t* __restrict__ angle, size_t px_stride,
+                                                    int iw, float* __restrict__ feat, size_t feat_stride, int fw, int hog_nr, int hog_nc,
+                                                    int oy, int ox)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= hog_nc) return;
+    float n[9], h[18], o[32];
+    const float* nb = norm + (size_t)b * px_stride;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) n[i * 3 + j] = nb[(size_t)(y + i) * iw + (x + j)];
+    const int a = angle[(size_t)b * px_stride + (size_t)(y + 1) * iw + (x + 1)];
+    const float mag = sqrtf(n[4]);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) h[k] = (k == a) ? mag : 0.0f;
+    cell_features(h, n, o);
+    float4* dst = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)(y + oy) * fw + (x + ox)) * PVF_FHOG_STRIDE);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw)
+{
+    int hog_nr, hog_nc;
+    if (cell == 1) { hog_nr = ih - 2; hog_nc = iw - 2; }
+    else {
+        const int cells_nr = (int)((double)ih / (double)cell + 0.5);
+        const int cells_nc = (int)((double)iw / (double)cell + 0.5);
+        hog_nr = cells_nr - 2; hog_nc = cells_nc - 2;
+    }
+    if (hog_nr <= 0 || hog_nc <= 0) { *fh = 0; *fw = 0; return; }
+    *fh = hog_nr + pad_r - 1;
+    *fw = hog_nc + pad_c - 1;
+}
+
+void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat, DevBuf& hist, DevBuf& norm)
+{
+    int fh, fw;
+    fhog_dims(h, w, cell, pad_r, pad_c, &fh, &fw);
+    PVF_REQUIRE(fh > 0 && fw > 0, "fhog: image too small");
+    const size_t feat_stride = (size_t)fh * fw * PVF_FHOG_STRIDE;
+    HIP_CHECK(hipMemsetAsync(d_feat, 0, feat_stride * n * sizeof(float), c->stream));
+    const int oy = (pad_r - 1) / 2, ox = (pad_c - 1) / 2;
+    const size_t img_stride = (size_t)h * w * 3;
+    if (cell == 1) {
+        const size_t px = (size_t)h * w;
+        norm.ensure(px * n * sizeof(float));
+        hist.ensure(px * n);
+        dim3 g1((w + 255) / 256, h, n);
+        hipLaunchKernelGGL(fhog1_grad_k, g1, dim3(256), 0, c->stream, d_img, img_stride, h, w, norm.as<float>(), hist.as<uint8_t>(), px);
+        dim3 g2((w - 2 + 255) / 256, h - 2, n);
+        hipLaunchKernelGGL(fhog1_feat_k, g2, dim3(256), 0, c->stream, norm.as<float>(), hist.as<uint8_t>(), px, w, d_feat, feat_stride, fw,
+                           h - 2, w - 2, oy, ox);
+        return;
+    }
+    PVF_REQUIRE(cell == 8 || cell == 4, "fhog: cell size 1, 4 or 8");
+    const int cells_nr = (int)((double)h / (double)cell + 0.5), cells_nc = (int)((double)w / (double)cell + 0.5);
+    const int hr = cells_nr + 2, hc = cells_nc + 2;
+    const int visible_nr = std::min(cells_nr * cell, h) - 1, visible_nc = std::min(cells_nc * cell, w) - 1;
+    const size_t hist_stride = (size_t)hr * hc * 18, norm_stride = (size_t)cells_nr * cells_nc;
+    hist.ensure(hist_stride * n * sizeof(float));
+    norm.ensure(norm_stride * n * sizeof(float));
+    constexpr int T = 8;
+    dim3 gh((hc + T - 1) / T, (hr + T - 1) / T, n);
+    if (cell == 8)
+        hipLaunchKernelGGL((fhog_hist_k<8, T>), gh, dim3(384), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, hist.as<float>(),
+                           hist_stride, hr, hc);
+    else
+        hipLaunchKernelGGL((fhog_hist_k<4, T>), gh, dim3(384), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, hist.as<float>(),
+                           hist_stride, hr, hc);
+    dim3 gn((cells_nc + 255) / 256, cells_nr, n);
+    hipLaunchKernelGGL(fhog_norm_k, gn, dim3(256), 0, c->stream, hist.as<float>(), hist_stride, hc, norm.as<float>(), norm_stride, cells_nr,
+                       cells_nc);
+    const int hog_nr = cells_nr - 2, hog_nc = cells_nc - 2;
+    dim3 gf((hog_nc + 255) / 256, hog_nr, n);
+    hipLaunchKernelGGL(fhog_feat_k, gf, dim3(256), 0, c->stream, hist.as<float>(), hist_stride, hc, norm.as<float>(), norm_stride, cells_nc,
+                       d_feat, feat_stride, fw, hog_nr, hog_nc, oy, ox);
+}
+
+void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, int pad_c, std::vector<float>& out, int* fh, int* fw)
+{
+    fhog_dims(h, w, cell, pad_r, pad_c, fh, fw);
+    PVF_REQUIRE(*fh > 0 && *fw > 0, "fhog: image too small");
+    c->s_pyr.ensure((size_t)h * w * 3);
+    HIP_CHECK(hipMemcpyAsync(c->s_pyr.p, himg, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream));
+    const size_t nf = (size_t)(*fh) * (*fw) * PVF_FHOG_STRIDE;
+    c->s_feat.ensure(nf * sizeof(float));
+    fhog_device(c, c->s_pyr.as<uint8_t>(), 1, h, w, cell, pad_r, pad_c, c->s_feat.as<float>(), c->s_hist, c->s_norm);
+    out.resize(nf);
+    HIP_CHECK(hipMemcpyAsync(out.data(), c->s_feat.p, nf * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+// =====================================================================================================
+// K3: filter scoring.  score[f](r,c) = fmaf chain over (m, n, p) -- identical order to the oracle.
+// v1: VALU, one output position per lane, features staged in LDS with a 36-float cell pitch (conflict-free b128 reads),
+// weights come through the scalar unit (uniform addresses).
+// =====================================================================================================
+struct ScoreParams { float thresh[8]; int n_filters; int level; int cap; };
+struct CandRec { float score; int32_t filter, level, r, c; };
+
+template <int NF>
+__global__ void __launch_bounds__(256) score_k(const float* __restrict__ feat, size_t feat_stride, int fh, int fw,
+                                               const float* __restrict__ w, ScoreParams sp, int* __restrict__ counts,
+                                               CandRec* __restrict__ cands)
+{
+    constexpr int TR = 8, TC = 32, FR = 10, FC = 10, PITCH = 36;
+    constexpr int LR = TR + FR - 1, LC = TC + FC - 1;
+    extern __shared__ __attribute__((aligned(16))) float s_f[]; // [LR][LC][PITCH]
+    const int b = blockIdx.z;
+    const int r_base = blockIdx.y * TR, c_base = blockIdx.x * TC; // top-left of the feature window of this tile
+    const float* fb = feat + (size_t)b * feat_stride;
+    for (int i = threadIdx.x; i < LR * LC * 8; i += blockDim.x) {
+        const int cell = i >> 3, q = i & 7;
+        const int ly = cell / LC, lx = cell % LC;
+        const int y = r_base + ly, x = c_base + lx;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < fh && x < fw) v = reinterpret_cast<const float4*>(fb + ((size_t)y * fw + x) * PVF_FHOG_STRIDE)[q];
+        reinterpret_cast<float4*>(s_f + (size_t)cell * PITCH)[q] = v;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / TC, tx = threadIdx.x % TC;
+    float acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] = 0.0f;
+    for (int m = 0; m < FR; ++m)
+        for (int n = 0; n < FC; ++n) {
+            const float* fp = s_f + ((size_t)(ty + m) * LC + (tx + n)) * PITCH;
+            const float* wp = w + ((size_t)m * FC + n) * PVF_FHOG_STRIDE;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = reinterpret_cast<const float4*>(fp)[q];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const float* wf = wp + (size_t)f * FR * FC * PVF_FHOG_STRIDE + 4 * q;
+                    acc[f] = fmaf(v.x, wf[0], acc[f]);
+                    acc[f] = fmaf(v.y, wf[1], acc[f]);
+                    acc[f] = fmaf(v.z, wf[2], acc[f]);
+                    if (q < 7) acc[f] = fmaf(v.w, wf[3], acc[f]);
+                }
+            }
+        }
+    // output position (centre convention of spatially_filter_image): r = top + FR/2, c = left + FC/2
+    const int r = r_base + ty + FR / 2, cc = c_base + tx + FC / 2;
+    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
+    if (r < r1 && cc < c1) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            if (acc[f] >= sp.thresh[f]) {
+                const int idx = atomicAdd(&counts[b], 1);
+                if (idx < sp.cap) {
+                    CandRec rec;
+                    rec.score = acc[f] - sp.thresh[f];
+                    rec.filter = f; rec.level = sp.level; rec.r = r; rec.c = cc;
+                    cands[(size_t)b * sp.cap + idx] = rec;
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// host side: level schedule, rectangle mapping, canonical sort, NMS
+// =====================================================================================================
+static inline long iround(double v) { return (long)std::floor(v + 0.5); }
+static void rect_down6(long r[4]) { const double ratio = (6 - 1.0) / 6; for (int i = 0; i < 4; ++i) r[i] = iround((r[i] - 0.3) * ratio + 0.3); }
+static void rect_up6(long r[4]) { const double ratio = 6 / (6 - 1.0); for (int i = 0; i < 4; ++i) r[i] = iround((r[i] - 0.3) * ratio + 0.3); }
+static void rect_down2i(long r[4])
+{
+    r[0] = iround(r[0] / 2.0 - 1.25); r[1] = iround(r[1] / 2.0 - 0.75);
+    r[2] = iround(r[2] / 2.0 - 1.25); r[3] = iround(r[3] / 2.0 - 0.75);
+}
+static int detector_levels(int h, int w, const DetectorModel& m)
+{
+    long r[4] = {0, 0, w - 1, h - 1};
+    int levels = 0;
+    do { rect_down6(r); ++levels; } while ((r[2] - r[0] + 1) >= m.min_w && (r[3] - r[1] + 1) >= m.min_h && levels < m.max_levels);
+    return levels;
+}
+static void fhog_to_image(long px, long py, int cell, int pad_r, int pad_c, long* ox, long* oy)
+{
+    long x = (px + 1 - (pad_c - 1) / 2) * cell + 1;
+    long y = (py + 1 - (pad_r - 1) / 2) * cell + 1;
+    x += (x >= 0) ? cell / 2 : -(cell / 2);
+    y += (y >= 0) ? cell / 2 : -(cell / 2);
+    *ox = x; *oy = y;
+}
+
+struct LevelDims { int h, w; };
+static std::vector<LevelDims> level_schedule(int h, int w, int upsample, const DetectorModel& m, std::vector<LevelDims>* ups)
+{
+    int ch = h, cw = w;
+    for (int u = 0; u < upsample; ++u) {
+        int nh, nw;
+        pyramid_up_dims(ch, cw, &nh, &nw);
+        ch = nh; cw = nw;
+        if (ups) ups->push_back({ch, cw});
+    }
+    const int levels = detector_levels(ch, cw, m);
+    std::vector<LevelDims> out;
+    out.push_back({ch, cw});
+    for (int l = 1; l < levels; ++l) { ch = (5 * ch) / 6; cw = (5 * cw) / 6; out.push_back({ch, cw}); }
+    return out;
+}
+
+static void upload_frame_ptrs(Ctx* c, const std::vector<Frame>& frames, const uint8_t*** d_ptrs)
+{
+    c->s_misc.ensure(frames.size() * sizeof(void*));
+    c->h_misc.ensure(frames.size() * sizeof(void*));
+    const uint8_t** hp = c->h_misc.as<const uint8_t*>();
+    for (size_t i = 0; i < frames.size(); ++i) hp[i] = frames[i].d;
+    HIP_CHECK(hipMemcpyAsync(c->s_misc.p, hp, frames.size() * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+    *d_ptrs = c->s_misc.as<const uint8_t*>();
+}
+
+// builds level `want_level` (or all levels when want_level < 0, calling per_level after each one); images ping-pong in s_pyr
+template <class F>
+static void run_pyramid(Ctx* c, const std::vector<Frame>& frames, int upsample, int want_level, F&& per_level)
+{
+    const DetectorModel& m = c->det;
+    const int B = (int)frames.size();
+    const int h = frames[0].h, w = frames[0].w;
+    for (auto& f : frames) PVF_REQUIRE(f.h == h && f.w == w, "batched frames must share one size");
+    std::vector<LevelDims> ups;
+    std::vector<LevelDims> lv = level_schedule(h, w, upsample, m, &ups);
+    const size_t max_img = (size_t)lv[0].h * lv[0].w * 3;
+    c->s_pyr.ensure(2 * max_img * B + 64);
+    uint8_t* buf[2] = {c->s_pyr.as<uint8_t>(), c->s_pyr.as<uint8_t>() + max_img * B};
+    const uint8_t** d_ptrs = nullptr;
+    upload_frame_ptrs(c, frames, &d_ptrs);
+    int cur = 0;
+    const uint8_t* cur_img = nullptr; // null => original frames via pointers
+    int ch = h, cw = w;
+    {
+        ProfScope ps(c, "pyramid");
+        for (size_t u = 0; u < ups.size(); ++u) {
+            launch_resize(c, cur_img ? nullptr : d_ptrs, cur_img, (size_t)ch * cw * 3, ch, cw, buf[cur], (size_t)ups[u].h * ups[u].w * 3,
+                          ups[u].h, ups[u].w, B);
+            cur_img = buf[cur]; cur ^= 1; ch = ups[u].h; cw = ups[u].w;
+        }
+    }
+    if (!cur_img) {
+        // no upsampling: copy frames into the ping-pong buffer so that every level has the same batched layout
+        for (int b = 0; b < B; ++b)
+            HIP_CHECK(hipMemcpyAsync(buf[cur] + (size_t)b * h * w * 3, frames[b].d, (size_t)h * w * 3, hipMemcpyDeviceToDevice, c->stream));
+        cur_img = buf[cur]; cur ^= 1;
+    }
+    for (int l = 0; l < (int)lv.size(); ++l) {
+        if (l > 0) {
+            ProfScope ps(c, "pyramid");
+            launch_resize(c, nullptr, cur_img, (size_t)ch * cw * 3, ch, cw, buf[cur], (size_t)lv[l].h * lv[l].w * 3, lv[l].h, lv[l].w, B);
+            cur_img = buf[cur]; cur ^= 1; ch = lv[l].h; cw = lv[l].w;
+        }
+        if (want_level < 0 || want_level == l) per_level(l, cur_img, ch, cw);
+        if (want_level == l) break;
+    }
+}
+
+void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* oh, int* ow)
+{
+    PVF_REQUIRE(c->det.loaded, "detector not loaded");
+    std::vector<Frame> fr{f};
+    bool hit = false;
+    run_pyramid(c, fr, upsample, level, [&](int, const uint8_t* img, int h, int w) {
+        *oh = h; *ow = w; hit = true;
+        if (out) {
+            out->resize((size_t)h * w * 3);
+            HIP_CHECK(hipMemcpyAsync(out->data(), img, out->size(), hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+    });
+    PVF_REQUIRE(hit, "pyramid level out of range");
+}
+
+static bool raw_less(const RawDet& x, const RawDet& y)
+{
+    if (x.score != y.score) return x.score > y.score;
+    if (x.filter != y.filter) return x.filter < y.filter;
+    if (x.level != y.level) return x.level < y.level;
+    if (x.r != y.r) return x.r < y.r;
+    return x.c < y.c;
+}
+
+void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, double adjust, std::vector<std::vector<RawDet>>& raw_sorted)
+{
+    const DetectorModel& m = c->det;
+    PVF_REQUIRE(m.loaded, "detector not loaded");
+    PVF_REQUIRE(!frames.empty(), "no frames");
+    const int B = (int)frames.size();
+    const int cap = 8192;
+    c->s_cand.ensure((size_t)B * cap * sizeof(CandRec) + (size_t)B * sizeof(int) + 64);
+    int* d_counts = c->s_cand.as<int>();
+    CandRec* d_cands = reinterpret_cast<CandRec*>(c->s_cand.as<uint8_t>() + (((size_t)B * sizeof(int) + 63) / 64) * 64);
+    HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), c->stream));
+    ScoreParams sp;
+    for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
+    sp.n_filters = m.n_filters; sp.cap = cap;
+    run_pyramid(c, frames, upsample, -1, [&](int l, const uint8_t* img, int h, int w) {
+        int fh, fw;
+        fhog_dims(h, w, m.cell, m.frows, m.fcols, &fh, &fw);
+        if (fh < m.frows || fw < m.fcols) return;
+        const size_t feat_stride = (size_t)fh * fw * PVF_FHOG_STRIDE;
+        c->s_feat.ensure(feat_stride * B * sizeof(float));
+        {
+            ProfScope ps(c, "fhog");
+            fhog_device(c, img, B, h, w, m.cell, m.frows, m.fcols, c->s_feat.as<float>(), c->s_hist, c->s_norm);
+        }
+        {
+            ProfScope ps(c, "score");
+            sp.level = l;
+            const int out_r = fh - 9, out_c = fw - 9;
+            dim3 grid((out_c + 31) / 32, (out_r + 7) / 8, B);
+            const size_t lds = (size_t)(8 + 9) * (32 + 9) * 36 * sizeof(float);
+#define LAUNCH_SCORE(NF)                                                                                                       \
+    {                                                                                                                          \
+        static bool attr_set = false;                                                                                          \
+        if (!attr_set) {                                                                                                       \
+            HIP_CHECK(hipFuncSetAttribute((const void*)score_k<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+            attr_set = true;                                                                                                   \
+        }                                                                                                                      \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((score_k<NF>), grid, dim3(256), lds, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_w, sp, \
+                       d_counts, d_cands)
+            switch (m.n_filters) {
+                case 1: LAUNCH_SCORE(1); break;
+                case 2: LAUNCH_SCORE(2); break;
+                case 3: LAUNCH_SCORE(3); break;
+                case 4: LAUNCH_SCORE(4); break;
+                case 5: LAUNCH_SCORE(5); break;
+                case 6: LAUNCH_SCORE(6); break;
+                case 7: LAUNCH_SCORE(7); break;
+                default: LAUNCH_SCORE(8); break;
+            }
+#undef LAUNCH_SCORE
+        }
+    });
+    HIP_CHECK(hipGetLastError());
+    c->h_cand.ensure((size_t)B * cap * sizeof(CandRec) + (size_t)B * sizeof(int) + 64);
+    int* h_counts = c->h_cand.as<int>();
+    CandRec* h_cands = reinterpret_cast<CandRec*>(c->h_cand.as<uint8_t>() + (((size_t)B * sizeof(int) + 63) / 64) * 64);
+    HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    raw_sorted.assign(B, {});
+    const int bw = m.fcols - 2 * m.padding, bh = m.frows - 2 * m.padding;
+    for (int b = 0; b < B; ++b) {
+        const int n = h_counts[b];
+        if (n > cap) throw PvfError("detector: candidate buffer overflow (threshold far too low for this input)");
+        if (n == 0) continue;
+        HIP_CHECK(hipMemcpyAsync(h_cands + (size_t)b * cap, d_cands + (size_t)b * cap, (size_t)n * sizeof(CandRec), hipMemcpyDeviceToHost,
+                                 c->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < B; ++b) {
+        const int n = h_counts[b];
+        auto& v = raw_sorted[b];
+        v.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const CandRec& q = h_cands[(size_t)b * cap + i];
+            long rect[4];
+            const long cl = q.c - bw / 2, ct = q.r - bh / 2;
+            fhog_to_image(cl, ct, m.cell, m.frows, m.fcols, &rect[0], &rect[1]);
+            fhog_to_image(cl + bw - 1, ct + bh - 1, m.cell, m.frows, m.fcols, &rect[2], &rect[3]);
+            for (int k = 0; k < q.level; ++k) rect_up6(rect);
+            for (int u = 0; u < upsample; ++u) rect_down2i(rect);
+            v[i] = RawDet{q.score, q.filter, q.level, q.r, q.c, (int32_t)rect[0], (int32_t)rect[1], (int32_t)rect[2], (int32_t)rect[3]};
+        }
+        std::sort(v.begin(), v.end(), raw_less);
+    }
+}
+
+static bool boxes_overlap(const RawDet& a, const RawDet& b, double iou, double covered)
+{
+    const long il = std::max(a.l, b.l), it = std::max(a.t, b.t), ir = std::min(a.rr, b.rr), ib = std::min(a.b, b.b);
+    if (il > ir || it > ib) return false;
+    const double inner = (double)(ir - il + 1) * (double)(ib - it + 1);
+    const long ol = std::min(a.l, b.l), ot = std::min(a.t, b.t), orr = std::max(a.rr, b.rr), ob = std::max(a.b, b.b);
+    const double outer = (double)(orr - ol + 1) * (double)(ob - ot + 1);
+    const double aa = (double)(a.rr - a.l + 1) * (double)(a.b - a.t + 1);
+    const double ab = (double)(b.rr - b.l + 1) * (double)(b.b - b.t + 1);
+    return inner / outer > iou || inner / aa > covered || inner / ab > covered;
+}
+
+void det_nms(const DetectorModel& m, const std::vector<RawDet>& sorted, std::vector<RawDet>& out)
+{
+    out.clear();
+    for (const RawDet& d : sorted) {
+        bool hit = false;
+        for (const RawDet& k : out) if (boxes_overlap(k, d, m.nms_iou, m.nms_covered)) { hit = true; break; }
+        if (!hit) out.push_back(d);
+    }
+}

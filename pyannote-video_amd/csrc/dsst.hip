@@ -1,0 +1,610 @@
+// dsst.hip -- K8: dlib.correlation_tracker (DSST) start_track / update, batched over trackers
+// (reference pyannote/video/tracking.py:250-251 start_track, :203 update -> PSR, :165,231 get_position).
+// Double precision like dlib; 64x64 2-D FFTs live in LDS (65-element row pitch), every sum keeps the order stated in
+// oracle/pvo_dsst.c, exp() is the shared deterministic polynomial -- so PSR and positions are bit-identical.
+#include "pvf_internal.h"
+#include <cmath>
+
+#define FS 64
+#define NPL 32
+#define NSC 32
+#define SWIN 23
+#define SDIM 512
+#define LP 65 // LDS row pitch (complex elements)
+
+static constexpr double REG_SPACE = 0.001, NU_SPACE = 0.025, REG_SCALE = 0.001, NU_SCALE = 0.025, ALPHA = 1.020;
+
+struct TrkJob {
+    double* state;
+    const uint8_t* img; int h, w;
+    double map[4];   // chip (x,y) -> image (map0 + x*map2, map1 + y*map3)
+    double cx, cy;   // start: object centre in chip coordinates
+};
+
+__device__ __forceinline__ double det_exp(double x)
+{
+    const double inv_ln2 = 1.4426950408889634074, ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    if (x < -700.0) return 0.0;
+    const double kf = floor(x * inv_ln2 + 0.5);
+    const double r = (x - kf * ln2_hi) - kf * ln2_lo;
+    const double c[14] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320,
+                          1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
+    double p = c[13];
+#pragma unroll
+    for (int i = 12; i >= 0; --i) p = p * r + c[i];
+    const long long k = (long long)kf;
+    const unsigned long long bits = (unsigned long long)(k + 1023) << 52;
+    return p * __longlong_as_double((long long)bits);
+}
+
+__device__ __forceinline__ int brev6(int v) { return (int)(__brev((unsigned)v) >> 26); }
+
+// in-place 2-D FFT of s[64][LP] (double2 = re,im); rows then columns; radix-2 DIT; blockDim.x = 256
+__device__ void fft2d_lds(double2* s, const double* __restrict__ tw, bool inverse)
+{
+    const int tid = threadIdx.x;
+    for (int pass = 0; pass < 2; ++pass) {
+        // bit reversal along the transformed axis
+        for (int idx = tid; idx < FS * FS; idx += 256) {
+            const int line = idx >> 6, e = idx & 63;
+            const int j = brev6(e);
+            if (j > e) {
+                const int p0 = pass == 0 ? line * LP + e : e * LP + line;
+                const int p1 = pass == 0 ? line * LP + j : j * LP + line;
+                const double2 t = s[p0]; s[p0] = s[p1]; s[p1] = t;
+            }
+        }
+        __syncthreads();
+        for (int st = 1; st <= 6; ++st) {
+            const int m = 1 << st, half = m >> 1, tstep = FS / m;
+            for (int idx = tid; idx < FS * 32; idx += 256) {
+                const int line = idx >> 5, b = idx & 31;
+                const int k = (b / half) * m, j = b % half;
+                const double wr = tw[2 * j * tstep];
+                const double wi = inverse ? tw[2 * j * tstep + 1] : -tw[2 * j * tstep + 1];
+                const int e0 = k + j, e1 = e0 + half;
+                const int p0 = pass == 0 ? line * LP + e0 : e0 * LP + line;
+                const int p1 = pass == 0 ? line * LP + e1 : e1 * LP + line;
+                const double2 a = s[p0], bb = s[p1];
+                const double tr = wr * bb.x - wi * bb.y;
+                const double ti = wr * bb.y + wi * bb.x;
+                s[p0] = make_double2(a.x + tr, a.y + ti);
+                s[p1] = make_double2(a.x - tr, a.y - ti);
+            }
+            __syncthreads();
+        }
+    }
+    if (inverse) {
+        const double sc = 1.0 / 64.0;
+        for (int idx = tid; idx < FS * FS; idx += 256) {
+            const int p = (idx >> 6) * LP + (idx & 63);
+            double2 v = s[p];
+            v.x = (v.x * sc) * sc; v.y = (v.y * sc) * sc;
+            s[p] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// sequential 32-point FFT on x[32] (double2), one thread
+__device__ void fft32_seq(double2* x, const double* __restrict__ tw, bool inverse)
+{
+    for (int i = 0; i < NSC; ++i) {
+        const int j = (int)(__brev((unsigned)i) >> 27);
+        if (j > i) { const double2 t = x[i]; x[i] = x[j]; x[j] = t; }
+    }
+    for (int st = 1; st <= 5; ++st) {
+        const int m = 1 << st, half = m >> 1, tstep = NSC / m;
+        for (int k = 0; k < NSC; k += m)
+            for (int j = 0; j < half; ++j) {
+                const double wr = tw[2 * j * tstep], wi = inverse ? tw[2 * j * tstep + 1] : -tw[2 * j * tstep + 1];
+                const double2 a = x[k + j], b = x[k + j + half];
+                const double tr = wr * b.x - wi * b.y;
+                const double ti = wr * b.y + wi * b.x;
+                x[k + j] = make_double2(a.x + tr, a.y + ti);
+                x[k + j + half] = make_double2(a.x - tr, a.y - ti);
+            }
+    }
+    if (inverse) {
+        const double sc = 1.0 / NSC;
+        for (int i = 0; i < NSC; ++i) { x[i].x *= sc; x[i].y *= sc; }
+    }
+}
+
+// ---- translation features: plane i of tracker b -> mask * value -> 2-D FFT -> F[b][i]
+__global__ void __launch_bounds__(256) trans_planes_fft_k(const uint8_t* __restrict__ chips, const float* __restrict__ feat,
+                                                          const double* __restrict__ mask64, const double* __restrict__ tw64,
+                                                          double2* __restrict__ F)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s[];
+    const int i = blockIdx.x, b = blockIdx.y;
+    const uint8_t* chip = chips + (size_t)b * FS * FS * 3;
+    const float* fb = feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE;
+    for (int q = threadIdx.x; q < FS * FS; q += 256) {
+        float v;
+        if (i < 31) v = fb[(size_t)q * PVF_FHOG_STRIDE + i];
+        else {
+            const uint8_t* p = chip + (size_t)q * 3;
+            v = (float)(((unsigned)p[0] + p[1] + p[2]) / 3) / 255.0f;
+        }
+        s[(q >> 6) * LP + (q & 63)] = make_double2((double)v * mask64[q], 0.0);
+    }
+    __syncthreads();
+    fft2d_lds(s, tw64, false);
+    double2* out = F + ((size_t)b * NPL + i) * FS * FS;
+    for (int q = threadIdx.x; q < FS * FS; q += 256) out[q] = s[(q >> 6) * LP + (q & 63)];
+}
+
+// target image exp(-dist/3) in a 21x21 window around (px,py), FFT, conj; result left in s
+__device__ void make_target_lds(double2* s, double px, double py, const double* __restrict__ tw64)
+{
+    for (int q = threadIdx.x; q < FS * FS; q += 256) s[(q >> 6) * LP + (q & 63)] = make_double2(0.0, 0.0);
+    __syncthreads();
+    const long cx = (long)floor(px + 0.5), cy = (long)floor(py + 0.5);
+    for (int q = threadIdx.x; q < 21 * 21; q += 256) {
+        const long r = cy - 10 + q / 21, c = cx - 10 + q % 21;
+        if (r < 0 || c < 0 || r > FS - 1 || c > FS - 1) continue;
+        const double dx = (double)c - px, dy = (double)r - py;
+        const double dist = sqrt(dx * dx + dy * dy);
+        s[r * LP + c] = make_double2(det_exp(-dist / 3.0), 0.0);
+    }
+    __syncthreads();
+    fft2d_lds(s, tw64, false);
+    for (int q = threadIdx.x; q < FS * FS; q += 256) { const int p = (q >> 6) * LP + (q & 63); s[p].y = -s[p].y; }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) target_fft_k(const TrkJob* __restrict__ jobs, const double* __restrict__ tw64, double2* __restrict__ Ghat)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s[];
+    const TrkJob j = jobs[blockIdx.x];
+    make_target_lds(s, j.cx, j.cy, tw64);
+    double2* out = Ghat + (size_t)blockIdx.x * FS * FS;
+    for (int q = threadIdx.x; q < FS * FS; q += 256) out[q] = s[(q >> 6) * LP + (q & 63)];
+}
+
+__global__ void __launch_bounds__(256) start_filters_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ F, const double2* __restrict__ Ghat)
+{
+    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    double* st = jobs[b].state;
+    double2* A = reinterpret_cast<double2*>(st + TRK_A);
+    const double2 g = Ghat[(size_t)b * FS * FS + q];
+    double bsum = 0;
+    for (int i = 0; i < NPL; ++i) {
+        const double2 f = F[((size_t)b * NPL + i) * FS * FS + q];
+        A[(size_t)i * FS * FS + q] = make_double2(g.x * f.x - g.y * f.y, g.x * f.y + g.y * f.x);
+        bsum = bsum + (f.x * f.x + f.y * f.y);
+    }
+    st[TRK_B + q] = bsum;
+}
+
+__global__ void __launch_bounds__(256) corr_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ F, double2* __restrict__ Gfreq)
+{
+    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    const double* st = jobs[b].state;
+    const double2* A = reinterpret_cast<const double2*>(st + TRK_A);
+    double gr = 0, gi = 0;
+    for (int i = 0; i < NPL; ++i) {
+        const double2 f = F[((size_t)b * NPL + i) * FS * FS + q];
+        const double2 a = A[(size_t)i * FS * FS + q];
+        gr = gr + (f.x * a.x + f.y * a.y);
+        gi = gi + (f.y * a.x - f.x * a.y);
+    }
+    const double rec = 1.0 / (st[TRK_B + q] + REG_SPACE);
+    Gfreq[(size_t)b * FS * FS + q] = make_double2(gr * rec, gi * rec);
+}
+
+// response -> peak, PSR, new position; then the new target's spectrum
+__global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ Gfreq, const double* __restrict__ tw64,
+                                              double* __restrict__ results /* [n][8] */, double2* __restrict__ Ghat)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s[];
+    __shared__ double red_v[256];
+    __shared__ int red_i[256];
+    __shared__ double row_s[FS], row_q[FS], row_c[FS];
+    __shared__ double pk[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const TrkJob j = jobs[b];
+    for (int q = tid; q < FS * FS; q += 256) s[(q >> 6) * LP + (q & 63)] = Gfreq[(size_t)b * FS * FS + q];
+    __syncthreads();
+    fft2d_lds(s, tw64, true);
+    // arg-max of the real part, first occurrence in row-major order
+    double bv = -INFINITY; int bi = 0x7fffffff;
+    for (int q = tid; q < FS * FS; q += 256) {
+        const double v = s[(q >> 6) * LP + (q & 63)].x;
+        if (v > bv) { bv = v; bi = q; }
+    }
+    red_v[tid] = bv; red_i[tid] = bi;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            const double ov = red_v[tid + off]; const int oi = red_i[tid + off];
+            if (ov > red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) { red_v[tid] = ov; red_i[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int py = red_i[0] >> 6, px = red_i[0] & 63;
+        double ox = px, oy = py;
+        if (!(px < 1 || py < 1 || px > FS - 2 || py > FS - 2)) {
+            double z[3][3];
+            for (int r = -1; r <= 1; ++r) for (int c = -1; c <= 1; ++c) z[r + 1][c + 1] = s[(py + r) * LP + (px + c)].x;
+            const double sx = ((z[0][2] + z[1][2]) + z[2][2]) - ((z[0][0] + z[1][0]) + z[2][0]);
+            const double sy = ((z[2][0] + z[2][1]) + z[2][2]) - ((z[0][0] + z[0][1]) + z[0][2]);
+            const double sxy = (z[0][0] + z[2][2]) - (z[0][2] + z[2][0]);
+            const double sxx = ((z[0][0] + z[1][0]) + z[2][0]) + ((z[0][2] + z[1][2]) + z[2][2]);
+            const double syy = ((z[0][0] + z[0][1]) + z[0][2]) + ((z[2][0] + z[2][1]) + z[2][2]);
+            const double sall = sxx + ((z[0][1] + z[1][1]) + z[2][1]);
+            const double k2 = sx / 6.0, k3 = sy / 6.0, k5 = sxy / 4.0;
+            const double k4 = sxx / 2.0 - sall / 3.0, k6 = syy / 2.0 - sall / 3.0;
+            const double h00 = 2 * k4, h01 = k5, h11 = 2 * k6;
+            const double det = h00 * h11 - h01 * h01;
+            if (det != 0) {
+                double dx = -((h11 * k2 - h01 * k3) / det);
+                double dy = -((h00 * k3 - h01 * k2) / det);
+                if (!(dx * k2 + dy * k3 < 0)) {
+                    if (dx < -1) dx = -1;
+                    if (dx > 1) dx = 1;
+                    if (dy < -1) dy = -1;
+                    if (dy > 1) dy = 1;
+                    ox = px + dx; oy = py + dy;
+                }
+            }
+        }
+        pk[0] = ox; pk[1] = oy;
+    }
+    __syncthreads();
+    const double ppx = pk[0], ppy = pk[1];
+    const long rx = (long)floor(ppx + 0.5), ry = (long)floor(ppy + 0.5);
+    if (tid < FS) {
+        const int r = tid;
+        double rs = 0, rq = 0, cnt = 0;
+        for (int c = 0; c < FS; ++c) {
+            if (c >= rx - 4 && c <= rx + 3 && r >= ry - 4 && r <= ry + 3) continue;
+            const double v = s[r * LP + c].x;
+            rs = rs + v;
+            rq = rq + v * v;
+            cnt += 1;
+        }
+        row_s[r] = rs; row_q[r] = rq; row_c[r] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sum = 0, sumsq = 0, cnt = 0;
+        for (int r = 0; r < FS; ++r) { sum = sum + row_s[r]; sumsq = sumsq + row_q[r]; cnt += row_c[r]; }
+        const double mean = sum / cnt;
+        double var = (1.0 / (cnt - 1)) * (sumsq - sum * sum / cnt);
+        if (!(var >= 0)) var = 0;
+        long qx = rx, qy = ry;
+        if (qx < 0) qx = 0;
+        if (qy < 0) qy = 0;
+        if (qx > FS - 1) qx = FS - 1;
+        if (qy > FS - 1) qy = FS - 1;
+        const double psr = (s[qy * LP + qx].x - mean) / sqrt(var);
+        double* st = j.state;
+        const double g0 = st[TRK_POS], g1 = st[TRK_POS + 1], g2 = st[TRK_POS + 2], g3 = st[TRK_POS + 3];
+        const double ix = j.map[0] + ppx * j.map[2], iy = j.map[1] + ppy * j.map[3];
+        const double vx = ix - (g0 + g2) / 2, vy = iy - (g1 + g3) / 2;
+        st[TRK_POS] = g0 + vx; st[TRK_POS + 1] = g1 + vy; st[TRK_POS + 2] = g2 + vx; st[TRK_POS + 3] = g3 + vy;
+        results[(size_t)b * 8] = psr;
+        results[(size_t)b * 8 + 5] = ppx; results[(size_t)b * 8 + 6] = ppy;
+    }
+    __syncthreads();
+    make_target_lds(s, ppx, ppy, tw64);
+    double2* out = Ghat + (size_t)b * FS * FS;
+    for (int q = tid; q < FS * FS; q += 256) out[q] = s[(q >> 6) * LP + (q & 63)];
+}
+
+__global__ void __launch_bounds__(256) filter_update_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ F, const double2* __restrict__ Ghat)
+{
+    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    double* st = jobs[b].state;
+    double2* A = reinterpret_cast<double2*>(st + TRK_A);
+    const double2 g = Ghat[(size_t)b * FS * FS + q];
+    double bq = st[TRK_B + q] * (1 - NU_SPACE);
+    for (int i = 0; i < NPL; ++i) {
+        const double2 f = F[((size_t)b * NPL + i) * FS * FS + q];
+        const double2 a = A[(size_t)i * FS * FS + q];
+        const double nr = g.x * f.x - g.y * f.y;
+        const double ni = g.x * f.y + g.y * f.x;
+        A[(size_t)i * FS * FS + q] = make_double2(NU_SPACE * nr + (1 - NU_SPACE) * a.x, NU_SPACE * ni + (1 - NU_SPACE) * a.y);
+        bq = bq + NU_SPACE * (f.x * f.x + f.y * f.y);
+    }
+    st[TRK_B + q] = bq;
+}
+
+__device__ __forceinline__ void scale_rect_d(double r[4], double s)
+{
+    const double cx = (r[0] + r[2]) / 2, cy = (r[1] + r[3]) / 2;
+    const double w = (r[2] - r[0]) * s, h = (r[3] - r[1]) * s;
+    r[0] = cx - w / 2; r[1] = cy - h / 2; r[2] = cx + w / 2; r[3] = cy + h / 2;
+}
+
+// 32 scale chips (23x23) around the tracker's current position, sampled straight from the frame
+__global__ void __launch_bounds__(256) scale_chips_k(const TrkJob* __restrict__ jobs, double alpha_pow_m16, uint8_t* __restrict__ chips)
+{
+    const int k = blockIdx.x, b = blockIdx.y;
+    const TrkJob j = jobs[b];
+    double ppp[4] = {j.state[TRK_POS], j.state[TRK_POS + 1], j.state[TRK_POS + 2], j.state[TRK_POS + 3]};
+    scale_rect_d(ppp, alpha_pow_m16);
+    for (int i = 0; i < k; ++i) scale_rect_d(ppp, ALPHA);
+    const double m0 = (ppp[2] - ppp[0]) / (double)(SWIN - 1), m3 = (ppp[3] - ppp[1]) / (double)(SWIN - 1);
+    uint8_t* out = chips + ((size_t)b * NSC + k) * SWIN * SWIN * 3;
+    for (int q = threadIdx.x; q < SWIN * SWIN; q += 256) {
+        const int r = q / SWIN, c = q % SWIN;
+        const double px = m0 * c + 0.0 * r + ppp[0];
+        const double py = 0.0 * c + m3 * r + ppp[1];
+        const double fx = floor(px), fy = floor(py);
+        uint8_t* o = out + (size_t)q * 3;
+        if (!(fx >= 0 && fy >= 0 && fx + 1 < j.w && fy + 1 < j.h)) { o[0] = 0; o[1] = 0; o[2] = 0; continue; }
+        const int left = (int)fx, top = (int)fy;
+        const double lr = px - left, tb = py - top;
+        const uint8_t* ptl = j.img + ((size_t)top * j.w + left) * 3;
+        const uint8_t* pbl = ptl + (size_t)j.w * 3;
+        for (int ch = 0; ch < 3; ++ch) {
+            const double tl = ptl[ch], tr = ptl[3 + ch], bl = pbl[ch], br = pbl[3 + ch];
+            const double v = (1 - tb) * ((1 - lr) * tl + lr * tr) + tb * ((1 - lr) * bl + lr * br);
+            o[ch] = (uint8_t)v;
+        }
+    }
+}
+
+// Fs[idx][k] = feature(idx) of scale chip k * mask_scale[k]; FFT over k; one thread per idx
+__global__ void __launch_bounds__(128) scale_fft_k(const uint8_t* __restrict__ chips, const float* __restrict__ feat,
+                                                   const double* __restrict__ mask_scale, const double* __restrict__ tw32,
+                                                   double2* __restrict__ Fs)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s[]; // [128][33]
+    const int b = blockIdx.y, idx = blockIdx.x * 128 + threadIdx.x;
+    const int cell = idx >> 5, jp = idx & 31, r = cell >> 2, c = cell & 3;
+    double2* x = s + (size_t)threadIdx.x * 33;
+    for (int k = 0; k < NSC; ++k) {
+        float v;
+        if (jp < 31) v = feat[(((size_t)b * NSC + k) * 16 + cell) * PVF_FHOG_STRIDE + jp];
+        else {
+            const uint8_t* q = chips + (((size_t)b * NSC + k) * SWIN * SWIN + (size_t)r * SWIN + c) * 3;
+            v = (float)(((unsigned)q[0] + q[1] + q[2]) / 3) / 255.0f;
+        }
+        x[k] = make_double2((double)v * mask_scale[k], 0.0);
+    }
+    fft32_seq(x, tw32, false);
+    double2* out = Fs + ((size_t)b * SDIM + idx) * NSC;
+    for (int k = 0; k < NSC; ++k) out[k] = x[k];
+}
+
+__device__ void scale_target_seq(double2* g, double pos, const double* __restrict__ tw32)
+{
+    for (int i = 0; i < NSC; ++i) {
+        const double dist = fabs((double)i - pos);
+        g[i] = make_double2(det_exp(-dist / 1.000), 0.0);
+    }
+    fft32_seq(g, tw32, false);
+    for (int i = 0; i < NSC; ++i) g[i].y = -g[i].y;
+}
+
+__global__ void __launch_bounds__(256) scale_start_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ Fs, const double* __restrict__ tw32)
+{
+    __shared__ double2 Gs[NSC];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double* st = jobs[b].state;
+    double2* As = reinterpret_cast<double2*>(st + TRK_AS);
+    if (tid == 0) scale_target_seq(Gs, NSC / 2, tw32);
+    __syncthreads();
+    for (int e = tid; e < SDIM * NSC; e += 256) {
+        const int k = e & 31;
+        const double2 f = Fs[(size_t)b * SDIM * NSC + e];
+        As[e] = make_double2(Gs[k].x * f.x - Gs[k].y * f.y, Gs[k].x * f.y + Gs[k].y * f.x);
+    }
+    if (tid < NSC) {
+        double bsum = 0;
+        for (int i = 0; i < SDIM; ++i) {
+            const double2 f = Fs[((size_t)b * SDIM + i) * NSC + tid];
+            bsum = bsum + (f.x * f.x + f.y * f.y);
+        }
+        st[TRK_BS + tid] = bsum;
+    }
+}
+
+__global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ Fs, const double* __restrict__ tw32,
+                                                      double ln_alpha, double* __restrict__ results)
+{
+    __shared__ double2 Gs[NSC];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double* st = jobs[b].state;
+    double2* As = reinterpret_cast<double2*>(st + TRK_AS);
+    if (tid < NSC) {
+        double gr = 0, gi = 0;
+        for (int i = 0; i < SDIM; ++i) {
+            const double2 f = Fs[((size_t)b * SDIM + i) * NSC + tid];
+            const double2 a = As[(size_t)i * NSC + tid];
+            gr = gr + (f.x * a.x + f.y * a.y);
+            gi = gi + (f.y * a.x - f.x * a.y);
+        }
+        const double rec = 1.0 / (st[TRK_BS + tid] + REG_SCALE);
+        Gs[tid] = make_double2(gr * rec, gi * rec);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        fft32_seq(Gs, tw32, true);
+        int bk = 0;
+        for (int k = 1; k < NSC; ++k) if (Gs[k].x > Gs[bk].x) bk = k;
+        double pos = bk;
+        if (bk > 0 && bk + 1 < NSC) {
+            const double p1 = bk - 1, p2 = bk, p3 = bk + 1, f1 = -Gs[bk - 1].x, f2 = -Gs[bk].x, f3 = -Gs[bk + 1].x;
+            const double d1 = p2 * p2 - p3 * p3, d2 = p3 * p3 - p1 * p1, d3 = p1 * p1 - p2 * p2;
+            const double t1 = (d1 * f1 + d2 * f2) + d3 * f3;
+            const double d4 = p2 - p3, d5 = p3 - p1, d6 = p1 - p2;
+            const double t2 = 2 * ((d4 * f1 + d5 * f2) + d6 * f3);
+            if (t1 != 0 && t2 != 0) {
+                pos = t1 / t2;
+                if (pos < p1) pos = p1;
+                if (pos > p3) pos = p3;
+            }
+        }
+        double r[4] = {st[TRK_POS], st[TRK_POS + 1], st[TRK_POS + 2], st[TRK_POS + 3]};
+        scale_rect_d(r, det_exp((pos - (double)NSC / 2) * ln_alpha));
+        st[TRK_POS] = r[0]; st[TRK_POS + 1] = r[1]; st[TRK_POS + 2] = r[2]; st[TRK_POS + 3] = r[3];
+        results[(size_t)b * 8 + 1] = r[0]; results[(size_t)b * 8 + 2] = r[1]; results[(size_t)b * 8 + 3] = r[2]; results[(size_t)b * 8 + 4] = r[3];
+        results[(size_t)b * 8 + 7] = pos;
+        scale_target_seq(Gs, pos, tw32);
+    }
+    __syncthreads();
+    for (int e = tid; e < SDIM * NSC; e += 256) {
+        const int k = e & 31;
+        const double2 f = Fs[(size_t)b * SDIM * NSC + e];
+        const double2 a = As[e];
+        const double nr = Gs[k].x * f.x - Gs[k].y * f.y;
+        const double ni = Gs[k].x * f.y + Gs[k].y * f.x;
+        As[e] = make_double2(NU_SCALE * nr + (1 - NU_SCALE) * a.x, NU_SCALE * ni + (1 - NU_SCALE) * a.y);
+    }
+    if (tid < NSC) {
+        double bq = st[TRK_BS + tid] * (1 - NU_SCALE);
+        for (int i = 0; i < SDIM; ++i) {
+            const double2 f = Fs[((size_t)b * SDIM + i) * NSC + tid];
+            bq = bq + NU_SCALE * (f.x * f.x + f.y * f.y);
+        }
+        st[TRK_BS + tid] = bq;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+static void scale_rect_h(double r[4], double s)
+{
+    const double cx = (r[0] + r[2]) / 2, cy = (r[1] + r[3]) / 2;
+    const double w = (r[2] - r[0]) * s, h = (r[3] - r[1]) * s;
+    r[0] = cx - w / 2; r[1] = cy - h / 2; r[2] = cx + w / 2; r[3] = cy + h / 2;
+}
+
+struct DsstBuffers { uint8_t* chips64; uint8_t* chips_sc; float* feat; double2* F; double2* G0; double2* G1; double2* Fs; double* results; TrkJob* jobs; };
+
+static DsstBuffers prepare(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes,
+                           std::vector<TrkJob>& jobs, std::vector<ChipJob>& cj)
+{
+    const int n = (int)t.size();
+    PVF_REQUIRE(c->ttab.set, "tracker tables not set (pvf_set_tracker_tables)");
+    jobs.resize(n); cj.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const double* p = boxes ? boxes + 4 * i : t[i]->pos;
+        double r[4] = {p[0], p[1], p[2], p[3]};
+        scale_rect_h(r, 1.4);
+        ChipDetails d{r[0], r[1], r[2], r[3], 1.0, 0.0, FS, FS};
+        cj[i] = chip_plan(f[i], d);
+        TrkJob& j = jobs[i];
+        j.state = t[i]->d_state; j.img = f[i].d; j.h = f[i].h; j.w = f[i].w;
+        j.map[0] = r[0]; j.map[1] = r[1];
+        j.map[2] = (r[2] - r[0]) / (double)(FS - 1);
+        j.map[3] = (r[3] - r[1]) / (double)(FS - 1);
+        j.cx = ((p[0] + p[2]) / 2 - j.map[0]) / j.map[2];
+        j.cy = ((p[1] + p[3]) / 2 - j.map[1]) / j.map[3];
+    }
+    DsstBuffers b;
+    const size_t chips64 = (size_t)n * FS * FS * 3, chips_sc = (size_t)n * NSC * SWIN * SWIN * 3;
+    c->s_trk0.ensure(chips64 + chips_sc + 256);
+    b.chips64 = c->s_trk0.as<uint8_t>();
+    b.chips_sc = b.chips64 + (chips64 + 63) / 64 * 64;
+    c->s_feat.ensure((size_t)n * FS * FS * PVF_FHOG_STRIDE * sizeof(float));
+    b.feat = c->s_feat.as<float>();
+    c->s_trk1.ensure((size_t)n * NPL * FS * FS * sizeof(double2));
+    b.F = c->s_trk1.as<double2>();
+    const size_t g = (size_t)n * FS * FS * sizeof(double2), fs = (size_t)n * SDIM * NSC * sizeof(double2);
+    c->s_trk2.ensure(2 * g + fs + (size_t)n * 8 * sizeof(double) + (size_t)n * sizeof(TrkJob) + 256);
+    uint8_t* q = c->s_trk2.as<uint8_t>();
+    b.G0 = reinterpret_cast<double2*>(q); q += g;
+    b.G1 = reinterpret_cast<double2*>(q); q += g;
+    b.Fs = reinterpret_cast<double2*>(q); q += fs;
+    b.results = reinterpret_cast<double*>(q); q += (size_t)n * 8 * sizeof(double);
+    b.jobs = reinterpret_cast<TrkJob*>(q);
+    HIP_CHECK(hipMemcpyAsync(b.jobs, jobs.data(), (size_t)n * sizeof(TrkJob), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    return b;
+}
+
+static const size_t LDS_FFT = (size_t)FS * LP * sizeof(double2);
+
+static void translation_features(Ctx* c, const DsstBuffers& b, const std::vector<ChipJob>& cj, int n)
+{
+    chip_extract_batch(c, cj, b.chips64);
+    ProfScope ps(c, "dsst");
+    fhog_device(c, b.chips64, n, FS, FS, 1, 3, 3, b.feat, c->s_hist, c->s_norm);
+    hipLaunchKernelGGL(trans_planes_fft_k, dim3(NPL, n), dim3(256), LDS_FFT, c->stream, b.chips64, b.feat, c->ttab.d_mask64, c->ttab.d_tw64, b.F);
+}
+
+static void scale_features(Ctx* c, const DsstBuffers& b, int n)
+{
+    ProfScope ps(c, "dsst");
+    hipLaunchKernelGGL(scale_chips_k, dim3(NSC, n), dim3(256), 0, c->stream, b.jobs, c->ttab.alpha_pow_m16, b.chips_sc);
+    float* feat = b.feat; // reuse: n*32 images of 4x4x32 floats
+    fhog_device(c, b.chips_sc, n * NSC, SWIN, SWIN, 4, 1, 1, feat, c->s_hist, c->s_norm);
+    hipLaunchKernelGGL(scale_fft_k, dim3(SDIM / 128, n), dim3(128), (size_t)128 * 33 * sizeof(double2), c->stream, b.chips_sc, feat,
+                       c->ttab.d_mask_scale, c->ttab.d_tw32, b.Fs);
+}
+
+static void ensure_fft_lds()
+{
+    static bool done = false;
+    if (done) return;
+    HIP_CHECK(hipFuncSetAttribute((const void*)trans_planes_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
+    HIP_CHECK(hipFuncSetAttribute((const void*)target_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
+    HIP_CHECK(hipFuncSetAttribute((const void*)peak_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
+    HIP_CHECK(hipFuncSetAttribute((const void*)scale_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 33 * sizeof(double2))));
+    done = true;
+}
+
+void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes)
+{
+    const int n = (int)t.size();
+    if (n == 0) return;
+    ensure_fft_lds();
+    for (int i = 0; i < n; ++i) {
+        memcpy(t[i]->pos, boxes + 4 * i, 4 * sizeof(double));
+        HIP_CHECK(hipMemcpyAsync(t[i]->d_state + TRK_POS, boxes + 4 * i, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        t[i]->started = true;
+    }
+    std::vector<TrkJob> jobs; std::vector<ChipJob> cj;
+    DsstBuffers b = prepare(c, t, f, boxes, jobs, cj);
+    translation_features(c, b, cj, n);
+    {
+        ProfScope ps(c, "dsst");
+        hipLaunchKernelGGL(target_fft_k, dim3(n), dim3(256), LDS_FFT, c->stream, b.jobs, c->ttab.d_tw64, b.G0);
+        hipLaunchKernelGGL(start_filters_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G0);
+    }
+    scale_features(c, b, n);
+    {
+        ProfScope ps(c, "dsst");
+        hipLaunchKernelGGL(scale_start_k, dim3(n), dim3(256), 0, c->stream, b.jobs, b.Fs, c->ttab.d_tw32);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, double* psr, double* boxes_out)
+{
+    const int n = (int)t.size();
+    if (n == 0) return;
+    ensure_fft_lds();
+    for (int i = 0; i < n; ++i) PVF_REQUIRE(t[i]->started, "tracker.update before start_track");
+    std::vector<TrkJob> jobs; std::vector<ChipJob> cj;
+    DsstBuffers b = prepare(c, t, f, nullptr, jobs, cj);
+    translation_features(c, b, cj, n);
+    {
+        ProfScope ps(c, "dsst");
+        hipLaunchKernelGGL(corr_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G0);
+        hipLaunchKernelGGL(peak_k, dim3(n), dim3(256), LDS_FFT, c->stream, b.jobs, b.G0, c->ttab.d_tw64, b.results, b.G1);
+        hipLaunchKernelGGL(filter_update_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G1);
+    }
+    scale_features(c, b, n);
+    {
+        ProfScope ps(c, "dsst");
+        hipLaunchKernelGGL(scale_update_k, dim3(n), dim3(256), 0, c->stream, b.jobs, b.Fs, c->ttab.d_tw32, c->ttab.ln_alpha, b.results);
+    }
+    HIP_CHECK(hipGetLastError());
+    c->h_misc.ensure((size_t)n * 8 * sizeof(double));
+    double* hr = c->h_misc.as<double>();
+    HIP_CHECK(hipMemcpyAsync(hr, b.results, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) {
+        psr[i] = hr[8 * i];
+        for (int k = 0; k < 4; ++k) t[i]->pos[k] = hr[8 * i + 1 + k];
+        if (boxes_out) memcpy(boxes_out + 4 * i, t[i]->pos, 4 * sizeof(double));
+    }
+}

@@ -1,0 +1,238 @@
+// pvf_internal.h -- shared declarations of libpvface.so (gfx950 only; no CPU fallback, no oracle code).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/pvface.h"
+
+#define PVF_FHOG_STRIDE 32
+
+struct PvfError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+#define HIP_CHECK(expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) {                                                                      \
+            char _b[512];                                                                            \
+            snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            throw PvfError(_b);                                                                      \
+        }                                                                                            \
+    } while (0)
+
+#define PVF_REQUIRE(cond, msg)                     \
+    do {                                           \
+        if (!(cond)) throw PvfError(std::string(msg)); \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) HIP_CHECK(hipFree(p));
+        p = nullptr; cap = 0;
+        size_t want = n + n / 8 + 256;
+        HIP_CHECK(hipMalloc(&p, want));
+        cap = want;
+    }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+// pinned host buffer
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) HIP_CHECK(hipHostFree(p));
+        p = nullptr; cap = 0;
+        HIP_CHECK(hipHostMalloc(&p, n + 256, hipHostMallocDefault));
+        cap = n + 256;
+    }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+    ~HostBuf() { if (p) (void)hipHostFree(p); }
+};
+
+struct Tensor {
+    std::string name;
+    int dtype = 0; // 0 f32, 1 i32, 2 f64, 3 u8
+    std::vector<int64_t> dims;
+    std::vector<uint8_t> data;
+    size_t numel() const { size_t n = 1; for (auto d : dims) n *= (size_t)d; return n; }
+    const float* f32() const { return reinterpret_cast<const float*>(data.data()); }
+    const int32_t* i32() const { return reinterpret_cast<const int32_t*>(data.data()); }
+    const double* f64() const { return reinterpret_cast<const double*>(data.data()); }
+};
+std::map<std::string, Tensor> pvf_read_container(const char* path);
+
+struct Frame {
+    const uint8_t* d = nullptr; // device, HWC RGB contiguous
+    int h = 0, w = 0;
+    bool owned = false;
+};
+
+struct ProfFamily {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double total_ms = 0;
+    int64_t launches = 0;
+};
+
+struct DetectorModel {
+    bool loaded = false;
+    int n_filters = 0, frows = 0, fcols = 0, cell = 0, padding = 0, win_w = 0, win_h = 0, min_w = 0, min_h = 0, max_levels = 0;
+    double nms_iou = 0, nms_covered = 0;
+    std::vector<float> thresh;
+    float* d_w = nullptr;    // [nf][frows][fcols][32]
+    float* d_wt = nullptr;   // [frows][fcols][32][8] filter-minor copy for the scoring kernel
+};
+
+struct ShapeModel {
+    bool loaded = false;
+    int n_cascades = 0, n_trees = 0, n_parts = 0, n_pix = 0, depth = 0;
+    float* d_initial = nullptr;
+    int32_t* d_anchor = nullptr;
+    float* d_deltas = nullptr;
+    int32_t* d_idx1 = nullptr;
+    int32_t* d_idx2 = nullptr;
+    float* d_thresh = nullptr;
+    float* d_leaves = nullptr;
+};
+
+struct ConvLayer {
+    int cin, cout, k, stride, pad;
+    float* d_w;     // [k*k*cin][cout]  (k index = (r*k+s)*cin + c)
+    float* d_bias;  // [cout]
+    float* d_gamma; // [cout]
+    float* d_beta;  // [cout]
+};
+
+struct EmbedModel {
+    bool loaded = false;
+    int chip_size = 150;
+    double chip_padding = 0.25;
+    std::vector<float> mean_shape; // 51*2
+    std::vector<ConvLayer> convs;  // 29
+    float* d_fc = nullptr;         // [256][128]
+    float* d_blob = nullptr;
+};
+
+struct TrackerTables {
+    bool set = false;
+    double* d_mask64 = nullptr;
+    double* d_mask_scale = nullptr;
+    double* d_tw64 = nullptr;
+    double* d_tw32 = nullptr;
+    double alpha_pow_m16 = 0, ln_alpha = 0;
+};
+
+struct Tracker {
+    double* d_state = nullptr; // A[32*64*64*2] B[64*64] As[512*32*2] Bs[32] pos[4]
+    double pos[4] = {0, 0, 0, 0};
+    bool started = false;
+};
+constexpr size_t TRK_A = 0;
+constexpr size_t TRK_B = TRK_A + (size_t)32 * 64 * 64 * 2;
+constexpr size_t TRK_AS = TRK_B + (size_t)64 * 64;
+constexpr size_t TRK_BS = TRK_AS + (size_t)512 * 32 * 2;
+constexpr size_t TRK_POS = TRK_BS + 32;
+constexpr size_t TRK_DOUBLES = TRK_POS + 4;
+
+// chip extraction plan (host geometry -> device pyramid + bilinear), see chip.hip
+struct ChipJob {
+    // source frame
+    const uint8_t* img; int h, w;
+    // bounding box of the needed sub image (inclusive), and number of pyramid_down<2> levels to build (0 = sample the frame)
+    int bx0, by0, sw, sh, levels;
+    // affine chip -> level image
+    double m[4], b[2];
+    int rows, cols;
+    bool empty;
+};
+struct ChipDetails { double l, t, r, b, cs, sn; int rows, cols; };
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DetectorModel det;
+    ShapeModel shape;
+    EmbedModel emb;
+    TrackerTables ttab;
+    std::unordered_map<uint64_t, Frame> frames;
+    std::unordered_map<uint64_t, std::unique_ptr<Tracker>> trackers;
+    std::vector<double*> tracker_pool; // freed tracker states for reuse
+    uint64_t next_id = 1;
+    bool prof_on = false;
+    std::map<std::string, ProfFamily> prof;
+    std::vector<hipEvent_t> event_pool;
+    // scratch (grow only)
+    DevBuf s_pyr, s_hist, s_norm, s_feat, s_cand, s_misc, s_chip, s_chip_pyr, s_act0, s_act1, s_act2, s_trk0, s_trk1, s_trk2, s_clu0, s_clu1;
+    HostBuf h_cand, h_misc;
+    int n_cu = 256;
+
+    Frame& frame(uint64_t id)
+    {
+        auto it = frames.find(id);
+        if (it == frames.end()) throw PvfError("unknown frame handle");
+        return it->second;
+    }
+    Tracker& tracker(uint64_t id)
+    {
+        auto it = trackers.find(id);
+        if (it == trackers.end()) throw PvfError("unknown tracker handle");
+        return *it->second;
+    }
+};
+
+struct ProfScope {
+    Ctx* c; ProfFamily* f = nullptr; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(Ctx* ctx, const char* family);
+    ~ProfScope();
+};
+
+Ctx* pvf_ctx(pvf_handle h);
+void pvf_set_error(const char* msg);
+
+// ---- subsystem entry points (C++ side; the extern "C" wrappers live in api.hip) ----
+// detector (detect.hip)
+struct RawDet { float score; int32_t filter, level, r, c, l, t, rr, b; };
+void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, double adjust,
+                   std::vector<std::vector<RawDet>>& raw_sorted);
+void det_nms(const DetectorModel& m, const std::vector<RawDet>& sorted, std::vector<RawDet>& out);
+void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* h, int* w);
+void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, int pad_c, std::vector<float>& out, int* fh, int* fw);
+// device fhog used by dsst.hip too: img u8 [n][h][w][3] -> feat [n][fh][fw][32]
+void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat,
+                 DevBuf& hist, DevBuf& norm);
+void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw);
+// chips (chip.hip)
+ChipJob chip_plan(const Frame& f, const ChipDetails& d);
+void chip_extract_batch(Ctx* c, const std::vector<ChipJob>& jobs, uint8_t* d_out /* n*rows*cols*3, same dims */);
+void transform_batch(Ctx* c, const std::vector<ChipJob>& jobs, uint8_t* d_out);
+// landmarks (ert.hip)
+void ert_run(Ctx* c, const std::vector<Frame>& frames, const pvf_rect_i32* boxes, int n, int32_t* pts);
+// embedding (resnet.hip)
+void face_chip_details(const EmbedModel& m, const int32_t* pts68, ChipDetails* out);
+void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out);
+// tracker (dsst.hip)
+void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes);
+void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, double* psr, double* boxes_out);
+// association (assoc.cpp part of api)
+void overlap_matrix_host(const double* a, int na, const double* b, int nb, double ratio, double* out);
+void munkres_host(const double* cost, int n, int32_t* row_to_col);
+// clustering (cluster.hip)
+void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* row_start, int T, double* h_D, double** d_D_keep);
+int hac_dev(Ctx* c, double* d_D, const int32_t* row_start, int T, double threshold, int32_t* labels, double* merge_log);

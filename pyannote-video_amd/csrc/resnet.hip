@@ -1,0 +1,305 @@
+// resnet.hip -- K7: the 29-conv ResNet of dlib's face_recognition_model_v1 (reference pyannote/video/face/face.py:62,74-76)
+// as NHWC implicit-GEMM convolutions on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 157 TF peak),
+// with bias + affine + residual add (incl. dlib's zero-extending add_prev and the 2x2 avg-pool skip) + ReLU fused
+// into the epilogue.  Batch = all faces of many frames.
+#include "pvf_internal.h"
+#include <cmath>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+// chip alignment geometry (host; a few doubles per face).  [EXT get_face_chip_details + chip_details]
+void face_chip_details(const EmbedModel& m, const int32_t* pts, ChipDetails* out)
+{
+    const double size = m.chip_size, padding = m.chip_padding;
+    double fx[51], fy[51], tx[51], ty[51];
+    int n = 0;
+    for (int i = 17; i < 68; ++i) {
+        if ((55 <= i && i <= 59) || (65 <= i && i <= 67)) continue;
+        if (17 <= i && i <= 26) continue;
+        fx[n] = ((padding + (double)m.mean_shape[2 * (i - 17)]) / (2 * padding + 1)) * size;
+        fy[n] = ((padding + (double)m.mean_shape[2 * (i - 17) + 1]) / (2 * padding + 1)) * size;
+        tx[n] = pts[2 * i]; ty[n] = pts[2 * i + 1];
+        ++n;
+    }
+    double mfx = 0, mfy = 0, mtx = 0, mty = 0;
+    for (int i = 0; i < n; ++i) { mfx += fx[i]; mfy += fy[i]; mtx += tx[i]; mty += ty[i]; }
+    mfx /= n; mfy /= n; mtx /= n; mty /= n;
+    double a = 0, b = 0, s = 0;
+    for (int i = 0; i < n; ++i) {
+        const double ax = fx[i] - mfx, ay = fy[i] - mfy, bx = tx[i] - mtx, by = ty[i] - mty;
+        a += ax * bx + ay * by;
+        b += ax * by - ay * bx;
+        s += ax * ax + ay * ay;
+    }
+    const double ca = a / s, cb = b / s;
+    const double scale = std::sqrt(ca * ca + cb * cb);
+    const double hx = size / 2.0, hy = size / 2.0;
+    const double cx = (ca * (hx - mfx) - cb * (hy - mfy)) + mtx;
+    const double cy = (cb * (hx - mfx) + ca * (hy - mfy)) + mty;
+    const double wv = size * scale;
+    out->l = cx - wv / 2; out->t = cy - wv / 2; out->r = cx + wv / 2; out->b = cy + wv / 2;
+    out->cs = ca / scale; out->sn = cb / scale;
+    out->rows = m.chip_size; out->cols = m.chip_size;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) prep_input_k(const uint8_t* __restrict__ chips, float* __restrict__ out, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % 3);
+    const float avg = c == 0 ? 122.782f : (c == 1 ? 117.001f : 104.298f);
+    out[i] = ((float)chips[i] - avg) / 256.0f;
+}
+
+struct ConvArgs {
+    const float* in; int B, H, W, Cin;
+    const float* w; int K;             // K = ksz*ksz*Cin (logical), weights [K][Cout]
+    const float* bias; const float* gamma; const float* beta;
+    float* out; int OH, OW, Cout;      // output tensor dims
+    int AH, AW;                        // conv-valid dims (<= OH, OW)
+    int ksz, stride, pad;
+    int relu;
+    int skip_mode;                     // 0 none, 1 identity [B][OH][OW][Cout], 2 avg-pool 2x2 s2 of x [B][XH][XW][XC]
+    const float* skip; int XH, XW, XC, SH, SW;
+};
+
+// BM = 32*WM output pixels, BN = 32*WN output channels, KC = 32 per stage
+template <int WM, int WN, bool GENERIC>
+__global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
+{
+    constexpr int BM = 32 * WM, BN = 32 * WN, KC = 32;
+    constexpr int PA = BM + 2, PB = BN + 2;
+    __shared__ float As[KC * PA];
+    __shared__ float Bs[KC * PB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long M = (long)a.B * a.OH * a.OW;
+    const long m0 = (long)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+    // staging roles. fast path: thread loads float4s of A: (pixel i, 4 channels); BM*KC/4 float4 per stage
+    constexpr int A_F4 = BM * KC / 4 / 256; // float4 per thread (2 for BM=64, 4 for BM=128)
+    constexpr int B_F4 = KC * BN / 4 / 256;
+    int pa_b[A_F4], pa_y[A_F4], pa_x[A_F4], pa_i[A_F4], pa_j[A_F4];
+    bool pa_ok[A_F4];
+    if (!GENERIC) {
+#pragma unroll
+        for (int q = 0; q < A_F4; ++q) {
+            const int idx = tid + q * 256;     // over BM * 8
+            const int i = idx >> 3, j = idx & 7;
+            const long m = m0 + i;
+            pa_i[q] = i; pa_j[q] = j;
+            pa_ok[q] = false; pa_b[q] = 0; pa_y[q] = 0; pa_x[q] = 0;
+            if (m < M) {
+                const int ox = (int)(m % a.OW);
+                const long t = m / a.OW;
+                const int oy = (int)(t % a.OH);
+                pa_b[q] = (int)(t / a.OH);
+                pa_ok[q] = (oy < a.AH && ox < a.AW);
+                pa_y[q] = oy * a.stride - a.pad; pa_x[q] = ox * a.stride - a.pad;
+            }
+        }
+    }
+    const int Kpad = (a.K + KC - 1) / KC * KC;
+    for (int k0 = 0; k0 < Kpad; k0 += KC) {
+        // ---- stage A
+        if (!GENERIC) {
+            const int tap = k0 / a.Cin, c0 = k0 % a.Cin;
+            const int r = tap / a.ksz, s = tap % a.ksz;
+#pragma unroll
+            for (int q = 0; q < A_F4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int iy = pa_y[q] + r, ix = pa_x[q] + s;
+                if (pa_ok[q] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                    v = *reinterpret_cast<const float4*>(a.in + (((size_t)pa_b[q] * a.H + iy) * a.W + ix) * a.Cin + c0 + 4 * pa_j[q]);
+                const int kk = 4 * pa_j[q];
+                As[(kk + 0) * PA + pa_i[q]] = v.x;
+                As[(kk + 1) * PA + pa_i[q]] = v.y;
+                As[(kk + 2) * PA + pa_i[q]] = v.z;
+                As[(kk + 3) * PA + pa_i[q]] = v.w;
+            }
+        } else {
+            for (int idx = tid; idx < BM * KC; idx += 256) {
+                const int i = idx / KC, kk = idx % KC;
+                const int k = k0 + kk;
+                const long m = m0 + i;
+                float v = 0.0f;
+                if (k < a.K && m < M) {
+                    const int ox = (int)(m % a.OW);
+                    const long t = m / a.OW;
+                    const int oy = (int)(t % a.OH);
+                    const int b = (int)(t / a.OH);
+                    const int tap = k / a.Cin, ci = k % a.Cin;
+                    const int r = tap / a.ksz, s = tap % a.ksz;
+                    const int iy = oy * a.stride - a.pad + r, ix = ox * a.stride - a.pad + s;
+                    if (oy < a.AH && ox < a.AW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                        v = a.in[(((size_t)b * a.H + iy) * a.W + ix) * a.Cin + ci];
+                }
+                As[kk * PA + i] = v;
+            }
+        }
+        // ---- stage B
+#pragma unroll
+        for (int q = 0; q < B_F4; ++q) {
+            const int idx = tid + q * 256;          // over KC * BN/4
+            const int kk = idx / (BN / 4), j4 = idx % (BN / 4);
+            const int k = k0 + kk;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < a.K) v = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + n0 + 4 * j4);
+            float* d = &Bs[kk * PB + 4 * j4];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        const int ai = wm * 32 + (lane & 31), bj = wn * 32 + (lane & 31), kh = lane >> 5;
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 2) {
+            const float av = As[(kk + kh) * PA + ai];
+            const float bv = Bs[(kk + kh) * PB + bj];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int col = n0 + wn * 32 + (lane & 31);
+    const float bias = a.bias[col], g = a.gamma[col], bt = a.beta[col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const long m = m0 + wm * 32 + row;
+        if (m >= M) continue;
+        const int ox = (int)(m % a.OW);
+        const long t = m / a.OW;
+        const int oy = (int)(t % a.OH);
+        const int b = (int)(t / a.OH);
+        float v = 0.0f;
+        if (oy < a.AH && ox < a.AW) v = (acc[reg] + bias) * g + bt;
+        if (a.skip_mode == 1) v += a.skip[(size_t)m * a.Cout + col];
+        else if (a.skip_mode == 2) {
+            if (col < a.XC && oy < a.SH && ox < a.SW) {
+                const float* q = a.skip + (((size_t)b * a.XH + 2 * oy) * a.XW + 2 * ox) * a.XC + col;
+                v += (((q[0] + q[a.XC]) + q[(size_t)a.XW * a.XC]) + q[(size_t)a.XW * a.XC + a.XC]) * 0.25f;
+            }
+        }
+        if (a.relu && v < 0.0f) v = 0.0f;
+        a.out[(size_t)m * a.Cout + col] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) maxpool3s2_k(const float* __restrict__ in, int B, int H, int W, int C, float* __restrict__ out, int OH, int OW)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * OH * OW * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH);
+    const int b = (int)(t / OH);
+    float mx = -INFINITY;
+    for (int r = 0; r < 3; ++r)
+        for (int s = 0; s < 3; ++s) {
+            const float v = in[(((size_t)b * H + oy * 2 + r) * W + ox * 2 + s) * C + c];
+            mx = fmaxf(mx, v);
+        }
+    out[i] = mx;
+}
+
+// avg_pool_everything + fc_no_bias<128>: one block per face
+__global__ void __launch_bounds__(256) head_k(const float* __restrict__ x, int HW, const float* __restrict__ fc, float* __restrict__ out)
+{
+    __shared__ float feat[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    float s = 0.0f;
+    for (int i = 0; i < HW; ++i) s += x[((size_t)b * HW + i) * 256 + t];
+    feat[t] = s / (float)HW;
+    __syncthreads();
+    if (t < 128) {
+        float acc = 0.0f;
+        for (int o = 0; o < 256; ++o) acc += feat[o] * fc[(size_t)o * 128 + t];
+        out[(size_t)b * 128 + t] = acc;
+    }
+}
+
+static void launch_conv(Ctx* c, const ConvArgs& a)
+{
+    const long M = (long)a.B * a.OH * a.OW;
+    if (a.Cin % 32 != 0) {
+        PVF_REQUIRE(a.Cout == 32, "generic conv path expects 32 output channels");
+        hipLaunchKernelGGL((conv_mfma_k<4, 1, true>), dim3((unsigned)((M + 127) / 128), 1), dim3(256), 0, c->stream, a);
+    } else if (a.Cout == 32) {
+        hipLaunchKernelGGL((conv_mfma_k<4, 1, false>), dim3((unsigned)((M + 127) / 128), 1), dim3(256), 0, c->stream, a);
+    } else {
+        PVF_REQUIRE(a.Cout % 64 == 0, "conv: Cout must be 32 or a multiple of 64");
+        hipLaunchKernelGGL((conv_mfma_k<2, 2, false>), dim3((unsigned)((M + 63) / 64), a.Cout / 64), dim3(256), 0, c->stream, a);
+    }
+}
+
+// d_chips: [n][150][150][3] u8 on device; h_out [n][128]
+void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
+{
+    const EmbedModel& e = c->emb;
+    PVF_REQUIRE(e.loaded, "embedder not loaded");
+    const int S = e.chip_size;
+    const int MAXB = 256;
+    const int h1 = 1 + (S - 7) / 2;       // 72
+    const int hp = 1 + (h1 - 3) / 2;      // 35
+    const size_t big = (size_t)MAXB * h1 * h1 * 32;
+    c->s_act0.ensure(std::max(big, (size_t)MAXB * S * S * 3) * sizeof(float));
+    c->s_act1.ensure(big * sizeof(float));
+    c->s_act2.ensure((size_t)MAXB * hp * hp * 32 * sizeof(float) + (size_t)MAXB * 128 * sizeof(float));
+    for (int b0 = 0; b0 < n; b0 += MAXB) {
+        const int B = std::min(MAXB, n - b0);
+        ProfScope ps(c, "conv");
+        float* x = c->s_act0.as<float>();
+        float* y = c->s_act1.as<float>();
+        float* z = c->s_act2.as<float>();
+        const size_t nin = (size_t)B * S * S * 3;
+        hipLaunchKernelGGL(prep_input_k, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, c->stream, d_chips + (size_t)b0 * S * S * 3, x, nin);
+        // conv1 -> y ; maxpool -> z
+        ConvArgs a;
+        memset(&a, 0, sizeof a);
+        const ConvLayer& L0 = e.convs[0];
+        a.in = x; a.B = B; a.H = S; a.W = S; a.Cin = 3; a.w = L0.d_w; a.K = 7 * 7 * 3; a.bias = L0.d_bias; a.gamma = L0.d_gamma; a.beta = L0.d_beta;
+        a.out = y; a.OH = h1; a.OW = h1; a.Cout = 32; a.AH = h1; a.AW = h1; a.ksz = 7; a.stride = 2; a.pad = 0; a.relu = 1; a.skip_mode = 0;
+        launch_conv(c, a);
+        const size_t npool = (size_t)B * hp * hp * 32;
+        hipLaunchKernelGGL(maxpool3s2_k, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, c->stream, y, B, h1, h1, 32, z, hp, hp);
+        // rotate buffers: cur = z (unit input), t1/t2 scratch
+        float* cur = z; float* t1 = x; float* t2 = y;
+        int H = hp, W = hp;
+        static const int UN[14][3] = {{32, 32, 0}, {32, 32, 0}, {32, 32, 0}, {32, 64, 1}, {64, 64, 0}, {64, 64, 0}, {64, 64, 0},
+                                      {64, 128, 1}, {128, 128, 0}, {128, 128, 0}, {128, 256, 1}, {256, 256, 0}, {256, 256, 0}, {256, 256, 1}};
+        for (int u = 0; u < 14; ++u) {
+            const int cin = UN[u][0], nn = UN[u][1], down = UN[u][2];
+            const ConvLayer& La = e.convs[1 + 2 * u];
+            const ConvLayer& Lb = e.convs[2 + 2 * u];
+            const int stride = down ? 2 : 1, pad = down ? 0 : 1;
+            const int ah = 1 + (H + 2 * pad - 3) / stride, aw = 1 + (W + 2 * pad - 3) / stride;
+            memset(&a, 0, sizeof a);
+            a.in = cur; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.w = La.d_w; a.K = 9 * cin; a.bias = La.d_bias; a.gamma = La.d_gamma; a.beta = La.d_beta;
+            a.out = t1; a.OH = ah; a.OW = aw; a.Cout = nn; a.AH = ah; a.AW = aw; a.ksz = 3; a.stride = stride; a.pad = pad; a.relu = 1; a.skip_mode = 0;
+            launch_conv(c, a);
+            int sh = H, sw = W;
+            if (down) { sh = 1 + (H - 2) / 2; sw = 1 + (W - 2) / 2; }
+            const int oh = std::max(ah, sh), ow = std::max(aw, sw);
+            memset(&a, 0, sizeof a);
+            a.in = t1; a.B = B; a.H = ah; a.W = aw; a.Cin = nn; a.w = Lb.d_w; a.K = 9 * nn; a.bias = Lb.d_bias; a.gamma = Lb.d_gamma; a.beta = Lb.d_beta;
+            a.out = t2; a.OH = oh; a.OW = ow; a.Cout = nn; a.AH = ah; a.AW = aw; a.ksz = 3; a.stride = 1; a.pad = 1; a.relu = 1;
+            a.skip_mode = down ? 2 : 1; a.skip = cur; a.XH = H; a.XW = W; a.XC = cin; a.SH = sh; a.SW = sw;
+            launch_conv(c, a);
+            float* old = cur; cur = t2; t2 = old;
+            H = oh; W = ow;
+        }
+        float* d_out = reinterpret_cast<float*>(c->s_act2.as<uint8_t>() + (size_t)MAXB * hp * hp * 32 * sizeof(float));
+        // cur may alias s_act2's front part; the embedding slot sits behind it
+        hipLaunchKernelGGL(head_k, dim3(B), dim3(256), 0, c->stream, cur, H * W, e.d_fc, d_out);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(h_out + (size_t)b0 * 128, d_out, (size_t)B * 128 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}

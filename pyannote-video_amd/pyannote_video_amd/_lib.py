@@ -1,0 +1,117 @@
+"""ctypes binding of libpvface.so (include/pvface.h).  No CPU fallback: if the library is missing the import of any
+compute entry point fails loudly, and `Context()` fails when no gfx950 device is visible."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpvface.so")
+
+_lib = None
+
+
+class PvfError(RuntimeError):
+    pass
+
+
+class Rect(C.Structure):
+    _fields_ = [("left", C.c_int32), ("top", C.c_int32), ("right", C.c_int32), ("bottom", C.c_int32)]
+
+
+H = C.c_uint64
+P = C.c_void_p
+_SIGS = {
+    "pvf_last_error": (C.c_char_p, []),
+    "pvf_version": (C.c_int32, []),
+    "pvf_device_count": (C.c_int32, [P]),
+    "pvf_ctx_create": (C.c_int32, [C.c_int32, P]),
+    "pvf_ctx_destroy": (C.c_int32, [H]),
+    "pvf_sync": (C.c_int32, [H]),
+    "pvf_load_detector": (C.c_int32, [H, C.c_char_p]),
+    "pvf_load_shape_predictor": (C.c_int32, [H, C.c_char_p]),
+    "pvf_load_embedder": (C.c_int32, [H, C.c_char_p]),
+    "pvf_set_tracker_tables": (C.c_int32, [H, P, P, P, P, C.c_double, C.c_double]),
+    "pvf_frame_upload": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int64, P]),
+    "pvf_frame_wrap_device": (C.c_int32, [H, P, C.c_int32, C.c_int32, P]),
+    "pvf_frame_release": (C.c_int32, [H, H]),
+    "pvf_detect": (C.c_int32, [H, H, C.c_int32, C.c_double, P, P, C.c_int32, P]),
+    "pvf_detect_batch": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_double, P, P, P, C.c_int32]),
+    "pvf_tracker_create": (C.c_int32, [H, P]),
+    "pvf_tracker_destroy": (C.c_int32, [H, H]),
+    "pvf_tracker_start": (C.c_int32, [H, H, H, P]),
+    "pvf_tracker_update": (C.c_int32, [H, H, H, P]),
+    "pvf_tracker_position": (C.c_int32, [H, H, P]),
+    "pvf_tracker_start_many": (C.c_int32, [H, P, P, P, C.c_int32]),
+    "pvf_tracker_update_many": (C.c_int32, [H, P, P, C.c_int32, P, P]),
+    "pvf_overlap_matrix": (C.c_int32, [P, C.c_int32, P, C.c_int32, C.c_double, P]),
+    "pvf_munkres": (C.c_int32, [P, C.c_int32, P]),
+    "pvf_landmarks": (C.c_int32, [H, P, P, C.c_int32, P]),
+    "pvf_embed": (C.c_int32, [H, P, P, C.c_int32, P]),
+    "pvf_embed_chips": (C.c_int32, [H, P, C.c_int32, P]),
+    "pvf_face_chips": (C.c_int32, [H, P, P, C.c_int32, P]),
+    "pvf_pair_mean_dist": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, P]),
+    "pvf_cluster_tracks": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
+    "pvf_prof_enable": (C.c_int32, [H, C.c_int32]),
+    "pvf_prof_reset": (C.c_int32, [H]),
+    "pvf_prof_get": (C.c_int32, [H, C.c_char_p, P, P]),
+    "pvf_debug_pyramid_level": (C.c_int32, [H, H, C.c_int32, C.c_int32, P, P, P]),
+    "pvf_debug_fhog": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
+    "pvf_debug_detect_raw": (C.c_int32, [H, H, C.c_int32, C.c_double, P, P, C.c_int32, P]),
+    "pvf_debug_extract_chip": (C.c_int32, [H, H, P, C.c_double, C.c_double, C.c_int32, C.c_int32, P]),
+    "pvf_debug_tracker_state": (C.c_int32, [H, H, P, P, P]),
+}
+EXPORTS = sorted(_SIGS)
+
+
+def lib():
+    """Load libpvface.so (built by `make -C pyannote-video_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PvfError("libpvface.so is not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                           "there is no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)   # AttributeError if an export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PvfError(lib().pvf_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def handles(seq):
+    return np.ascontiguousarray(np.asarray(seq, dtype=np.uint64))
+
+
+def device_count():
+    n = C.c_int32(0)
+    check(lib().pvf_device_count(C.byref(n)))
+    return n.value
+
+
+# ---- host-only helpers (usable without a GPU) ---------------------------------------------------------
+def overlap_matrix(a, b, ratio):
+    a = np.ascontiguousarray(a, np.float64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, np.float64).reshape(-1, 4)
+    out = np.zeros((len(a), len(b)), np.float64)
+    check(lib().pvf_overlap_matrix(ptr(a), len(a), ptr(b), len(b), float(ratio), ptr(out)))
+    return out
+
+
+def munkres(cost):
+    """Munkres().compute(cost) for a square matrix: list of (row, column)"""
+    cost = np.ascontiguousarray(cost, np.float64)
+    n = cost.shape[0]
+    assert cost.shape == (n, n)
+    out = np.zeros(n, np.int32)
+    check(lib().pvf_munkres(ptr(cost), n, ptr(out)))
+    return [(i, int(out[i])) for i in range(n)]

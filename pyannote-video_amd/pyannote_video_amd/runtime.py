@@ -1,0 +1,298 @@
+"""`Context`: one GPU, one HIP stream, the loaded models and the frames staged in HBM.  Thin Python over the C ABI."""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import check, ptr, handles, Rect
+from . import models as _models
+
+
+class DeviceFrame(object):
+    """A frame resident in HBM (uint8 RGB HWC).  `keep` pins whatever owns the memory (e.g. a torch tensor)."""
+    __slots__ = ("ctx", "handle", "height", "width", "keep", "__weakref__")
+
+    def __init__(self, ctx, handle, height, width, keep=None):
+        self.ctx, self.handle, self.height, self.width, self.keep = ctx, handle, height, width, keep
+
+    @property
+    def shape(self):
+        return (self.height, self.width, 3)
+
+    def release(self):
+        if self.handle is not None and self.ctx._h is not None:
+            _lib.lib().pvf_frame_release(self.ctx._h, self.handle)
+        self.handle = None
+        self.keep = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class Context(object):
+    def __init__(self, device=0, detector=_models.DEFAULT_DETECTOR, landmarks=None, embedding=None):
+        self._h = None
+        l = _lib.lib()
+        h = C.c_uint64(0)
+        check(l.pvf_ctx_create(int(device), C.byref(h)))
+        self._h = h.value
+        self.device = int(device)
+        self._l = l
+        self._staged = {}      # (id, data ptr) -> DeviceFrame for numpy frames passed through the dlib-like API
+        self._staged_order = []
+        self.stage_capacity = 1024
+        self._tables = False
+        if detector:
+            self.load_detector(detector)
+        if landmarks:
+            self.load_shape_predictor(landmarks)
+        if embedding:
+            self.load_embedder(embedding)
+
+    def close(self):
+        if self._h is not None:
+            for f in list(self._staged.values()):
+                f.release()
+            self._staged.clear()
+            self._l.pvf_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self._l.pvf_sync(self._h))
+
+    # ---- models
+    def load_detector(self, path):
+        check(self._l.pvf_load_detector(self._h, str(path).encode()))
+
+    def load_shape_predictor(self, path):
+        check(self._l.pvf_load_shape_predictor(self._h, str(path).encode()))
+
+    def load_embedder(self, path):
+        check(self._l.pvf_load_embedder(self._h, str(path).encode()))
+
+    def ensure_tracker_tables(self):
+        if not self._tables:
+            t = _models.dsst_tables()
+            self._tab_keep = t
+            check(self._l.pvf_set_tracker_tables(self._h, ptr(t["mask64"]), ptr(t["mask_scale"]), ptr(t["tw64"]), ptr(t["tw32"]),
+                                                 t["alpha_pow_m16"], t["ln_alpha"]))
+            self._tables = True
+
+    # ---- frames
+    def upload(self, rgb):
+        rgb = np.asarray(rgb)
+        if rgb.dtype != np.uint8 or rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise TypeError("frames must be uint8 arrays of shape (H, W, 3)")   # dlib raises on unsupported arrays too
+        if not rgb.flags["C_CONTIGUOUS"]:
+            rgb = np.ascontiguousarray(rgb)
+        h = C.c_uint64(0)
+        check(self._l.pvf_frame_upload(self._h, ptr(rgb), rgb.shape[0], rgb.shape[1], rgb.strides[0], C.byref(h)))
+        return DeviceFrame(self, h.value, rgb.shape[0], rgb.shape[1])
+
+    def wrap_device(self, data_ptr, height, width, keep=None):
+        h = C.c_uint64(0)
+        check(self._l.pvf_frame_wrap_device(self._h, C.c_void_p(int(data_ptr)), int(height), int(width), C.byref(h)))
+        return DeviceFrame(self, h.value, int(height), int(width), keep)
+
+    def wrap_torch(self, t):
+        """t: torch.uint8 CUDA tensor [H, W, 3], contiguous"""
+        assert t.is_cuda and t.is_contiguous() and t.dim() == 3 and t.shape[2] == 3 and t.element_size() == 1
+        return self.wrap_device(t.data_ptr(), t.shape[0], t.shape[1], keep=t)
+
+    def stage(self, rgb):
+        """DeviceFrame for whatever the caller holds: DeviceFrame (as is) or numpy array (uploaded once, cached by identity)."""
+        if isinstance(rgb, DeviceFrame):
+            return rgb
+        key = (id(rgb), rgb.__array_interface__["data"][0] if hasattr(rgb, "__array_interface__") else 0)
+        f = self._staged.get(key)
+        if f is None or f.keep is not rgb:
+            f = self.upload(rgb)
+            f.keep = rgb   # keeps the id stable while cached
+            self._staged[key] = f
+            self._staged_order.append(key)
+            while len(self._staged_order) > self.stage_capacity:
+                old = self._staged_order.pop(0)
+                g = self._staged.pop(old, None)
+                if g is not None:
+                    g.release()
+        return f
+
+    def unstage_all(self):
+        for f in self._staged.values():
+            f.release()
+        self._staged.clear()
+        self._staged_order = []
+
+    # ---- S1
+    def detect_batch(self, frames, upsample=1, adjust_threshold=0.0, cap=256):
+        fr = [self.stage(f) for f in frames]
+        hs = handles([f.handle for f in fr])
+        n = len(fr)
+        out = np.zeros((n, cap, 4), np.int32)
+        scores = np.zeros((n, cap), np.float32)
+        counts = np.zeros(n, np.int32)
+        check(self._l.pvf_detect_batch(self._h, ptr(hs), n, int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
+        return [([tuple(int(v) for v in out[i, k]) for k in range(counts[i])], scores[i, :counts[i]].copy()) for i in range(n)]
+
+    def detect(self, frame, upsample=1, adjust_threshold=0.0):
+        return self.detect_batch([frame], upsample, adjust_threshold)[0]
+
+    def detect_raw(self, frame, upsample=1, adjust_threshold=0.0, cap=65536):
+        f = self.stage(frame)
+        scores = np.zeros(cap, np.float32)
+        meta = np.zeros((cap, 8), np.int32)
+        n = C.c_int32(0)
+        check(self._l.pvf_debug_detect_raw(self._h, f.handle, int(upsample), float(adjust_threshold), ptr(scores), ptr(meta), cap, C.byref(n)))
+        k = min(n.value, cap)
+        return [(float(scores[i]), int(meta[i, 0]), int(meta[i, 1]), int(meta[i, 2]), int(meta[i, 3]),
+                 tuple(int(v) for v in meta[i, 4:8])) for i in range(k)]
+
+    def pyramid_level(self, frame, upsample, level):
+        f = self.stage(frame)
+        oh, ow = C.c_int32(0), C.c_int32(0)
+        check(self._l.pvf_debug_pyramid_level(self._h, f.handle, upsample, level, None, C.byref(oh), C.byref(ow)))
+        out = np.zeros((oh.value, ow.value, 3), np.uint8)
+        check(self._l.pvf_debug_pyramid_level(self._h, f.handle, upsample, level, ptr(out), C.byref(oh), C.byref(ow)))
+        return out
+
+    def fhog(self, img, cell, pad_r, pad_c):
+        img = np.ascontiguousarray(img, np.uint8)
+        fh, fw = C.c_int32(0), C.c_int32(0)
+        check(self._l.pvf_debug_fhog(self._h, ptr(img), img.shape[0], img.shape[1], cell, pad_r, pad_c, None, C.byref(fh), C.byref(fw)))
+        out = np.zeros((fh.value, fw.value, 32), np.float32)
+        check(self._l.pvf_debug_fhog(self._h, ptr(img), img.shape[0], img.shape[1], cell, pad_r, pad_c, ptr(out), C.byref(fh), C.byref(fw)))
+        return out
+
+    # ---- S2
+    def tracker_create(self):
+        self.ensure_tracker_tables()
+        h = C.c_uint64(0)
+        check(self._l.pvf_tracker_create(self._h, C.byref(h)))
+        return h.value
+
+    def tracker_destroy(self, trk):
+        if self._h is not None:
+            check(self._l.pvf_tracker_destroy(self._h, trk))
+
+    def tracker_start_many(self, trks, frames, boxes):
+        if not len(trks):
+            return
+        fr = [self.stage(f) for f in frames]
+        b = np.ascontiguousarray(boxes, np.float64).reshape(-1, 4)
+        check(self._l.pvf_tracker_start_many(self._h, ptr(handles(trks)), ptr(handles([f.handle for f in fr])), ptr(b), len(trks)))
+
+    def tracker_update_many(self, trks, frames):
+        n = len(trks)
+        if not n:
+            return np.zeros(0), np.zeros((0, 4))
+        fr = [self.stage(f) for f in frames]
+        psr = np.zeros(n, np.float64)
+        boxes = np.zeros((n, 4), np.float64)
+        check(self._l.pvf_tracker_update_many(self._h, ptr(handles(trks)), ptr(handles([f.handle for f in fr])), n, ptr(psr), ptr(boxes)))
+        return psr, boxes
+
+    def tracker_position(self, trk):
+        b = np.zeros(4, np.float64)
+        check(self._l.pvf_tracker_position(self._h, trk, ptr(b)))
+        return tuple(b.tolist())
+
+    def tracker_state(self, trk):
+        F = np.zeros((32, 64, 64, 2), np.float64)
+        A = np.zeros((32, 64, 64, 2), np.float64)
+        B = np.zeros((64, 64), np.float64)
+        check(self._l.pvf_debug_tracker_state(self._h, trk, ptr(F), ptr(A), ptr(B)))
+        return F, A, B
+
+    # ---- S4
+    def landmarks(self, frames, boxes):
+        n = len(boxes)
+        pts = np.zeros((n, 68, 2), np.int32)
+        if n == 0:
+            return pts
+        fr = [self.stage(f) for f in frames]
+        r = (Rect * n)()
+        for i, b in enumerate(boxes):
+            r[i] = Rect(int(b[0]), int(b[1]), int(b[2]), int(b[3]))
+        check(self._l.pvf_landmarks(self._h, ptr(handles([f.handle for f in fr])), r, n, ptr(pts)))
+        return pts
+
+    def embed(self, frames, pts):
+        pts = np.ascontiguousarray(pts, np.int32).reshape(-1, 68, 2)
+        n = len(pts)
+        out = np.zeros((n, 128), np.float32)
+        if n == 0:
+            return out
+        fr = [self.stage(f) for f in frames]
+        check(self._l.pvf_embed(self._h, ptr(handles([f.handle for f in fr])), ptr(pts), n, ptr(out)))
+        return out
+
+    def face_chips(self, frames, pts):
+        pts = np.ascontiguousarray(pts, np.int32).reshape(-1, 68, 2)
+        n = len(pts)
+        out = np.zeros((n, 150, 150, 3), np.uint8)
+        fr = [self.stage(f) for f in frames]
+        check(self._l.pvf_face_chips(self._h, ptr(handles([f.handle for f in fr])), ptr(pts), n, ptr(out)))
+        return out
+
+    def embed_chips(self, chips):
+        chips = np.ascontiguousarray(chips, np.uint8).reshape(-1, 150, 150, 3)
+        out = np.zeros((len(chips), 128), np.float32)
+        check(self._l.pvf_embed_chips(self._h, ptr(chips), len(chips), ptr(out)))
+        return out
+
+    def extract_chip(self, frame, rect, cs, sn, rows, cols):
+        f = self.stage(frame)
+        r = np.asarray(rect, np.float64)
+        out = np.zeros((rows, cols, 3), np.uint8)
+        check(self._l.pvf_debug_extract_chip(self._h, f.handle, ptr(r), float(cs), float(sn), rows, cols, ptr(out)))
+        return out
+
+    # ---- S5
+    def pair_mean_dist(self, X, row_start):
+        X = np.ascontiguousarray(X, np.float64)
+        rs = np.ascontiguousarray(row_start, np.int32)
+        T = len(rs) - 1
+        D = np.zeros((T, T), np.float64)
+        check(self._l.pvf_pair_mean_dist(self._h, ptr(X), X.shape[0], X.shape[1], ptr(rs), T, ptr(D)))
+        return D
+
+    def cluster_tracks(self, X, row_start, threshold):
+        X = np.ascontiguousarray(X, np.float64)
+        rs = np.ascontiguousarray(row_start, np.int32)
+        T = len(rs) - 1
+        labels = np.zeros(T, np.int32)
+        log = np.zeros((max(T - 1, 1), 4), np.float64)
+        n = C.c_int32(0)
+        check(self._l.pvf_cluster_tracks(self._h, ptr(X), X.shape[0], X.shape[1], ptr(rs), T, float(threshold), ptr(labels), ptr(log), C.byref(n)))
+        return labels, log[:n.value]
+
+    # ---- measurement
+    def prof_enable(self, on=True):
+        check(self._l.pvf_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self._l.pvf_prof_reset(self._h))
+
+    def prof_get(self, family):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(self._l.pvf_prof_get(self._h, family.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+
+_default = None
+
+
+def default_context():
+    """Process-wide context on the GPU of this rank (LOCAL_RANK) -- what the dlib-like shim objects use."""
+    global _default
+    if _default is None:
+        import os
+        _default = Context(device=int(os.environ.get("LOCAL_RANK", "0")))
+    return _default

@@ -1,0 +1,183 @@
+"""GPU parity: every HIP stage against the CPU oracle on identical seeded inputs, through the C ABI.
+Integer / byte outputs must be bit-exact; the 128-D embedding within L2 1e-4 (BASELINE.json north_star)."""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dump(name, **arrays):
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    np.savez_compressed(os.path.join(d, name + ".npz"), **arrays)
+
+
+def _detector(oracle):
+    from pyannote_video_amd import models
+    return oracle.Detector(models.load_container(models.DEFAULT_DETECTOR))
+
+
+def test_pyramid_levels_bit_exact(ctx, oracle, small_video):
+    det = _detector(oracle)
+    f = small_video.frame(0)
+    up = oracle.Detector.pyramid_level(det, f, 1, 0)
+    n = det.levels(up.shape[0], up.shape[1])
+    assert n >= 5
+    for l in range(n):
+        a = ctx.pyramid_level(f, 1, l)
+        b = det.pyramid_level(f, 1, l)
+        assert a.shape == b.shape, (l, a.shape, b.shape)
+        bad = int((a != b).sum())
+        if bad:
+            _dump("pyr_mismatch_l%d" % l, gpu=a, cpu=b)
+        assert bad == 0, "level %d: %d differing bytes" % (l, bad)
+
+
+@pytest.mark.parametrize("cell,pad,shape", [(8, 10, (200, 264)), (8, 10, (97, 131)), (4, 1, (23, 23)), (1, 3, (64, 64)), (4, 1, (40, 52))])
+def test_fhog_bit_exact(ctx, oracle, small_video, cell, pad, shape):
+    f = small_video.frame(1)[40:40 + shape[0], 100:100 + shape[1]]
+    a = ctx.fhog(f, cell, pad, pad)
+    b = oracle.fhog(f, cell, pad, pad)
+    assert a.shape == b.shape
+    bad = int((a.view(np.uint32) != b.view(np.uint32)).sum())
+    if bad:
+        _dump("fhog_mismatch_c%d" % cell, gpu=a, cpu=b)
+    assert bad == 0, "fhog cell %d: %d of %d floats differ (max abs %g)" % (cell, bad, a.size, np.abs(a - b).max())
+
+
+def test_detector_raw_and_boxes_bit_exact(ctx, oracle, small_video):
+    det = _detector(oracle)
+    for i in (0, 7):
+        f = small_video.frame(i)
+        raw_g = ctx.detect_raw(f, 1)
+        raw_c = det.detect_raw(f, 1)
+        assert len(raw_c) > 0
+        if raw_g != raw_c:
+            _dump("raw_mismatch_%d" % i, gpu=np.array([(r[0],) + r[1:5] + r[5] for r in raw_g], np.float64),
+                  cpu=np.array([(r[0],) + r[1:5] + r[5] for r in raw_c], np.float64))
+        assert len(raw_g) == len(raw_c)
+        assert raw_g == raw_c
+        boxes_g, scores_g = ctx.detect(f, 1)
+        fin_c = det.detect(f, 1)
+        assert boxes_g == [d[5] for d in fin_c]
+        assert np.array_equal(scores_g, np.array([d[0] for d in fin_c], np.float32))
+        assert len(boxes_g) == small_video.faces
+
+
+def test_detect_batch_equals_single(ctx, small_video):
+    frames = [small_video.frame(i) for i in range(4)]
+    single = [ctx.detect(f, 1)[0] for f in frames]
+    batch = [b for b, _ in ctx.detect_batch(frames, 1)]
+    assert single == batch
+
+
+def test_chips_bit_exact(ctx, oracle, small_video):
+    f = small_video.frame(2)
+    cases = [((100.5, 60.25, 180.75, 140.0), 1.0, 0.0, 64, 64),        # mild scale
+             ((50.0, 30.0, 450.0, 330.0), 1.0, 0.0, 64, 64),           # two pyramid levels
+             ((200.0, 100.0, 330.0, 230.0), 0.9659258262890683, 0.25881904510252074, 150, 150),  # rotated
+             ((-40.0, -30.0, 120.0, 130.0), 1.0, 0.0, 64, 64),         # partly outside
+             ((300.0, 200.0, 320.0, 220.0), 0.8, 0.6, 150, 150),       # upsampling chip
+             ((1000.0, 1000.0, 1100.0, 1100.0), 1.0, 0.0, 64, 64)]     # fully outside
+    for rect, cs, sn, rows, cols in cases:
+        a = ctx.extract_chip(f, rect, cs, sn, rows, cols)
+        b = oracle.extract_chip(f, rect, cs, sn, rows, cols)
+        bad = int((a != b).sum())
+        if bad:
+            _dump("chip_mismatch", gpu=a, cpu=b)
+        assert bad == 0, (rect, bad)
+
+
+def test_landmarks_bit_exact(ctx, oracle, small_video, model_paths):
+    from pyannote_video_amd import models
+    sp = oracle.ShapePredictor(models.load_container(model_paths[0]))
+    frames, boxes = [], []
+    for i in (0, 3, 8):
+        f = small_video.frame(i)
+        for b in ctx.detect(f, 1)[0]:
+            frames.append(f); boxes.append(b)
+    boxes.append((-20, -10, 60, 70)); frames.append(small_video.frame(0))   # box leaving the frame
+    pts = ctx.landmarks(frames, boxes)
+    for k, (f, b) in enumerate(zip(frames, boxes)):
+        ref = sp(f, b)
+        assert np.array_equal(pts[k], ref), (k, b, np.abs(pts[k] - ref).max())
+
+
+def test_face_chips_and_embedding(ctx, oracle, small_video, model_paths):
+    from pyannote_video_amd import models
+    sp = oracle.ShapePredictor(models.load_container(model_paths[0]))
+    emb = oracle.Embedder(models.load_container(model_paths[1]))
+    frames, pts = [], []
+    for i in (0, 5):
+        f = small_video.frame(i)
+        for b in ctx.detect(f, 1)[0]:
+            frames.append(f); pts.append(sp(f, b))
+    chips = ctx.face_chips(frames, pts)
+    ref_chips = np.stack([emb.chip(f, p) for f, p in zip(frames, pts)])
+    assert np.array_equal(chips, ref_chips), int((chips != ref_chips).sum())
+    out = ctx.embed(frames, pts)
+    ref = np.stack([emb.forward(c) for c in ref_chips])
+    err = np.linalg.norm(out - ref, axis=1)
+    scale = np.linalg.norm(ref, axis=1)
+    _dump("embed_check", gpu=out, cpu=ref)
+    assert err.max() <= 1e-4, (err.max(), scale.mean())
+    out2 = ctx.embed_chips(ref_chips)
+    assert np.array_equal(out, out2)
+
+
+def test_tracker_bit_exact(ctx, oracle, small_video):
+    from pyannote_video_amd import models
+    tabs = models.dsst_tables()
+    f0 = small_video.frame(0)
+    boxes = ctx.detect(f0, 1)[0]
+    assert boxes
+    ref = [oracle.Tracker(tabs) for _ in boxes]
+    trk = [ctx.tracker_create() for _ in boxes]
+    dbox = [tuple(float(v) for v in b) for b in boxes]
+    ctx.tracker_start_many(trk, [f0] * len(trk), dbox)
+    for r, b in zip(ref, dbox):
+        r.start_track(f0, b)
+    F, A, B = ctx.tracker_state(trk[0])
+    Ar, Br = ref[0].debug_state()
+    Fr = ref[0].debug_F()
+    assert np.array_equal(F, Fr), np.abs(F - Fr).max()
+    assert np.array_equal(A, Ar), np.abs(A - Ar).max()
+    assert np.array_equal(B, Br)
+    for i in range(1, 5):
+        f = small_video.frame(i)
+        psr, pos = ctx.tracker_update_many(trk, [f] * len(trk))
+        for k, r in enumerate(ref):
+            p = r.update(f)
+            assert psr[k] == p, (i, k, psr[k], p)
+            assert tuple(pos[k]) == r.get_position(), (i, k, pos[k], r.get_position())
+            assert ctx.tracker_position(trk[k]) == r.get_position()
+        assert psr.min() > 5.0
+    for t in trk:
+        ctx.tracker_destroy(t)
+
+
+def test_pair_mean_dist_and_hac(ctx, oracle):
+    rng = np.random.default_rng(5)
+    K, T = 9, 60
+    centres = rng.normal(0, 1, (K, 128)); centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    sizes = rng.integers(1, 12, T)
+    ident = rng.integers(0, K, T)
+    rows = []
+    for t in range(T):
+        x = centres[ident[t]] + 0.05 * rng.normal(0, 1, (sizes[t], 128))
+        rows.append(np.round(0.55 * x / np.linalg.norm(x, axis=1, keepdims=True), 5))
+    X = np.concatenate(rows)
+    rs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    D = ctx.pair_mean_dist(X, rs)
+    Dr = oracle.pair_mean_dist(X, rs)
+    assert np.allclose(D, Dr, rtol=1e-12, atol=1e-13), np.abs(D - Dr).max()
+    labels, log = ctx.cluster_tracks(X, rs, 0.6)
+    lr, logr = oracle.hac(Dr, sizes, 0.6)
+    assert np.array_equal(labels, lr)
+    assert len(log) == len(logr)
+    assert np.array_equal(log[:, :2], logr[:, :2])
+    # ground truth: tracks of one identity end up together
+    for t in range(T):
+        assert ident[labels[t]] == ident[t]
+    assert len(set(labels.tolist())) == len(set(ident.tolist()))

@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Fit the 5 synthetic HOG face filters to the synthetic face renderer and write
+pyannote-video_amd/pyannote_video_amd/data/frontal_face_detector.pvfm.
+
+Why: dlib's frontal face detector (reference face.py:54) is a blob compiled into dlib, absent here.  The bench
+needs filters of the same shape (5 x 10x10 cells x 31 planes, 80x80 window, cell 8, padding 1) that actually fire
+on the synthetic faces.  This tool is self-contained: it uses its own numpy FHOG
+(an independent third implementation; tests compare it with the oracle) and regularised LDA per pose.
+
+Run:  python tools/fit_detector.py   (deterministic; ~1-2 min)
+"""
+import os
+import sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pyannote-video_amd"))
+from pyannote_video_amd import synth, models  # noqa: E402
+
+DIRX = np.array([1.0000, 0.9397, 0.7660, 0.500, 0.1736, -0.1736, -0.5000, -0.7660, -0.9397], np.float32)
+DIRY = np.array([0.0000, 0.3420, 0.6428, 0.8660, 0.9848, 0.9848, 0.8660, 0.6428, 0.3420], np.float32)
+
+
+def fhog_numpy(img, cell=8, pad_r=10, pad_c=10):
+    """Felzenszwalb HOG as dlib extracts it ([EXT] fhog.h), vectorised numpy; returns [fh][fw][32] float32."""
+    img = img.astype(np.int32)
+    ih, iw = img.shape[:2]
+    cells_nr = int(ih / float(cell) + 0.5)
+    cells_nc = int(iw / float(cell) + 0.5)
+    hog_nr, hog_nc = cells_nr - 2, cells_nc - 2
+    vis_nr = min(cells_nr * cell, ih) - 1
+    vis_nc = min(cells_nc * cell, iw) - 1
+    ys = np.arange(1, vis_nr)
+    xs = np.arange(1, vis_nc)
+    gx = img[1:vis_nr, 2:vis_nc + 1] - img[1:vis_nr, 0:vis_nc - 1]
+    gy = img[2:vis_nr + 1, 1:vis_nc] - img[0:vis_nr - 1, 1:vis_nc]
+    v2 = gx * gx + gy * gy
+    best = np.zeros(v2.shape[:2], np.int64)
+    bv = v2[..., 0].copy()
+    for k in (1, 2):
+        m = v2[..., k] > bv
+        bv[m] = v2[..., k][m]
+        best[m] = k
+    ii, jj = np.indices(best.shape)
+    gxf = gx[ii, jj, best].astype(np.float32)
+    gyf = gy[ii, jj, best].astype(np.float32)
+    best_dot = np.zeros(gxf.shape, np.float32)
+    best_o = np.zeros(gxf.shape, np.int64)
+    for o in range(9):
+        dot = gxf * DIRX[o] + gyf * DIRY[o]
+        m1 = dot > best_dot
+        m2 = (~m1) & (-dot > best_dot)
+        best_dot = np.where(m1, dot, np.where(m2, -dot, best_dot))
+        best_o = np.where(m1, o, np.where(m2, o + 9, best_o))
+    v = np.sqrt(bv.astype(np.float32))
+    yp = (ys.astype(np.float32) + 0.5) / np.float32(cell) - 0.5
+    xp = (xs.astype(np.float32) + 0.5) / np.float32(cell) - 0.5
+    iyp = np.floor(yp).astype(np.int64)
+    ixp = np.floor(xp).astype(np.int64)
+    vy0 = (yp - iyp).astype(np.float32)[:, None]
+    vx0 = (xp - ixp).astype(np.float32)[None, :]
+    vy1, vx1 = 1 - vy0, 1 - vx0
+    hist = np.zeros((cells_nr + 2, cells_nc + 2, 18), np.float32)
+    IY = np.broadcast_to(iyp[:, None], v.shape)
+    IX = np.broadcast_to(ixp[None, :], v.shape)
+    np.add.at(hist, (IY + 1, IX + 1, best_o), vy1 * vx1 * v)
+    np.add.at(hist, (IY + 2, IX + 1, best_o), vy0 * vx1 * v)
+    np.add.at(hist, (IY + 1, IX + 2, best_o), vy1 * vx0 * v)
+    np.add.at(hist, (IY + 2, IX + 2, best_o), vy0 * vx0 * v)
+    h = hist[1:-1, 1:-1]
+    norm = ((h[..., :9] + h[..., 9:]) ** 2).sum(-1)
+    eps = np.float32(0.0001)
+    hc = h[1:-1, 1:-1]                         # cells (y+1, x+1)
+    n = norm
+    blocks = []
+    for dy, dx in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        z = n[dy:dy + hog_nr, dx:dx + hog_nc] + n[dy:dy + hog_nr, dx + 1:dx + 1 + hog_nc] + \
+            n[dy + 1:dy + 1 + hog_nr, dx:dx + hog_nc] + n[dy + 1:dy + 1 + hog_nr, dx + 1:dx + 1 + hog_nc]
+        blocks.append(np.float32(0.2) * np.sqrt(z + eps))
+    out = np.zeros((hog_nr, hog_nc, 32), np.float32)
+    t = [np.zeros((hog_nr, hog_nc), np.float32) for _ in range(4)]
+    for o in range(18):
+        acc = 0
+        for k in range(4):
+            hh = np.minimum(hc[..., o], blocks[k]) * (np.float32(0.1) / blocks[k])
+            acc = acc + hh
+            t[k] += hh
+        out[..., o] = acc
+    for o in range(9):
+        s = hc[..., o] + hc[..., o + 9]
+        acc = 0
+        for k in range(4):
+            acc = acc + np.minimum(s, blocks[k]) * (np.float32(0.1) / blocks[k])
+        out[..., 18 + o] = acc
+    for k in range(4):
+        out[..., 27 + k] = t[k] * np.float32(2 * 0.2357)
+    oy, ox = (pad_r - 1) // 2, (pad_c - 1) // 2
+    full = np.zeros((hog_nr + pad_r - 1, hog_nc + pad_c - 1, 32), np.float32)
+    full[oy:oy + hog_nr, ox:ox + hog_nc] = out
+    return full
+
+
+def make_context(rng, ident, pose, size, ctx=176):
+    """face of `size` px pasted at a random sub-cell offset into a ctx x ctx noisy background; returns img, centre"""
+    bg = synth.lowpass_noise(rng, ctx, ctx) + rng.uniform(60, 180)
+    rgb, a = synth.render_face(size, ident, pose)
+    cx = ctx / 2.0 + rng.uniform(-4, 4)
+    cy = ctx / 2.0 + rng.uniform(-4, 4)
+    l = int(np.floor(cx - size / 2.0)); t = int(np.floor(cy - size / 2.0))
+    sub = bg[t:t + size, l:l + size]
+    sub[...] = rgb * a[..., None] + sub * (1 - a[..., None])
+    img = bg + rng.normal(0, 3.0, (ctx, ctx, 1))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8), (l + size / 2.0, t + size / 2.0)
+
+
+def window_at(feat, cx, cy):
+    """10x10 feature window whose 80x80 px footprint is centred closest to (cx, cy)"""
+    c0 = int(round((cx - 40) / 8.0)); r0 = int(round((cy - 40) / 8.0))
+    return feat[r0 + 3:r0 + 13, c0 + 3:c0 + 13, :31].copy()
+
+
+def main():
+    rng = np.random.default_rng(424242)
+    pos = {p: [] for p in synth.POSES}
+    neg = []
+    idents = list(range(16))
+    for pose in synth.POSES:
+        for rep in range(26):
+            for ident in idents:
+                size = int(rng.integers(72, 91))
+                img, (cx, cy) = make_context(rng, ident, pose, size)
+                f = fhog_numpy(img)
+                pos[pose].append(window_at(f, cx, cy).reshape(-1))
+                # shifted / partial windows as negatives (keep NMS work small and boxes tight)
+                for _ in range(2):
+                    dx, dy = rng.choice([-1, 1]) * rng.uniform(24, 56), rng.choice([-1, 1]) * rng.uniform(24, 56)
+                    neg.append(window_at(f, cx + dx, cy + dy).reshape(-1))
+                # wrong-scale negatives
+            if rep % 5 == 0:
+                for ident in idents[:6]:
+                    size = int(rng.choice([48, 56, 120, 136]))
+                    img, (cx, cy) = make_context(rng, ident, pose, size)
+                    neg.append(window_at(fhog_numpy(img), cx, cy).reshape(-1))
+    for _ in range(1500):
+        ctx = 176
+        bg = synth.lowpass_noise(rng, ctx, ctx) + rng.uniform(60, 180) + rng.normal(0, 3.0, (ctx, ctx, 1))
+        f = fhog_numpy(np.clip(np.rint(bg), 0, 255).astype(np.uint8))
+        neg.append(window_at(f, 88 + rng.uniform(-20, 20), 88 + rng.uniform(-20, 20)).reshape(-1))
+    neg = np.array(neg, np.float64)
+    allpos = np.concatenate([np.array(pos[p], np.float64) for p in synth.POSES])
+    mu_n = neg.mean(0)
+    Xc = np.concatenate([neg - mu_n] + [np.array(pos[p]) - np.array(pos[p]).mean(0) for p in synth.POSES])
+    cov = Xc.T @ Xc / len(Xc)
+    cov += 0.05 * np.trace(cov) / cov.shape[0] * np.eye(cov.shape[0])
+    W = np.zeros((5, 10, 10, 32), np.float32)
+    TH = np.zeros(5, np.float32)
+    for k, p in enumerate(synth.POSES):
+        P = np.array(pos[p], np.float64)
+        w = np.linalg.solve(cov, P.mean(0) - mu_n)
+        w /= np.linalg.norm(w)
+        sp = P @ w
+        sn = neg @ w
+        so = allpos @ w
+        lo, hi = np.percentile(sn, 99.95), np.percentile(sp, 2.0)
+        th = lo + 0.45 * (hi - lo)
+        print("%-10s pos[min %.3f p2 %.3f med %.3f] neg[max %.3f p99.95 %.3f] other-pose med %.3f  -> thresh %.3f  miss %.1f%%" % (
+            p, sp.min(), hi, np.median(sp), sn.max(), lo, np.median(so), th, 100.0 * (sp < th).mean()))
+        W[k, :, :, :31] = w.reshape(10, 10, 31).astype(np.float32)
+        TH[k] = th
+    out = {
+        "det.meta": np.array([5, 10, 10, 8, 1, 80, 80, 64, 64, 1000], np.int32),
+        "det.nms": np.array([0.30, 0.90], np.float64),
+        "det.w": W,
+        "det.thresh": TH,
+    }
+    os.makedirs(models.DATA_DIR, exist_ok=True)
+    models.save_container(models.DEFAULT_DETECTOR, out)
+    print("wrote", models.DEFAULT_DETECTOR)
+
+
+if __name__ == "__main__":
+    main()
