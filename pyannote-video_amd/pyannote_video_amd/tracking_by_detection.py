@@ -1,0 +1,347 @@
+"""Forward/backward tracking by detection -- host state machine of the reference, re-stated around batched GPU calls.
+
+Reference: pyannote/video/tracking.py (TrackingByDetection :68-434).  Semantics kept verbatim because they decide the
+integer outputs (track ids, boxes, status strings):
+  - shot membership / flush order                      (:44-58, :406-417)
+  - graph nodes (t, (l,t,r,b), status), same insertion order of nodes and edges   (:214-259, :420-427)
+  - association = overlap gating on BOTH boxes + Munkres on max-overlap cost      (:129-182)
+  - _fix: per-timestamp mean + banker's int(round()), status join order, error()  (:261-296)
+  - _fill_gaps on (last, first) items in (min_t, max_t) order                     (:298-329)
+  - tracks yielded sorted by (min_t, max_t), normalised by the frame size          (:331-372)
+
+What is different is *how* the work is issued: detections of a whole shot are computed in batches before the passes,
+and the forward and backward passes (of one shot, or of many shots) advance in lock-step so that every frame step issues
+ONE batched `tracker.update` and ONE batched `start_track` for all lanes (pvf_tracker_update_many / _start_many).
+The passes only communicate through the graph, and each lane's graph mutations are replayed in the reference's order
+(forward pass first, then backward), so the resulting graph is identical.
+"""
+from __future__ import division
+import itertools
+import numpy as np
+import networkx as nx
+from . import _lib
+from .shim import drectangle
+
+FORWARD = 'forward'
+BACKWARD = 'backward'
+DETECTION = 'detection'
+ERROR = 'error'
+
+_STATUS_ORDER = {FORWARD: 1, DETECTION: 2, BACKWARD: 3}
+
+
+def get_segment_generator(segmentation):
+    """Time-driven segment generator (tracking.py:44-58): send(t) returns the end of a segment once t has passed it.
+    Segments need `.end`; (start, end) tuples are accepted too."""
+    t = yield
+    for segment in segmentation:
+        T = segment.end if hasattr(segment, 'end') else segment[1]
+        while True:
+            if T > t:
+                t = yield
+                continue
+            t = yield T
+            break
+
+
+def get_min_max_t(track):
+    return (min(t for t, _, _ in track), max(t for t, _, _ in track))
+
+
+class HipTrackers(object):
+    """Batched tracker backend on one Context (default)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def start_many(self, frames, boxes):
+        hs = [self.ctx.tracker_create() for _ in boxes]
+        self.ctx.tracker_start_many(hs, frames, boxes)
+        return hs
+
+    def update_many(self, handles, frames):
+        return self.ctx.tracker_update_many(handles, frames)
+
+    def release(self, handle):
+        self.ctx.tracker_destroy(handle)
+
+
+class ObjectTrackers(object):
+    """Adapter for any per-object tracker class with dlib's start_track / update / get_position (test seam, S2)."""
+
+    def __init__(self, factory, rect_factory=drectangle):
+        self.factory, self.rect = factory, rect_factory
+
+    def start_many(self, frames, boxes):
+        out = []
+        for f, b in zip(frames, boxes):
+            t = self.factory()
+            t.start_track(f, self.rect(*b))
+            out.append(t)
+        return out
+
+    def update_many(self, handles, frames):
+        psr = np.array([h.update(f) for h, f in zip(handles, frames)], np.float64)
+        pos = []
+        for h in handles:
+            p = h.get_position()
+            pos.append((p.left(), p.top(), p.right(), p.bottom()))
+        return psr, np.array(pos, np.float64).reshape(-1, 4)
+
+    def release(self, handle):
+        pass
+
+
+class TrackingByDetection(object):
+    """(Forward/backward) tracking by detection -- same constructor and call contract as the reference class."""
+
+    def __init__(self, detect_func, detect_smallest=1, detect_min_size=0., detect_every=0.,
+                 track_min_confidence=10., track_min_overlap_ratio=0.3, track_max_gap=0.,
+                 trackers=None, detect_batch_func=None, detect_batch_size=8):
+        super(TrackingByDetection, self).__init__()
+        self.detect_func = detect_func
+        self.detect_batch_func = detect_batch_func
+        self.detect_batch_size = detect_batch_size
+        self.detect_smallest = detect_smallest
+        self.detect_min_size = detect_min_size
+        self.detect_every = detect_every
+        self.track_min_confidence = track_min_confidence
+        self.track_min_overlap_ratio = track_min_overlap_ratio
+        self.track_max_gap = track_max_gap
+        self._trackers_backend = trackers
+
+    # ---- geometry -------------------------------------------------------------------------------------
+    def _match(self, rectangle1, rectangle2):
+        overlap = rectangle1.intersect(rectangle2).area()
+        if ((overlap < self.track_min_overlap_ratio * rectangle1.area()) or
+                (overlap < self.track_min_overlap_ratio * rectangle2.area())):
+            overlap = 0.
+        return overlap
+
+    def _associate(self, positions, detections):
+        """positions: [(identifier, (l,t,r,b))] in tracker order. Returns {detection index: identifier} (tracking.py:136-182)."""
+        n_trackers, n_detections = len(positions), len(detections)
+        if n_trackers < 1 or n_detections < 1:
+            return dict()
+        n = max(n_trackers, n_detections)
+        overlap_area = np.zeros((n, n))
+        overlap_area[:n_trackers, :n_detections] = _lib.overlap_matrix(
+            [p for _, p in positions], [tuple(float(v) for v in d) for d in detections], self.track_min_overlap_ratio)
+        match = {}
+        mapping = _lib.munkres(np.max(overlap_area) - overlap_area)
+        for t, d in mapping:
+            if t >= n_trackers or d >= n_detections:
+                continue
+            if overlap_area[t, d] > 0.:
+                match[d] = positions[t][0]
+        return match
+
+    # ---- one pass over one shot, written as a coroutine that asks for batched tracker work -------------------
+    def _lane(self, cache, detections_at, direction, edges):
+        """cache: [(t, frame)] in processing order; detections_at: {t: [box]}; edges: list receiving
+        (u, v, confidence) in the order the reference calls add_edge (tracking.py:214-259)."""
+        trackers = {}      # identifier -> backend handle  (dict order == creation order, like the reference's dict)
+        position = {}      # identifier -> (l,t,r,b) doubles after the last update
+        confidences = {}
+        previous = {}
+        new_identifier = 0
+        for t, frame in cache:
+            ids = list(trackers)
+            if ids:
+                psr, boxes = yield ('update', [trackers[i] for i in ids], [frame] * len(ids))
+                for k, identifier in enumerate(ids):
+                    confidences[identifier] = float(psr[k])
+                    position[identifier] = tuple(float(v) for v in boxes[k])
+                    if confidences[identifier] < self.track_min_confidence:
+                        yield ('release', trackers[identifier])
+                        del trackers[identifier]
+            detections = detections_at.get(t, [])
+            match = self._associate([(i, position[i]) for i in trackers], detections)
+            for d, identifier in match.items():
+                current = (t, detections[d], DETECTION)
+                edges.append((previous[identifier], current, confidences[identifier]))
+                yield ('release', trackers[identifier])
+                del trackers[identifier]
+            for identifier in trackers:
+                current = (t, position[identifier], direction)
+                edges.append((previous[identifier], current, confidences[identifier]))
+                previous[identifier] = current
+            if detections:
+                handles = yield ('start', [frame] * len(detections), [tuple(float(v) for v in d) for d in detections])
+                for d, detection in enumerate(detections):
+                    trackers[new_identifier] = handles[d]
+                    previous[new_identifier] = (t, detection, DETECTION)
+                    new_identifier += 1
+        for identifier in list(trackers):
+            yield ('release', trackers[identifier])
+
+    @staticmethod
+    def _run_lanes(lanes, backend):
+        """Advance all lane coroutines in lock-step; merge their requests into one update batch + one start batch per round."""
+        pending = {}
+        for k, g in enumerate(lanes):
+            try:
+                pending[k] = next(g)
+            except StopIteration:
+                pass
+        while pending:
+            replies = {}
+            upd = [(k, r) for k, r in pending.items() if r[0] == 'update']
+            if upd:
+                hs = [h for _, r in upd for h in r[1]]
+                fr = [f for _, r in upd for f in r[2]]
+                psr, boxes = backend.update_many(hs, fr)
+                o = 0
+                for k, r in upd:
+                    n = len(r[1])
+                    replies[k] = (psr[o:o + n], boxes[o:o + n])
+                    o += n
+            st = [(k, r) for k, r in pending.items() if r[0] == 'start']
+            if st:
+                fr = [f for _, r in st for f in r[1]]
+                bx = [b for _, r in st for b in r[2]]
+                hs = backend.start_many(fr, bx)
+                o = 0
+                for k, r in st:
+                    n = len(r[2])
+                    replies[k] = hs[o:o + n]
+                    o += n
+            for k, r in pending.items():
+                if r[0] == 'release':
+                    backend.release(r[1])
+                    replies[k] = None
+            nxt = {}
+            for k in pending:
+                try:
+                    nxt[k] = lanes[k].send(replies[k])
+                except StopIteration:
+                    pass
+            pending = nxt
+
+    # ---- merging ----------------------------------------------------------------------------------------
+    def _fix(self, track):
+        """Merge forward / backward / detection boxes of one timestamp (tracking.py:261-296)."""
+        fixed_track = []
+        for t, group in itertools.groupby(sorted(track), key=lambda x: x[0]):
+            group = list(group)
+            error = False
+            for (_, pos1, _), (_, pos2, _) in itertools.combinations(group, 2):
+                if self._match(drectangle(*pos1), drectangle(*pos2)) == 0:
+                    error = True
+                    break
+            status = "+".join(sorted((status for _, _, status in group), key=lambda s: _STATUS_ORDER[s]))
+            if error:
+                status = "error({0})".format(status)
+            pos = tuple(int(round(v)) for v in np.mean(np.vstack([p for _, p, _ in group]), axis=0))
+            fixed_track.append((t, pos, status))
+        return fixed_track
+
+    def _fill_gaps(self, tracks):
+        tracks = sorted(tracks, key=get_min_max_t)
+        graph = nx.Graph()
+        for i in range(len(tracks)):
+            graph.add_node(i)
+        for i, j in itertools.combinations(range(len(tracks)), 2):
+            ti = tracks[i][-1][0]
+            tj = tracks[j][0][0]
+            if (tj < ti) or (tj - ti > self.track_max_gap):
+                continue
+            if self._match(drectangle(*tracks[i][-1][1]), drectangle(*tracks[j][0][1])):
+                graph.add_edge(i, j)
+        merged_tracks = []
+        for group in nx.connected_components(graph):
+            merged_tracks.append([item for t in sorted(group) for item in tracks[t]])
+        return merged_tracks
+
+    def _tracks_from_graph(self, graph):
+        timestamps = [t for t in graph if not isinstance(t, tuple)]
+        graph.remove_nodes_from(timestamps)
+        tracks = nx.connected_components(graph.to_undirected(reciprocal=False))
+        tracks = [self._fix(track) for track in tracks]
+        tracks = self._fill_gaps(tracks)
+        return sorted(tracks, key=get_min_max_t)
+
+    @staticmethod
+    def _normalize_track(track, frame_width, frame_height):
+        return [(t, (l / frame_width, tp / frame_height, r / frame_width, b / frame_height), status)
+                for (t, (l, tp, r, b), status) in track]
+
+    # ---- shots --------------------------------------------------------------------------------------------
+    def _detect_shot(self, cache, flags):
+        """detections per cached frame (only where flags[i]); batched when a batch function is available"""
+        out = [[] for _ in cache]
+        idx = [i for i, f in enumerate(flags) if f]
+        if self.detect_batch_func is not None:
+            bs = max(1, int(self.detect_batch_size))
+            for o in range(0, len(idx), bs):
+                chunk = idx[o:o + bs]
+                res = self.detect_batch_func([cache[i][1] for i in chunk])
+                for i, dets in zip(chunk, res):
+                    out[i] = [tuple(d) for d in dets]
+        else:
+            for i in idx:
+                out[i] = [tuple(d) for d in self.detect_func(cache[i][1])]
+        return out
+
+    def process_shots(self, shots, backend):
+        """shots: list of (cache, flags) -- [(t, frame)], [run detection on frame i].  Returns one track list per shot.
+        All shots' forward and backward passes run in lock-step (they are independent: tracking.py:359-362,410-417)."""
+        graphs, lanes, lane_edges = [], [], []
+        for cache, flags in shots:
+            dets = self._detect_shot(cache, flags)
+            g = nx.DiGraph()
+            det_at = {}
+            for (t, _), d in zip(cache, dets):
+                g.add_node(t)
+                for box in d:
+                    g.add_edge(t, (t, box, DETECTION))
+                det_at[t] = d
+            graphs.append(g)
+            ef, eb = [], []
+            lanes.append(self._lane(cache, det_at, FORWARD, ef))
+            lanes.append(self._lane(list(reversed(cache)), det_at, BACKWARD, eb))
+            lane_edges.append((ef, eb))
+        self._run_lanes(lanes, backend)
+        out = []
+        for g, (ef, eb) in zip(graphs, lane_edges):
+            for u, v, conf in ef:
+                g.add_edge(u, v, confidence=conf)
+            for u, v, conf in eb:
+                g.add_edge(u, v, confidence=conf)
+            out.append(self._tracks_from_graph(g))
+        return out
+
+    def _backend(self):
+        if self._trackers_backend is None:
+            from . import runtime
+            self._trackers_backend = HipTrackers(runtime.default_context())
+        return self._trackers_backend
+
+    def __call__(self, video, segmentation):
+        """Yield normalised tracks, shot after shot, in the reference's order (tracking.py:374-434)."""
+        every_x_frames = int(self.detect_every * video.frame_rate) if self.detect_every > 0.0 else 1
+        if every_x_frames < 1:
+            every_x_frames = 1
+        width, height = video.size
+        ratio = 1.0
+        if self.detect_min_size > 0.0:
+            ratio = min(1.0, self.detect_smallest / (self.detect_min_size * height))
+        old_frame_size = video.frame_size
+        frame_width, frame_height = int(width * ratio), int(height * ratio)
+        video.frame_size = (frame_width, frame_height)
+        segment_generator = get_segment_generator(segmentation)
+        segment_generator.send(None)
+        backend = self._backend()
+        cache, flags = [], []
+        for i, (t, frame) in enumerate(video):
+            segment = segment_generator.send(t)
+            if segment:
+                for track in self.process_shots([(cache, flags)], backend)[0]:
+                    yield self._normalize_track(track, frame_width, frame_height)
+                cache, flags = [], []
+            cache.append((t, frame))
+            flags.append(i % every_x_frames == 0)
+        for track in self.process_shots([(cache, flags)], backend)[0]:
+            yield self._normalize_track(track, frame_width, frame_height)
+        if self.detect_min_size > 0.0:
+            video.frame_size = old_frame_size
