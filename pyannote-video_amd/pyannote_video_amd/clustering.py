@@ -1,0 +1,84 @@
+"""Face clustering -- drop-in for `pyannote.video.face.clustering.FaceClustering` (reference clustering.py:49-148).
+
+Usage contract kept (clustering.py:130-134):
+    >>> clustering = FaceClustering()
+    >>> starting_point, features = clustering.model.preprocess(embedding)
+    >>> result = clustering(starting_point, features=features)
+
+The N x N `pdist` matrix (clustering.py:100-101), the T x T block means (:104-112) and the agglomeration loop of
+pyannote.algorithms' HierarchicalAgglomerativeClustering run on the GPU (pvf_cluster_tracks)."""
+import numpy as np
+from ._core import Segment, Annotation
+from . import runtime
+from . import formats
+
+
+class Features(object):
+    """what `preprocess` returns as `data` (a DataFrame in the reference): rows sorted by (track, time)"""
+
+    def __init__(self, time, track, X):
+        order = np.lexsort((time, track))
+        self.time, self.track, self.X = time[order], track[order], np.ascontiguousarray(X[order])
+
+    def __len__(self):
+        return len(self.time)
+
+
+class _Model(object):
+    """Average Euclidean distance between face embeddings (reference _Model, clustering.py:49-119)"""
+
+    def preprocess(self, embedding):
+        """embedding: path of embedding.txt, or a (time, track, X) triple already in memory"""
+        if isinstance(embedding, str):
+            time, track, X = formats.read_embeddings(embedding)
+        else:
+            time, track, X = embedding
+        data = Features(np.asarray(time, np.float64), np.asarray(track, np.int64), np.asarray(X, np.float64))
+        starting_point = Annotation(modality='face')
+        for trk in np.unique(data.track):
+            t = data.time[data.track == trk]
+            segment = Segment(np.min(t), np.max(t))
+            if not segment:          # single-timestamp tracks are skipped (clustering.py:78-79)
+                continue
+            starting_point[segment, int(trk)] = int(trk)
+        return starting_point, data
+
+
+class FaceClustering(object):
+    """Face clustering
+
+    Parameters
+    ----------
+    threshold : float, optional    stop merging when the closest pair's mean distance exceeds it. Defaults to 0.6.
+    force : bool, optional         (reference: keep the violating merge) -- not supported, must stay False
+    """
+
+    def __init__(self, threshold=0.6, force=False, logger=None, ctx=None):
+        if force:
+            raise NotImplementedError("force=True is not on the reference's documented path")
+        self.threshold = threshold
+        self.model = _Model()
+        self.ctx = ctx
+        self.logger = logger
+        self.history = None
+
+    def cluster_arrays(self, track_ids, row_track, X):
+        """labels for `track_ids` (sorted unique ints) given per-row track ids; X float64 [N, dim]"""
+        ctx = self.ctx or runtime.default_context()
+        order = np.argsort(row_track, kind="stable")
+        keep = np.isin(row_track[order], track_ids)
+        rows = order[keep]
+        rt = row_track[rows]
+        Xs = np.ascontiguousarray(X[rows], np.float64)
+        counts = np.array([(rt == t).sum() for t in track_ids], np.int64)
+        row_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        labels, log = ctx.cluster_tracks(Xs, row_start, self.threshold)
+        self.history = [(int(track_ids[int(a)]), int(track_ids[int(b)]), float(d)) for a, b, d, _ in log]
+        return [int(track_ids[int(l)]) for l in labels]
+
+    def __call__(self, starting_point, features=None):
+        tracks = sorted(set(label for _, _, label in starting_point.itertracks(yield_label=True)))
+        if not tracks:
+            return starting_point.copy()
+        labels = self.cluster_arrays(np.asarray(tracks, np.int64), features.track, features.X)
+        return starting_point.rename_labels(dict(zip(tracks, labels)))

@@ -1,0 +1,69 @@
+"""Multi-GPU: one process per GPU; a long video is cut into contiguous frame ranges at shot boundaries, every rank runs
+detect -> track -> extract on its range with no data-path collective, then ONE exchange step: an all-gather of the
+per-rank (time, track id, 128-D embedding) rows over RCCL/xGMI, followed by a single global clustering.
+
+Track ids: the reference numbers tracks in yield order over the whole video (pyannote-face.py:261) and tracks never span
+shots (tracking.py:359-362,410-417), so global id = local id + exclusive prefix sum of the per-rank track counts."""
+import numpy as np
+
+
+def shard_shots(shot_ranges, world_size):
+    """Contiguous groups of shots per rank, balancing frame counts greedily. shot_ranges: [(i0, i1)]. -> [(s0, s1)] per rank"""
+    n = len(shot_ranges)
+    total = sum(b - a for a, b in shot_ranges)
+    out, s = [], 0
+    acc = 0
+    for r in range(world_size):
+        if r == world_size - 1:
+            out.append((s, n))
+            break
+        target = total * (r + 1) / float(world_size)
+        e = s
+        while e < n - (world_size - 1 - r) and (acc + (shot_ranges[e][1] - shot_ranges[e][0]) <= target or e == s):
+            acc += shot_ranges[e][1] - shot_ranges[e][0]
+            e += 1
+        out.append((s, e))
+        s = e
+    return out
+
+
+def gather_rows(face_T, face_id, X, n_tracks, device=None):
+    """All-gather variable-length rows from every rank.  Returns (T, id_global, X) concatenated in rank order and the
+    per-rank track offsets.  Uses torch.distributed (backend nccl == RCCL on ROCm, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return np.asarray(face_T, np.float64), np.asarray(face_id, np.int64), np.asarray(X, np.float64), [0]
+    world = dist.get_world_size()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    counts = torch.tensor([len(face_T), int(n_tracks)], dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(allc, counts)
+    rows = [int(c[0]) for c in allc]
+    tracks = [int(c[1]) for c in allc]
+    offsets = [0]
+    for k in tracks[:-1]:
+        offsets.append(offsets[-1] + k)
+    cap = max(max(rows), 1)
+    # one padded payload per rank: [cap, 130] float64 = (T, local id, 128 values); <= 32 MB/rank even at 3e4 rows
+    pay = torch.zeros((cap, 130), dtype=torch.float64, device=dev)
+    if len(face_T):
+        loc = np.concatenate([np.asarray(face_T, np.float64)[:, None], np.asarray(face_id, np.float64)[:, None],
+                              np.asarray(X, np.float64)], axis=1)
+        pay[:len(face_T)] = torch.from_numpy(loc).to(dev)
+    allp = [torch.zeros_like(pay) for _ in range(world)]
+    dist.all_gather(allp, pay)
+    Ts, ids, Xs = [], [], []
+    for r in range(world):
+        a = allp[r][:rows[r]].cpu().numpy()
+        Ts.append(a[:, 0]); ids.append(a[:, 1].astype(np.int64) + offsets[r]); Xs.append(a[:, 2:])
+    return np.concatenate(Ts), np.concatenate(ids), np.ascontiguousarray(np.concatenate(Xs)), offsets
+
+
+def global_cluster(clustering, face_T, face_id, X):
+    """single global clustering on the gathered rows (computed identically on every rank)"""
+    if len(face_T) == 0:
+        return {}
+    sp, data = clustering.model.preprocess((face_T, face_id, X))
+    res = clustering(sp, features=data)
+    return {int(track): int(label) for _, track, label in res.itertracks(yield_label=True)}

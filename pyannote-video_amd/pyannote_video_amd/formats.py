@@ -1,0 +1,76 @@
+"""On-disk formats that couple the reference's stages (scripts/pyannote-face.py).  Byte-compatible writers and the
+parsing rules that decide integer outputs downstream:
+
+  track.txt      "{t:.3f} {identifier:d} {left:.3f} {top:.3f} {right:.3f} {bottom:.3f} {status:s}\\n"  (:116-118,263-267)
+  landmarks.txt  "{t:.3f} {identifier:d}" + 68 x " {x/w:.5f} {y/h:.5f}"                                 (:299-305)
+  embedding.txt  "{t:.3f} {identifier:d}" + 128 x " {x:.5f}"                                            (:307-311)
+
+`quantise_track_box` is the in-memory equivalent of writing a box to track.txt and reading it back in `extract`
+(float32 parse :125-127, multiply by the frame size, int() truncation :142-145)."""
+import numpy as np
+
+FACE_TEMPLATE = ('{t:.3f} {identifier:d} '
+                 '{left:.3f} {top:.3f} {right:.3f} {bottom:.3f} '
+                 '{status:s}\n')
+
+
+def track_lines(identifier, track):
+    for t, (left, top, right, bottom), status in track:
+        yield FACE_TEMPLATE.format(t=t, identifier=identifier, status=status, left=left, right=right, top=top, bottom=bottom)
+
+
+def write_tracks(path, tracks):
+    """tracks: iterable of normalised tracks in yield order; the track id is the enumeration index (:261)"""
+    with open(path, 'w') as f:
+        for identifier, track in enumerate(tracks):
+            for line in track_lines(identifier, track):
+                f.write(line)
+            f.flush()
+
+
+def quantise_track_box(box, frame_width, frame_height):
+    """(l,t,r,b) normalised -> integer pixel rectangle exactly as `extract` rebuilds it from track.txt"""
+    q = [np.float32("%.3f" % v) for v in box]
+    return (int(q[0] * frame_width), int(q[1] * frame_height), int(q[2] * frame_width), int(q[3] * frame_height))
+
+
+def quantise_time(t):
+    return float("%.3f" % t)
+
+
+def read_tracks(path):
+    """[(T, identifier, (l,t,r,b) float32 normalised, status)] sorted by time (stable), like getFaceGenerator (:121-130)"""
+    rows = []
+    with open(path) as f:
+        for line in f:
+            p = line.split()
+            if not p:
+                continue
+            rows.append((float(p[0]), int(p[1]), tuple(np.float32(v) for v in p[2:6]), p[6]))
+    rows.sort(key=lambda r: r[0])   # pandas sort_values('t') default quicksort is not stable; ties keep file order here
+    return rows
+
+
+def landmark_line(T, identifier, pts, frame_width, frame_height):
+    s = '{t:.3f} {identifier:d}'.format(t=T, identifier=identifier)
+    for x, y in pts:
+        s += ' {x:.5f} {y:.5f}'.format(x=int(x) / frame_width, y=int(y) / frame_height)
+    return s + '\n'
+
+
+def embedding_line(T, identifier, embedding):
+    s = '{t:.3f} {identifier:d}'.format(t=T, identifier=identifier)
+    for x in embedding:
+        s += ' {x:.5f}'.format(x=float(x))
+    return s + '\n'
+
+
+def quantise_embedding(embedding):
+    """float64 values as `preprocess` reads them back from the 5-decimal text (clustering.py:70-74)"""
+    return np.array([float('{x:.5f}'.format(x=float(x))) for x in embedding], np.float64)
+
+
+def read_embeddings(path):
+    """-> (time[N], track[N] int, X float64 [N,128]) in file order"""
+    data = np.loadtxt(path, dtype=np.float64, ndmin=2)
+    return data[:, 0], data[:, 1].astype(np.int64), np.ascontiguousarray(data[:, 2:])

@@ -247,3 +247,28 @@ class SyntheticVideo(object):
         oy, ox = self._noise_off[i]
         out = img.astype(np.int16) + self._noise[oy:oy + h, ox:ox + w]
         return np.ascontiguousarray(np.clip(out, 0, 255).astype(np.uint8))
+
+    # ---- HBM-resident generation (bench): identical bytes to frame(i), integer ops only on the device ------------------
+    def frames_torch(self, device, indices=None):
+        """uint8 tensor [n, H, W, 3] on `device`, bit-identical to np.stack([self.frame(i)]).  The per-face alpha blend
+        is done on the host on the small patch (float32, same expression as frame()); the full-frame work (background copy,
+        paste, noise add, clamp) is int16 arithmetic on the device."""
+        import torch
+        w, h = self._size
+        idx = list(range(self.n_frames)) if indices is None else list(indices)
+        out = torch.empty((len(idx), h, w, 3), dtype=torch.uint8, device=device)
+        bg_dev = [torch.from_numpy(b).to(device) for b in self._bg]
+        noise_dev = torch.from_numpy(self._noise).to(device)
+        for n, i in enumerate(idx):
+            k = self.shot_of(i)
+            img = bg_dev[k].clone()
+            bg = self._bg[k]
+            for l, t, rgb, a in self.paste_list(i):
+                s = rgb.shape[0]
+                sub = bg[t:t + s, l:l + s].astype(np.float32)
+                patch = np.rint(rgb * a + sub * (1 - a)).astype(np.int16)
+                img[t:t + s, l:l + s] = torch.from_numpy(patch).to(device)
+            oy, ox = self._noise_off[i]
+            img = img + noise_dev[oy:oy + h, ox:ox + w]
+            out[n] = img.clamp_(0, 255).to(torch.uint8)
+        return out

@@ -1,0 +1,64 @@
+"""GPU: the whole flow (detect -> track fwd/bwd -> landmarks -> embed -> cluster) through the product pipeline against the
+sequential CPU oracle flow on the same synthetic clip.  Track boxes / ids / statuses, landmarks and cluster labels are
+compared exactly; embeddings within L2 1e-4."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipeline_matches_oracle_flow(ctx, oracle, small_video, model_paths):
+    from pyannote_video_amd import models, pipeline
+    from oracle import ref_flow
+    v = small_video
+    frames_np = [v.frame(i) for i in range(v.n_frames)]
+    times = [v.timestamp(i) for i in range(v.n_frames)]
+    pipe = pipeline.FacePipeline(ctx, model_paths[0], model_paths[1], detect_batch_size=5)
+    res = pipe.run([ctx.upload(f) for f in frames_np], times, v.frame_rate, v.shots())
+
+    det = oracle.Detector(models.load_container(models.DEFAULT_DETECTOR))
+    sp = oracle.ShapePredictor(models.load_container(model_paths[0]))
+    emb = oracle.Embedder(models.load_container(model_paths[1]))
+    tabs = models.dsst_tables()
+    ref_tracks = ref_flow.track_video(frames_np, times, v.shots(), det, lambda: oracle.Tracker(tabs), v.frame_rate,
+                                      min_conf=10., ratio=0.5, max_gap=1.0)
+    assert len(ref_tracks) >= v.faces * v.n_shots
+    assert res["tracks"] == ref_tracks
+    lines = ref_flow.track_text(ref_tracks)
+    assert lines == [l.rstrip("\n") for i, tr in enumerate(res["tracks"]) for l in __import__("pyannote_video_amd").formats.track_lines(i, tr)]
+    got_pts = []
+    lm, em = ref_flow.extract(lines, frames_np, times, lambda f, b: got_pts.append(sp(f, b)) or got_pts[-1], emb)
+    assert len(got_pts) == len(res["landmarks"]) > 0
+    assert np.array_equal(np.stack(got_pts), res["landmarks"])
+    ref_e = np.array([[float(x) for x in line.split()[2:]] for line in em]).reshape(-1, 128)
+    assert np.linalg.norm(ref_e - res["embeddings"], axis=1).max() <= 1e-4 + 128 ** 0.5 * 5e-6   # text rounding of the reference side
+    assert [int(l.split()[1]) for l in em] == res["face_id"].tolist()
+    assert ref_flow.cluster(em, 0.6) == res["labels"]
+
+
+def test_reference_api_surface(ctx, small_video, model_paths):
+    """Face / FaceTracking / FaceClustering used the way scripts/pyannote-face.py uses them (:247-267, :281-311)"""
+    from pyannote_video_amd import Face, FaceTracking, FaceClustering
+    from pyannote_video_amd._core import Segment
+    from pyannote_video_amd import shim
+    v = small_video
+    tracking = FaceTracking(track_min_overlap_ratio=0.5, track_max_gap=1.0, ctx=ctx)
+    shots = [Segment(a, b) for a, b in v.shots()]
+    tracks = list(tracking(v, shots))
+    assert len(tracks) >= v.faces * v.n_shots
+    face = Face(landmarks=model_paths[0], embedding=model_paths[1], ctx=ctx)
+    rgb = v.frame(0)
+    faces = list(face.iterfaces(rgb))
+    assert len(faces) == v.faces and all(isinstance(f, shim.rectangle) for f in faces)
+    lms = face.get_landmarks(rgb, faces[0])
+    assert len(lms.parts()) == 68
+    e = list(face.get_embedding(rgb, lms))
+    assert len(e) == 128
+    triples = list(face(rgb, return_landmarks=True, return_embedding=True))
+    assert len(triples) == v.faces and np.allclose(list(triples[0][2]), e)
+    trk = shim.correlation_tracker(ctx)
+    trk.start_track(rgb, shim.drectangle(*[float(x) for x in faces[0].as_tuple()]))
+    conf = trk.update(v.frame(1))
+    pos = trk.get_position()
+    assert conf > 5 and pos.intersect(shim.drectangle(*faces[0].as_tuple())).area() > 0
+    ctx.unstage_all()

@@ -1,0 +1,156 @@
+"""CPU: the product's lock-step tracking state machine against the sequential restatement of the reference
+(oracle/ref_flow.py), with scripted detections and a scripted tracker plugged into the reference's own seams
+(detect_func: tracking.py:104,112,426; tracker object start_track/update/get_position: :203,231,250-251)."""
+import numpy as np
+import pytest
+from pyannote_video_amd.tracking_by_detection import TrackingByDetection, ObjectTrackers, get_segment_generator
+from pyannote_video_amd import formats, pipeline
+from pyannote_video_amd._core import Segment
+
+
+class ScriptFrame(object):
+    """stands for a frame: carries its index and the true boxes"""
+    def __init__(self, i, boxes, shape=(360, 640, 3)):
+        self.i, self.boxes, self.shape = i, boxes, shape
+
+
+class ScriptTracker(object):
+    """follows the nearest true box with a lag; confidence drops when nothing is near"""
+    def __init__(self):
+        self.box = None
+
+    def start_track(self, frame, box):
+        self.box = tuple(box.as_tuple() if hasattr(box, "as_tuple") else box)
+
+    def update(self, frame):
+        cx, cy = (self.box[0] + self.box[2]) / 2, (self.box[1] + self.box[3]) / 2
+        best, bd = None, 1e9
+        for b in frame.boxes:
+            d = abs((b[0] + b[2]) / 2 - cx) + abs((b[1] + b[3]) / 2 - cy)
+            if d < bd:
+                best, bd = b, d
+        if best is None or bd > 60:
+            return 3.0
+        self.box = tuple(0.5 * self.box[k] + 0.5 * best[k] + 0.25 * ((frame.i * 7 + k) % 3) for k in range(4))
+        return 12.0 + (frame.i % 5) - 0.05 * bd
+
+    def get_position(self):
+        class R(object):
+            def __init__(s, b): s.b = b
+            def left(s): return s.b[0]
+            def top(s): return s.b[1]
+            def right(s): return s.b[2]
+            def bottom(s): return s.b[3]
+            def __iter__(s): return iter(s.b)
+        return R(self.box)
+
+
+class RefTracker(ScriptTracker):
+    def get_position(self):
+        return self.box
+
+
+def scenario(seed, n=40, faces=3, p_miss=0.3, p_false=0.05):
+    rng = np.random.default_rng(seed)
+    frames, dets = [], []
+    pos = rng.uniform(60, 300, (faces, 2)); size = rng.uniform(40, 90, faces)
+    alive = [(int(rng.integers(0, n // 3)), int(rng.integers(2 * n // 3, n))) for _ in range(faces)]
+    for i in range(n):
+        pos += rng.normal(0, 2.0, pos.shape)
+        boxes = [tuple(int(round(v)) for v in (pos[k, 0] - size[k] / 2, pos[k, 1] - size[k] / 2, pos[k, 0] + size[k] / 2, pos[k, 1] + size[k] / 2))
+                 for k in range(faces) if alive[k][0] <= i <= alive[k][1]]
+        d = [b for b in boxes if rng.random() > p_miss]
+        if rng.random() < p_false:
+            d.append((500, 20, 560, 80))
+        frames.append(ScriptFrame(i, boxes)); dets.append(d)
+    return frames, dets
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("params", [dict(ratio=0.3, gap=0.0), dict(ratio=0.5, gap=1.0)])
+def test_shot_tracks_equal_sequential_reference(seed, params):
+    from oracle import ref_flow
+    frames, dets = scenario(seed)
+    times = [i / 25.0 for i in range(len(frames))]
+    cache = list(zip(times, frames))
+    det_of = {id(f): d for f, d in zip(frames, dets)}
+    tbd = TrackingByDetection(detect_func=lambda f: det_of[id(f)], track_min_overlap_ratio=params["ratio"], track_max_gap=params["gap"],
+                              trackers=ObjectTrackers(ScriptTracker))
+    got = tbd.process_shots([(cache, [True] * len(cache))], tbd._backend())[0]
+    ref = ref_flow.track_shot(cache, dets, RefTracker, 10., params["ratio"], params["gap"])
+    assert got == ref
+    assert len(got) >= 1
+
+
+def test_several_shots_in_lockstep_equal_one_by_one():
+    shots, refs = [], []
+    from oracle import ref_flow
+    for seed in (11, 12, 13):
+        frames, dets = scenario(seed, n=25 + seed)
+        times = [100 * seed + i / 25.0 for i in range(len(frames))]
+        cache = list(zip(times, frames))
+        shots.append((cache, dets))
+        refs.append(ref_flow.track_shot(cache, dets, RefTracker, 10., 0.5, 1.0))
+    table = {id(f): d for cache, dets in shots for (_, f), d in zip(cache, dets)}
+    tbd = TrackingByDetection(detect_func=lambda f: table[id(f)], track_min_overlap_ratio=0.5, track_max_gap=1.0,
+                              trackers=ObjectTrackers(ScriptTracker))
+    got = tbd.process_shots([(cache, [True] * len(cache)) for cache, _ in shots], tbd._backend())
+    assert got == refs
+
+
+class ScriptVideo(object):
+    def __init__(self, frames, fps=25.0, size=(640, 360)):
+        self.frames, self.frame_rate, self.size, self.frame_size = frames, fps, size, size
+
+    def __iter__(self):
+        for i, f in enumerate(self.frames):
+            yield i / self.frame_rate, f
+
+
+@pytest.mark.parametrize("every", [0.0, 0.2])
+def test_call_contract_shots_and_detect_every(every):
+    from oracle import ref_flow
+    frames, dets = scenario(21, n=60)
+    det_of = {id(f): d for f, d in zip(frames, dets)}
+    shots = [Segment(0, 0.8), Segment(0.8, 1.64), Segment(1.64, 2.4)]
+    tbd = TrackingByDetection(detect_func=lambda f: det_of[id(f)], detect_every=every, track_min_overlap_ratio=0.5, track_max_gap=1.0,
+                              trackers=ObjectTrackers(ScriptTracker))
+    got = list(tbd(ScriptVideo(frames), shots))
+    times = [i / 25.0 for i in range(len(frames))]
+    ref = ref_flow.track_video(frames, times, [(s.start, s.end) for s in shots], lambda f: det_of[id(f)], RefTracker, 25.0,
+                               detect_every=every, min_conf=10., ratio=0.5, max_gap=1.0)
+    assert got == ref
+    # a frame exactly at a segment end belongs to the next shot (tracking.py:44-58,406-417)
+    assert pipeline.split_into_shots(times, [(s.start, s.end) for s in shots]) == [(0, 20), (20, 41), (41, 60)]
+
+
+def test_extract_time_sync_equals_reference_generator():
+    from oracle import ref_flow
+    rng = np.random.default_rng(3)
+    for fps in (25.0, 50.0, 23.976):
+        times = [i / fps for i in range(40)]
+        tracks = []
+        for ident in range(4):
+            a, b = sorted(rng.integers(0, 40, 2))
+            tracks.append([(times[i], tuple(rng.uniform(0.1, 0.9, 4)), 'detection') for i in range(a, b + 1)])
+        lines = ref_flow.track_text(tracks)
+        frames = [np.zeros((100, 200, 3), np.uint8)] * 40
+        seen = []
+        ref_flow.extract(lines, frames, times, lambda f, box: seen.append(box) or np.zeros((68, 2), int), lambda f, p: np.zeros(128))
+        rows = []
+        for identifier, track in enumerate(tracks):
+            for t, box, status in track:
+                rows.append((formats.quantise_time(t), identifier, tuple(np.float32("%.3f" % v) for v in box), status))
+        rows.sort(key=lambda r: r[0])
+        got = [box for _, _, g in pipeline.faces_per_frame(rows, times, 200, 100) for _, box in g]
+        assert got == seen
+
+
+def test_text_quantisation_helpers():
+    rng = np.random.default_rng(4)
+    e = rng.normal(0, 0.3, 4096).astype(np.float32)
+    assert np.array_equal(np.round(e.astype(np.float64), 5), formats.quantise_embedding(e))
+    box = (0.123456, 0.5, 0.987654, 0.75)
+    line = list(formats.track_lines(3, [(1.23456, box, 'detection')]))[0]
+    assert line == '1.235 3 0.123 0.500 0.988 0.750 detection\n'
+    assert formats.quantise_track_box(box, 1920, 1080) == (int(np.float32('0.123') * 1920), 540, int(np.float32('0.988') * 1920), 810)

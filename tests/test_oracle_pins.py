@@ -1,0 +1,137 @@
+"""CPU: pin the oracle against independent implementations available in this container
+(numpy FHOG, torch conv, numpy FFT, scipy pdist / linear_sum_assignment).  The reference itself ships no vectors."""
+import math
+import numpy as np
+import pytest
+from scipy.optimize import linear_sum_assignment
+from scipy.spatial.distance import pdist, squareform
+
+
+def _img(rng, h, w):
+    from pyannote_video_amd import synth
+    v = synth.SyntheticVideo(width=w, height=h, n_frames=1, n_shots=1, faces=2, min_face=40, max_face=90, seed=int(rng.integers(1 << 30)))
+    return v.frame(0)
+
+
+def test_fhog_matches_numpy_restatement(oracle):
+    from tools.fit_detector import fhog_numpy
+    rng = np.random.default_rng(0)
+    for h, w in ((160, 200), (97, 131)):
+        img = _img(rng, h, w)
+        a = oracle.fhog(img, 8, 10, 10)
+        b = fhog_numpy(img, 8, 10, 10)
+        assert a.shape == b.shape
+        assert np.abs(a - b).max() < 2e-6
+
+
+def test_resize_matches_numpy_bilinear(oracle):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    oh, ow = 30, 44
+    out = oracle.resize_bilinear(img, oh, ow)
+    ys = np.arange(oh) * ((37 - 1) / (oh - 1.0)); xs = np.arange(ow) * ((53 - 1) / (ow - 1.0))
+    y0 = np.floor(ys).astype(int); x0 = np.floor(xs).astype(int)
+    y1 = np.minimum(y0 + 1, 36); x1 = np.minimum(x0 + 1, 52)
+    fy = (ys - y0)[:, None, None]; fx = (xs - x0)[None, :, None]
+    f = img.astype(np.float64)
+    ref = (1 - fy) * ((1 - fx) * f[y0][:, x0] + fx * f[y0][:, x1]) + fy * ((1 - fx) * f[y1][:, x0] + fx * f[y1][:, x1])
+    assert np.array_equal(out, (ref + 0.5).astype(np.uint8))
+
+
+def test_pyr_down2_is_binomial_filter(oracle):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (31, 41, 3), dtype=np.uint8)
+    out = oracle.pyr_down2(img)
+    k = np.array([1, 4, 6, 4, 1])
+    assert out.shape == ((31 - 3) // 2, (41 - 3) // 2, 3)
+    for r in (0, 5, out.shape[0] - 1):
+        for c in (0, 7, out.shape[1] - 1):
+            win = img[2 * r:2 * r + 5, 2 * c:2 * c + 5].astype(np.int64)
+            ref = (k[:, None, None] * k[None, :, None] * win).sum((0, 1)) // 256
+            assert np.array_equal(out[r, c], ref)
+
+
+def test_resnet_matches_torch(oracle, model_paths):
+    from pyannote_video_amd import models
+    import torch_ref
+    m = models.load_container(model_paths[1])
+    emb = oracle.Embedder(m)
+    rng = np.random.default_rng(3)
+    chip = rng.integers(0, 256, (150, 150, 3), dtype=np.uint8)
+    a = emb.forward(chip)
+    b = torch_ref.forward(chip, models.split_resnet_blob(m["emb.blob"]), models.RESNET_UNITS)
+    assert np.linalg.norm(a - b) < 1e-4 * max(1.0, np.linalg.norm(b))
+
+
+def test_fft_and_exp(oracle):
+    from pyannote_video_amd import models
+    rng = np.random.default_rng(4)
+    t = models.dsst_tables()
+    x = rng.normal(size=(64, 64, 2))
+    f = oracle.fft64x64(x, t["tw64"])
+    ref = np.fft.fft2(x[..., 0] + 1j * x[..., 1])
+    assert np.abs(f[..., 0] + 1j * f[..., 1] - ref).max() < 1e-10
+    back = oracle.fft64x64(f, t["tw64"], inverse=True)
+    assert np.abs(back - x).max() < 1e-13
+    for v in (-0.0, -0.1, -1.0, -3.3333, -7.5, -20.0, 0.25, 0.0039):
+        assert abs(oracle.det_exp(v) - math.exp(v)) <= 4e-16 * math.exp(v)
+
+
+def test_pair_mean_dist_matches_scipy(oracle):
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(1, 7, 15)
+    X = np.round(rng.normal(size=(sizes.sum(), 128)) * 0.1, 5)
+    rs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    D = oracle.pair_mean_dist(X, rs)
+    full = squareform(pdist(X, metric='euclidean'))
+    for i in range(15):
+        for j in range(15):
+            if i != j:
+                assert abs(D[i, j] - full[rs[i]:rs[i + 1], rs[j]:rs[j + 1]].mean()) < 1e-13
+
+
+def test_munkres_is_optimal_and_matches_product_host_code(oracle):
+    from pyannote_video_amd import _lib
+    rng = np.random.default_rng(6)
+    for n in (1, 2, 3, 5, 8, 13):
+        for rep in range(6):
+            c = rng.integers(0, 6, (n, n)).astype(np.float64) if rep % 2 else rng.random((n, n))
+            a = oracle.munkres(c)
+            b = _lib.munkres(c)
+            assert a == b
+            r, col = linear_sum_assignment(c)
+            assert abs(sum(c[i, j] for i, j in a) - c[r, col].sum()) < 1e-12
+            assert sorted(j for _, j in a) == list(range(n))
+
+
+def test_overlap_matrix_host_equals_oracle(oracle):
+    from pyannote_video_amd import _lib
+    rng = np.random.default_rng(7)
+    a = rng.uniform(0, 100, (6, 4)); a[:, 2:] += a[:, :2]
+    b = rng.uniform(0, 100, (4, 4)); b[:, 2:] += b[:, :2]
+    b[0] = a[0]
+    for ratio in (0.3, 0.5):
+        assert np.array_equal(_lib.overlap_matrix(a, b, ratio), oracle.overlap_matrix(a, b, ratio))
+    assert _lib.overlap_matrix(a, b, 0.3)[0, 0] == (a[0, 2] - a[0, 0]) * (a[0, 3] - a[0, 1])
+
+
+def test_hac_matches_numpy_restatement(oracle):
+    from oracle import ref_flow
+    rng = np.random.default_rng(8)
+    K, T = 5, 24
+    centres = rng.normal(size=(K, 128)); centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    lines, sizes, rows = [], [], []
+    for t in range(T):
+        n = int(rng.integers(2, 6))
+        sizes.append(n)
+        x = centres[t % K] + 0.05 * rng.normal(size=(n, 128))
+        x = 0.55 * x / np.linalg.norm(x, axis=1, keepdims=True)
+        for k in range(n):
+            lines.append('%.3f %d' % (t + 0.04 * k, t) + ''.join(' %.5f' % v for v in x[k]))
+            rows.append(np.array([float('%.5f' % v) for v in x[k]]))
+    ref = ref_flow.cluster(lines, 0.6)
+    X = np.array(rows)
+    rs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    labels, _ = oracle.hac(oracle.pair_mean_dist(X, rs), sizes, 0.6)
+    assert {t: int(labels[t]) for t in range(T)} == ref
+    assert len(set(ref.values())) == K
