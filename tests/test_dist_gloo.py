@@ -1,0 +1,60 @@
+"""CPU, world_size 2 over gloo: the one exchange step of the multi-GPU path (all-gather of per-rank embedding rows with
+global track-id offsets) and the shard planner.  Rendezvous on 127.0.0.1."""
+import os
+import sys
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "pyannote-video_amd"))
+import torch.distributed as dist
+from pyannote_video_amd import dist as pd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(100 + rank)
+n_tracks = 3 + rank
+rows = 5 + 2 * rank
+T = rng.random(rows) + 10 * rank
+ids = rng.integers(0, n_tracks, rows)
+X = np.round(rng.normal(size=(rows, 128)), 5)
+gT, gid, gX, offsets = pd.gather_rows(T, ids, X, n_tracks)
+out = {"rank": rank, "n": int(len(gT)), "offsets": offsets, "ids": gid.tolist(), "sumX": float(gX.sum()), "T0": float(gT[0]), "Tlast": float(gT[-1])}
+open(sys.argv[2] + ".%d" % rank, "w").write(json.dumps(out))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_gather_rows_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = str(tmp_path / "out")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29613", str(script), ROOT, out], env=env, timeout=240)
+    import json
+    r0, r1 = (json.loads(open(out + ".%d" % r).read()) for r in (0, 1))
+    assert r0["n"] == r1["n"] == 5 + 7
+    assert r0["offsets"] == r1["offsets"] == [0, 3]
+    assert r0["ids"] == r1["ids"]                       # every rank sees the same global rows, rank order
+    assert max(r0["ids"][:5]) < 3 and min(r0["ids"][5:]) >= 3
+    assert abs(r0["sumX"] - r1["sumX"]) < 1e-9
+    rng0, rng1 = np.random.default_rng(100), np.random.default_rng(101)
+    t0 = rng0.random(5); t1 = rng1.random(7) + 10
+    assert r0["T0"] == t0[0] and r0["Tlast"] == t1[-1]
+
+
+def test_shard_planner_contiguous_and_balanced():
+    from pyannote_video_amd import dist as pd
+    shots = [(i * 250, (i + 1) * 250) for i in range(32)]
+    plan = pd.shard_shots(shots, 8)
+    assert plan[0][0] == 0 and plan[-1][1] == 32
+    assert all(a[1] == b[0] for a, b in zip(plan, plan[1:]))
+    assert all(e - s == 4 for s, e in plan)
+    uneven = [(0, 100), (100, 900), (900, 1000), (1000, 1100), (1100, 2000)]
+    plan = pd.shard_shots(uneven, 2)
+    assert plan == [(0, 3), (3, 5)] or plan == [(0, 2), (2, 5)]
+    assert all(e > s for s, e in pd.shard_shots(shots[:3], 3))
