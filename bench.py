@@ -94,8 +94,18 @@ def main():
     barrier()
     t0 = time.perf_counter()
     last = None
+    prof_path = os.environ.get("PVF_PYPROF")
+    if prof_path:
+        import cProfile
+        pr = cProfile.Profile()
+        pr.enable()
     for _ in range(args.steps):
         last = step()
+    if prof_path:
+        pr.disable()
+        import pstats
+        with open(prof_path, "w") as f:
+            pstats.Stats(pr, stream=f).sort_stats("cumulative").print_stats(45)
     barrier()
     elapsed = time.perf_counter() - t0
     ctx.prof_enable(False)

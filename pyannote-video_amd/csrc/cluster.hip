@@ -15,22 +15,37 @@ __global__ void __launch_bounds__(256) transpose_k(const double* __restrict__ X,
     Xt[(size_t)k * N + a] = X[i];
 }
 
+// one block per row a: lanes sweep all rows b (dimension-major X => coalesced), distances of a 2048-row chunk sit in LDS,
+// then one lane per track continues that track's running sum over the chunk in row order (a single sequential chain).
+#define PD_CHUNK 2048
 __global__ void __launch_bounds__(256) row_track_sums_k(const double* __restrict__ X, const double* __restrict__ Xt, int N, int dim,
                                                         const int32_t* __restrict__ row_start, int T, double* __restrict__ S)
 {
-    extern __shared__ __attribute__((aligned(16))) double xa[]; // [dim]
-    const int a = blockIdx.y;
-    for (int k = threadIdx.x; k < dim; k += blockDim.x) xa[k] = X[(size_t)a * dim + k];
+    extern __shared__ __attribute__((aligned(16))) double sm[]; // xa[dim] + dist[PD_CHUNK]
+    double* xa = sm;
+    double* dist = sm + dim;
+    const int a = blockIdx.x, tid = threadIdx.x;
+    for (int k = tid; k < dim; k += 256) xa[k] = X[(size_t)a * dim + k];
+    for (int j = tid; j < T; j += 256) S[(size_t)a * T + j] = 0.0;
     __syncthreads();
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= T) return;
-    double sum = 0;
-    for (int b = row_start[j]; b < row_start[j + 1]; ++b) {
-        double s = 0;
-        for (int k = 0; k < dim; ++k) { const double d = xa[k] - Xt[(size_t)k * N + b]; s += d * d; }
-        sum += sqrt(s);
+    for (int c0 = 0; c0 < N; c0 += PD_CHUNK) {
+        const int c1 = min(c0 + PD_CHUNK, N);
+        for (int b = c0 + tid; b < c1; b += 256) {
+            double s = 0;
+            for (int k = 0; k < dim; ++k) { const double d = xa[k] - Xt[(size_t)k * N + b]; s += d * d; }
+            dist[b - c0] = sqrt(s);
+        }
+        __syncthreads();
+        for (int j = tid; j < T; j += 256) {
+            const int b0 = max(row_start[j], c0), b1 = min(row_start[j + 1], c1);
+            if (b0 < b1) {
+                double run = S[(size_t)a * T + j];
+                for (int b = b0; b < b1; ++b) run += dist[b - c0];
+                S[(size_t)a * T + j] = run;
+            }
+        }
+        __syncthreads();
     }
-    S[(size_t)a * T + j] = sum;
 }
 
 __global__ void __launch_bounds__(256) track_pair_mean_k(const double* __restrict__ S, const int32_t* __restrict__ row_start, int T,
@@ -65,7 +80,7 @@ void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* 
     {
         ProfScope ps(c, "pdist");
         hipLaunchKernelGGL(transpose_k, dim3((unsigned)(((size_t)N * dim + 255) / 256)), dim3(256), 0, c->stream, dX, N, dim, dXt);
-        hipLaunchKernelGGL(row_track_sums_k, dim3((T + 255) / 256, N), dim3(256), dim * sizeof(double), c->stream, dX, dXt, N, dim, dR, T, dS);
+        hipLaunchKernelGGL(row_track_sums_k, dim3(N), dim3(256), (dim + PD_CHUNK) * sizeof(double), c->stream, dX, dXt, N, dim, dR, T, dS);
         hipLaunchKernelGGL(track_pair_mean_k, dim3((T + 255) / 256, T), dim3(256), 0, c->stream, dS, dR, T, dD);
     }
     HIP_CHECK(hipGetLastError());

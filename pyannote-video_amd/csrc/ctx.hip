@@ -94,6 +94,22 @@ static void load_detector(Ctx* c, const char* path)
     for (int f = 0; f < d.n_filters; ++f)
         for (int i = 0; i < d.frows * d.fcols * 32; ++i) wt[(size_t)i * 8 + f] = w.f32()[(size_t)f * d.frows * d.fcols * 32 + i];
     d.d_wt = upload<float>(wt.data(), wt.size());
+    if (d.d_bmfma) { (void)hipFree(d.d_bmfma); d.d_bmfma = nullptr; }
+    if (d.n_filters == 5) {
+        // B fragments of score_mfma_k: index ((m*12 + n')*8 + pq)*64 + lane ; lane -> k = lane>>4 (plane 4pq+k), column j = lane&15 = 5*s + f
+        std::vector<float> bm((size_t)10 * 12 * 8 * 64, 0.0f);
+        for (int mm = 0; mm < 10; ++mm)
+            for (int np = 0; np < 12; ++np)
+                for (int pq = 0; pq < 8; ++pq)
+                    for (int l = 0; l < 64; ++l) {
+                        const int kq = l >> 4, j = l & 15, p = 4 * pq + kq;
+                        if (j >= 15 || p >= 31) continue;
+                        const int s = j / 5, f = j % 5, n = np - s;
+                        if (n < 0 || n >= 10) continue;
+                        bm[(((size_t)mm * 12 + np) * 8 + pq) * 64 + l] = w.f32()[(((size_t)f * 10 + mm) * 10 + n) * 32 + p];
+                    }
+        d.d_bmfma = upload<float>(bm.data(), bm.size());
+    }
     d.loaded = true;
 }
 

@@ -88,66 +88,75 @@ __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, co
     *bo = best_o;
 }
 
-// one block = TxT histogram cells; LDS holds the (T+1)C x (T+1)C pixel window (+1 px halo) and its (bin, magnitude)
-template <int C, int T>
-__global__ void __launch_bounds__(384) fhog_hist_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
-                                                   int visible_nc, float* __restrict__ hist, size_t hist_stride, int hr, int hc)
+// Pass 1: per pixel (orientation bin, gradient magnitude), written in a cell-blocked transposed layout so that pass 2's
+// lanes (= neighbouring cells) read consecutive addresses:  pixel (y,x) -> yy = y + 3C/2, xx = x + 3C/2,
+//   index = (yy * C + xx % C) * NBX + xx / C          (NBX = padded number of C-wide column blocks)
+// Histogram cell (hy,hx) receives votes from rows yy in [C*hy, C*hy + 2C) and column blocks hx, hx+1.
+template <int C>
+__global__ void __launch_bounds__(256) fhog_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
+                                                   int visible_nc, float* __restrict__ mag, uint8_t* __restrict__ bin, size_t px_stride,
+                                                   int rows_t, int nbx)
 {
-    constexpr int R = (T + 1) * C;      // window side in pixels
-    constexpr int RH = R + 2;           // with halo
-    __shared__ uint8_t s_img[RH][RH * 3 + 2];
-    __shared__ float s_v[R][R + 1];
-    __shared__ uint8_t s_o[R][R + 4];
-    const int b = blockIdx.z;
-    const int hy0 = blockIdx.y * T, hx0 = blockIdx.x * T;
-    const uint8_t* im = img + (size_t)b * img_stride;
-    const int py0 = C * hy0 - 3 * C / 2, px0 = C * hx0 - 3 * C / 2; // image coords of window pixel (0,0)
-    // stage bytes (zero outside the image)
-    for (int i = threadIdx.x; i < RH * RH * 3; i += blockDim.x) {
-        const int ry = i / (RH * 3), rb = i % (RH * 3);
-        const int y = py0 - 1 + ry, xb = (px0 - 1) * 3 + rb;
-        uint8_t v = 0;
-        if (y >= 0 && y < ih && xb >= 0 && xb < iw * 3) v = im[(size_t)y * iw * 3 + xb];
-        s_img[ry][rb] = v;
+    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y, b = blockIdx.z;
+    if (xx >= nbx * C || yy >= rows_t) return;
+    const int y = yy - 3 * C / 2, x = xx - 3 * C / 2;
+    float v = 0.0f;
+    int o = 0;
+    if (y >= 1 && y < visible_nr && x >= 1 && x < visible_nc) {
+        const uint8_t* im = img + (size_t)b * img_stride;
+        float v2;
+        pixel_grad(im + (size_t)(y - 1) * iw * 3, im + (size_t)y * iw * 3, im + (size_t)(y + 1) * iw * 3, x * 3, &v2, &o);
+        v = sqrtf(v2);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < R * R; i += blockDim.x) {
-        const int ly = i / R, lx = i % R;
-        const int y = py0 + ly, x = px0 + lx;
-        float v = 0.0f;
-        int o = 0;
-        if (y >= 1 && y < visible_nr && x >= 1 && x < visible_nc) {
-            float v2;
-            pixel_grad(&s_img[ly][0], &s_img[ly + 1][0], &s_img[ly + 2][0], (lx + 1) * 3, &v2, &o);
-            v = sqrtf(v2);
-        }
-        s_v[ly][lx] = v;
-        s_o[ly][lx] = (uint8_t)o;
-    }
-    __syncthreads();
-    // gather: work item = (cell, bin)
-    for (int item = threadIdx.x; item < T * T * 18; item += blockDim.x) {
-        const int cell = item / 18, bin = item % 18;
-        const int cy = cell / T, cx = cell % T;
-        const int hy = hy0 + cy, hx = hx0 + cx;
-        if (hy >= hr || hx >= hc) continue;
-        float acc = 0.0f;
+    const size_t idx = (size_t)b * px_stride + ((size_t)yy * C + (xx % C)) * nbx + (xx / C);
+    mag[idx] = v;
+    bin[idx] = (uint8_t)o;
+}
+
+// Pass 2: one lane per histogram cell walks its 2C x 2C window in row-major order (== the order dlib's scatter loop adds in),
+// adding each vote to the bin's running sum kept in LDS (acc[bin][lane]: conflict-free).  Also emits the cell energy.
+template <int C>
+__global__ void __launch_bounds__(256) fhog_hist_k(const float* __restrict__ mag, const uint8_t* __restrict__ bin, size_t px_stride, int nbx,
+                                                   float* __restrict__ hist, size_t hist_stride, int hr, int hc,
+                                                   float* __restrict__ norm, size_t norm_stride, int cells_nr, int cells_nc)
+{
+    __shared__ float acc[18][256];
+    const int hx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int hy = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int o = 0; o < 18; ++o) acc[o][tid] = 0.0f;
+    if (hx < hc) {
+        const float* mg = mag + (size_t)b * px_stride;
+        const uint8_t* bn = bin + (size_t)b * px_stride;
         for (int wy = 0; wy < 2 * C; ++wy) {
             const int i = wy % C;
             const float fy = ((float)i + 0.5f) / (float)C;
             const float wyv = (wy < C) ? fy : 1.0f - fy;
-            const int ly = cy * C + wy;
-#pragma unroll 4
+            const size_t row = ((size_t)(C * hy + wy) * C) * nbx;
+#pragma unroll
             for (int wx = 0; wx < 2 * C; ++wx) {
                 const int j = wx % C;
                 const float fx = ((float)j + 0.5f) / (float)C;
                 const float wxv = (wx < C) ? fx : 1.0f - fx;
-                const int lx = cx * C + wx;
-                const float contrib = (wyv * wxv) * s_v[ly][lx];
-                acc += (s_o[ly][lx] == bin) ? contrib : 0.0f;
+                const size_t idx = row + (size_t)j * nbx + hx + (wx / C);
+                const float v = mg[idx];
+                const int o = bn[idx];
+                acc[o][tid] = acc[o][tid] + (wyv * wxv) * v;
             }
         }
-        hist[(size_t)b * hist_stride + ((size_t)hy * hc + hx) * 18 + bin] = acc;
+        float* h = hist + (size_t)b * hist_stride + ((size_t)hy * hc + hx) * 18;
+        float e = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 9; ++o) {
+            const float a0 = acc[o][tid], a1 = acc[o + 9][tid];
+            h[o] = a0; h[o + 9] = a1;
+            const float s2 = a0 + a1;
+            e = e + s2 * s2;
+        }
+        if (hy >= 1 && hy <= cells_nr && hx >= 1 && hx <= cells_nc)
+            norm[(size_t)b * norm_stride + (size_t)(hy - 1) * cells_nc + (hx - 1)] = e;
     }
 }
 
@@ -282,6 +291,7 @@ void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw)
 
 void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat, DevBuf& hist, DevBuf& norm)
 {
+    DevBuf& grad = c->s_grad;
     int fh, fw;
     fhog_dims(h, w, cell, pad_r, pad_c, &fh, &fw);
     PVF_REQUIRE(fh > 0 && fw > 0, "fhog: image too small");
@@ -307,17 +317,23 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
     const size_t hist_stride = (size_t)hr * hc * 18, norm_stride = (size_t)cells_nr * cells_nc;
     hist.ensure(hist_stride * n * sizeof(float));
     norm.ensure(norm_stride * n * sizeof(float));
-    constexpr int T = 8;
-    dim3 gh((hc + T - 1) / T, (hr + T - 1) / T, n);
-    if (cell == 8)
-        hipLaunchKernelGGL((fhog_hist_k<8, T>), gh, dim3(384), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, hist.as<float>(),
-                           hist_stride, hr, hc);
-    else
-        hipLaunchKernelGGL((fhog_hist_k<4, T>), gh, dim3(384), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, hist.as<float>(),
-                           hist_stride, hr, hc);
-    dim3 gn((cells_nc + 255) / 256, cells_nr, n);
-    hipLaunchKernelGGL(fhog_norm_k, gn, dim3(256), 0, c->stream, hist.as<float>(), hist_stride, hc, norm.as<float>(), norm_stride, cells_nr,
-                       cells_nc);
+    // pass 1: (bin, magnitude) planes in the cell-blocked layout; pass 2: per-cell ordered accumulation + cell energy
+    const int rows_t = cell * (hr + 1), nbx = ((hc + 1) + 7) / 8 * 8;
+    const size_t px_stride = (size_t)rows_t * cell * nbx;
+    grad.ensure(px_stride * n * 5 + 256);
+    float* d_mag = grad.as<float>();
+    uint8_t* d_bin = grad.as<uint8_t>() + px_stride * n * 4;
+    dim3 gg((nbx * cell + 255) / 256, rows_t, n);
+    dim3 gh((hc + 255) / 256, hr, n);
+    if (cell == 8) {
+        hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, nbx);
+        hipLaunchKernelGGL((fhog_hist_k<8>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, nbx, hist.as<float>(), hist_stride, hr, hc,
+                           norm.as<float>(), norm_stride, cells_nr, cells_nc);
+    } else {
+        hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, nbx);
+        hipLaunchKernelGGL((fhog_hist_k<4>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, nbx, hist.as<float>(), hist_stride, hr, hc,
+                           norm.as<float>(), norm_stride, cells_nr, cells_nc);
+    }
     const int hog_nr = cells_nr - 2, hog_nc = cells_nc - 2;
     dim3 gf((hog_nc + 255) / 256, hog_nr, n);
     hipLaunchKernelGGL(fhog_feat_k, gf, dim3(256), 0, c->stream, hist.as<float>(), hist_stride, hc, norm.as<float>(), norm_stride, cells_nc,
@@ -403,6 +419,86 @@ __global__ void __launch_bounds__(256) score_k(const float* __restrict__ feat, s
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3 on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, same k-ordered fmaf chain as the VALU form).
+// N = 5 filters would use 5 of 16 MFMA columns, so three neighbouring output columns share one tile:
+//   column j = 5*s + f  (s = 0..2 shift, f = filter)  ->  15 of 16 columns carry work, K grows from 10 to 12 cells per row.
+//   A[i][k]  = F[r + m][c0 + 3 i + n'][p]          i = 16 window positions spaced 3 cells apart, k = (n', p), n' in [0,12)
+//   B[k][j]  = W[f][m][n' - s][p]  (0 outside the 10-cell filter row): zero terms are exact no-ops in the chain, the
+//   non-zero ones arrive in (m, n, p) order  =>  bit-identical to the oracle's chain.  Useful MACs / issued = 75.7 %.
+// One wave = one output row x 96 columns (two 16-position tiles); its feature row segment lives in a wave-private LDS slab
+// (34-float cell pitch: conflict-free ds_read_b32 for lanes 3 cells apart), B fragments stream from L2.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ feat, size_t feat_stride, int fh, int fw,
+                                                    const float* __restrict__ Bg, ScoreParams sp, int* __restrict__ counts,
+                                                    CandRec* __restrict__ cands)
+{
+    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11;
+    extern __shared__ __attribute__((aligned(16))) float s_seg[]; // [4 waves][SEG][PITCH]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int r_top = blockIdx.y * 4 + wave, c_base = blockIdx.x * WCOLS;
+    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
+    if (r_top + FR / 2 >= r1) return;               // wave-uniform
+    float* seg = s_seg + (size_t)wave * SEG * PITCH;
+    const float* fb = feat + (size_t)b * feat_stride;
+    const int i = lane & 15, kq = lane >> 4;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < FR; ++m) {
+        const int fr = r_top + m;
+        // stage SEG cells x 32 floats of feature row fr (zeros outside) into the slab
+        for (int idx = lane; idx < SEG * 8; idx += 64) {
+            const int cell = idx >> 3, q = idx & 7;
+            const int x = c_base + cell;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (fr < fh && x < fw) v = reinterpret_cast<const float4*>(fb + ((size_t)fr * fw + x) * PVF_FHOG_STRIDE)[q];
+            float2* d = reinterpret_cast<float2*>(seg + cell * PITCH + 4 * q);
+            d[0] = make_float2(v.x, v.y);
+            d[1] = make_float2(v.z, v.w);
+        }
+        const float* bp = Bg + (size_t)m * NK * 8 * 64 + lane;
+        const float* a0 = seg + (3 * i) * PITCH + kq;
+#pragma unroll 2
+        for (int n = 0; n < NK; ++n) {
+#pragma unroll
+            for (int pq = 0; pq < 8; ++pq) {
+                const float bv = bp[(n * 8 + pq) * 64];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const float av = a0[(t * 48 + n) * PITCH + 4 * pq];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout of the 16x16 MFMA: column j = lane & 15, row = 4 * (lane >> 4) + reg
+    const int j = lane & 15;
+    if (j < 15) {
+        const int s = j / 5, f = j % 5;
+        const float th = sp.thresh[f];
+        const int r = r_top + FR / 2;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int pos = 4 * (lane >> 4) + reg;
+                const int cc = c_base + t * 48 + 3 * pos + s + FC / 2;
+                const float v = acc[t][reg];
+                if (cc < c1 && v >= th) {
+                    const int idx = atomicAdd(&counts[b], 1);
+                    if (idx < sp.cap) {
+                        CandRec rec;
+                        rec.score = v - th; rec.filter = f; rec.level = sp.level; rec.r = r; rec.c = cc;
+                        cands[(size_t)b * sp.cap + idx] = rec;
+                    }
+                }
+            }
     }
 }
 
@@ -568,6 +664,12 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     }                                                                                                                        \
     hipLaunchKernelGGL((score_k<NF>), grid, dim3(256), lds, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_w, sp, \
                        d_counts, d_cands)
+            if (m.n_filters == 5 && m.d_bmfma) {
+                const size_t lds2 = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
+                dim3 g2((out_c + 95) / 96, (out_r + 3) / 4, B);
+                hipLaunchKernelGGL(score_mfma_k, g2, dim3(256), lds2, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_bmfma, sp,
+                                   d_counts, d_cands);
+            } else
             switch (m.n_filters) {
                 case 1: LAUNCH_SCORE(1); break;
                 case 2: LAUNCH_SCORE(2); break;

@@ -97,7 +97,8 @@ struct DetectorModel {
     double nms_iou = 0, nms_covered = 0;
     std::vector<float> thresh;
     float* d_w = nullptr;    // [nf][frows][fcols][32]
-    float* d_wt = nullptr;   // [frows][fcols][32][8] filter-minor copy for the scoring kernel
+    float* d_wt = nullptr;   // [frows][fcols][32][8] filter-minor copy (unused by the current kernels)
+    float* d_bmfma = nullptr; // [10][12][8][64] B fragments of score_mfma_k (3 shifts x 5 filters per 16-column tile)
 };
 
 struct ShapeModel {
@@ -179,7 +180,7 @@ struct Ctx {
     std::map<std::string, ProfFamily> prof;
     std::vector<hipEvent_t> event_pool;
     // scratch (grow only)
-    DevBuf s_pyr, s_hist, s_norm, s_feat, s_cand, s_misc, s_chip, s_chip_pyr, s_act0, s_act1, s_act2, s_trk0, s_trk1, s_trk2, s_clu0, s_clu1;
+    DevBuf s_grad, s_pyr, s_hist, s_norm, s_feat, s_cand, s_misc, s_chip, s_chip_pyr, s_act0, s_act1, s_act2, s_trk0, s_trk1, s_trk2, s_clu0, s_clu1;
     HostBuf h_cand, h_misc;
     int n_cu = 256;
 

@@ -162,7 +162,7 @@ def main():
         sn = neg @ w
         so = allpos @ w
         lo, hi = np.percentile(sn, 99.95), np.percentile(sp, 2.0)
-        th = lo + 0.45 * (hi - lo)
+        th = lo + 0.75 * (hi - lo)
         print("%-10s pos[min %.3f p2 %.3f med %.3f] neg[max %.3f p99.95 %.3f] other-pose med %.3f  -> thresh %.3f  miss %.1f%%" % (
             p, sp.min(), hi, np.median(sp), sn.max(), lo, np.median(so), th, 100.0 * (sp < th).mean()))
         W[k, :, :, :31] = w.reshape(10, 10, 31).astype(np.float32)
