@@ -81,16 +81,20 @@ def main():
         tm["cluster_s"] = time.perf_counter() - t0
         return res, labels, tm
 
+    ctxs = [ctx] + ([pipe.det_ctx] if pipe.det_ctx is not None else [])
+
     def barrier():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
 
     for _ in range(args.warmup):
         step()
-    ctx.prof_reset()
-    ctx.prof_enable(True)
+    for c in ctxs:
+        c.prof_reset()
+        c.prof_enable(True)
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -108,18 +112,28 @@ def main():
             pstats.Stats(pr, stream=f).sort_stats("cumulative").print_stats(45)
     barrier()
     elapsed = time.perf_counter() - t0
-    ctx.prof_enable(False)
+    for c in ctxs:
+        c.prof_enable(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     res, labels, tm = last
+    if os.environ.get("PVF_DUMP") and rank == 0:
+        ident_of_track = {}
+        np.savez_compressed(os.environ["PVF_DUMP"], X=res["X"], emb=res["embeddings"], face_id=res["face_id"], face_T=res["face_T"],
+                            boxes=np.array(res["face_boxes"]), labels=np.array(sorted(labels.items())),
+                            gt=np.array([[k, f, tr["ident"]] for k, shot in enumerate(video.tracks) for f, tr in enumerate(shot)]),
+                            track_first=np.array([[i, tr[0][0]] + list(tr[0][1]) for i, tr in enumerate(res["tracks"])]))
     total_frames = args.frames * world * args.steps
     fps = total_frames / elapsed
 
     fam = {}
     for name in ("pyramid", "fhog", "score", "chip", "ert", "conv", "dsst", "pdist", "hac"):
-        ms, n = ctx.prof_get(name)
+        ms, n = 0.0, 0
+        for c in ctxs:
+            a, b = c.prof_get(name)
+            ms += a; n += b
         fam[name] = {"ms": round(ms, 3), "launches": int(n)}
 
     if rank != 0:

@@ -53,6 +53,8 @@ int32_t pvf_frame_upload(pvf_handle ctx, const uint8_t* rgb, int32_t h, int32_t 
 /* wrap a frame that already lives in HBM (no copy; the caller keeps it alive until pvf_frame_release) */
 int32_t pvf_frame_wrap_device(pvf_handle ctx, const void* dev_rgb, int32_t h, int32_t w, pvf_handle* frame);
 int32_t pvf_frame_release(pvf_handle ctx, pvf_handle frame);
+/* device address of a staged frame (to share it with a second context on the same GPU, e.g. a detector stream) */
+int32_t pvf_frame_device_ptr(pvf_handle ctx, pvf_handle frame, const void** dev_rgb);
 
 /* ---- S1 detector ---------------------------------------------------------------------------------- */
 /* ref: face.py:64-67  for face in self.face_detector_(rgb, 1)  -> dlib.rectangle list, NMS order.

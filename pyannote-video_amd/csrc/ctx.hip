@@ -362,6 +362,14 @@ extern "C" int32_t pvf_frame_wrap_device(pvf_handle h, const void* dev, int32_t 
     API_END
 }
 
+extern "C" int32_t pvf_frame_device_ptr(pvf_handle h, pvf_handle frame, const void** dev)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    *dev = c->frame(frame).d;
+    API_END
+}
+
 extern "C" int32_t pvf_frame_release(pvf_handle h, pvf_handle frame)
 {
     API_BEGIN

@@ -88,36 +88,67 @@ __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, co
     *bo = best_o;
 }
 
-// Pass 1: per pixel (orientation bin, gradient magnitude), written in a cell-blocked transposed layout so that pass 2's
-// lanes (= neighbouring cells) read consecutive addresses:  pixel (y,x) -> yy = y + 3C/2, xx = x + 3C/2,
-//   index = (yy * C + xx % C) * NBX + xx / C          (NBX = padded number of C-wide column blocks)
-// Histogram cell (hy,hx) receives votes from rows yy in [C*hy, C*hy + 2C) and column blocks hx, hx+1.
+// Pass 1: per pixel (orientation bin, gradient magnitude) into planes shifted by 3C/2 so that histogram cell (hy,hx)
+// owns rows yy in [C*hy, C*hy+2C) and columns xx in [C*hx, C*hx+2C)  (yy = y + 3C/2, xx = x + 3C/2; pitch = multiple of 8 floats).
+// A block handles 128 x 8 pixels; the (8+2) x (128+2) RGB neighbourhood is staged in LDS with coalesced dword loads.
 template <int C>
 __global__ void __launch_bounds__(256) fhog_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
                                                    int visible_nc, float* __restrict__ mag, uint8_t* __restrict__ bin, size_t px_stride,
-                                                   int rows_t, int nbx)
+                                                   int rows_t, int pitch)
 {
-    const int xx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int yy = blockIdx.y, b = blockIdx.z;
-    if (xx >= nbx * C || yy >= rows_t) return;
-    const int y = yy - 3 * C / 2, x = xx - 3 * C / 2;
-    float v = 0.0f;
-    int o = 0;
-    if (y >= 1 && y < visible_nr && x >= 1 && x < visible_nc) {
-        const uint8_t* im = img + (size_t)b * img_stride;
-        float v2;
-        pixel_grad(im + (size_t)(y - 1) * iw * 3, im + (size_t)y * iw * 3, im + (size_t)(y + 1) * iw * 3, x * 3, &v2, &o);
-        v = sqrtf(v2);
+    constexpr int TW = 128, TH = 8, RB = (TW + 2) * 3, RD = (RB + 3 + 3) / 4 + 1; // bytes per staged row, dwords incl. alignment slack
+    __shared__ uint32_t s_raw[TH + 2][RD];
+    const int b = blockIdx.z;
+    const int xx0 = blockIdx.x * TW, yy0 = blockIdx.y * TH;
+    const int x0 = xx0 - 3 * C / 2, y0 = yy0 - 3 * C / 2;      // image coords of the tile's first pixel
+    const uint8_t* im = img + (size_t)b * img_stride;
+    const long row_bytes = (long)iw * 3;
+    // stage rows y0-1 .. y0+TH, bytes [(x0-1)*3, (x0+TW+1)*3) ; dword-aligned window per row (global address % 4 kept)
+    for (int i = threadIdx.x; i < (TH + 2) * RD; i += blockDim.x) {
+        const int ry = i / RD, d = i % RD;
+        const int y = y0 - 1 + ry;
+        uint32_t v = 0;
+        if (y >= 0 && y < ih) {
+            const long start = (long)y * row_bytes + (long)(x0 - 1) * 3;      // may be negative / unaligned
+            const long a0 = (start >= 0 ? (start & ~3L) : -((-start + 3) & ~3L)); // floor to multiple of 4
+            const long off = a0 + 4L * d;
+            const long lo = (long)y * row_bytes, hi = lo + row_bytes;          // valid byte range of this row
+            if (off >= lo && off + 4 <= hi && off + 4 <= (long)ih * row_bytes) v = *reinterpret_cast<const uint32_t*>(im + off);
+            else {
+                for (int k = 0; k < 4; ++k) { const long o = off + k; if (o >= lo && o < hi) v |= (uint32_t)im[o] << (8 * k); }
+            }
+        }
+        s_raw[ry][d] = v;
     }
-    const size_t idx = (size_t)b * px_stride + ((size_t)yy * C + (xx % C)) * nbx + (xx / C);
-    mag[idx] = v;
-    bin[idx] = (uint8_t)o;
+    __syncthreads();
+    for (int p = threadIdx.x; p < TW * TH; p += blockDim.x) {
+        const int ly = p / TW, lx = p % TW;
+        const int xx = xx0 + lx, yy = yy0 + ly;
+        if (xx >= pitch || yy >= rows_t) continue;
+        const int y = y0 + ly, x = x0 + lx;
+        float v = 0.0f;
+        int o = 0;
+        if (y >= 1 && y < visible_nr && x >= 1 && x < visible_nc) {
+            // byte offset of pixel (x-1) within the staged row = ((y*row_bytes + (x0-1)*3) mod 4) + lx*3
+            const long start_c = (long)y * row_bytes + (long)(x0 - 1) * 3;
+            const long start_u = start_c - row_bytes, start_d = start_c + row_bytes;
+            const uint8_t* rc = reinterpret_cast<const uint8_t*>(&s_raw[ly + 1][0]) + (int)(((start_c % 4) + 4) % 4) + lx * 3;
+            const uint8_t* ru = reinterpret_cast<const uint8_t*>(&s_raw[ly][0]) + (int)(((start_u % 4) + 4) % 4) + lx * 3;
+            const uint8_t* rd = reinterpret_cast<const uint8_t*>(&s_raw[ly + 2][0]) + (int)(((start_d % 4) + 4) % 4) + lx * 3;
+            float v2;
+            pixel_grad(ru, rc, rd, 3, &v2, &o);
+            v = sqrtf(v2);
+        }
+        const size_t idx = (size_t)b * px_stride + (size_t)yy * pitch + xx;
+        mag[idx] = v;
+        bin[idx] = (uint8_t)o;
+    }
 }
 
 // Pass 2: one lane per histogram cell walks its 2C x 2C window in row-major order (== the order dlib's scatter loop adds in),
-// adding each vote to the bin's running sum kept in LDS (acc[bin][lane]: conflict-free).  Also emits the cell energy.
+// adding each vote to the bin's running sum kept in LDS (acc[bin][lane]: conflict-free).  Rows are read with 16-byte loads.
 template <int C>
-__global__ void __launch_bounds__(256) fhog_hist_k(const float* __restrict__ mag, const uint8_t* __restrict__ bin, size_t px_stride, int nbx,
+__global__ void __launch_bounds__(256) fhog_hist_k(const float* __restrict__ mag, const uint8_t* __restrict__ bin, size_t px_stride, int pitch,
                                                    float* __restrict__ hist, size_t hist_stride, int hr, int hc,
                                                    float* __restrict__ norm, size_t norm_stride, int cells_nr, int cells_nc)
 {
@@ -128,22 +159,38 @@ __global__ void __launch_bounds__(256) fhog_hist_k(const float* __restrict__ mag
 #pragma unroll
     for (int o = 0; o < 18; ++o) acc[o][tid] = 0.0f;
     if (hx < hc) {
-        const float* mg = mag + (size_t)b * px_stride;
-        const uint8_t* bn = bin + (size_t)b * px_stride;
+        const float* mg = mag + (size_t)b * px_stride + (size_t)C * hx;
+        const uint8_t* bn = bin + (size_t)b * px_stride + (size_t)C * hx;
         for (int wy = 0; wy < 2 * C; ++wy) {
             const int i = wy % C;
             const float fy = ((float)i + 0.5f) / (float)C;
             const float wyv = (wy < C) ? fy : 1.0f - fy;
-            const size_t row = ((size_t)(C * hy + wy) * C) * nbx;
+            const size_t row = (size_t)(C * hy + wy) * pitch;
+            float v[2 * C];
+            uint8_t ob[2 * C];
+#pragma unroll
+            for (int q = 0; q < 2 * C / 4; ++q) {
+                const float4 t = *reinterpret_cast<const float4*>(mg + row + 4 * q);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+            if (C == 8) {
+                const uint4 t = *reinterpret_cast<const uint4*>(bn + row);
+                const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ob[k] = (uint8_t)((w4[k >> 2] >> (8 * (k & 3))) & 0xff);
+            } else {
+                const uint2 t = *reinterpret_cast<const uint2*>(bn + row);
+                const uint32_t w2[2] = {t.x, t.y};
+#pragma unroll
+                for (int k = 0; k < 2 * C; ++k) ob[k] = (uint8_t)((w2[k >> 2] >> (8 * (k & 3))) & 0xff);
+            }
 #pragma unroll
             for (int wx = 0; wx < 2 * C; ++wx) {
                 const int j = wx % C;
                 const float fx = ((float)j + 0.5f) / (float)C;
                 const float wxv = (wx < C) ? fx : 1.0f - fx;
-                const size_t idx = row + (size_t)j * nbx + hx + (wx / C);
-                const float v = mg[idx];
-                const int o = bn[idx];
-                acc[o][tid] = acc[o][tid] + (wyv * wxv) * v;
+                const int o = ob[wx];
+                acc[o][tid] = acc[o][tid] + (wyv * wxv) * v[wx];
             }
         }
         float* h = hist + (size_t)b * hist_stride + ((size_t)hy * hc + hx) * 18;
@@ -318,20 +365,20 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
     hist.ensure(hist_stride * n * sizeof(float));
     norm.ensure(norm_stride * n * sizeof(float));
     // pass 1: (bin, magnitude) planes in the cell-blocked layout; pass 2: per-cell ordered accumulation + cell energy
-    const int rows_t = cell * (hr + 1), nbx = ((hc + 1) + 7) / 8 * 8;
-    const size_t px_stride = (size_t)rows_t * cell * nbx;
+    const int rows_t = cell * (hr + 1), pitch = (cell * (hc + 1) + 15) / 16 * 16;
+    const size_t px_stride = (size_t)rows_t * pitch;            // multiple of 16 => every row / batch plane stays 16-byte aligned
     grad.ensure(px_stride * n * 5 + 256);
     float* d_mag = grad.as<float>();
     uint8_t* d_bin = grad.as<uint8_t>() + px_stride * n * 4;
-    dim3 gg((nbx * cell + 255) / 256, rows_t, n);
+    dim3 gg((pitch + 127) / 128, (rows_t + 7) / 8, n);
     dim3 gh((hc + 255) / 256, hr, n);
     if (cell == 8) {
-        hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, nbx);
-        hipLaunchKernelGGL((fhog_hist_k<8>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, nbx, hist.as<float>(), hist_stride, hr, hc,
+        hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch);
+        hipLaunchKernelGGL((fhog_hist_k<8>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     } else {
-        hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, nbx);
-        hipLaunchKernelGGL((fhog_hist_k<4>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, nbx, hist.as<float>(), hist_stride, hr, hc,
+        hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch);
+        hipLaunchKernelGGL((fhog_hist_k<4>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     }
     const int hog_nr = cells_nr - 2, hog_nc = cells_nc - 2;
@@ -452,27 +499,40 @@ __global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ fe
     for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int m = 0; m < FR; ++m) {
         const int fr = r_top + m;
-        // stage SEG cells x 32 floats of feature row fr (zeros outside) into the slab
-        for (int idx = lane; idx < SEG * 8; idx += 64) {
+        // issue every load of this filter row up front: 96 B fragments (L2) + the feature row segment, then fill the slab
+        float bv[NK * 8];
+        const float* bp = Bg + (size_t)m * NK * 8 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NK * 8; ++q) bv[q] = bp[q * 64];
+        constexpr int NST = (SEG * 8 + 63) / 64;
+        float4 sv[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = lane + 64 * u;
             const int cell = idx >> 3, q = idx & 7;
             const int x = c_base + cell;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (fr < fh && x < fw) v = reinterpret_cast<const float4*>(fb + ((size_t)fr * fw + x) * PVF_FHOG_STRIDE)[q];
-            float2* d = reinterpret_cast<float2*>(seg + cell * PITCH + 4 * q);
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
+            sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < SEG * 8 && fr < fh && x < fw) sv[u] = reinterpret_cast<const float4*>(fb + ((size_t)fr * fw + x) * PVF_FHOG_STRIDE)[q];
         }
-        const float* bp = Bg + (size_t)m * NK * 8 * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < SEG * 8) {
+                const int cell = idx >> 3, q = idx & 7;
+                float2* d = reinterpret_cast<float2*>(seg + cell * PITCH + 4 * q);
+                d[0] = make_float2(sv[u].x, sv[u].y);
+                d[1] = make_float2(sv[u].z, sv[u].w);
+            }
+        }
         const float* a0 = seg + (3 * i) * PITCH + kq;
-#pragma unroll 2
+#pragma unroll
         for (int n = 0; n < NK; ++n) {
 #pragma unroll
             for (int pq = 0; pq < 8; ++pq) {
-                const float bv = bp[(n * 8 + pq) * 64];
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const float av = a0[(t * 48 + n) * PITCH + 4 * pq];
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n * 8 + pq], acc[t], 0, 0, 0);
                 }
             }
         }

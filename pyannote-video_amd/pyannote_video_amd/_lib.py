@@ -34,6 +34,7 @@ _SIGS = {
     "pvf_frame_upload": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int64, P]),
     "pvf_frame_wrap_device": (C.c_int32, [H, P, C.c_int32, C.c_int32, P]),
     "pvf_frame_release": (C.c_int32, [H, H]),
+    "pvf_frame_device_ptr": (C.c_int32, [H, H, P]),
     "pvf_detect": (C.c_int32, [H, H, C.c_int32, C.c_double, P, P, C.c_int32, P]),
     "pvf_detect_batch": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_double, P, P, P, C.c_int32]),
     "pvf_tracker_create": (C.c_int32, [H, P]),

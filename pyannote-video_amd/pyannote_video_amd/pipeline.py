@@ -66,8 +66,16 @@ def faces_per_frame(rows, frame_times, frame_width, frame_height):
 class FacePipeline(object):
     def __init__(self, ctx, landmarks, embedding, detect_min_size=0.0, detect_every=0.0,
                  track_min_overlap_ratio=CLI_MIN_OVERLAP_RATIO, track_min_confidence=CLI_MIN_CONFIDENCE,
-                 track_max_gap=CLI_MAX_GAP, threshold=0.6, detect_batch_size=8):
+                 track_max_gap=CLI_MAX_GAP, threshold=0.6, detect_batch_size=8, overlap=True):
         self.ctx = ctx
+        # The detector is throughput-bound (big kernels), the trackers are latency-bound (many tiny dependent launches):
+        # a second context (own HIP stream + scratch) lets a host thread run detection ahead, shot by shot, while the
+        # main thread tracks the previous shot.  Both streams share the GPU; results are identical to the serial order.
+        self.det_ctx = None
+        if overlap:
+            from .runtime import Context
+            self.det_ctx = Context(device=ctx.device)
+        self.detect_batch_size = detect_batch_size
         ctx.load_shape_predictor(landmarks)
         ctx.load_embedder(embedding)
         self.tracking = FaceTracking(detect_min_size=detect_min_size, detect_every=detect_every,
@@ -76,6 +84,50 @@ class FacePipeline(object):
                                      track_max_gap=track_max_gap, ctx=ctx, detect_batch_size=detect_batch_size)
         self.clustering = FaceClustering(threshold=threshold, ctx=ctx)
         self.detect_every = detect_every
+
+    def _track_overlapped(self, shot_inputs, backend):
+        """detector thread (second context) runs ahead shot by shot; the caller's thread tracks shot k as soon as its
+        detections exist.  ctypes releases the GIL inside every library call."""
+        import threading
+        dctx = self.det_ctx
+        n = len(shot_inputs)
+        dets = [None] * n
+        ready = [threading.Event() for _ in range(n)]
+        err = []
+        bs = max(1, int(self.detect_batch_size))
+
+        def worker():
+            try:
+                for k, (cache, flags) in enumerate(shot_inputs):
+                    out = [[] for _ in cache]
+                    idx = [i for i, f in enumerate(flags) if f]
+                    shared = {i: dctx.share(cache[i][1]) if hasattr(cache[i][1], "handle") else cache[i][1] for i in idx}
+                    for o in range(0, len(idx), bs):
+                        chunk = idx[o:o + bs]
+                        res = dctx.detect_batch([shared[i] for i in chunk], 1)
+                        for i, (boxes, _) in zip(chunk, res):
+                            out[i] = [tuple(b) for b in boxes]
+                    dets[k] = out
+                    ready[k].set()
+            except BaseException as e:   # surface in the caller's thread
+                err.append(e)
+                for ev in ready:
+                    ev.set()
+
+        th = threading.Thread(target=worker, name="pvface-detector")
+        th.start()
+        per_shot = []
+        try:
+            for k, (cache, flags) in enumerate(shot_inputs):
+                ready[k].wait()
+                if err:
+                    raise err[0]
+                per_shot.append(self.tracking.process_shots([(cache, flags, dets[k])], backend)[0])
+        finally:
+            th.join()
+        if err:
+            raise err[0]
+        return per_shot
 
     def run(self, frames, times, frame_rate, shots, timings=None, cluster=True):
         """frames: list of DeviceFrame (or numpy arrays), one size; times: their timestamps; shots: [(start, end)].
@@ -91,7 +143,11 @@ class FacePipeline(object):
             cache = [(times[i], frames[i]) for i in range(i0, i1)]
             flags = [(i % every == 0) for i in range(i0, i1)]
             shot_inputs.append((cache, flags))
-        per_shot = self.tracking.process_shots(shot_inputs, HipTrackers(self.ctx))
+        backend = HipTrackers(self.ctx)
+        if self.det_ctx is None:
+            per_shot = self.tracking.process_shots(shot_inputs, backend)
+        else:
+            per_shot = self._track_overlapped(shot_inputs, backend)
         tracks = [self.tracking._normalize_track(tr, w, h) for shot in per_shot for tr in shot]
         tm["track_s"] = _time.perf_counter() - t0
         t1 = _time.perf_counter()
@@ -123,6 +179,10 @@ class FacePipeline(object):
         tm["total_s"] = _time.perf_counter() - t0
         return {"tracks": tracks, "track_rows": rows, "face_T": face_T, "face_id": face_id, "face_boxes": face_boxes,
                 "landmarks": pts, "embeddings": emb, "X": Xq, "labels": labels, "shot_ranges": ranges}
+
+
+def _noop():
+    pass
 
 
 def detector_geometry(height, width, upsample=1, cell=8, frows=10, fcols=10, min_w=64, min_h=64):

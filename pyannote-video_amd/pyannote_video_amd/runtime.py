@@ -101,6 +101,14 @@ class Context(object):
         check(self._l.pvf_frame_wrap_device(self._h, C.c_void_p(int(data_ptr)), int(height), int(width), C.byref(h)))
         return DeviceFrame(self, h.value, int(height), int(width), keep)
 
+    def share(self, frame):
+        """DeviceFrame of THIS context for a frame staged in another context on the same GPU (no copy)"""
+        if frame.ctx is self:
+            return frame
+        p = C.c_void_p(0)
+        check(self._l.pvf_frame_device_ptr(frame.ctx._h, frame.handle, C.byref(p)))
+        return self.wrap_device(p.value, frame.height, frame.width, keep=frame)
+
     def wrap_torch(self, t):
         """t: torch.uint8 CUDA tensor [H, W, 3], contiguous"""
         assert t.is_cuda and t.is_contiguous() and t.dim() == 3 and t.shape[2] == 3 and t.element_size() == 1

@@ -232,7 +232,15 @@ class TrackingByDetection(object):
             status = "+".join(sorted((status for _, _, status in group), key=lambda s: _STATUS_ORDER[s]))
             if error:
                 status = "error({0})".format(status)
-            pos = tuple(int(round(v)) for v in np.mean(np.vstack([p for _, p, _ in group]), axis=0))
+            # == np.mean(np.vstack(boxes), axis=0): float64 row-by-row sum, then one division (same IEEE operations)
+            n = len(group)
+            pos = []
+            for k in range(4):
+                s = float(group[0][1][k])
+                for g in group[1:]:
+                    s = s + float(g[1][k])
+                pos.append(int(round(np.float64(s) / n)))
+            pos = tuple(pos)
             fixed_track.append((t, pos, status))
         return fixed_track
 
@@ -256,7 +264,7 @@ class TrackingByDetection(object):
     def _tracks_from_graph(self, graph):
         timestamps = [t for t in graph if not isinstance(t, tuple)]
         graph.remove_nodes_from(timestamps)
-        tracks = nx.connected_components(graph.to_undirected(reciprocal=False))
+        tracks = nx.connected_components(graph.to_undirected(reciprocal=False, as_view=True))   # same node order, no copy
         tracks = [self._fix(track) for track in tracks]
         tracks = self._fill_gaps(tracks)
         return sorted(tracks, key=get_min_max_t)
@@ -284,11 +292,13 @@ class TrackingByDetection(object):
         return out
 
     def process_shots(self, shots, backend):
-        """shots: list of (cache, flags) -- [(t, frame)], [run detection on frame i].  Returns one track list per shot.
+        """shots: list of (cache, flags[, detections]) -- [(t, frame)], [run detection on frame i], optional precomputed
+        [[box]] per frame (e.g. from a detector stream running ahead).  Returns one track list per shot.
         All shots' forward and backward passes run in lock-step (they are independent: tracking.py:359-362,410-417)."""
         graphs, lanes, lane_edges = [], [], []
-        for cache, flags in shots:
-            dets = self._detect_shot(cache, flags)
+        for shot in shots:
+            cache, flags = shot[0], shot[1]
+            dets = shot[2] if len(shot) > 2 and shot[2] is not None else self._detect_shot(cache, flags)
             g = nx.DiGraph()
             det_at = {}
             for (t, _), d in zip(cache, dets):
