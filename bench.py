@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--shots", type=int, default=4)
     ap.add_argument("--detect-batch", type=int, default=8)
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--no-overlap", action="store_true", help="run detector and trackers on one stream (clean per-kernel timings)")
     ap.add_argument("--small-models", action="store_true", help="debug only: reduced landmark model")
     args = ap.parse_args()
 
@@ -68,9 +69,9 @@ def main():
     times = [t_off + video.timestamp(i) for i in range(args.frames)]
     shots = [(t_off + a, t_off + b) for a, b in video.shots()]
 
-    ctx = Context(device=local_rank)
+    ctx = Context(device=local_rank, priority=1)   # tracker / extract stream: latency-bound, high priority
     frames = [ctx.wrap_torch(frames_t[i]) for i in range(args.frames)]
-    pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch)
+    pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap)
 
     def step():
         tm = {}

@@ -31,6 +31,8 @@ const char* pvf_last_error(void);
 int32_t pvf_version(void);
 int32_t pvf_device_count(int32_t* n);
 int32_t pvf_ctx_create(int32_t device, pvf_handle* ctx);
+/* same, choosing the HIP stream priority class: -1 low, 0 default, +1 high (latency-bound work such as trackers) */
+int32_t pvf_ctx_create_prio(int32_t device, int32_t priority_class, pvf_handle* ctx);
 int32_t pvf_ctx_destroy(pvf_handle ctx);
 int32_t pvf_sync(pvf_handle ctx);
 

@@ -236,7 +236,7 @@ extern "C" int32_t pvf_device_count(int32_t* n)
     API_END
 }
 
-extern "C" int32_t pvf_ctx_create(int32_t device, pvf_handle* out)
+extern "C" int32_t pvf_ctx_create_prio(int32_t device, int32_t priority_class, pvf_handle* out)
 {
     API_BEGIN
     int k = 0;
@@ -250,13 +250,20 @@ extern "C" int32_t pvf_ctx_create(int32_t device, pvf_handle* out)
     std::unique_ptr<Ctx> c(new Ctx());
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
-    HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;   // numerically lower = higher priority
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        const int prio = priority_class > 0 ? hi : (priority_class < 0 ? lo : (lo + hi) / 2);
+        HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio));
+    }
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     uint64_t id = g_next_ctx++;
     g_ctxs[id] = std::move(c);
     *out = id;
     API_END
 }
+
+extern "C" int32_t pvf_ctx_create(int32_t device, pvf_handle* out) { return pvf_ctx_create_prio(device, 0, out); }
 
 extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
 {

@@ -8,33 +8,79 @@
 // =====================================================================================================
 // K1: bilinear resize (pyramid_up / pyramid_down<6>), uint8 RGB HWC, double coordinates, (v + 0.5) truncation
 // =====================================================================================================
+// One block = 256 consecutive pixels of one output row.  The two source rows' byte ranges are staged in LDS with dword loads,
+// every lane blends its pixel (double arithmetic, identical expression to the oracle), the 768 output bytes go back through LDS
+// as aligned dword stores.
 __global__ void __launch_bounds__(256) resize_bilinear_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
                                                          size_t in_stride, int ih, int iw, uint8_t* __restrict__ out, size_t out_stride,
                                                          int oh, int ow, double x_scale, double y_scale)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    const int b = blockIdx.z;
-    if (c >= ow) return;
+    constexpr int TW = 256, SRCW = 2 * TW + 8;                 // source pixels per tile: <= TW * x_scale + 2 with x_scale <= 2
+    __shared__ uint32_t s_src[2][(SRCW * 3 + 3) / 4 + 2];
+    __shared__ uint32_t s_out[TW * 3 / 4];
+    const int c0 = blockIdx.x * TW, r = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
     const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
     const double y = r * y_scale;
     const int top = (int)floor(y);
     const int bottom = min(top + 1, ih - 1);
     const double tb = y - top;
-    const double x = c * x_scale;
-    const int left = (int)floor(x);
-    const int right = min(left + 1, iw - 1);
-    const double lr = x - left;
-    const uint8_t* ptl = in + ((size_t)top * iw + left) * 3;
-    const uint8_t* ptr = in + ((size_t)top * iw + right) * 3;
-    const uint8_t* pbl = in + ((size_t)bottom * iw + left) * 3;
-    const uint8_t* pbr = in + ((size_t)bottom * iw + right) * 3;
-    uint8_t* o = out + (size_t)b * out_stride + ((size_t)r * ow + c) * 3;
+    const int cl = min(c0 + TW - 1, ow - 1);
+    const int left_min = (int)floor(c0 * x_scale);
+    const int right_max = min((int)floor(cl * x_scale) + 1, iw - 1);
+    const int nsrc = right_max - left_min + 1;                 // pixels
+    const long row_bytes = (long)iw * 3;
+    const long img_bytes = row_bytes * ih;
+    int mis[2];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double tl = ptl[k], tr = ptr[k], bl = pbl[k], br = pbr[k];
-        const double v = (1 - tb) * ((1 - lr) * tl + lr * tr) + tb * ((1 - lr) * bl + lr * br);
-        o[k] = (uint8_t)(v + 0.5);
+    for (int k = 0; k < 2; ++k) {
+        const long start = (long)(k == 0 ? top : bottom) * row_bytes + (long)left_min * 3;
+        const long a0 = start & ~3L;
+        mis[k] = (int)(start - a0);
+        const int nd = (mis[k] + nsrc * 3 + 3) / 4;
+        for (int d = tid; d < nd; d += TW) {
+            const long off = a0 + 4L * d;
+            uint32_t v;
+            if (off + 4 <= img_bytes) v = *reinterpret_cast<const uint32_t*>(in + off);
+            else { v = 0; for (int q = 0; q < 4; ++q) if (off + q < img_bytes) v |= (uint32_t)in[off + q] << (8 * q); }
+            s_src[k][d] = v;
+        }
+    }
+    __syncthreads();
+    const int c = c0 + tid;
+    if (c < ow) {
+        const double x = c * x_scale;
+        const int left = (int)floor(x);
+        const int right = min(left + 1, iw - 1);
+        const double lr = x - left;
+        const uint8_t* rt = reinterpret_cast<const uint8_t*>(&s_src[0][0]) + mis[0];
+        const uint8_t* rb = reinterpret_cast<const uint8_t*>(&s_src[1][0]) + mis[1];
+        const int ol = (left - left_min) * 3, orr = (right - left_min) * 3;
+        uint8_t* o = reinterpret_cast<uint8_t*>(&s_out[0]) + tid * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double tl = rt[ol + k], tr = rt[orr + k], bl = rb[ol + k], br = rb[orr + k];
+            const double v = (1 - tb) * ((1 - lr) * tl + lr * tr) + tb * ((1 - lr) * bl + lr * br);
+            o[k] = (uint8_t)(v + 0.5);
+        }
+    }
+    __syncthreads();
+    // write back [g0, g1) bytes of the output row segment
+    uint8_t* ob = out + (size_t)b * out_stride;
+    const long g0 = ((long)r * ow + c0) * 3, g1 = ((long)r * ow + min(c0 + TW, ow)) * 3;
+    const long a0 = (g0 + 3) & ~3L, a1 = g1 & ~3L;            // aligned dword range (relative to ob; ob itself is >= 4-aligned or handled bytewise)
+    const bool base_aligned = ((reinterpret_cast<uintptr_t>(ob) & 3) == 0);
+    const uint8_t* so = reinterpret_cast<const uint8_t*>(&s_out[0]);
+    if (base_aligned && a0 < a1) {
+        for (long p = g0 + tid; p < a0; p += TW) ob[p] = so[p - g0];
+        for (long p = a0 + 4L * tid; p < a1; p += 4L * TW) {
+            const long q = p - g0;
+            const uint32_t v = (uint32_t)so[q] | ((uint32_t)so[q + 1] << 8) | ((uint32_t)so[q + 2] << 16) | ((uint32_t)so[q + 3] << 24);
+            *reinterpret_cast<uint32_t*>(ob + p) = v;
+        }
+        for (long p = a1 + tid; p < g1; p += TW) ob[p] = so[p - g0];
+    } else {
+        for (long p = g0 + tid; p < g1; p += TW) ob[p] = so[p - g0];
     }
 }
 
@@ -43,6 +89,7 @@ static void launch_resize(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* 
 {
     const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
     const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
+    PVF_REQUIRE(x_scale <= 2.0, "resize: more than 2x horizontal decimation is not used on this path");
     dim3 grid((ow + 255) / 256, oh, batch);
     hipLaunchKernelGGL(resize_bilinear_k, grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
                        x_scale, y_scale);
@@ -60,13 +107,41 @@ static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
 // K2: FHOG.  gradient -> (orientation bin, magnitude) per pixel; histogram cells gather their 2C x 2C window in
 // row-major pixel order (== the order dlib's scatter loop adds in); 4-way block normalisation -> 31 features.
 // =====================================================================================================
-__constant__ float c_dirx[9] = {1.0000f, 0.9397f, 0.7660f, 0.500f, 0.1736f, -0.1736f, -0.5000f, -0.7660f, -0.9397f};
-__constant__ float c_diry[9] = {0.0000f, 0.3420f, 0.6428f, 0.8660f, 0.9848f, 0.9848f, 0.8660f, 0.6428f, 0.3420f};
+
+// Orientation snap of dlib's FHOG: arg-max over 9 directions of +-dot(direction, gradient), first maximum wins.
+// The gradient of a uint8 image is a pair of integers in [-255,255]^2, so the bin is a pure function of 511x511 inputs:
+// it is tabulated once on the host with exactly these float operations (mul, mul, add, strict compares; no contraction),
+// which makes the table bit-identical to evaluating the chain per pixel.
+static const float h_dirx[9] = {1.0000f, 0.9397f, 0.7660f, 0.500f, 0.1736f, -0.1736f, -0.5000f, -0.7660f, -0.9397f};
+static const float h_diry[9] = {0.0000f, 0.3420f, 0.6428f, 0.8660f, 0.9848f, 0.9848f, 0.8660f, 0.6428f, 0.3420f};
+
+const uint8_t* orientation_lut(Ctx* c)
+{
+    if (c->d_orient_lut) return c->d_orient_lut;
+    std::vector<uint8_t> lut((size_t)511 * 511);
+    for (int by = -255; by <= 255; ++by)
+        for (int bx = -255; bx <= 255; ++bx) {
+            const volatile float gx = (float)bx, gy = (float)by;
+            float best_dot = 0.0f;
+            int best_o = 0;
+            for (int o = 0; o < 9; ++o) {
+                const volatile float a = gx * h_dirx[o];
+                const volatile float b = gy * h_diry[o];
+                const float dot = a + b;
+                if (dot > best_dot) { best_dot = dot; best_o = o; }
+                else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
+            }
+            lut[(size_t)(by + 255) * 511 + (bx + 255)] = (uint8_t)best_o;
+        }
+    HIP_CHECK(hipMalloc((void**)&c->d_orient_lut, lut.size()));
+    HIP_CHECK(hipMemcpy(c->d_orient_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
+    return c->d_orient_lut;
+}
 
 __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, const uint8_t* __restrict__ row_c,
-                                           const uint8_t* __restrict__ row_d, int x3, float* v2, int* bo)
+                                           const uint8_t* __restrict__ row_d, int x3, const uint8_t* __restrict__ lut, float* v2, int* bo)
 {
-    // row_* point at the byte rows; x3 = 3*x (pixel x of the centre row)
+    // row_* point at the byte rows; x3 = 3*x (pixel x of the centre row); colour channel with the largest |g|^2, first wins
     int bx = (int)row_c[x3 + 3] - (int)row_c[x3 - 3], by = (int)row_d[x3] - (int)row_u[x3];
     int bv = bx * bx + by * by;
 #pragma unroll
@@ -75,17 +150,8 @@ __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, co
         const int cv = cx * cx + cy * cy;
         if (cv > bv) { bv = cv; bx = cx; by = cy; }
     }
-    const float gx = (float)bx, gy = (float)by;
-    float best_dot = 0.0f;
-    int best_o = 0;
-#pragma unroll
-    for (int o = 0; o < 9; ++o) {
-        const float dot = gx * c_dirx[o] + gy * c_diry[o];
-        if (dot > best_dot) { best_dot = dot; best_o = o; }
-        else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
-    }
     *v2 = (float)bv;
-    *bo = best_o;
+    *bo = lut[(by + 255) * 511 + (bx + 255)];
 }
 
 // Pass 1: per pixel (orientation bin, gradient magnitude) into planes shifted by 3C/2 so that histogram cell (hy,hx)
@@ -94,7 +160,7 @@ __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, co
 template <int C>
 __global__ void __launch_bounds__(256) fhog_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
                                                    int visible_nc, float* __restrict__ mag, uint8_t* __restrict__ bin, size_t px_stride,
-                                                   int rows_t, int pitch)
+                                                   int rows_t, int pitch, const uint8_t* __restrict__ lut)
 {
     constexpr int TW = 128, TH = 8, RB = (TW + 2) * 3, RD = (RB + 3 + 3) / 4 + 1; // bytes per staged row, dwords incl. alignment slack
     __shared__ uint32_t s_raw[TH + 2][RD];
@@ -136,7 +202,7 @@ __global__ void __launch_bounds__(256) fhog_grad_k(const uint8_t* __restrict__ i
             const uint8_t* ru = reinterpret_cast<const uint8_t*>(&s_raw[ly][0]) + (int)(((start_u % 4) + 4) % 4) + lx * 3;
             const uint8_t* rd = reinterpret_cast<const uint8_t*>(&s_raw[ly + 2][0]) + (int)(((start_d % 4) + 4) % 4) + lx * 3;
             float v2;
-            pixel_grad(ru, rc, rd, 3, &v2, &o);
+            pixel_grad(ru, rc, rd, 3, lut, &v2, &o);
             v = sqrtf(v2);
         }
         const size_t idx = (size_t)b * px_stride + (size_t)yy * pitch + xx;
@@ -284,7 +350,7 @@ __global__ void __launch_bounds__(256) fhog_feat_k(const float* __restrict__ his
 
 // cell size 1 (correlation tracker translation chip): every pixel is a cell
 __global__ void __launch_bounds__(256) fhog1_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw,
-                                                    float* __restrict__ norm, uint8_t* __restrict__ angle, size_t px_stride)
+                                                    float* __restrict__ norm, uint8_t* __restrict__ angle, size_t px_stride, const uint8_t* __restrict__ lut)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, b = blockIdx.z;
@@ -293,7 +359,7 @@ __global__ void __launch_bounds__(256) fhog1_grad_k(const uint8_t* __restrict__ 
     int o = 0;
     if (y >= 1 && y < ih - 1 && x >= 1 && x < iw - 1) {
         const uint8_t* im = img + (size_t)b * img_stride;
-        pixel_grad(im + (size_t)(y - 1) * iw * 3, im + (size_t)y * iw * 3, im + (size_t)(y + 1) * iw * 3, x * 3, &v, &o);
+        pixel_grad(im + (size_t)(y - 1) * iw * 3, im + (size_t)y * iw * 3, im + (size_t)(y + 1) * iw * 3, x * 3, lut, &v, &o);
     }
     norm[(size_t)b * px_stride + (size_t)y * iw + x] = v;
     angle[(size_t)b * px_stride + (size_t)y * iw + x] = (uint8_t)o;
@@ -336,22 +402,24 @@ void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw)
     *fw = hog_nc + pad_c - 1;
 }
 
-void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat, DevBuf& hist, DevBuf& norm)
+void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat, DevBuf& hist, DevBuf& norm,
+                 size_t img_stride_in)
 {
     DevBuf& grad = c->s_grad;
+    const uint8_t* lut = orientation_lut(c);
     int fh, fw;
     fhog_dims(h, w, cell, pad_r, pad_c, &fh, &fw);
     PVF_REQUIRE(fh > 0 && fw > 0, "fhog: image too small");
     const size_t feat_stride = (size_t)fh * fw * PVF_FHOG_STRIDE;
     HIP_CHECK(hipMemsetAsync(d_feat, 0, feat_stride * n * sizeof(float), c->stream));
     const int oy = (pad_r - 1) / 2, ox = (pad_c - 1) / 2;
-    const size_t img_stride = (size_t)h * w * 3;
+    const size_t img_stride = img_stride_in ? img_stride_in : (size_t)h * w * 3;
     if (cell == 1) {
         const size_t px = (size_t)h * w;
         norm.ensure(px * n * sizeof(float));
         hist.ensure(px * n);
         dim3 g1((w + 255) / 256, h, n);
-        hipLaunchKernelGGL(fhog1_grad_k, g1, dim3(256), 0, c->stream, d_img, img_stride, h, w, norm.as<float>(), hist.as<uint8_t>(), px);
+        hipLaunchKernelGGL(fhog1_grad_k, g1, dim3(256), 0, c->stream, d_img, img_stride, h, w, norm.as<float>(), hist.as<uint8_t>(), px, lut);
         dim3 g2((w - 2 + 255) / 256, h - 2, n);
         hipLaunchKernelGGL(fhog1_feat_k, g2, dim3(256), 0, c->stream, norm.as<float>(), hist.as<uint8_t>(), px, w, d_feat, feat_stride, fw,
                            h - 2, w - 2, oy, ox);
@@ -373,11 +441,11 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
     dim3 gg((pitch + 127) / 128, (rows_t + 7) / 8, n);
     dim3 gh((hc + 255) / 256, hr, n);
     if (cell == 8) {
-        hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch);
+        hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
         hipLaunchKernelGGL((fhog_hist_k<8>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     } else {
-        hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch);
+        hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
         hipLaunchKernelGGL((fhog_hist_k<4>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     }
@@ -395,7 +463,7 @@ void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, 
     HIP_CHECK(hipMemcpyAsync(c->s_pyr.p, himg, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream));
     const size_t nf = (size_t)(*fh) * (*fw) * PVF_FHOG_STRIDE;
     c->s_feat.ensure(nf * sizeof(float));
-    fhog_device(c, c->s_pyr.as<uint8_t>(), 1, h, w, cell, pad_r, pad_c, c->s_feat.as<float>(), c->s_hist, c->s_norm);
+    fhog_device(c, c->s_pyr.as<uint8_t>(), 1, h, w, cell, pad_r, pad_c, c->s_feat.as<float>(), c->s_hist, c->s_norm, 0);
     out.resize(nf);
     HIP_CHECK(hipMemcpyAsync(out.data(), c->s_feat.p, nf * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -626,7 +694,8 @@ static void run_pyramid(Ctx* c, const std::vector<Frame>& frames, int upsample, 
     for (auto& f : frames) PVF_REQUIRE(f.h == h && f.w == w, "batched frames must share one size");
     std::vector<LevelDims> ups;
     std::vector<LevelDims> lv = level_schedule(h, w, upsample, m, &ups);
-    const size_t max_img = (size_t)lv[0].h * lv[0].w * 3;
+    auto padded = [](int hh, int ww) { return ((size_t)hh * ww * 3 + 15) & ~(size_t)15; };
+    const size_t max_img = padded(lv[0].h, lv[0].w);
     c->s_pyr.ensure(2 * max_img * B + 64);
     uint8_t* buf[2] = {c->s_pyr.as<uint8_t>(), c->s_pyr.as<uint8_t>() + max_img * B};
     const uint8_t** d_ptrs = nullptr;
@@ -637,7 +706,7 @@ static void run_pyramid(Ctx* c, const std::vector<Frame>& frames, int upsample, 
     {
         ProfScope ps(c, "pyramid");
         for (size_t u = 0; u < ups.size(); ++u) {
-            launch_resize(c, cur_img ? nullptr : d_ptrs, cur_img, (size_t)ch * cw * 3, ch, cw, buf[cur], (size_t)ups[u].h * ups[u].w * 3,
+            launch_resize(c, cur_img ? nullptr : d_ptrs, cur_img, padded(ch, cw), ch, cw, buf[cur], padded(ups[u].h, ups[u].w),
                           ups[u].h, ups[u].w, B);
             cur_img = buf[cur]; cur ^= 1; ch = ups[u].h; cw = ups[u].w;
         }
@@ -645,13 +714,13 @@ static void run_pyramid(Ctx* c, const std::vector<Frame>& frames, int upsample, 
     if (!cur_img) {
         // no upsampling: copy frames into the ping-pong buffer so that every level has the same batched layout
         for (int b = 0; b < B; ++b)
-            HIP_CHECK(hipMemcpyAsync(buf[cur] + (size_t)b * h * w * 3, frames[b].d, (size_t)h * w * 3, hipMemcpyDeviceToDevice, c->stream));
+            HIP_CHECK(hipMemcpyAsync(buf[cur] + (size_t)b * padded(h, w), frames[b].d, (size_t)h * w * 3, hipMemcpyDeviceToDevice, c->stream));
         cur_img = buf[cur]; cur ^= 1;
     }
     for (int l = 0; l < (int)lv.size(); ++l) {
         if (l > 0) {
             ProfScope ps(c, "pyramid");
-            launch_resize(c, nullptr, cur_img, (size_t)ch * cw * 3, ch, cw, buf[cur], (size_t)lv[l].h * lv[l].w * 3, lv[l].h, lv[l].w, B);
+            launch_resize(c, nullptr, cur_img, padded(ch, cw), ch, cw, buf[cur], padded(lv[l].h, lv[l].w), lv[l].h, lv[l].w, B);
             cur_img = buf[cur]; cur ^= 1; ch = lv[l].h; cw = lv[l].w;
         }
         if (want_level < 0 || want_level == l) per_level(l, cur_img, ch, cw);
@@ -706,7 +775,7 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
         c->s_feat.ensure(feat_stride * B * sizeof(float));
         {
             ProfScope ps(c, "fhog");
-            fhog_device(c, img, B, h, w, m.cell, m.frows, m.fcols, c->s_feat.as<float>(), c->s_hist, c->s_norm);
+            fhog_device(c, img, B, h, w, m.cell, m.frows, m.fcols, c->s_feat.as<float>(), c->s_hist, c->s_norm, (((size_t)h * w * 3 + 15) & ~(size_t)15));
         }
         {
             ProfScope ps(c, "score");

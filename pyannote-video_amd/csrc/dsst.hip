@@ -19,6 +19,7 @@ struct TrkJob {
     const uint8_t* img; int h, w;
     double map[4];   // chip (x,y) -> image (map0 + x*map2, map1 + y*map3)
     double cx, cy;   // start: object centre in chip coordinates
+    double box[4];   // start: initial position (written to the tracker state by target_fft_k)
 };
 
 __device__ __forceinline__ double det_exp(double x)
@@ -158,6 +159,7 @@ __global__ void __launch_bounds__(256) target_fft_k(const TrkJob* __restrict__ j
 {
     extern __shared__ __attribute__((aligned(16))) double2 s[];
     const TrkJob j = jobs[blockIdx.x];
+    if (threadIdx.x < 4) j.state[TRK_POS + threadIdx.x] = j.box[threadIdx.x];
     make_target_lds(s, j.cx, j.cy, tw64);
     double2* out = Ghat + (size_t)blockIdx.x * FS * FS;
     for (int q = threadIdx.x; q < FS * FS; q += 256) out[q] = s[(q >> 6) * LP + (q & 63)];
@@ -496,6 +498,7 @@ static DsstBuffers prepare(Ctx* c, const std::vector<Tracker*>& t, const std::ve
         j.map[3] = (r[3] - r[1]) / (double)(FS - 1);
         j.cx = ((p[0] + p[2]) / 2 - j.map[0]) / j.map[2];
         j.cy = ((p[1] + p[3]) / 2 - j.map[1]) / j.map[3];
+        for (int k = 0; k < 4; ++k) j.box[k] = p[k];
     }
     DsstBuffers b;
     const size_t chips64 = (size_t)n * FS * FS * 3, chips_sc = (size_t)n * NSC * SWIN * SWIN * 3;
@@ -557,7 +560,6 @@ void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<F
     ensure_fft_lds();
     for (int i = 0; i < n; ++i) {
         memcpy(t[i]->pos, boxes + 4 * i, 4 * sizeof(double));
-        HIP_CHECK(hipMemcpyAsync(t[i]->d_state + TRK_POS, boxes + 4 * i, 4 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         t[i]->started = true;
     }
     std::vector<TrkJob> jobs; std::vector<ChipJob> cj;

@@ -183,6 +183,7 @@ struct Ctx {
     DevBuf s_grad, s_pyr, s_hist, s_norm, s_feat, s_cand, s_misc, s_chip, s_chip_pyr, s_act0, s_act1, s_act2, s_trk0, s_trk1, s_trk2, s_clu0, s_clu1;
     HostBuf h_cand, h_misc;
     int n_cu = 256;
+    uint8_t* d_orient_lut = nullptr; // 511x511 orientation bins (detect.hip)
 
     Frame& frame(uint64_t id)
     {
@@ -217,7 +218,7 @@ void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vec
 void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, int pad_c, std::vector<float>& out, int* fh, int* fw);
 // device fhog used by dsst.hip too: img u8 [n][h][w][3] -> feat [n][fh][fw][32]
 void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat,
-                 DevBuf& hist, DevBuf& norm);
+                 DevBuf& hist, DevBuf& norm, size_t img_stride_in = 0);
 void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw);
 // chips (chip.hip)
 ChipJob chip_plan(const Frame& f, const ChipDetails& d);

@@ -25,6 +25,7 @@ _SIGS = {
     "pvf_version": (C.c_int32, []),
     "pvf_device_count": (C.c_int32, [P]),
     "pvf_ctx_create": (C.c_int32, [C.c_int32, P]),
+    "pvf_ctx_create_prio": (C.c_int32, [C.c_int32, C.c_int32, P]),
     "pvf_ctx_destroy": (C.c_int32, [H]),
     "pvf_sync": (C.c_int32, [H]),
     "pvf_load_detector": (C.c_int32, [H, C.c_char_p]),

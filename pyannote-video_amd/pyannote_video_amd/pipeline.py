@@ -74,7 +74,7 @@ class FacePipeline(object):
         self.det_ctx = None
         if overlap:
             from .runtime import Context
-            self.det_ctx = Context(device=ctx.device)
+            self.det_ctx = Context(device=ctx.device, priority=-1)
         self.detect_batch_size = detect_batch_size
         ctx.load_shape_predictor(landmarks)
         ctx.load_embedder(embedding)
@@ -116,18 +116,29 @@ class FacePipeline(object):
 
         th = threading.Thread(target=worker, name="pvface-detector")
         th.start()
-        per_shot = []
+        from .tracking_by_detection import LaneScheduler
+        sched = LaneScheduler(backend)
+        jobs = [None] * n
+        nxt = 0
         try:
-            for k, (cache, flags) in enumerate(shot_inputs):
-                ready[k].wait()
-                if err:
-                    raise err[0]
-                per_shot.append(self.tracking.process_shots([(cache, flags, dets[k])], backend)[0])
+            while nxt < n or len(sched):
+                # admit every shot whose detections exist; block only when there is nothing to track
+                while nxt < n and (ready[nxt].is_set() or len(sched) == 0):
+                    ready[nxt].wait()
+                    if err:
+                        raise err[0]
+                    cache, flags = shot_inputs[nxt]
+                    jobs[nxt] = self.tracking.begin_shot(cache, flags, dets[nxt])
+                    for lane in jobs[nxt]["lanes"]:
+                        sched.add(lane)
+                    nxt += 1
+                if len(sched):
+                    sched.round()
         finally:
             th.join()
         if err:
             raise err[0]
-        return per_shot
+        return [self.tracking.finish_shot(j) for j in jobs]
 
     def run(self, frames, times, frame_rate, shots, timings=None, cluster=True):
         """frames: list of DeviceFrame (or numpy arrays), one size; times: their timestamps; shots: [(start, end)].

@@ -31,11 +31,11 @@ class DeviceFrame(object):
 
 
 class Context(object):
-    def __init__(self, device=0, detector=_models.DEFAULT_DETECTOR, landmarks=None, embedding=None):
+    def __init__(self, device=0, detector=_models.DEFAULT_DETECTOR, landmarks=None, embedding=None, priority=0):
         self._h = None
         l = _lib.lib()
         h = C.c_uint64(0)
-        check(l.pvf_ctx_create(int(device), C.byref(h)))
+        check(l.pvf_ctx_create_prio(int(device), int(priority), C.byref(h)))
         self._h = h.value
         self.device = int(device)
         self._l = l

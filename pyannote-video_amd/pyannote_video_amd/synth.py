@@ -162,7 +162,10 @@ class SyntheticVideo(object):
                 cy = (y0 + y1) / 2 + pos[:, 1]
                 cx = np.clip(cx, x0 + half, x1 - half)
                 cy = np.clip(cy, y0 + half, y1 - half)
-                tr.append({"ident": int(idents[f]), "pose": POSES[int(rng.integers(0, len(POSES)))],
+                rng.integers(0, len(POSES))   # (keeps the random stream of earlier revisions)
+                # the pose is part of the identity: the synthetic landmark model is box-relative, so a different pose of the
+                # same person would yield a differently aligned chip -- something real landmarks would undo
+                tr.append({"ident": int(idents[f]), "pose": POSES[int(idents[f]) % len(POSES)],
                            "cx": cx, "cy": cy, "size": size})
             self.tracks.append(tr)
         self._patch_cache = {}

@@ -92,6 +92,65 @@ class ObjectTrackers(object):
         pass
 
 
+class LaneScheduler(object):
+    """Runs any number of lane coroutines in lock-step; lanes may be added between rounds (shots whose detections
+    became available).  One round = every lane's pending request served with ONE update batch and ONE start batch."""
+
+    def __init__(self, backend):
+        self.backend = backend
+        self.lanes = {}
+        self.pending = {}
+        self._next = 0
+
+    def __len__(self):
+        return len(self.pending)
+
+    def add(self, gen):
+        k = self._next
+        self._next += 1
+        try:
+            self.pending[k] = next(gen)
+            self.lanes[k] = gen
+        except StopIteration:
+            pass
+        return k
+
+    def round(self):
+        pending, backend = self.pending, self.backend
+        replies = {}
+        upd = [(k, r) for k, r in pending.items() if r[0] == 'update']
+        if upd:
+            hs = [h for _, r in upd for h in r[1]]
+            fr = [f for _, r in upd for f in r[2]]
+            psr, boxes = backend.update_many(hs, fr)
+            o = 0
+            for k, r in upd:
+                n = len(r[1])
+                replies[k] = (psr[o:o + n], boxes[o:o + n])
+                o += n
+        st = [(k, r) for k, r in pending.items() if r[0] == 'start']
+        if st:
+            fr = [f for _, r in st for f in r[1]]
+            bx = [b for _, r in st for b in r[2]]
+            hs = backend.start_many(fr, bx)
+            o = 0
+            for k, r in st:
+                n = len(r[2])
+                replies[k] = hs[o:o + n]
+                o += n
+        for k, r in pending.items():
+            if r[0] == 'release':
+                backend.release(r[1])
+                replies[k] = None
+        nxt = {}
+        for k in pending:
+            try:
+                nxt[k] = self.lanes[k].send(replies[k])
+            except StopIteration:
+                del self.lanes[k]
+        self.pending = nxt
+
+
 class TrackingByDetection(object):
     """(Forward/backward) tracking by detection -- same constructor and call contract as the reference class."""
 
@@ -178,45 +237,11 @@ class TrackingByDetection(object):
     @staticmethod
     def _run_lanes(lanes, backend):
         """Advance all lane coroutines in lock-step; merge their requests into one update batch + one start batch per round."""
-        pending = {}
-        for k, g in enumerate(lanes):
-            try:
-                pending[k] = next(g)
-            except StopIteration:
-                pass
-        while pending:
-            replies = {}
-            upd = [(k, r) for k, r in pending.items() if r[0] == 'update']
-            if upd:
-                hs = [h for _, r in upd for h in r[1]]
-                fr = [f for _, r in upd for f in r[2]]
-                psr, boxes = backend.update_many(hs, fr)
-                o = 0
-                for k, r in upd:
-                    n = len(r[1])
-                    replies[k] = (psr[o:o + n], boxes[o:o + n])
-                    o += n
-            st = [(k, r) for k, r in pending.items() if r[0] == 'start']
-            if st:
-                fr = [f for _, r in st for f in r[1]]
-                bx = [b for _, r in st for b in r[2]]
-                hs = backend.start_many(fr, bx)
-                o = 0
-                for k, r in st:
-                    n = len(r[2])
-                    replies[k] = hs[o:o + n]
-                    o += n
-            for k, r in pending.items():
-                if r[0] == 'release':
-                    backend.release(r[1])
-                    replies[k] = None
-            nxt = {}
-            for k in pending:
-                try:
-                    nxt[k] = lanes[k].send(replies[k])
-                except StopIteration:
-                    pass
-            pending = nxt
+        sched = LaneScheduler(backend)
+        for g in lanes:
+            sched.add(g)
+        while len(sched):
+            sched.round()
 
     # ---- merging ----------------------------------------------------------------------------------------
     def _fix(self, track):
@@ -291,35 +316,37 @@ class TrackingByDetection(object):
                 out[i] = [tuple(d) for d in self.detect_func(cache[i][1])]
         return out
 
+    def begin_shot(self, cache, flags, dets=None):
+        """graph with the detections of one shot + its two lane coroutines (not started)"""
+        if dets is None:
+            dets = self._detect_shot(cache, flags)
+        g = nx.DiGraph()
+        det_at = {}
+        for (t, _), d in zip(cache, dets):
+            g.add_node(t)
+            for box in d:
+                g.add_edge(t, (t, box, DETECTION))
+            det_at[t] = d
+        ef, eb = [], []
+        lanes = [self._lane(cache, det_at, FORWARD, ef), self._lane(list(reversed(cache)), det_at, BACKWARD, eb)]
+        return {"graph": g, "ef": ef, "eb": eb, "lanes": lanes}
+
+    def finish_shot(self, job):
+        """replay the lanes' graph mutations in the reference's order (forward pass, then backward) and extract the tracks"""
+        g = job["graph"]
+        for u, v, conf in job["ef"]:
+            g.add_edge(u, v, confidence=conf)
+        for u, v, conf in job["eb"]:
+            g.add_edge(u, v, confidence=conf)
+        return self._tracks_from_graph(g)
+
     def process_shots(self, shots, backend):
         """shots: list of (cache, flags[, detections]) -- [(t, frame)], [run detection on frame i], optional precomputed
         [[box]] per frame (e.g. from a detector stream running ahead).  Returns one track list per shot.
         All shots' forward and backward passes run in lock-step (they are independent: tracking.py:359-362,410-417)."""
-        graphs, lanes, lane_edges = [], [], []
-        for shot in shots:
-            cache, flags = shot[0], shot[1]
-            dets = shot[2] if len(shot) > 2 and shot[2] is not None else self._detect_shot(cache, flags)
-            g = nx.DiGraph()
-            det_at = {}
-            for (t, _), d in zip(cache, dets):
-                g.add_node(t)
-                for box in d:
-                    g.add_edge(t, (t, box, DETECTION))
-                det_at[t] = d
-            graphs.append(g)
-            ef, eb = [], []
-            lanes.append(self._lane(cache, det_at, FORWARD, ef))
-            lanes.append(self._lane(list(reversed(cache)), det_at, BACKWARD, eb))
-            lane_edges.append((ef, eb))
-        self._run_lanes(lanes, backend)
-        out = []
-        for g, (ef, eb) in zip(graphs, lane_edges):
-            for u, v, conf in ef:
-                g.add_edge(u, v, confidence=conf)
-            for u, v, conf in eb:
-                g.add_edge(u, v, confidence=conf)
-            out.append(self._tracks_from_graph(g))
-        return out
+        jobs = [self.begin_shot(s[0], s[1], s[2] if len(s) > 2 else None) for s in shots]
+        self._run_lanes([l for j in jobs for l in j["lanes"]], backend)
+        return [self.finish_shot(j) for j in jobs]
 
     def _backend(self):
         if self._trackers_backend is None:
