@@ -13,13 +13,16 @@
 // as aligned dword stores.
 __global__ void __launch_bounds__(256) resize_bilinear_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
                                                          size_t in_stride, int ih, int iw, uint8_t* __restrict__ out, size_t out_stride,
-                                                         int oh, int ow, double x_scale, double y_scale)
+                                                         int oh, int ow, double x_scale, double y_scale, int batch)
 {
     constexpr int TW = 256, SRCW = 2 * TW + 8;                 // source pixels per tile: <= TW * x_scale + 2 with x_scale <= 2
     __shared__ uint32_t s_src[2][(SRCW * 3 + 3) / 4 + 2];
     __shared__ uint32_t s_out[TW * 3 / 4];
-    const int c0 = blockIdx.x * TW, r = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x;
+    const int ncb = (ow + TW - 1) / TW;
+    const long ntiles = (long)ncb * oh * batch;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int c0 = (int)(tile % ncb) * TW, r = (int)((tile / ncb) % oh), b = (int)(tile / ((long)ncb * oh));
     const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
     const double y = r * y_scale;
     const int top = (int)floor(y);
@@ -82,6 +85,8 @@ __global__ void __launch_bounds__(256) resize_bilinear_k(const uint8_t* const* _
     } else {
         for (long p = g0 + tid; p < g1; p += TW) ob[p] = so[p - g0];
     }
+    __syncthreads();
+    } // tile loop
 }
 
 static void launch_resize(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* in_base, size_t in_stride, int ih, int iw,
@@ -90,9 +95,10 @@ static void launch_resize(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* 
     const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
     const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
     PVF_REQUIRE(x_scale <= 2.0, "resize: more than 2x horizontal decimation is not used on this path");
-    dim3 grid((ow + 255) / 256, oh, batch);
-    hipLaunchKernelGGL(resize_bilinear_k, grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
-                       x_scale, y_scale);
+    const long ntiles = (long)((ow + 255) / 256) * oh * batch;
+    const unsigned nblk = (unsigned)std::min<long>(ntiles, (long)c->n_cu * 16);   // persistent: a few blocks per CU walk the tiles
+    hipLaunchKernelGGL(resize_bilinear_k, dim3(nblk), dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
+                       x_scale, y_scale, batch);
 }
 
 static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
@@ -160,12 +166,15 @@ __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, co
 template <int C>
 __global__ void __launch_bounds__(256) fhog_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
                                                    int visible_nc, float* __restrict__ mag, uint8_t* __restrict__ bin, size_t px_stride,
-                                                   int rows_t, int pitch, const uint8_t* __restrict__ lut)
+                                                   int rows_t, int pitch, const uint8_t* __restrict__ lut, int batch)
 {
     constexpr int TW = 128, TH = 8, RB = (TW + 2) * 3, RD = (RB + 3 + 3) / 4 + 1; // bytes per staged row, dwords incl. alignment slack
     __shared__ uint32_t s_raw[TH + 2][RD];
-    const int b = blockIdx.z;
-    const int xx0 = blockIdx.x * TW, yy0 = blockIdx.y * TH;
+    const int ntx = (pitch + TW - 1) / TW, nty = (rows_t + TH - 1) / TH;
+    const long ntiles = (long)ntx * nty * batch;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = (int)(tile / ((long)ntx * nty));
+    const int xx0 = (int)(tile % ntx) * TW, yy0 = (int)((tile / ntx) % nty) * TH;
     const int x0 = xx0 - 3 * C / 2, y0 = yy0 - 3 * C / 2;      // image coords of the tile's first pixel
     const uint8_t* im = img + (size_t)b * img_stride;
     const long row_bytes = (long)iw * 3;
@@ -209,6 +218,8 @@ __global__ void __launch_bounds__(256) fhog_grad_k(const uint8_t* __restrict__ i
         mag[idx] = v;
         bin[idx] = (uint8_t)o;
     }
+    __syncthreads();
+    } // tile loop
 }
 
 // Pass 2: one lane per histogram cell walks its 2C x 2C window in row-major order (== the order dlib's scatter loop adds in),
@@ -438,14 +449,15 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
     grad.ensure(px_stride * n * 5 + 256);
     float* d_mag = grad.as<float>();
     uint8_t* d_bin = grad.as<uint8_t>() + px_stride * n * 4;
-    dim3 gg((pitch + 127) / 128, (rows_t + 7) / 8, n);
+    const long gtiles = (long)((pitch + 127) / 128) * ((rows_t + 7) / 8) * n;
+    dim3 gg((unsigned)std::min<long>(gtiles, (long)c->n_cu * 16));
     dim3 gh((hc + 255) / 256, hr, n);
     if (cell == 8) {
-        hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
+        hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
         hipLaunchKernelGGL((fhog_hist_k<8>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     } else {
-        hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
+        hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
         hipLaunchKernelGGL((fhog_hist_k<4>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     }

@@ -128,7 +128,7 @@ class FacePipeline(object):
                     if err:
                         raise err[0]
                     cache, flags = shot_inputs[nxt]
-                    jobs[nxt] = self.tracking.begin_shot(cache, flags, dets[nxt])
+                    jobs[nxt] = self.tracking.begin_shot(cache, flags, dets[nxt], backend)
                     for lane in jobs[nxt]["lanes"]:
                         sched.add(lane)
                     nxt += 1

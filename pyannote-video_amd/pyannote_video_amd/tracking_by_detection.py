@@ -65,6 +65,40 @@ class HipTrackers(object):
     def release(self, handle):
         self.ctx.tracker_destroy(handle)
 
+    def speculate(self, cache, detections_at, chunk=1024):
+        """Issue EVERY start_track of a lane and the first update of every started tracker as large batches.
+
+        In the reference loop (tracking.py:199-259) a tracker started on the detections of frame i is unconditionally
+        updated on frame i+1 (:202-203) before anything can kill it, so these two operations never depend on the
+        association logic; each tracker's arithmetic is independent of the batch it runs in, so the results are the
+        ones the frame-by-frame order produces.  Returns {t: (handles, psr or None, boxes or None)}."""
+        flat_f, flat_b, owner = [], [], []
+        for i, (t, frame) in enumerate(cache):
+            for d in detections_at.get(t, []):
+                flat_f.append(frame)
+                flat_b.append(tuple(float(v) for v in d))
+                owner.append(i)
+        n = len(flat_b)
+        hs = []
+        for o in range(0, n, chunk):
+            hs.extend(self.start_many(flat_f[o:o + chunk], flat_b[o:o + chunk]))
+        last = len(cache) - 1
+        upd = [k for k in range(n) if owner[k] < last]
+        psr = np.zeros(n, np.float64)
+        pos = np.zeros((n, 4), np.float64)
+        for o in range(0, len(upd), chunk):
+            ks = upd[o:o + chunk]
+            p, b = self.update_many([hs[k] for k in ks], [cache[owner[k] + 1][1] for k in ks])
+            psr[ks] = p
+            pos[ks] = b
+        plan, k = {}, 0
+        for i, (t, _) in enumerate(cache):
+            m = len(detections_at.get(t, []))
+            if m:
+                plan[t] = (hs[k:k + m], psr[k:k + m] if i < last else None, pos[k:k + m] if i < last else None)
+                k += m
+        return plan
+
 
 class ObjectTrackers(object):
     """Adapter for any per-object tracker class with dlib's start_track / update / get_position (test seam, S2)."""
@@ -196,43 +230,73 @@ class TrackingByDetection(object):
         return match
 
     # ---- one pass over one shot, written as a coroutine that asks for batched tracker work -------------------
-    def _lane(self, cache, detections_at, direction, edges):
+    def _lane(self, cache, detections_at, direction, edges, backend=None):
         """cache: [(t, frame)] in processing order; detections_at: {t: [box]}; edges: list receiving
-        (u, v, confidence) in the order the reference calls add_edge (tracking.py:214-259)."""
+        (u, v, confidence) in the order the reference calls add_edge (tracking.py:214-259).
+        A coroutine: it yields ('update', handles, frames) / ('start', frames, boxes) and receives the results, so that a
+        scheduler can batch the requests of many lanes.  With a speculating backend (HipTrackers.speculate) the starts and
+        first updates were already issued in bulk and only trackers that survive an association need on-demand updates."""
+        plan = backend.speculate(cache, detections_at) if (backend is not None and hasattr(backend, 'speculate')) else None
+        release = backend.release if backend is not None else None
         trackers = {}      # identifier -> backend handle  (dict order == creation order, like the reference's dict)
         position = {}      # identifier -> (l,t,r,b) doubles after the last update
         confidences = {}
         previous = {}
+        cached = {}        # identifier -> (psr, box) of a first update computed ahead
         new_identifier = 0
+
+        def kill(identifier):
+            h = trackers.pop(identifier)
+            cached.pop(identifier, None)
+            if release is not None:
+                release(h)
+            return h
+
         for t, frame in cache:
             ids = list(trackers)
             if ids:
-                psr, boxes = yield ('update', [trackers[i] for i in ids], [frame] * len(ids))
-                for k, identifier in enumerate(ids):
-                    confidences[identifier] = float(psr[k])
-                    position[identifier] = tuple(float(v) for v in boxes[k])
-                    if confidences[identifier] < self.track_min_confidence:
-                        yield ('release', trackers[identifier])
-                        del trackers[identifier]
+                need = [i for i in ids if i not in cached]
+                fresh = {}
+                if need:
+                    psr, boxes = yield ('update', [trackers[i] for i in need], [frame] * len(need))
+                    for k, identifier in enumerate(need):
+                        fresh[identifier] = (float(psr[k]), tuple(float(v) for v in boxes[k]))
+                for identifier in ids:
+                    conf, pos = cached.pop(identifier) if identifier in cached else fresh[identifier]
+                    confidences[identifier] = conf
+                    position[identifier] = pos
+                    if conf < self.track_min_confidence:
+                        h = kill(identifier)
+                        if release is None:
+                            yield ('release', h)
             detections = detections_at.get(t, [])
             match = self._associate([(i, position[i]) for i in trackers], detections)
             for d, identifier in match.items():
                 current = (t, detections[d], DETECTION)
                 edges.append((previous[identifier], current, confidences[identifier]))
-                yield ('release', trackers[identifier])
-                del trackers[identifier]
+                h = kill(identifier)
+                if release is None:
+                    yield ('release', h)
             for identifier in trackers:
                 current = (t, position[identifier], direction)
                 edges.append((previous[identifier], current, confidences[identifier]))
                 previous[identifier] = current
             if detections:
-                handles = yield ('start', [frame] * len(detections), [tuple(float(v) for v in d) for d in detections])
+                if plan is not None:
+                    handles, ppsr, ppos = plan[t]
+                else:
+                    handles = yield ('start', [frame] * len(detections), [tuple(float(v) for v in d) for d in detections])
+                    ppsr = ppos = None
                 for d, detection in enumerate(detections):
                     trackers[new_identifier] = handles[d]
                     previous[new_identifier] = (t, detection, DETECTION)
+                    if ppsr is not None:
+                        cached[new_identifier] = (float(ppsr[d]), tuple(float(v) for v in ppos[d]))
                     new_identifier += 1
         for identifier in list(trackers):
-            yield ('release', trackers[identifier])
+            h = kill(identifier)
+            if release is None:
+                yield ('release', h)
 
     @staticmethod
     def _run_lanes(lanes, backend):
@@ -316,7 +380,7 @@ class TrackingByDetection(object):
                 out[i] = [tuple(d) for d in self.detect_func(cache[i][1])]
         return out
 
-    def begin_shot(self, cache, flags, dets=None):
+    def begin_shot(self, cache, flags, dets=None, backend=None):
         """graph with the detections of one shot + its two lane coroutines (not started)"""
         if dets is None:
             dets = self._detect_shot(cache, flags)
@@ -328,7 +392,7 @@ class TrackingByDetection(object):
                 g.add_edge(t, (t, box, DETECTION))
             det_at[t] = d
         ef, eb = [], []
-        lanes = [self._lane(cache, det_at, FORWARD, ef), self._lane(list(reversed(cache)), det_at, BACKWARD, eb)]
+        lanes = [self._lane(cache, det_at, FORWARD, ef, backend), self._lane(list(reversed(cache)), det_at, BACKWARD, eb, backend)]
         return {"graph": g, "ef": ef, "eb": eb, "lanes": lanes}
 
     def finish_shot(self, job):
@@ -344,7 +408,7 @@ class TrackingByDetection(object):
         """shots: list of (cache, flags[, detections]) -- [(t, frame)], [run detection on frame i], optional precomputed
         [[box]] per frame (e.g. from a detector stream running ahead).  Returns one track list per shot.
         All shots' forward and backward passes run in lock-step (they are independent: tracking.py:359-362,410-417)."""
-        jobs = [self.begin_shot(s[0], s[1], s[2] if len(s) > 2 else None) for s in shots]
+        jobs = [self.begin_shot(s[0], s[1], s[2] if len(s) > 2 else None, backend) for s in shots]
         self._run_lanes([l for j in jobs for l in j["lanes"]], backend)
         return [self.finish_shot(j) for j in jobs]
 

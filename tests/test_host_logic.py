@@ -98,6 +98,25 @@ def test_several_shots_in_lockstep_equal_one_by_one():
     assert got == refs
 
 
+class SpeculatingObjectTrackers(ObjectTrackers):
+    """per-object trackers behind the bulk start / first-update path the GPU backend uses"""
+    from pyannote_video_amd.tracking_by_detection import HipTrackers as _H
+    speculate = _H.speculate
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_speculative_bulk_path_equals_sequential_reference(seed):
+    from oracle import ref_flow
+    frames, dets = scenario(100 + seed, n=50, p_miss=0.35)
+    times = [i / 25.0 for i in range(len(frames))]
+    cache = list(zip(times, frames))
+    tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0,
+                              trackers=SpeculatingObjectTrackers(ScriptTracker))
+    got = tbd.process_shots([(cache, [True] * len(cache), dets)], tbd._backend())[0]
+    ref = ref_flow.track_shot(cache, dets, RefTracker, 10., 0.5, 1.0)
+    assert got == ref
+
+
 class ScriptVideo(object):
     def __init__(self, frames, fps=25.0, size=(640, 360)):
         self.frames, self.frame_rate, self.size, self.frame_size = frames, fps, size, size
