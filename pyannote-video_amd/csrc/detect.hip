@@ -4,6 +4,7 @@
 #include "pvf_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 // =====================================================================================================
 // K1: bilinear resize (pyramid_up / pyramid_down<6>), uint8 RGB HWC, double coordinates, (v + 0.5) truncation
@@ -89,12 +90,74 @@ __global__ void __launch_bounds__(256) resize_bilinear_k(const uint8_t* const* _
     } // tile loop
 }
 
+// K1, lean form: one lane = one output column, walking RS consecutive output rows.  The horizontal blend of a source row,
+//   H_s = (1 - lr) * S[s][left] + lr * S[s][right],
+// depends only on (s, column), and consecutive output rows share source rows, so each H_s is evaluated once and kept in
+// registers (two-entry cache; the hit test depends on the row only => wave-uniform).  The value written is the same expression
+// as before:  v = (1 - tb) * H_top + tb * H_bottom ; out = (uint8)(v + 0.5).
+template <int RS>
+__global__ void __launch_bounds__(256) resize_strip_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
+                                                      size_t in_stride, int ih, int iw, uint8_t* __restrict__ out, size_t out_stride,
+                                                      int oh, int ow, double x_scale, double y_scale)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * RS, b = blockIdx.z;
+    if (c >= ow) return;
+    const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
+    uint8_t* ob = out + (size_t)b * out_stride;
+    const double x = c * x_scale;
+    const int left = (int)floor(x);
+    const int right = min(left + 1, iw - 1);
+    const double lr = x - left, lr1 = 1 - lr;
+    const int ol = left * 3, orr = right * 3;
+    int s0 = -1, s1 = -1;              // cached source rows
+    double h0[3], h1[3];
+    const int r_end = min(r0 + RS, oh);
+    for (int r = r0; r < r_end; ++r) {
+        const double y = r * y_scale;
+        const int top = (int)floor(y);
+        const int bottom = min(top + 1, ih - 1);
+        const double tb = y - top, tb1 = 1 - tb;
+        // make (s0 == top, s1 == bottom)
+        if (s1 == top) { s0 = s1; h0[0] = h1[0]; h0[1] = h1[1]; h0[2] = h1[2]; s1 = -1; }
+        if (s0 != top) {
+            const uint8_t* p = in + (size_t)top * iw * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { const double tl = p[ol + k], tr = p[orr + k]; h0[k] = lr1 * tl + lr * tr; }
+            s0 = top;
+        }
+        if (s1 != bottom) {
+            if (bottom == top) { h1[0] = h0[0]; h1[1] = h0[1]; h1[2] = h0[2]; }
+            else {
+                const uint8_t* p = in + (size_t)bottom * iw * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double bl = p[ol + k], br = p[orr + k]; h1[k] = lr1 * bl + lr * br; }
+            }
+            s1 = bottom;
+        }
+        uint8_t* o = ob + ((size_t)r * ow + c) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v = tb1 * h0[k] + tb * h1[k];
+            o[k] = (uint8_t)(v + 0.5);
+        }
+    }
+}
+
 static void launch_resize(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* in_base, size_t in_stride, int ih, int iw,
                           uint8_t* out, size_t out_stride, int oh, int ow, int batch)
 {
     const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
     const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
     PVF_REQUIRE(x_scale <= 2.0, "resize: more than 2x horizontal decimation is not used on this path");
+    static const bool old_resize = getenv("PVF_OLD_RESIZE") != nullptr;
+    if (!old_resize) {
+        constexpr int RS = 16;
+        dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
+        hipLaunchKernelGGL((resize_strip_k<RS>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
+                           x_scale, y_scale);
+        return;
+    }
     const long ntiles = (long)((ow + 255) / 256) * oh * batch;
     const unsigned nblk = (unsigned)std::min<long>(ntiles, (long)c->n_cu * 16);   // persistent: a few blocks per CU walk the tiles
     hipLaunchKernelGGL(resize_bilinear_k, dim3(nblk), dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
@@ -222,6 +285,81 @@ __global__ void __launch_bounds__(256) fhog_grad_k(const uint8_t* __restrict__ i
     } // tile loop
 }
 
+// Pass 1, lean form: one lane = 4 consecutive pixels of one row; interior quads fetch their 3 x 18-byte neighbourhood with
+// 11 (unaligned) dword loads and pick the bytes with constant shifts; results leave as one float4 + one packed dword.
+__device__ __forceinline__ void grad_from_bytes(const int u[3], const int d[3], const int l[3], const int r[3],
+                                                const uint8_t* __restrict__ lut, float* v, int* o)
+{
+    int bx = r[0] - l[0], by = d[0] - u[0];
+    int bv = bx * bx + by * by;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+        const int cx = r[k] - l[k], cy = d[k] - u[k];
+        const int cv = cx * cx + cy * cy;
+        if (cv > bv) { bv = cv; bx = cx; by = cy; }
+    }
+    *v = sqrtf((float)bv);
+    *o = lut[(by + 255) * 511 + (bx + 255)];
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) fhog_grad4_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
+                                                    int visible_nc, float* __restrict__ mag, uint8_t* __restrict__ bin, size_t px_stride,
+                                                    int rows_t, int pitch, const uint8_t* __restrict__ lut)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;       // quad index within the row
+    const int yy = blockIdx.y, b = blockIdx.z;
+    const int xx = 4 * q;
+    if (xx >= pitch) return;
+    const int y = yy - 3 * C / 2, x0 = xx - 3 * C / 2;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int o[4] = {0, 0, 0, 0};
+    if (y >= 1 && y < visible_nr && x0 + 3 >= 1 && x0 < visible_nc) {
+        const uint8_t* im = img + (size_t)b * img_stride;
+        const int rb = iw * 3;
+        const uint8_t* rc = im + (size_t)y * rb;
+        const uint8_t* ru = rc - rb;
+        const uint8_t* rd = rc + rb;
+        if (x0 >= 1 && x0 + 4 <= visible_nc && x0 + 6 <= iw) {
+            uint32_t wc[5], wu[3], wd[3];
+            const uint8_t* pc = rc + 3 * x0 - 3;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) wc[k] = *reinterpret_cast<const uint32_t*>(pc + 4 * k);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                wu[k] = *reinterpret_cast<const uint32_t*>(ru + 3 * x0 + 4 * k);
+                wd[k] = *reinterpret_cast<const uint32_t*>(rd + 3 * x0 + 4 * k);
+            }
+#define BYTE_OF(w, i) (int)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                int u[3], d[3], l[3], r[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    u[k] = BYTE_OF(wu, 3 * p + k); d[k] = BYTE_OF(wd, 3 * p + k);
+                    l[k] = BYTE_OF(wc, 3 * p + k); r[k] = BYTE_OF(wc, 3 * p + 6 + k);
+                }
+                grad_from_bytes(u, d, l, r, lut, &v[p], &o[p]);
+            }
+#undef BYTE_OF
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int x = x0 + p;
+                if (x >= 1 && x < visible_nc) {
+                    int u[3], d[3], l[3], r[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { u[k] = ru[3 * x + k]; d[k] = rd[3 * x + k]; l[k] = rc[3 * x - 3 + k]; r[k] = rc[3 * x + 3 + k]; }
+                    grad_from_bytes(u, d, l, r, lut, &v[p], &o[p]);
+                }
+            }
+        }
+    }
+    const size_t idx = (size_t)b * px_stride + (size_t)yy * pitch + xx;
+    *reinterpret_cast<float4*>(mag + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<uint32_t*>(bin + idx) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+}
+
 // Pass 2: one lane per histogram cell walks its 2C x 2C window in row-major order (== the order dlib's scatter loop adds in),
 // adding each vote to the bin's running sum kept in LDS (acc[bin][lane]: conflict-free).  Rows are read with 16-byte loads.
 template <int C>
@@ -341,9 +479,16 @@ __global__ void __launch_bounds__(256) fhog_feat_k(const float* __restrict__ his
                                                    size_t norm_stride, int cells_nc, float* __restrict__ feat, size_t feat_stride, int fw,
                                                    int hog_nr, int hog_nc, int oy, int ox)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, b = blockIdx.z;
-    if (x >= hog_nc) return;
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;      // padded output coordinates
+    const int py = blockIdx.y, b = blockIdx.z;
+    if (px >= fw) return;
+    const int x = px - ox, y = py - oy;
+    if (x < 0 || y < 0 || x >= hog_nc || y >= hog_nr) {
+        float4* z = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)py * fw + px) * PVF_FHOG_STRIDE);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     float n[9], h[18], o[32];
     const float* nb = norm + (size_t)b * norm_stride;
 #pragma unroll
@@ -380,9 +525,16 @@ __global__ void __launch_bounds__(256) fhog1_feat_k(const float* __restrict__ no
                                                     int iw, float* __restrict__ feat, size_t feat_stride, int fw, int hog_nr, int hog_nc,
                                                     int oy, int ox)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, b = blockIdx.z;
-    if (x >= hog_nc) return;
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    const int py = blockIdx.y, b = blockIdx.z;
+    if (px >= fw) return;
+    const int x = px - ox, y = py - oy;
+    if (x < 0 || y < 0 || x >= hog_nc || y >= hog_nr) {
+        float4* z = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)py * fw + px) * PVF_FHOG_STRIDE);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     float n[9], h[18], o[32];
     const float* nb = norm + (size_t)b * px_stride;
 #pragma unroll
@@ -422,7 +574,6 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
     fhog_dims(h, w, cell, pad_r, pad_c, &fh, &fw);
     PVF_REQUIRE(fh > 0 && fw > 0, "fhog: image too small");
     const size_t feat_stride = (size_t)fh * fw * PVF_FHOG_STRIDE;
-    HIP_CHECK(hipMemsetAsync(d_feat, 0, feat_stride * n * sizeof(float), c->stream));
     const int oy = (pad_r - 1) / 2, ox = (pad_c - 1) / 2;
     const size_t img_stride = img_stride_in ? img_stride_in : (size_t)h * w * 3;
     if (cell == 1) {
@@ -431,7 +582,7 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
         hist.ensure(px * n);
         dim3 g1((w + 255) / 256, h, n);
         hipLaunchKernelGGL(fhog1_grad_k, g1, dim3(256), 0, c->stream, d_img, img_stride, h, w, norm.as<float>(), hist.as<uint8_t>(), px, lut);
-        dim3 g2((w - 2 + 255) / 256, h - 2, n);
+        dim3 g2((fw + 255) / 256, fh, n);
         hipLaunchKernelGGL(fhog1_feat_k, g2, dim3(256), 0, c->stream, norm.as<float>(), hist.as<uint8_t>(), px, w, d_feat, feat_stride, fw,
                            h - 2, w - 2, oy, ox);
         return;
@@ -452,17 +603,23 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
     const long gtiles = (long)((pitch + 127) / 128) * ((rows_t + 7) / 8) * n;
     dim3 gg((unsigned)std::min<long>(gtiles, (long)c->n_cu * 16));
     dim3 gh((hc + 255) / 256, hr, n);
+    static const bool old_grad = getenv("PVF_OLD_GRAD") != nullptr;
+    dim3 g4((pitch / 4 + 255) / 256, rows_t, n);
+    if (!old_grad) {
+        if (cell == 8) hipLaunchKernelGGL((fhog_grad4_k<8>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
+        else hipLaunchKernelGGL((fhog_grad4_k<4>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
+    }
     if (cell == 8) {
-        hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
+        if (old_grad) hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
         hipLaunchKernelGGL((fhog_hist_k<8>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     } else {
-        hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
+        if (old_grad) hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
         hipLaunchKernelGGL((fhog_hist_k<4>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     }
     const int hog_nr = cells_nr - 2, hog_nc = cells_nc - 2;
-    dim3 gf((hog_nc + 255) / 256, hog_nr, n);
+    dim3 gf((fw + 255) / 256, fh, n);
     hipLaunchKernelGGL(fhog_feat_k, gf, dim3(256), 0, c->stream, hist.as<float>(), hist_stride, hc, norm.as<float>(), norm_stride, cells_nc,
                        d_feat, feat_stride, fw, hog_nr, hog_nc, oy, ox);
 }
@@ -618,6 +775,104 @@ __global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ fe
         }
     }
     // C/D layout of the 16x16 MFMA: column j = lane & 15, row = 4 * (lane >> 4) + reg
+    const int j = lane & 15;
+    if (j < 15) {
+        const int s = j / 5, f = j % 5;
+        const float th = sp.thresh[f];
+        const int r = r_top + FR / 2;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int pos = 4 * (lane >> 4) + reg;
+                const int cc = c_base + t * 48 + 3 * pos + s + FC / 2;
+                const float v = acc[t][reg];
+                if (cc < c1 && v >= th) {
+                    const int idx = atomicAdd(&counts[b], 1);
+                    if (idx < sp.cap) {
+                        CandRec rec;
+                        rec.score = v - th; rec.filter = f; rec.level = sp.level; rec.r = r; rec.c = cc;
+                        cands[(size_t)b * sp.cap + idx] = rec;
+                    }
+                }
+            }
+    }
+}
+
+// score_mfma2_k: same tiling and the same accumulation order as score_mfma_k, but software-pipelined for ONE wave per SIMD:
+// while the 192 MFMAs of filter row m run from slab[m & 1] with the B fragments of row m, the 96 B fragments and the feature
+// row segment of row m+1 are already in flight (second register set, second slab).  launch_bounds(256, 1) => 512 VGPRs.
+__global__ void __launch_bounds__(256, 1) score_mfma2_k(const float* __restrict__ feat, size_t feat_stride, int fh, int fw,
+                                                        const float* __restrict__ Bg, ScoreParams sp, int* __restrict__ counts,
+                                                        CandRec* __restrict__ cands)
+{
+    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11;
+    constexpr int NST = (SEG * 8 + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) float s_seg[]; // [4 waves][2][SEG][PITCH]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.z;
+    const int r_top = blockIdx.y * 4 + wave, c_base = blockIdx.x * WCOLS;
+    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
+    if (r_top + FR / 2 >= r1) return;               // wave-uniform; no block-level barrier is used below
+    float* slab0 = s_seg + (size_t)wave * 2 * SEG * PITCH;
+    float* slab1 = slab0 + SEG * PITCH;
+    const float* fb = feat + (size_t)b * feat_stride;
+    const int i = lane & 15, kq = lane >> 4;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define SCORE_ISSUE(M, BV, SV)                                                                                              \
+    {                                                                                                                       \
+        const float* bp_ = Bg + (size_t)(M) * NK * 8 * 64 + lane;                                                           \
+        _Pragma("unroll") for (int q_ = 0; q_ < NK * 8; ++q_) BV[q_] = bp_[q_ * 64];                                        \
+        const int fr_ = r_top + (M);                                                                                        \
+        _Pragma("unroll") for (int u_ = 0; u_ < NST; ++u_) {                                                                \
+            const int idx_ = lane + 64 * u_;                                                                                \
+            const int cell_ = idx_ >> 3, q4_ = idx_ & 7;                                                                    \
+            const int x_ = c_base + cell_;                                                                                  \
+            SV[u_] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                       \
+            if (idx_ < SEG * 8 && fr_ < fh && x_ < fw)                                                                      \
+                SV[u_] = reinterpret_cast<const float4*>(fb + ((size_t)fr_ * fw + x_) * PVF_FHOG_STRIDE)[q4_];              \
+        }                                                                                                                   \
+    }
+#define SCORE_FILL(SLAB, SV)                                                                                                \
+    {                                                                                                                       \
+        _Pragma("unroll") for (int u_ = 0; u_ < NST; ++u_) {                                                                \
+            const int idx_ = lane + 64 * u_;                                                                                \
+            if (idx_ < SEG * 8) {                                                                                           \
+                const int cell_ = idx_ >> 3, q4_ = idx_ & 7;                                                                \
+                float2* d_ = reinterpret_cast<float2*>((SLAB) + cell_ * PITCH + 4 * q4_);                                   \
+                d_[0] = make_float2(SV[u_].x, SV[u_].y);                                                                    \
+                d_[1] = make_float2(SV[u_].z, SV[u_].w);                                                                    \
+            }                                                                                                               \
+        }                                                                                                                   \
+    }
+#define SCORE_MFMA(SLAB, BV)                                                                                                \
+    {                                                                                                                       \
+        const float* a0_ = (SLAB) + (3 * i) * PITCH + kq;                                                                   \
+        _Pragma("unroll") for (int n_ = 0; n_ < NK; ++n_)                                                                   \
+            _Pragma("unroll") for (int pq_ = 0; pq_ < 8; ++pq_)                                                             \
+                _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_) {                                                         \
+                    const float av_ = a0_[(t_ * 48 + n_) * PITCH + 4 * pq_];                                                \
+                    acc[t_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, BV[n_ * 8 + pq_], acc[t_], 0, 0, 0);                \
+                }                                                                                                           \
+    }
+    float bA[NK * 8], bB[NK * 8];
+    float4 sv[NST];
+    SCORE_ISSUE(0, bA, sv)
+    SCORE_FILL(slab0, sv)
+    for (int m = 0; m < FR; m += 2) {
+        SCORE_ISSUE(m + 1, bB, sv)                  // FR is even: row m+1 always exists
+        SCORE_MFMA(slab0, bA)
+        SCORE_FILL(slab1, sv)
+        if (m + 2 < FR) SCORE_ISSUE(m + 2, bA, sv)
+        SCORE_MFMA(slab1, bB)
+        if (m + 2 < FR) SCORE_FILL(slab0, sv)
+    }
+#undef SCORE_ISSUE
+#undef SCORE_FILL
+#undef SCORE_MFMA
     const int j = lane & 15;
     if (j < 15) {
         const int s = j / 5, f = j % 5;
@@ -805,7 +1060,18 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     }                                                                                                                        \
     hipLaunchKernelGGL((score_k<NF>), grid, dim3(256), lds, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_w, sp, \
                        d_counts, d_cands)
-            if (m.n_filters == 5 && m.d_bmfma) {
+            static const bool old_score = getenv("PVF_OLD_SCORE") != nullptr;
+            if (m.n_filters == 5 && m.d_bmfma && !old_score) {
+                const size_t lds3 = (size_t)4 * 2 * (2 * 48 + 11) * 34 * sizeof(float);
+                static bool attr3 = false;
+                if (!attr3) {
+                    HIP_CHECK(hipFuncSetAttribute((const void*)score_mfma2_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+                    attr3 = true;
+                }
+                dim3 g2((out_c + 95) / 96, (out_r + 3) / 4, B);
+                hipLaunchKernelGGL(score_mfma2_k, g2, dim3(256), lds3, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_bmfma, sp,
+                                   d_counts, d_cands);
+            } else if (m.n_filters == 5 && m.d_bmfma) {
                 const size_t lds2 = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
                 dim3 g2((out_c + 95) / 96, (out_r + 3) / 4, B);
                 hipLaunchKernelGGL(score_mfma_k, g2, dim3(256), lds2, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_bmfma, sp,
