@@ -34,8 +34,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--faces", type=int, default=8)
     ap.add_argument("--shots", type=int, default=4)
-    ap.add_argument("--detect-batch", type=int, default=8)
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--detect-batch", type=int, default=32)
+    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle sample (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="run detector and trackers on one stream (clean per-kernel timings)")
     ap.add_argument("--small-models", action="store_true", help="debug only: reduced landmark model")
     args = ap.parse_args()
@@ -185,7 +185,7 @@ def cpu_baseline(video, lp, ep, n_frames):
     import numpy as np
     from pyannote_video_amd import models, pipeline
     from oracle import oracle, ref_flow
-    oracle.lib().pvo_set_threads(os.cpu_count() or 1)
+    oracle.lib().pvo_set_threads(min(os.cpu_count() or 1, 32))   # more threads than rows per level only adds overhead
     cores = oracle.lib().pvo_get_max_threads()
     frames = [video.frame(i) for i in range(n_frames)]
     times = [video.timestamp(i) for i in range(n_frames)]

@@ -762,16 +762,30 @@ __global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ fe
             }
         }
         const float* a0 = seg + (3 * i) * PITCH + kq;
+        // A fragments are fetched one cell column (8 k-steps x MT tiles) ahead of the MFMAs that consume them
+        float an[8 * MT];
+#pragma unroll
+        for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) an[pq * MT + t] = a0[(t * 48) * PITCH + 4 * pq];
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
+            float ac[8 * MT];
 #pragma unroll
-            for (int pq = 0; pq < 8; ++pq) {
+            for (int q = 0; q < 8 * MT; ++q) ac[q] = an[q];
+            if (n + 1 < NK) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const float av = a0[(t * 48 + n) * PITCH + 4 * pq];
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[n * 8 + pq], acc[t], 0, 0, 0);
-                }
+                for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) an[pq * MT + t] = a0[(t * 48 + n + 1) * PITCH + 4 * pq];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + t], bv[n * 8 + pq], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // C/D layout of the 16x16 MFMA: column j = lane & 15, row = 4 * (lane >> 4) + reg
@@ -851,12 +865,23 @@ __global__ void __launch_bounds__(256, 1) score_mfma2_k(const float* __restrict_
 #define SCORE_MFMA(SLAB, BV)                                                                                                \
     {                                                                                                                       \
         const float* a0_ = (SLAB) + (3 * i) * PITCH + kq;                                                                   \
-        _Pragma("unroll") for (int n_ = 0; n_ < NK; ++n_)                                                                   \
+        float an_[8 * MT];                                                                                                  \
+        _Pragma("unroll") for (int pq_ = 0; pq_ < 8; ++pq_)                                                                 \
+            _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_) an_[pq_ * MT + t_] = a0_[(t_ * 48) * PITCH + 4 * pq_];        \
+        _Pragma("unroll") for (int n_ = 0; n_ < NK; ++n_) {                                                                 \
+            float ac_[8 * MT];                                                                                              \
+            _Pragma("unroll") for (int q_ = 0; q_ < 8 * MT; ++q_) ac_[q_] = an_[q_];                                        \
+            if (n_ + 1 < NK) {                                                                                              \
+                _Pragma("unroll") for (int pq_ = 0; pq_ < 8; ++pq_)                                                         \
+                    _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_)                                                       \
+                        an_[pq_ * MT + t_] = a0_[(t_ * 48 + n_ + 1) * PITCH + 4 * pq_];                                     \
+            }                                                                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                                              \
             _Pragma("unroll") for (int pq_ = 0; pq_ < 8; ++pq_)                                                             \
-                _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_) {                                                         \
-                    const float av_ = a0_[(t_ * 48 + n_) * PITCH + 4 * pq_];                                                \
-                    acc[t_] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_, BV[n_ * 8 + pq_], acc[t_], 0, 0, 0);                \
-                }                                                                                                           \
+                _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_)                                                           \
+                    acc[t_] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac_[pq_ * MT + t_], BV[n_ * 8 + pq_], acc[t_], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                              \
+        }                                                                                                                   \
     }
     float bA[NK * 8], bB[NK * 8];
     float4 sv[NST];
@@ -1060,8 +1085,8 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     }                                                                                                                        \
     hipLaunchKernelGGL((score_k<NF>), grid, dim3(256), lds, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_w, sp, \
                        d_counts, d_cands)
-            static const bool old_score = getenv("PVF_OLD_SCORE") != nullptr;
-            if (m.n_filters == 5 && m.d_bmfma && !old_score) {
+            static const bool pipe_score = getenv("PVF_PIPE_SCORE") != nullptr;
+            if (m.n_filters == 5 && m.d_bmfma && pipe_score) {
                 const size_t lds3 = (size_t)4 * 2 * (2 * 48 + 11) * 34 * sizeof(float);
                 static bool attr3 = false;
                 if (!attr3) {

@@ -124,7 +124,7 @@ RESNET_UNITS = [(32, 32, 0)] * 3 + [(32, 64, 1)] + [(64, 64, 0)] * 3 + [(64, 128
 
 # scale of the final fc layer, calibrated once (tools/calibrate_embedder.py) so that different synthetic
 # identities land ~1.0 apart and the same identity well under the reference threshold 0.6 (clustering.py:138)
-FC_SCALE = 1.7
+FC_SCALE = 1.3
 
 
 def resnet_param_layout():
