@@ -376,35 +376,38 @@ __global__ void __launch_bounds__(256) fhog_hist_k(const float* __restrict__ mag
     if (hx < hc) {
         const float* mg = mag + (size_t)b * px_stride + (size_t)C * hx;
         const uint8_t* bn = bin + (size_t)b * px_stride + (size_t)C * hx;
+        constexpr int NV = 2 * C / 4;            // float4 loads per row
+        float4 pv[2][NV];
+        uint32_t pb[2][4];
+        auto load_row = [&](int wy, float4* dv, uint32_t* db) {
+            const size_t row = (size_t)(C * hy + wy) * pitch;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) dv[q] = *reinterpret_cast<const float4*>(mg + row + 4 * q);
+            if (C == 8) {
+                const uint4 t = *reinterpret_cast<const uint4*>(bn + row);
+                db[0] = t.x; db[1] = t.y; db[2] = t.z; db[3] = t.w;
+            } else {
+                const uint2 t = *reinterpret_cast<const uint2*>(bn + row);
+                db[0] = t.x; db[1] = t.y; db[2] = 0; db[3] = 0;
+            }
+        };
+        load_row(0, pv[0], pb[0]);
+#pragma unroll
         for (int wy = 0; wy < 2 * C; ++wy) {
+            const int cur = wy & 1;
+            if (wy + 1 < 2 * C) load_row(wy + 1, pv[cur ^ 1], pb[cur ^ 1]);   // next row is in flight while this one is accumulated
             const int i = wy % C;
             const float fy = ((float)i + 0.5f) / (float)C;
             const float wyv = (wy < C) ? fy : 1.0f - fy;
-            const size_t row = (size_t)(C * hy + wy) * pitch;
             float v[2 * C];
-            uint8_t ob[2 * C];
 #pragma unroll
-            for (int q = 0; q < 2 * C / 4; ++q) {
-                const float4 t = *reinterpret_cast<const float4*>(mg + row + 4 * q);
-                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-            }
-            if (C == 8) {
-                const uint4 t = *reinterpret_cast<const uint4*>(bn + row);
-                const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                for (int k = 0; k < 16; ++k) ob[k] = (uint8_t)((w4[k >> 2] >> (8 * (k & 3))) & 0xff);
-            } else {
-                const uint2 t = *reinterpret_cast<const uint2*>(bn + row);
-                const uint32_t w2[2] = {t.x, t.y};
-#pragma unroll
-                for (int k = 0; k < 2 * C; ++k) ob[k] = (uint8_t)((w2[k >> 2] >> (8 * (k & 3))) & 0xff);
-            }
+            for (int q = 0; q < NV; ++q) { v[4 * q] = pv[cur][q].x; v[4 * q + 1] = pv[cur][q].y; v[4 * q + 2] = pv[cur][q].z; v[4 * q + 3] = pv[cur][q].w; }
 #pragma unroll
             for (int wx = 0; wx < 2 * C; ++wx) {
                 const int j = wx % C;
                 const float fx = ((float)j + 0.5f) / (float)C;
                 const float wxv = (wx < C) ? fx : 1.0f - fx;
-                const int o = ob[wx];
+                const int o = (int)((pb[cur][wx >> 2] >> (8 * (wx & 3))) & 0xffu);
                 acc[o][tid] = acc[o][tid] + (wyv * wxv) * v[wx];
             }
         }
@@ -734,6 +737,7 @@ __global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ fe
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool two_tiles = (c_base + 48 + FC / 2 < c1);   // wave-uniform: ragged row ends run one 48-column tile only
     for (int m = 0; m < FR; ++m) {
         const int fr = r_top + m;
         // issue every load of this filter row up front: 96 B fragments (L2) + the feature row segment, then fill the slab
@@ -780,11 +784,17 @@ __global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ fe
                     for (int t = 0; t < MT; ++t) an[pq * MT + t] = a0[(t * 48 + n + 1) * PITCH + 4 * pq];
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (two_tiles) {
 #pragma unroll
-            for (int pq = 0; pq < 8; ++pq)
+                for (int pq = 0; pq < 8; ++pq)
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + t], bv[n * 8 + pq], acc[t], 0, 0, 0);
+                    for (int t = 0; t < MT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + t], bv[n * 8 + pq], acc[t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int pq = 0; pq < 8; ++pq)
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT], bv[n * 8 + pq], acc[0], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }

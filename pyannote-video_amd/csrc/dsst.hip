@@ -56,11 +56,12 @@ __device__ void fft2d_lds(double2* s, const double* __restrict__ tw, bool invers
             }
         }
         __syncthreads();
+#pragma unroll
         for (int st = 1; st <= 6; ++st) {
             const int m = 1 << st, half = m >> 1, tstep = FS / m;
             for (int idx = tid; idx < FS * 32; idx += 256) {
                 const int line = idx >> 5, b = idx & 31;
-                const int k = (b / half) * m, j = b % half;
+                const int k = (b >> (st - 1)) << st, j = b & (half - 1);
                 const double wr = tw[2 * j * tstep];
                 const double wi = inverse ? tw[2 * j * tstep + 1] : -tw[2 * j * tstep + 1];
                 const int e0 = k + j, e1 = e0 + half;

@@ -70,9 +70,9 @@ template <int WM, int WN, bool GENERIC>
 __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
 {
     constexpr int BM = 32 * WM, BN = 32 * WN, KC = 32;
-    constexpr int PA = BM + 2, PB = BN + 2;
+    constexpr int PA = BM + 2, PB = BN + 4;     // PB: 16-byte aligned rows -> one ds_write_b128 per staged float4
     __shared__ float As[KC * PA];
-    __shared__ float Bs[KC * PB];
+    __shared__ __attribute__((aligned(16))) float Bs[KC * PB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const long M = (long)a.B * a.OH * a.OW;
@@ -151,8 +151,7 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
             const int k = k0 + kk;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k < a.K) v = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + n0 + 4 * j4);
-            float* d = &Bs[kk * PB + 4 * j4];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            *reinterpret_cast<float4*>(&Bs[kk * PB + 4 * j4]) = v;
         }
         __syncthreads();
         const int ai = wm * 32 + (lane & 31), bj = wn * 32 + (lane & 31), kh = lane >> 5;
@@ -245,7 +244,7 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
     const EmbedModel& e = c->emb;
     PVF_REQUIRE(e.loaded, "embedder not loaded");
     const int S = e.chip_size;
-    const int MAXB = 256;
+    const int MAXB = 1024;   // faces per forward: deep layers (4x4, 2x2 maps) need the batch to fill 256 CUs
     const int h1 = 1 + (S - 7) / 2;       // 72
     const int hp = 1 + (h1 - 3) / 2;      // 35
     const size_t big = (size_t)MAXB * h1 * h1 * 32;
