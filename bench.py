@@ -152,6 +152,17 @@ def main():
                 "avg_launch_ms": round(score_ms / launches, 4),
                 "flop_per_launch": flop_per_frame * n_score_frames / launches}
 
+    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read inside this process);
+    # the committed measurement is attached when it was taken on this configuration.
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_score.json")))
+        if pm["detect_batch"] == args.detect_batch and pm["frame"] == "%dx%d" % (args.width, args.height):
+            roofline["traffic"] = pm["traffic_bytes_per_launch"]
+            roofline["traffic_source"] = pm["source"]
+            roofline["algorithmic_bytes_per_launch"] = sum(g[2] * g[3] for g in geo) * 128.0 * args.detect_batch / max(len(geo), 1)
+    except Exception:
+        pass
+
     cpu = None
     if world == 1 and args.cpu_frames > 0:
         cpu = cpu_baseline(video, lp, ep, args.cpu_frames)
