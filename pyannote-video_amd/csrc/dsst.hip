@@ -28,11 +28,21 @@ __device__ __forceinline__ double det_exp(double x)
     if (x < -700.0) return 0.0;
     const double kf = floor(x * inv_ln2 + 0.5);
     const double r = (x - kf * ln2_hi) - kf * ln2_lo;
-    const double c[14] = {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320,
-                          1.0 / 362880, 1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0};
-    double p = c[13];
-#pragma unroll
-    for (int i = 12; i >= 0; --i) p = p * r + c[i];
+    // Horner form of sum_{i<=13} r^i / i!  (same coefficients and order as the oracle's loop)
+    double p = 1.0 / 6227020800.0;
+    p = p * r + 1.0 / 479001600;
+    p = p * r + 1.0 / 39916800;
+    p = p * r + 1.0 / 3628800;
+    p = p * r + 1.0 / 362880;
+    p = p * r + 1.0 / 40320;
+    p = p * r + 1.0 / 5040;
+    p = p * r + 1.0 / 720;
+    p = p * r + 1.0 / 120;
+    p = p * r + 1.0 / 24;
+    p = p * r + 1.0 / 6;
+    p = p * r + 1.0 / 2;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
     const long long k = (long long)kf;
     const unsigned long long bits = (unsigned long long)(k + 1023) << 52;
     return p * __longlong_as_double((long long)bits);
@@ -40,49 +50,93 @@ __device__ __forceinline__ double det_exp(double x)
 
 __device__ __forceinline__ int brev6(int v) { return (int)(__brev((unsigned)v) >> 26); }
 
-// in-place 2-D FFT of s[64][LP] (double2 = re,im); rows then columns; radix-2 DIT; blockDim.x = 256
+// One radix-2 DIT butterfly exactly as the oracle writes it: t = w * b ; (a, b) <- (a + t, a - t)
+__device__ __forceinline__ void bfly(double2& a, double2& b, double wr, double wi)
+{
+    const double tr = wr * b.x - wi * b.y;
+    const double ti = wr * b.y + wi * b.x;
+    const double2 u = a;
+    a = make_double2(u.x + tr, u.y + ti);
+    b = make_double2(u.x - tr, u.y - ti);
+}
+
+// In-place 2-D FFT of s[64][LP] (double2 = re,im); rows then columns; blockDim.x = 256.
+// The 64-point radix-2 DIT of each line is evaluated as two register-resident groups of three stages:
+//   phase 1: lane owns x[8q .. 8q+7] of the bit-reversed line        -> stages 1-3 (pairs at distance 1, 2, 4)
+//   phase 2: lane owns x[8a + b], a = 0..7                            -> stages 4-6 (pairs at distance 8, 16, 32)
+// Butterflies, operand order and twiddles are those of the stage-by-stage form (oracle/pvo_dsst.c fft1d), so values are
+// bit-identical.  Everything is done IN PLACE on the positions a lane reads (no intra-phase barrier, 8 live values per lane):
+// element x_br[k] never moves from position brev6(k), hence the OUTPUT IS LEFT IN BIT-REVERSED POSITIONS along both axes:
+//   X[kr][kc]  is found at  s[brev6(kr) * LP + brev6(kc)]            (use FFT_AT below).
+#define FFT_AT(s, r, c) (s)[brev6(r) * LP + brev6(c)]
 __device__ void fft2d_lds(double2* s, const double* __restrict__ tw, bool inverse)
 {
     const int tid = threadIdx.x;
+    const double sg = inverse ? 1.0 : -1.0;      // wi = +sin (inverse) / -sin (forward)
+#pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-        // bit reversal along the transformed axis
-        for (int idx = tid; idx < FS * FS; idx += 256) {
-            const int line = idx >> 6, e = idx & 63;
-            const int j = brev6(e);
-            if (j > e) {
-                const int p0 = pass == 0 ? line * LP + e : e * LP + line;
-                const int p1 = pass == 0 ? line * LP + j : j * LP + line;
-                const double2 t = s[p0]; s[p0] = s[p1]; s[p1] = t;
+        // ---- phase 1: task (line, q): positions brev6(8q + i) = 8 * brev3(i) + brev3(q)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int tt = tid + 256 * u, line = tt >> 3, q = tt & 7;
+            const int rq = (int)(__brev((unsigned)q) >> 29);
+            double2 e[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ri = ((i & 1) << 2) | (i & 2) | ((i >> 2) & 1);
+                const int pos = ri * 8 + rq;
+                e[i] = s[pass == 0 ? line * LP + pos : pos * LP + line];
+            }
+            {
+                const double wr = tw[0], wi = sg * tw[1];                         // stage 1 (m = 2)
+                bfly(e[0], e[1], wr, wi); bfly(e[2], e[3], wr, wi); bfly(e[4], e[5], wr, wi); bfly(e[6], e[7], wr, wi);
+                const double w1r = tw[2 * 16], w1i = sg * tw[2 * 16 + 1];        // stage 2 (m = 4, tstep 16)
+                bfly(e[0], e[2], wr, wi); bfly(e[1], e[3], w1r, w1i);
+                bfly(e[4], e[6], wr, wi); bfly(e[5], e[7], w1r, w1i);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfly(e[j], e[j + 4], tw[2 * 8 * j], sg * tw[2 * 8 * j + 1]);   // stage 3 (m = 8, tstep 8)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ri = ((i & 1) << 2) | (i & 2) | ((i >> 2) & 1);
+                const int pos = ri * 8 + rq;
+                s[pass == 0 ? line * LP + pos : pos * LP + line] = e[i];
             }
         }
         __syncthreads();
+        // ---- phase 2: task (line, b): x[8a + b] lives at brev6(8a + b) = 8 * brev3(b) + brev3(a)
 #pragma unroll
-        for (int st = 1; st <= 6; ++st) {
-            const int m = 1 << st, half = m >> 1, tstep = FS / m;
-            for (int idx = tid; idx < FS * 32; idx += 256) {
-                const int line = idx >> 5, b = idx & 31;
-                const int k = (b >> (st - 1)) << st, j = b & (half - 1);
-                const double wr = tw[2 * j * tstep];
-                const double wi = inverse ? tw[2 * j * tstep + 1] : -tw[2 * j * tstep + 1];
-                const int e0 = k + j, e1 = e0 + half;
-                const int p0 = pass == 0 ? line * LP + e0 : e0 * LP + line;
-                const int p1 = pass == 0 ? line * LP + e1 : e1 * LP + line;
-                const double2 a = s[p0], bb = s[p1];
-                const double tr = wr * bb.x - wi * bb.y;
-                const double ti = wr * bb.y + wi * bb.x;
-                s[p0] = make_double2(a.x + tr, a.y + ti);
-                s[p1] = make_double2(a.x - tr, a.y - ti);
+        for (int u = 0; u < 2; ++u) {
+            const int tt = tid + 256 * u, line = tt >> 3, b = tt & 7;
+            const int rb = (int)(__brev((unsigned)b) >> 29);
+            double2 f[8];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const int ra = ((a & 1) << 2) | (a & 2) | ((a >> 2) & 1);
+                const int pos = rb * 8 + ra;
+                f[a] = s[pass == 0 ? line * LP + pos : pos * LP + line];
             }
-            __syncthreads();
-        }
-    }
-    if (inverse) {
-        const double sc = 1.0 / 64.0;
-        for (int idx = tid; idx < FS * FS; idx += 256) {
-            const int p = (idx >> 6) * LP + (idx & 63);
-            double2 v = s[p];
-            v.x = (v.x * sc) * sc; v.y = (v.y * sc) * sc;
-            s[p] = v;
+            {
+                const double wr = tw[2 * 4 * b], wi = sg * tw[2 * 4 * b + 1];     // stage 4 (m = 16, tstep 4): j = b
+                bfly(f[0], f[1], wr, wi); bfly(f[2], f[3], wr, wi); bfly(f[4], f[5], wr, wi); bfly(f[6], f[7], wr, wi);
+                const double w0r = tw[2 * 2 * b], w0i = sg * tw[2 * 2 * b + 1];   // stage 5 (m = 32, tstep 2): j = 8 (a & 1) + b
+                const double w1r = tw[2 * 2 * (8 + b)], w1i = sg * tw[2 * 2 * (8 + b) + 1];
+                bfly(f[0], f[2], w0r, w0i); bfly(f[1], f[3], w1r, w1i);
+                bfly(f[4], f[6], w0r, w0i); bfly(f[5], f[7], w1r, w1i);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) bfly(f[a], f[a + 4], tw[2 * (8 * a + b)], sg * tw[2 * (8 * a + b) + 1]);   // stage 6: j = 8a + b
+            if (inverse && pass == 1) {
+                const double sc = 1.0 / 64.0;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) { f[a].x = (f[a].x * sc) * sc; f[a].y = (f[a].y * sc) * sc; }
+            }
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                const int ra = ((a & 1) << 2) | (a & 2) | ((a >> 2) & 1);
+                const int pos = rb * 8 + ra;
+                s[pass == 0 ? line * LP + pos : pos * LP + line] = f[a];
+            }
         }
         __syncthreads();
     }
@@ -134,10 +188,10 @@ __global__ void __launch_bounds__(256) trans_planes_fft_k(const uint8_t* __restr
     __syncthreads();
     fft2d_lds(s, tw64, false);
     double2* out = F + ((size_t)b * NPL + i) * FS * FS;
-    for (int q = threadIdx.x; q < FS * FS; q += 256) out[q] = s[(q >> 6) * LP + (q & 63)];
+    for (int q = threadIdx.x; q < FS * FS; q += 256) out[q] = FFT_AT(s, q >> 6, q & 63);
 }
 
-// target image exp(-dist/3) in a 21x21 window around (px,py), FFT, conj; result left in s
+// target image exp(-dist/3) in a 21x21 window around (px,py), FFT, conj; spectrum left in s in bit-reversed positions (FFT_AT)
 __device__ void make_target_lds(double2* s, double px, double py, const double* __restrict__ tw64)
 {
     for (int q = threadIdx.x; q < FS * FS; q += 256) s[(q >> 6) * LP + (q & 63)] = make_double2(0.0, 0.0);
@@ -163,7 +217,7 @@ __global__ void __launch_bounds__(256) target_fft_k(const TrkJob* __restrict__ j
     if (threadIdx.x < 4) j.state[TRK_POS + threadIdx.x] = j.box[threadIdx.x];
     make_target_lds(s, j.cx, j.cy, tw64);
     double2* out = Ghat + (size_t)blockIdx.x * FS * FS;
-    for (int q = threadIdx.x; q < FS * FS; q += 256) out[q] = s[(q >> 6) * LP + (q & 63)];
+    for (int q = threadIdx.x; q < FS * FS; q += 256) out[q] = FFT_AT(s, q >> 6, q & 63);
 }
 
 __global__ void __launch_bounds__(256) start_filters_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ F, const double2* __restrict__ Ghat)
@@ -214,7 +268,7 @@ __global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, c
     // arg-max of the real part, first occurrence in row-major order
     double bv = -INFINITY; int bi = 0x7fffffff;
     for (int q = tid; q < FS * FS; q += 256) {
-        const double v = s[(q >> 6) * LP + (q & 63)].x;
+        const double v = FFT_AT(s, q >> 6, q & 63).x;
         if (v > bv) { bv = v; bi = q; }
     }
     red_v[tid] = bv; red_i[tid] = bi;
@@ -231,7 +285,7 @@ __global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, c
         double ox = px, oy = py;
         if (!(px < 1 || py < 1 || px > FS - 2 || py > FS - 2)) {
             double z[3][3];
-            for (int r = -1; r <= 1; ++r) for (int c = -1; c <= 1; ++c) z[r + 1][c + 1] = s[(py + r) * LP + (px + c)].x;
+            for (int r = -1; r <= 1; ++r) for (int c = -1; c <= 1; ++c) z[r + 1][c + 1] = FFT_AT(s, py + r, px + c).x;
             const double sx = ((z[0][2] + z[1][2]) + z[2][2]) - ((z[0][0] + z[1][0]) + z[2][0]);
             const double sy = ((z[2][0] + z[2][1]) + z[2][2]) - ((z[0][0] + z[0][1]) + z[0][2]);
             const double sxy = (z[0][0] + z[2][2]) - (z[0][2] + z[2][0]);
@@ -264,7 +318,7 @@ __global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, c
         double rs = 0, rq = 0, cnt = 0;
         for (int c = 0; c < FS; ++c) {
             if (c >= rx - 4 && c <= rx + 3 && r >= ry - 4 && r <= ry + 3) continue;
-            const double v = s[r * LP + c].x;
+            const double v = FFT_AT(s, r, c).x;
             rs = rs + v;
             rq = rq + v * v;
             cnt += 1;
@@ -283,7 +337,7 @@ __global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, c
         if (qy < 0) qy = 0;
         if (qx > FS - 1) qx = FS - 1;
         if (qy > FS - 1) qy = FS - 1;
-        const double psr = (s[qy * LP + qx].x - mean) / sqrt(var);
+        const double psr = (FFT_AT(s, (int)qy, (int)qx).x - mean) / sqrt(var);
         double* st = j.state;
         const double g0 = st[TRK_POS], g1 = st[TRK_POS + 1], g2 = st[TRK_POS + 2], g3 = st[TRK_POS + 3];
         const double ix = j.map[0] + ppx * j.map[2], iy = j.map[1] + ppy * j.map[3];
@@ -295,7 +349,7 @@ __global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, c
     __syncthreads();
     make_target_lds(s, ppx, ppy, tw64);
     double2* out = Ghat + (size_t)b * FS * FS;
-    for (int q = tid; q < FS * FS; q += 256) out[q] = s[(q >> 6) * LP + (q & 63)];
+    for (int q = tid; q < FS * FS; q += 256) out[q] = FFT_AT(s, q >> 6, q & 63);
 }
 
 __global__ void __launch_bounds__(256) filter_update_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ F, const double2* __restrict__ Ghat)
