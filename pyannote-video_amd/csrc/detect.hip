@@ -9,87 +9,6 @@
 // =====================================================================================================
 // K1: bilinear resize (pyramid_up / pyramid_down<6>), uint8 RGB HWC, double coordinates, (v + 0.5) truncation
 // =====================================================================================================
-// One block = 256 consecutive pixels of one output row.  The two source rows' byte ranges are staged in LDS with dword loads,
-// every lane blends its pixel (double arithmetic, identical expression to the oracle), the 768 output bytes go back through LDS
-// as aligned dword stores.
-__global__ void __launch_bounds__(256) resize_bilinear_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
-                                                         size_t in_stride, int ih, int iw, uint8_t* __restrict__ out, size_t out_stride,
-                                                         int oh, int ow, double x_scale, double y_scale, int batch)
-{
-    constexpr int TW = 256, SRCW = 2 * TW + 8;                 // source pixels per tile: <= TW * x_scale + 2 with x_scale <= 2
-    __shared__ uint32_t s_src[2][(SRCW * 3 + 3) / 4 + 2];
-    __shared__ uint32_t s_out[TW * 3 / 4];
-    const int tid = threadIdx.x;
-    const int ncb = (ow + TW - 1) / TW;
-    const long ntiles = (long)ncb * oh * batch;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int c0 = (int)(tile % ncb) * TW, r = (int)((tile / ncb) % oh), b = (int)(tile / ((long)ncb * oh));
-    const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
-    const double y = r * y_scale;
-    const int top = (int)floor(y);
-    const int bottom = min(top + 1, ih - 1);
-    const double tb = y - top;
-    const int cl = min(c0 + TW - 1, ow - 1);
-    const int left_min = (int)floor(c0 * x_scale);
-    const int right_max = min((int)floor(cl * x_scale) + 1, iw - 1);
-    const int nsrc = right_max - left_min + 1;                 // pixels
-    const long row_bytes = (long)iw * 3;
-    const long img_bytes = row_bytes * ih;
-    int mis[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const long start = (long)(k == 0 ? top : bottom) * row_bytes + (long)left_min * 3;
-        const long a0 = start & ~3L;
-        mis[k] = (int)(start - a0);
-        const int nd = (mis[k] + nsrc * 3 + 3) / 4;
-        for (int d = tid; d < nd; d += TW) {
-            const long off = a0 + 4L * d;
-            uint32_t v;
-            if (off + 4 <= img_bytes) v = *reinterpret_cast<const uint32_t*>(in + off);
-            else { v = 0; for (int q = 0; q < 4; ++q) if (off + q < img_bytes) v |= (uint32_t)in[off + q] << (8 * q); }
-            s_src[k][d] = v;
-        }
-    }
-    __syncthreads();
-    const int c = c0 + tid;
-    if (c < ow) {
-        const double x = c * x_scale;
-        const int left = (int)floor(x);
-        const int right = min(left + 1, iw - 1);
-        const double lr = x - left;
-        const uint8_t* rt = reinterpret_cast<const uint8_t*>(&s_src[0][0]) + mis[0];
-        const uint8_t* rb = reinterpret_cast<const uint8_t*>(&s_src[1][0]) + mis[1];
-        const int ol = (left - left_min) * 3, orr = (right - left_min) * 3;
-        uint8_t* o = reinterpret_cast<uint8_t*>(&s_out[0]) + tid * 3;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double tl = rt[ol + k], tr = rt[orr + k], bl = rb[ol + k], br = rb[orr + k];
-            const double v = (1 - tb) * ((1 - lr) * tl + lr * tr) + tb * ((1 - lr) * bl + lr * br);
-            o[k] = (uint8_t)(v + 0.5);
-        }
-    }
-    __syncthreads();
-    // write back [g0, g1) bytes of the output row segment
-    uint8_t* ob = out + (size_t)b * out_stride;
-    const long g0 = ((long)r * ow + c0) * 3, g1 = ((long)r * ow + min(c0 + TW, ow)) * 3;
-    const long a0 = (g0 + 3) & ~3L, a1 = g1 & ~3L;            // aligned dword range (relative to ob; ob itself is >= 4-aligned or handled bytewise)
-    const bool base_aligned = ((reinterpret_cast<uintptr_t>(ob) & 3) == 0);
-    const uint8_t* so = reinterpret_cast<const uint8_t*>(&s_out[0]);
-    if (base_aligned && a0 < a1) {
-        for (long p = g0 + tid; p < a0; p += TW) ob[p] = so[p - g0];
-        for (long p = a0 + 4L * tid; p < a1; p += 4L * TW) {
-            const long q = p - g0;
-            const uint32_t v = (uint32_t)so[q] | ((uint32_t)so[q + 1] << 8) | ((uint32_t)so[q + 2] << 16) | ((uint32_t)so[q + 3] << 24);
-            *reinterpret_cast<uint32_t*>(ob + p) = v;
-        }
-        for (long p = a1 + tid; p < g1; p += TW) ob[p] = so[p - g0];
-    } else {
-        for (long p = g0 + tid; p < g1; p += TW) ob[p] = so[p - g0];
-    }
-    __syncthreads();
-    } // tile loop
-}
-
 // K1, lean form: one lane = one output column, walking RS consecutive output rows.  The horizontal blend of a source row,
 //   H_s = (1 - lr) * S[s][left] + lr * S[s][right],
 // depends only on (s, column), and consecutive output rows share source rows, so each H_s is evaluated once and kept in
@@ -150,18 +69,10 @@ static void launch_resize(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* 
     const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
     const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
     PVF_REQUIRE(x_scale <= 2.0, "resize: more than 2x horizontal decimation is not used on this path");
-    static const bool old_resize = getenv("PVF_OLD_RESIZE") != nullptr;
-    if (!old_resize) {
-        constexpr int RS = 16;
-        dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
-        hipLaunchKernelGGL((resize_strip_k<RS>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
-                           x_scale, y_scale);
-        return;
-    }
-    const long ntiles = (long)((ow + 255) / 256) * oh * batch;
-    const unsigned nblk = (unsigned)std::min<long>(ntiles, (long)c->n_cu * 16);   // persistent: a few blocks per CU walk the tiles
-    hipLaunchKernelGGL(resize_bilinear_k, dim3(nblk), dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
-                       x_scale, y_scale, batch);
+    constexpr int RS = 16;
+    dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
+    hipLaunchKernelGGL((resize_strip_k<RS>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
+                       x_scale, y_scale);
 }
 
 static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
@@ -223,69 +134,9 @@ __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, co
     *bo = lut[(by + 255) * 511 + (bx + 255)];
 }
 
-// Pass 1: per pixel (orientation bin, gradient magnitude) into planes shifted by 3C/2 so that histogram cell (hy,hx)
-// owns rows yy in [C*hy, C*hy+2C) and columns xx in [C*hx, C*hx+2C)  (yy = y + 3C/2, xx = x + 3C/2; pitch = multiple of 8 floats).
-// A block handles 128 x 8 pixels; the (8+2) x (128+2) RGB neighbourhood is staged in LDS with coalesced dword loads.
-template <int C>
-__global__ void __launch_bounds__(256) fhog_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
-                                                   int visible_nc, float* __restrict__ mag, uint8_t* __restrict__ bin, size_t px_stride,
-                                                   int rows_t, int pitch, const uint8_t* __restrict__ lut, int batch)
-{
-    constexpr int TW = 128, TH = 8, RB = (TW + 2) * 3, RD = (RB + 3 + 3) / 4 + 1; // bytes per staged row, dwords incl. alignment slack
-    __shared__ uint32_t s_raw[TH + 2][RD];
-    const int ntx = (pitch + TW - 1) / TW, nty = (rows_t + TH - 1) / TH;
-    const long ntiles = (long)ntx * nty * batch;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int b = (int)(tile / ((long)ntx * nty));
-    const int xx0 = (int)(tile % ntx) * TW, yy0 = (int)((tile / ntx) % nty) * TH;
-    const int x0 = xx0 - 3 * C / 2, y0 = yy0 - 3 * C / 2;      // image coords of the tile's first pixel
-    const uint8_t* im = img + (size_t)b * img_stride;
-    const long row_bytes = (long)iw * 3;
-    // stage rows y0-1 .. y0+TH, bytes [(x0-1)*3, (x0+TW+1)*3) ; dword-aligned window per row (global address % 4 kept)
-    for (int i = threadIdx.x; i < (TH + 2) * RD; i += blockDim.x) {
-        const int ry = i / RD, d = i % RD;
-        const int y = y0 - 1 + ry;
-        uint32_t v = 0;
-        if (y >= 0 && y < ih) {
-            const long start = (long)y * row_bytes + (long)(x0 - 1) * 3;      // may be negative / unaligned
-            const long a0 = (start >= 0 ? (start & ~3L) : -((-start + 3) & ~3L)); // floor to multiple of 4
-            const long off = a0 + 4L * d;
-            const long lo = (long)y * row_bytes, hi = lo + row_bytes;          // valid byte range of this row
-            if (off >= lo && off + 4 <= hi && off + 4 <= (long)ih * row_bytes) v = *reinterpret_cast<const uint32_t*>(im + off);
-            else {
-                for (int k = 0; k < 4; ++k) { const long o = off + k; if (o >= lo && o < hi) v |= (uint32_t)im[o] << (8 * k); }
-            }
-        }
-        s_raw[ry][d] = v;
-    }
-    __syncthreads();
-    for (int p = threadIdx.x; p < TW * TH; p += blockDim.x) {
-        const int ly = p / TW, lx = p % TW;
-        const int xx = xx0 + lx, yy = yy0 + ly;
-        if (xx >= pitch || yy >= rows_t) continue;
-        const int y = y0 + ly, x = x0 + lx;
-        float v = 0.0f;
-        int o = 0;
-        if (y >= 1 && y < visible_nr && x >= 1 && x < visible_nc) {
-            // byte offset of pixel (x-1) within the staged row = ((y*row_bytes + (x0-1)*3) mod 4) + lx*3
-            const long start_c = (long)y * row_bytes + (long)(x0 - 1) * 3;
-            const long start_u = start_c - row_bytes, start_d = start_c + row_bytes;
-            const uint8_t* rc = reinterpret_cast<const uint8_t*>(&s_raw[ly + 1][0]) + (int)(((start_c % 4) + 4) % 4) + lx * 3;
-            const uint8_t* ru = reinterpret_cast<const uint8_t*>(&s_raw[ly][0]) + (int)(((start_u % 4) + 4) % 4) + lx * 3;
-            const uint8_t* rd = reinterpret_cast<const uint8_t*>(&s_raw[ly + 2][0]) + (int)(((start_d % 4) + 4) % 4) + lx * 3;
-            float v2;
-            pixel_grad(ru, rc, rd, 3, lut, &v2, &o);
-            v = sqrtf(v2);
-        }
-        const size_t idx = (size_t)b * px_stride + (size_t)yy * pitch + xx;
-        mag[idx] = v;
-        bin[idx] = (uint8_t)o;
-    }
-    __syncthreads();
-    } // tile loop
-}
-
-// Pass 1, lean form: one lane = 4 consecutive pixels of one row; interior quads fetch their 3 x 18-byte neighbourhood with
+// Pass 1: per pixel (orientation bin, gradient magnitude) into planes shifted by 3C/2 so that histogram cell (hy,hx) owns rows
+// yy in [C*hy, C*hy+2C) and columns xx in [C*hx, C*hx+2C)  (yy = y + 3C/2, xx = x + 3C/2; pitch = multiple of 16 floats).
+// One lane = 4 consecutive pixels of one row; interior quads fetch their 3 x 18-byte neighbourhood with
 // 11 (unaligned) dword loads and pick the bytes with constant shifts; results leave as one float4 + one packed dword.
 __device__ __forceinline__ void grad_from_bytes(const int u[3], const int d[3], const int l[3], const int r[3],
                                                 const uint8_t* __restrict__ lut, float* v, int* o)
@@ -423,19 +274,6 @@ __global__ void __launch_bounds__(256) fhog_hist_k(const float* __restrict__ mag
         if (hy >= 1 && hy <= cells_nr && hx >= 1 && hx <= cells_nc)
             norm[(size_t)b * norm_stride + (size_t)(hy - 1) * cells_nc + (hx - 1)] = e;
     }
-}
-
-__global__ void __launch_bounds__(256) fhog_norm_k(const float* __restrict__ hist, size_t hist_stride, int hc, float* __restrict__ norm,
-                                                   size_t norm_stride, int cells_nr, int cells_nc)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y, b = blockIdx.z;
-    if (c >= cells_nc) return;
-    const float* h = hist + (size_t)b * hist_stride + ((size_t)(r + 1) * hc + (c + 1)) * 18;
-    float acc = 0.0f;
-#pragma unroll
-    for (int o = 0; o < 9; ++o) { const float s = h[o] + h[o + 9]; acc = acc + s * s; }
-    norm[(size_t)b * norm_stride + (size_t)r * cells_nc + c] = acc;
 }
 
 __device__ __forceinline__ void cell_features(const float* h, const float* n, float* o)
@@ -603,21 +441,14 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
     grad.ensure(px_stride * n * 5 + 256);
     float* d_mag = grad.as<float>();
     uint8_t* d_bin = grad.as<uint8_t>() + px_stride * n * 4;
-    const long gtiles = (long)((pitch + 127) / 128) * ((rows_t + 7) / 8) * n;
-    dim3 gg((unsigned)std::min<long>(gtiles, (long)c->n_cu * 16));
-    dim3 gh((hc + 255) / 256, hr, n);
-    static const bool old_grad = getenv("PVF_OLD_GRAD") != nullptr;
     dim3 g4((pitch / 4 + 255) / 256, rows_t, n);
-    if (!old_grad) {
-        if (cell == 8) hipLaunchKernelGGL((fhog_grad4_k<8>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
-        else hipLaunchKernelGGL((fhog_grad4_k<4>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
-    }
+    dim3 gh((hc + 255) / 256, hr, n);
     if (cell == 8) {
-        if (old_grad) hipLaunchKernelGGL((fhog_grad_k<8>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
+        hipLaunchKernelGGL((fhog_grad4_k<8>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
         hipLaunchKernelGGL((fhog_hist_k<8>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     } else {
-        if (old_grad) hipLaunchKernelGGL((fhog_grad_k<4>), gg, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
+        hipLaunchKernelGGL((fhog_grad4_k<4>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
         hipLaunchKernelGGL((fhog_hist_k<4>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
                            norm.as<float>(), norm_stride, cells_nr, cells_nc);
     }
@@ -823,115 +654,6 @@ __global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ fe
     }
 }
 
-// score_mfma2_k: same tiling and the same accumulation order as score_mfma_k, but software-pipelined for ONE wave per SIMD:
-// while the 192 MFMAs of filter row m run from slab[m & 1] with the B fragments of row m, the 96 B fragments and the feature
-// row segment of row m+1 are already in flight (second register set, second slab).  launch_bounds(256, 1) => 512 VGPRs.
-__global__ void __launch_bounds__(256, 1) score_mfma2_k(const float* __restrict__ feat, size_t feat_stride, int fh, int fw,
-                                                        const float* __restrict__ Bg, ScoreParams sp, int* __restrict__ counts,
-                                                        CandRec* __restrict__ cands)
-{
-    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11;
-    constexpr int NST = (SEG * 8 + 63) / 64;
-    extern __shared__ __attribute__((aligned(16))) float s_seg[]; // [4 waves][2][SEG][PITCH]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.z;
-    const int r_top = blockIdx.y * 4 + wave, c_base = blockIdx.x * WCOLS;
-    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
-    if (r_top + FR / 2 >= r1) return;               // wave-uniform; no block-level barrier is used below
-    float* slab0 = s_seg + (size_t)wave * 2 * SEG * PITCH;
-    float* slab1 = slab0 + SEG * PITCH;
-    const float* fb = feat + (size_t)b * feat_stride;
-    const int i = lane & 15, kq = lane >> 4;
-    f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#define SCORE_ISSUE(M, BV, SV)                                                                                              \
-    {                                                                                                                       \
-        const float* bp_ = Bg + (size_t)(M) * NK * 8 * 64 + lane;                                                           \
-        _Pragma("unroll") for (int q_ = 0; q_ < NK * 8; ++q_) BV[q_] = bp_[q_ * 64];                                        \
-        const int fr_ = r_top + (M);                                                                                        \
-        _Pragma("unroll") for (int u_ = 0; u_ < NST; ++u_) {                                                                \
-            const int idx_ = lane + 64 * u_;                                                                                \
-            const int cell_ = idx_ >> 3, q4_ = idx_ & 7;                                                                    \
-            const int x_ = c_base + cell_;                                                                                  \
-            SV[u_] = make_float4(0.f, 0.f, 0.f, 0.f);                                                                       \
-            if (idx_ < SEG * 8 && fr_ < fh && x_ < fw)                                                                      \
-                SV[u_] = reinterpret_cast<const float4*>(fb + ((size_t)fr_ * fw + x_) * PVF_FHOG_STRIDE)[q4_];              \
-        }                                                                                                                   \
-    }
-#define SCORE_FILL(SLAB, SV)                                                                                                \
-    {                                                                                                                       \
-        _Pragma("unroll") for (int u_ = 0; u_ < NST; ++u_) {                                                                \
-            const int idx_ = lane + 64 * u_;                                                                                \
-            if (idx_ < SEG * 8) {                                                                                           \
-                const int cell_ = idx_ >> 3, q4_ = idx_ & 7;                                                                \
-                float2* d_ = reinterpret_cast<float2*>((SLAB) + cell_ * PITCH + 4 * q4_);                                   \
-                d_[0] = make_float2(SV[u_].x, SV[u_].y);                                                                    \
-                d_[1] = make_float2(SV[u_].z, SV[u_].w);                                                                    \
-            }                                                                                                               \
-        }                                                                                                                   \
-    }
-#define SCORE_MFMA(SLAB, BV)                                                                                                \
-    {                                                                                                                       \
-        const float* a0_ = (SLAB) + (3 * i) * PITCH + kq;                                                                   \
-        float an_[8 * MT];                                                                                                  \
-        _Pragma("unroll") for (int pq_ = 0; pq_ < 8; ++pq_)                                                                 \
-            _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_) an_[pq_ * MT + t_] = a0_[(t_ * 48) * PITCH + 4 * pq_];        \
-        _Pragma("unroll") for (int n_ = 0; n_ < NK; ++n_) {                                                                 \
-            float ac_[8 * MT];                                                                                              \
-            _Pragma("unroll") for (int q_ = 0; q_ < 8 * MT; ++q_) ac_[q_] = an_[q_];                                        \
-            if (n_ + 1 < NK) {                                                                                              \
-                _Pragma("unroll") for (int pq_ = 0; pq_ < 8; ++pq_)                                                         \
-                    _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_)                                                       \
-                        an_[pq_ * MT + t_] = a0_[(t_ * 48 + n_ + 1) * PITCH + 4 * pq_];                                     \
-            }                                                                                                               \
-            __builtin_amdgcn_sched_barrier(0);                                                                              \
-            _Pragma("unroll") for (int pq_ = 0; pq_ < 8; ++pq_)                                                             \
-                _Pragma("unroll") for (int t_ = 0; t_ < MT; ++t_)                                                           \
-                    acc[t_] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac_[pq_ * MT + t_], BV[n_ * 8 + pq_], acc[t_], 0, 0, 0); \
-            __builtin_amdgcn_sched_barrier(0);                                                                              \
-        }                                                                                                                   \
-    }
-    float bA[NK * 8], bB[NK * 8];
-    float4 sv[NST];
-    SCORE_ISSUE(0, bA, sv)
-    SCORE_FILL(slab0, sv)
-    for (int m = 0; m < FR; m += 2) {
-        SCORE_ISSUE(m + 1, bB, sv)                  // FR is even: row m+1 always exists
-        SCORE_MFMA(slab0, bA)
-        SCORE_FILL(slab1, sv)
-        if (m + 2 < FR) SCORE_ISSUE(m + 2, bA, sv)
-        SCORE_MFMA(slab1, bB)
-        if (m + 2 < FR) SCORE_FILL(slab0, sv)
-    }
-#undef SCORE_ISSUE
-#undef SCORE_FILL
-#undef SCORE_MFMA
-    const int j = lane & 15;
-    if (j < 15) {
-        const int s = j / 5, f = j % 5;
-        const float th = sp.thresh[f];
-        const int r = r_top + FR / 2;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int pos = 4 * (lane >> 4) + reg;
-                const int cc = c_base + t * 48 + 3 * pos + s + FC / 2;
-                const float v = acc[t][reg];
-                if (cc < c1 && v >= th) {
-                    const int idx = atomicAdd(&counts[b], 1);
-                    if (idx < sp.cap) {
-                        CandRec rec;
-                        rec.score = v - th; rec.filter = f; rec.level = sp.level; rec.r = r; rec.c = cc;
-                        cands[(size_t)b * sp.cap + idx] = rec;
-                    }
-                }
-            }
-    }
-}
-
 // =====================================================================================================
 // host side: level schedule, rectangle mapping, canonical sort, NMS
 // =====================================================================================================
@@ -1030,20 +752,435 @@ static void run_pyramid(Ctx* c, const std::vector<Frame>& frames, int upsample, 
     }
 }
 
+// =====================================================================================================
+// All pyramid levels in one launch per stage.  HBM is large (288 GB): the whole pyramid of a batch stays resident
+// (81 MB of images + 136 MB of gradient planes + 33 MB of histograms + 58 MB of features per 1080p frame), so after the
+// (sequentially dependent) resize chain, FHOG pass 1, pass 2, the feature pass and the scoring each run as ONE grid that
+// covers every level -- 4 launches instead of 80 per batch, and the small levels fill the CUs the big ones leave idle.
+// A block finds its level with a short scan of block-start offsets passed by value (kernarg / scalar cache).
+// =====================================================================================================
+#define ML_MAX 32
+struct LvDesc {
+    int h, w;                                   // level image
+    int cells_nr, cells_nc, hr, hc, visible_nr, visible_nc;
+    int rows_t, pitch;                          // gradient planes
+    int fh, fw, hog_nr, hog_nc;                 // features
+    int grad_bx, hist_bx, feat_bx, score_bx, score_by;
+    int valid_score;
+    long long img_off, img_stride;              // bytes
+    long long px_off, px_stride;                // elements
+    long long hist_off, hist_stride, norm_off, norm_stride, feat_off, feat_stride;   // floats
+};
+struct MlStarts { int nl; int b0[ML_MAX + 1]; };
+
+__device__ __forceinline__ int ml_level(const MlStarts& st, int g)
+{
+    int l = 0;
+    while (l + 1 < st.nl && g >= st.b0[l + 1]) ++l;
+    return l;
+}
+
+__global__ void __launch_bounds__(256) fhog_grad4_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
+                                                       float* __restrict__ mag_base, uint8_t* __restrict__ bin_base,
+                                                       const uint8_t* __restrict__ lut)
+{
+    constexpr int C = 8;
+    const int l = ml_level(st, blockIdx.x);
+    const LvDesc d = lv[l];
+    const int local = blockIdx.x - st.b0[l];
+    const int qb = local % d.grad_bx;
+    const int yy = (local / d.grad_bx) % d.rows_t;
+    const int b = local / (d.grad_bx * d.rows_t);
+    const int xx = 4 * (qb * 256 + threadIdx.x);
+    if (xx >= d.pitch) return;
+    const int y = yy - 3 * C / 2, x0 = xx - 3 * C / 2;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    int o[4] = {0, 0, 0, 0};
+    if (y >= 1 && y < d.visible_nr && x0 + 3 >= 1 && x0 < d.visible_nc) {
+        const uint8_t* im = img_base + d.img_off + (size_t)b * d.img_stride;
+        const int rb = d.w * 3;
+        const uint8_t* rc = im + (size_t)y * rb;
+        const uint8_t* ru = rc - rb;
+        const uint8_t* rd = rc + rb;
+        if (x0 >= 1 && x0 + 4 <= d.visible_nc && x0 + 6 <= d.w) {
+            uint32_t wc[5], wu[3], wd[3];
+            const uint8_t* pc = rc + 3 * x0 - 3;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) wc[k] = *reinterpret_cast<const uint32_t*>(pc + 4 * k);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                wu[k] = *reinterpret_cast<const uint32_t*>(ru + 3 * x0 + 4 * k);
+                wd[k] = *reinterpret_cast<const uint32_t*>(rd + 3 * x0 + 4 * k);
+            }
+#define BYTE_OF(w, i) (int)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                int u[3], dd[3], ll[3], r[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    u[k] = BYTE_OF(wu, 3 * p + k); dd[k] = BYTE_OF(wd, 3 * p + k);
+                    ll[k] = BYTE_OF(wc, 3 * p + k); r[k] = BYTE_OF(wc, 3 * p + 6 + k);
+                }
+                grad_from_bytes(u, dd, ll, r, lut, &v[p], &o[p]);
+            }
+#undef BYTE_OF
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int x = x0 + p;
+                if (x >= 1 && x < d.visible_nc) {
+                    int u[3], dd[3], ll[3], r[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { u[k] = ru[3 * x + k]; dd[k] = rd[3 * x + k]; ll[k] = rc[3 * x - 3 + k]; r[k] = rc[3 * x + 3 + k]; }
+                    grad_from_bytes(u, dd, ll, r, lut, &v[p], &o[p]);
+                }
+            }
+        }
+    }
+    const size_t idx = (size_t)d.px_off + (size_t)b * d.px_stride + (size_t)yy * d.pitch + xx;
+    *reinterpret_cast<float4*>(mag_base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<uint32_t*>(bin_base + idx) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+}
+
+__global__ void __launch_bounds__(256) fhog_hist_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ mag_base,
+                                                      const uint8_t* __restrict__ bin_base, float* __restrict__ hist_base,
+                                                      float* __restrict__ norm_base)
+{
+    constexpr int C = 8, NV = 2 * C / 4;
+    __shared__ float acc[18][256];
+    const int l = ml_level(st, blockIdx.x);
+    const LvDesc d = lv[l];
+    const int local = blockIdx.x - st.b0[l];
+    const int xb = local % d.hist_bx;
+    const int hy = (local / d.hist_bx) % d.hr;
+    const int b = local / (d.hist_bx * d.hr);
+    const int hx = xb * 256 + threadIdx.x;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int o = 0; o < 18; ++o) acc[o][tid] = 0.0f;
+    if (hx >= d.hc) return;
+    const float* mg = mag_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx;
+    const uint8_t* bn = bin_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx;
+    float4 pv[2][NV];
+    uint32_t pb[2][4];
+    auto load_row = [&](int wy, float4* dv, uint32_t* db) {
+        const size_t row = (size_t)(C * hy + wy) * d.pitch;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) dv[q] = *reinterpret_cast<const float4*>(mg + row + 4 * q);
+        const uint4 t = *reinterpret_cast<const uint4*>(bn + row);
+        db[0] = t.x; db[1] = t.y; db[2] = t.z; db[3] = t.w;
+    };
+    load_row(0, pv[0], pb[0]);
+#pragma unroll
+    for (int wy = 0; wy < 2 * C; ++wy) {
+        const int cur = wy & 1;
+        if (wy + 1 < 2 * C) load_row(wy + 1, pv[cur ^ 1], pb[cur ^ 1]);
+        const int i = wy % C;
+        const float fy = ((float)i + 0.5f) / (float)C;
+        const float wyv = (wy < C) ? fy : 1.0f - fy;
+        float v[2 * C];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) { v[4 * q] = pv[cur][q].x; v[4 * q + 1] = pv[cur][q].y; v[4 * q + 2] = pv[cur][q].z; v[4 * q + 3] = pv[cur][q].w; }
+#pragma unroll
+        for (int wx = 0; wx < 2 * C; ++wx) {
+            const int j = wx % C;
+            const float fx = ((float)j + 0.5f) / (float)C;
+            const float wxv = (wx < C) ? fx : 1.0f - fx;
+            const int o = (int)((pb[cur][wx >> 2] >> (8 * (wx & 3))) & 0xffu);
+            acc[o][tid] = acc[o][tid] + (wyv * wxv) * v[wx];
+        }
+    }
+    float* h = hist_base + d.hist_off + (size_t)b * d.hist_stride + ((size_t)hy * d.hc + hx) * 18;
+    float e = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+        const float a0 = acc[o][tid], a1 = acc[o + 9][tid];
+        h[o] = a0; h[o + 9] = a1;
+        const float s2 = a0 + a1;
+        e = e + s2 * s2;
+    }
+    if (hy >= 1 && hy <= d.cells_nr && hx >= 1 && hx <= d.cells_nc)
+        norm_base[d.norm_off + (size_t)b * d.norm_stride + (size_t)(hy - 1) * d.cells_nc + (hx - 1)] = e;
+}
+
+__global__ void __launch_bounds__(256) fhog_feat_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ hist_base,
+                                                      const float* __restrict__ norm_base, float* __restrict__ feat_base, int oy, int ox)
+{
+    const int l = ml_level(st, blockIdx.x);
+    const LvDesc d = lv[l];
+    const int local = blockIdx.x - st.b0[l];
+    const int xb = local % d.feat_bx;
+    const int py = (local / d.feat_bx) % d.fh;
+    const int b = local / (d.feat_bx * d.fh);
+    const int px = xb * 256 + threadIdx.x;
+    if (px >= d.fw) return;
+    float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)py * d.fw + px) * PVF_FHOG_STRIDE);
+    const int x = px - ox, y = py - oy;
+    if (x < 0 || y < 0 || x >= d.hog_nc || y >= d.hog_nr) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    float n[9], h[18], o[32];
+    const float* nb = norm_base + d.norm_off + (size_t)b * d.norm_stride;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) n[i * 3 + j] = nb[(size_t)(y + i) * d.cells_nc + (x + j)];
+    const float* hp = hist_base + d.hist_off + (size_t)b * d.hist_stride + ((size_t)(y + 2) * d.hc + (x + 2)) * 18;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) h[k] = hp[k];
+    cell_features(h, n, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+// scoring of every level: same body as score_mfma_k, level geometry from the table
+__global__ void __launch_bounds__(256) score_mfma_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base,
+                                                       const float* __restrict__ Bg, ScoreParams sp, int* __restrict__ counts,
+                                                       CandRec* __restrict__ cands)
+{
+    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11;
+    extern __shared__ __attribute__((aligned(16))) float s_seg[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = ml_level(st, blockIdx.x);
+    const LvDesc d = lv[l];
+    const int local = blockIdx.x - st.b0[l];
+    const int bx = local % d.score_bx;
+    const int by = (local / d.score_bx) % d.score_by;
+    const int b = local / (d.score_bx * d.score_by);
+    const int fh = d.fh, fw = d.fw;
+    const int r_top = by * 4 + wave, c_base = bx * WCOLS;
+    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
+    if (r_top + FR / 2 >= r1) return;
+    float* seg = s_seg + (size_t)wave * SEG * PITCH;
+    const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride;
+    const int i = lane & 15, kq = lane >> 4;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool two_tiles = (c_base + 48 + FC / 2 < c1);
+    for (int m = 0; m < FR; ++m) {
+        const int fr = r_top + m;
+        float bv[NK * 8];
+        const float* bp = Bg + (size_t)m * NK * 8 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NK * 8; ++q) bv[q] = bp[q * 64];
+        constexpr int NST = (SEG * 8 + 63) / 64;
+        float4 sv[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = lane + 64 * u;
+            const int cell = idx >> 3, q = idx & 7;
+            const int x = c_base + cell;
+            sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < SEG * 8 && fr < fh && x < fw) sv[u] = reinterpret_cast<const float4*>(fb + ((size_t)fr * fw + x) * PVF_FHOG_STRIDE)[q];
+        }
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < SEG * 8) {
+                const int cell = idx >> 3, q = idx & 7;
+                float2* dd = reinterpret_cast<float2*>(seg + cell * PITCH + 4 * q);
+                dd[0] = make_float2(sv[u].x, sv[u].y);
+                dd[1] = make_float2(sv[u].z, sv[u].w);
+            }
+        }
+        const float* a0 = seg + (3 * i) * PITCH + kq;
+        float an[8 * MT];
+#pragma unroll
+        for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) an[pq * MT + t] = a0[(t * 48) * PITCH + 4 * pq];
+#pragma unroll
+        for (int n = 0; n < NK; ++n) {
+            float ac[8 * MT];
+#pragma unroll
+            for (int q = 0; q < 8 * MT; ++q) ac[q] = an[q];
+            if (n + 1 < NK) {
+#pragma unroll
+                for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) an[pq * MT + t] = a0[(t * 48 + n + 1) * PITCH + 4 * pq];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (two_tiles) {
+#pragma unroll
+                for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + t], bv[n * 8 + pq], acc[t], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int pq = 0; pq < 8; ++pq)
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT], bv[n * 8 + pq], acc[0], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int j = lane & 15;
+    if (j < 15) {
+        const int s = j / 5, f = j % 5;
+        const float th = sp.thresh[f];
+        const int r = r_top + FR / 2;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int pos = 4 * (lane >> 4) + reg;
+                const int cc = c_base + t * 48 + 3 * pos + s + FC / 2;
+                const float v = acc[t][reg];
+                if (cc < c1 && v >= th) {
+                    const int idx = atomicAdd(&counts[b], 1);
+                    if (idx < sp.cap) {
+                        CandRec rec;
+                        rec.score = v - th; rec.filter = f; rec.level = l; rec.r = r; rec.c = cc;
+                        cands[(size_t)b * sp.cap + idx] = rec;
+                    }
+                }
+            }
+    }
+}
+
+struct MlPlan {
+    int h = 0, w = 0, upsample = -1, B = 0;
+    std::vector<LvDesc> lv;
+    std::vector<LevelDims> ups;
+    MlStarts grad, hist, feat, score;
+    int grad_blocks = 0, hist_blocks = 0, feat_blocks = 0, score_blocks = 0;
+    size_t img_bytes = 0, px_elems = 0, hist_floats = 0, norm_floats = 0, feat_floats = 0, up_bytes = 0;
+    LvDesc* d_lv = nullptr;
+};
+
+static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
+{
+    static std::map<std::pair<Ctx*, std::vector<int>>, MlPlan> cache;
+    auto key = std::make_pair(c, std::vector<int>{h, w, upsample, B});
+    auto it = cache.find(key);
+    if (it != cache.end()) return &it->second;
+    const DetectorModel& m = c->det;
+    MlPlan p;
+    p.h = h; p.w = w; p.upsample = upsample; p.B = B;
+    std::vector<LevelDims> dims = level_schedule(h, w, upsample, m, &p.ups);
+    PVF_REQUIRE((int)dims.size() <= ML_MAX, "too many pyramid levels");
+    auto al = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+    for (size_t u = 0; u + 1 < p.ups.size(); ++u) p.up_bytes = std::max(p.up_bytes, al((size_t)p.ups[u].h * p.ups[u].w * 3, 16) * B);
+    p.grad.nl = p.hist.nl = p.feat.nl = p.score.nl = (int)dims.size();
+    for (size_t l = 0; l < dims.size(); ++l) {
+        LvDesc d;
+        memset(&d, 0, sizeof d);
+        d.h = dims[l].h; d.w = dims[l].w;
+        d.cells_nr = (int)((double)d.h / 8.0 + 0.5); d.cells_nc = (int)((double)d.w / 8.0 + 0.5);
+        d.hr = d.cells_nr + 2; d.hc = d.cells_nc + 2;
+        d.visible_nr = std::min(d.cells_nr * 8, d.h) - 1; d.visible_nc = std::min(d.cells_nc * 8, d.w) - 1;
+        d.rows_t = 8 * (d.hr + 1); d.pitch = (8 * (d.hc + 1) + 15) / 16 * 16;
+        d.hog_nr = d.cells_nr - 2; d.hog_nc = d.cells_nc - 2;
+        const bool feat_ok = d.hog_nr > 0 && d.hog_nc > 0;
+        d.fh = feat_ok ? d.hog_nr + m.frows - 1 : 0; d.fw = feat_ok ? d.hog_nc + m.fcols - 1 : 0;
+        d.valid_score = (d.fh >= m.frows && d.fw >= m.fcols) ? 1 : 0;
+        d.img_off = (long long)p.img_bytes; d.img_stride = (long long)al((size_t)d.h * d.w * 3, 16);
+        p.img_bytes += (size_t)d.img_stride * B;
+        d.px_off = (long long)p.px_elems; d.px_stride = (long long)d.rows_t * d.pitch;
+        p.px_elems += (size_t)d.px_stride * B;
+        d.hist_off = (long long)p.hist_floats; d.hist_stride = (long long)d.hr * d.hc * 18;
+        p.hist_floats += al((size_t)d.hist_stride * B, 4);
+        d.norm_off = (long long)p.norm_floats; d.norm_stride = (long long)d.cells_nr * d.cells_nc;
+        p.norm_floats += al((size_t)d.norm_stride * B, 4);
+        d.feat_off = (long long)p.feat_floats; d.feat_stride = (long long)d.fh * d.fw * PVF_FHOG_STRIDE;
+        p.feat_floats += (size_t)d.feat_stride * B;
+        d.grad_bx = (d.pitch / 4 + 255) / 256; d.hist_bx = (d.hc + 255) / 256; d.feat_bx = std::max((d.fw + 255) / 256, 0);
+        const int out_r = d.fh - 9, out_c = d.fw - 9;
+        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + 3) / 4 : 0;
+        p.grad.b0[l] = p.grad_blocks; p.grad_blocks += d.grad_bx * d.rows_t * B;
+        p.hist.b0[l] = p.hist_blocks; p.hist_blocks += d.hist_bx * d.hr * B;
+        p.feat.b0[l] = p.feat_blocks; p.feat_blocks += d.feat_bx * d.fh * B;
+        p.score.b0[l] = p.score_blocks; p.score_blocks += d.score_bx * d.score_by * B;
+        p.lv.push_back(d);
+    }
+    const int nl = (int)dims.size();
+    p.grad.b0[nl] = p.grad_blocks; p.hist.b0[nl] = p.hist_blocks; p.feat.b0[nl] = p.feat_blocks; p.score.b0[nl] = p.score_blocks;
+    HIP_CHECK(hipMalloc((void**)&p.d_lv, sizeof(LvDesc) * nl));
+    HIP_CHECK(hipMemcpy(p.d_lv, p.lv.data(), sizeof(LvDesc) * nl, hipMemcpyHostToDevice));
+    auto res = cache.emplace(key, std::move(p));
+    return &res.first->second;
+}
+
+// builds the whole pyramid of the batch into s_pyr (level images at plan->lv[l].img_off); returns the plan
+static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int upsample)
+{
+    const int B = (int)frames.size();
+    const int h = frames[0].h, w = frames[0].w;
+    for (auto& f : frames) PVF_REQUIRE(f.h == h && f.w == w, "batched frames must share one size");
+    MlPlan* p = ml_plan(c, h, w, upsample, B);
+    c->s_pyr.ensure(p->img_bytes + p->up_bytes + 256);
+    uint8_t* base = c->s_pyr.as<uint8_t>();
+    uint8_t* up_tmp = base + ((p->img_bytes + 63) / 64) * 64;
+    const uint8_t** d_ptrs = nullptr;
+    upload_frame_ptrs(c, frames, &d_ptrs);
+    ProfScope ps(c, "pyramid");
+    auto al = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
+    const uint8_t* cur = nullptr;
+    int ch = h, cw = w;
+    size_t cstride = 0;
+    for (size_t u = 0; u < p->ups.size(); ++u) {
+        const bool last = (u + 1 == p->ups.size());
+        uint8_t* dst = last ? base + p->lv[0].img_off : up_tmp;
+        const size_t dstride = last ? (size_t)p->lv[0].img_stride : al((size_t)p->ups[u].h * p->ups[u].w * 3, 16);
+        launch_resize(c, cur ? nullptr : d_ptrs, cur, cstride, ch, cw, dst, dstride, p->ups[u].h, p->ups[u].w, B);
+        cur = dst; cstride = dstride; ch = p->ups[u].h; cw = p->ups[u].w;
+    }
+    if (!cur) {
+        for (int b = 0; b < B; ++b)
+            HIP_CHECK(hipMemcpyAsync(base + p->lv[0].img_off + (size_t)b * p->lv[0].img_stride, frames[b].d, (size_t)h * w * 3,
+                                     hipMemcpyDeviceToDevice, c->stream));
+    }
+    for (size_t l = 1; l < p->lv.size(); ++l)
+        launch_resize(c, nullptr, base + p->lv[l - 1].img_off, (size_t)p->lv[l - 1].img_stride, p->lv[l - 1].h, p->lv[l - 1].w,
+                      base + p->lv[l].img_off, (size_t)p->lv[l].img_stride, p->lv[l].h, p->lv[l].w, B);
+    return p;
+}
+
+static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsample, const ScoreParams& sp0, int* d_counts, CandRec* d_cands)
+{
+    const DetectorModel& m = c->det;
+    const int B = (int)frames.size();
+    MlPlan* p = ml_build_pyramid(c, frames, upsample);
+    const uint8_t* lut = orientation_lut(c);
+    c->s_grad.ensure(p->px_elems * 5 + 256);
+    c->s_hist.ensure(p->hist_floats * sizeof(float) + 64);
+    c->s_norm.ensure(p->norm_floats * sizeof(float) + 64);
+    c->s_feat.ensure(p->feat_floats * sizeof(float) + 64);
+    float* d_mag = c->s_grad.as<float>();
+    uint8_t* d_bin = c->s_grad.as<uint8_t>() + p->px_elems * 4;
+    {
+        ProfScope ps(c, "fhog");
+        hipLaunchKernelGGL(fhog_grad4_ml_k, dim3(p->grad_blocks), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_mag, d_bin, lut);
+        hipLaunchKernelGGL(fhog_hist_ml_k, dim3(p->hist_blocks), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_mag, d_bin, c->s_hist.as<float>(),
+                           c->s_norm.as<float>());
+        if (p->feat_blocks > 0)
+            hipLaunchKernelGGL(fhog_feat_ml_k, dim3(p->feat_blocks), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_hist.as<float>(),
+                               c->s_norm.as<float>(), c->s_feat.as<float>(), (m.frows - 1) / 2, (m.fcols - 1) / 2);
+    }
+    if (p->score_blocks > 0) {
+        ProfScope ps(c, "score");
+        const size_t lds = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
+        hipLaunchKernelGGL(score_mfma_ml_k, dim3(p->score_blocks), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), m.d_bmfma,
+                           sp0, d_counts, d_cands);
+    }
+}
+
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* oh, int* ow)
 {
     PVF_REQUIRE(c->det.loaded, "detector not loaded");
     std::vector<Frame> fr{f};
-    bool hit = false;
-    run_pyramid(c, fr, upsample, level, [&](int, const uint8_t* img, int h, int w) {
-        *oh = h; *ow = w; hit = true;
-        if (out) {
-            out->resize((size_t)h * w * 3);
-            HIP_CHECK(hipMemcpyAsync(out->data(), img, out->size(), hipMemcpyDeviceToHost, c->stream));
-            HIP_CHECK(hipStreamSynchronize(c->stream));
-        }
-    });
-    PVF_REQUIRE(hit, "pyramid level out of range");
+    MlPlan* p = ml_build_pyramid(c, fr, upsample);
+    PVF_REQUIRE(level >= 0 && level < (int)p->lv.size(), "pyramid level out of range");
+    *oh = p->lv[level].h; *ow = p->lv[level].w;
+    if (out) {
+        out->resize((size_t)(*oh) * (*ow) * 3);
+        HIP_CHECK(hipMemcpyAsync(out->data(), c->s_pyr.as<uint8_t>() + p->lv[level].img_off, out->size(), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 
 static bool raw_less(const RawDet& x, const RawDet& y)
@@ -1069,6 +1206,10 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     ScoreParams sp;
     for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
     sp.n_filters = m.n_filters; sp.cap = cap;
+    static const bool per_level = getenv("PVF_PER_LEVEL") != nullptr;
+    if (m.n_filters == 5 && m.d_bmfma && !per_level) {
+        det_run_batch_ml(c, frames, upsample, sp, d_counts, d_cands);
+    } else
     run_pyramid(c, frames, upsample, -1, [&](int l, const uint8_t* img, int h, int w) {
         int fh, fw;
         fhog_dims(h, w, m.cell, m.frows, m.fcols, &fh, &fw);
@@ -1095,17 +1236,7 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     }                                                                                                                        \
     hipLaunchKernelGGL((score_k<NF>), grid, dim3(256), lds, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_w, sp, \
                        d_counts, d_cands)
-            static const bool pipe_score = getenv("PVF_PIPE_SCORE") != nullptr;
-            if (m.n_filters == 5 && m.d_bmfma && pipe_score) {
-                const size_t lds3 = (size_t)4 * 2 * (2 * 48 + 11) * 34 * sizeof(float);
-                static bool attr3 = false;
-                if (!attr3) {
-                    HIP_CHECK(hipFuncSetAttribute((const void*)score_mfma2_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-                    attr3 = true;
-                }
-                dim3 g2((out_c + 95) / 96, (out_r + 3) / 4, B);
-                hipLaunchKernelGGL(score_mfma2_k, g2, dim3(256), lds3, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_bmfma, sp,
-                                   d_counts, d_cands);
+            if (false) {
             } else if (m.n_filters == 5 && m.d_bmfma) {
                 const size_t lds2 = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
                 dim3 g2((out_c + 95) / 96, (out_r + 3) / 4, B);
