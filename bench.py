@@ -48,7 +48,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("PVF_DIST_BACKEND", "nccl"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -75,7 +75,7 @@ def main():
 
     def step():
         tm = {}
-        res = pipe.run(frames, times, video.frame_rate, shots, timings=tm, cluster=False)
+        res = pipe.run(frames, times, video.frame_rate, shots, timings=tm, cluster=False, last_shard=(rank == world - 1))
         T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["X"], len(res["tracks"]), device=device)
         t0 = time.perf_counter()
         labels = pdist.global_cluster(pipe.clustering, T, ids, X)

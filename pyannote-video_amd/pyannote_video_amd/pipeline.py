@@ -35,7 +35,7 @@ def split_into_shots(times, shots):
     return out
 
 
-def faces_per_frame(rows, frame_times, frame_width, frame_height):
+def faces_per_frame(rows, frame_times, frame_width, frame_height, drop_last=True):
     """Replays getFaceGenerator (pyannote-face.py:121-175): rows = [(T, id, box_norm_f32, status)] sorted by T.
     Returns [(frame index, T, [(id, (l,t,r,b) int)])] for the frames that receive faces."""
     out = []
@@ -50,7 +50,8 @@ def faces_per_frame(rows, frame_times, frame_width, frame_height):
                               int(box[2] * frame_width), int(box[3] * frame_height))))
             k += 1
         groups.append((T, g))
-    groups = groups[:-1]
+    if drop_last:
+        groups = groups[:-1]   # a shard that is not the end of the video keeps its last group (see dist.py)
     gi = 0
     for fi, t in enumerate(frame_times):
         if gi >= len(groups):
@@ -140,7 +141,7 @@ class FacePipeline(object):
             raise err[0]
         return [self.tracking.finish_shot(j) for j in jobs]
 
-    def run(self, frames, times, frame_rate, shots, timings=None, cluster=True):
+    def run(self, frames, times, frame_rate, shots, timings=None, cluster=True, last_shard=True):
         """frames: list of DeviceFrame (or numpy arrays), one size; times: their timestamps; shots: [(start, end)].
         Returns dict(tracks, track_rows, faces, landmarks, embeddings, labels)."""
         tm = timings if timings is not None else {}
@@ -168,7 +169,7 @@ class FacePipeline(object):
             for t, box, status in track:
                 rows.append((formats.quantise_time(t), identifier, tuple(np.float32("%.3f" % v) for v in box), status))
         rows.sort(key=lambda r: r[0])
-        per_frame = faces_per_frame(rows, times, w, h)
+        per_frame = faces_per_frame(rows, times, w, h, drop_last=last_shard)
         face_frames, face_boxes, face_T, face_id = [], [], [], []
         for fi, T, g in per_frame:
             for ident, box in g:
