@@ -109,6 +109,13 @@ static void load_detector(Ctx* c, const char* path)
                         bm[(((size_t)mm * 12 + np) * 8 + pq) * 64 + l] = w.f32()[(((size_t)f * 10 + mm) * 10 + n) * 32 + p];
                     }
         d.d_bmfma = upload<float>(bm.data(), bm.size());
+        // the same fragments packed four k-steps per lane for score_mfma_rows_ml_k: [m][n'][half][lane][4]
+        std::vector<float> b4(bm.size());
+        for (int mn = 0; mn < 10 * 12; ++mn)
+            for (int pq = 0; pq < 8; ++pq)
+                for (int l = 0; l < 64; ++l) b4[(((size_t)mn * 2 + (pq >> 2)) * 64 + l) * 4 + (pq & 3)] = bm[((size_t)mn * 8 + pq) * 64 + l];
+        if (d.d_bmfma4) (void)hipFree(d.d_bmfma4);
+        d.d_bmfma4 = upload<float>(b4.data(), b4.size());
     }
     d.loaded = true;
 }

@@ -550,6 +550,7 @@ __global__ void __launch_bounds__(256) score_k(const float* __restrict__ feat, s
 // One wave = one output row x 96 columns (two 16-position tiles); its feature row segment lives in a wave-private LDS slab
 // (34-float cell pitch: conflict-free ds_read_b32 for lanes 3 cells apart), B fragments stream from L2.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ feat, size_t feat_stride, int fh, int fw,
                                                     const float* __restrict__ Bg, ScoreParams sp, int* __restrict__ counts,
@@ -1042,6 +1043,191 @@ __global__ void __launch_bounds__(256) score_mfma_ml_k(MlStarts st, const LvDesc
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// K3 v3: one wave owns R consecutive output rows x 96 columns and walks the R + 9 feature rows it needs ONCE.
+// Staged feature row t feeds output row j through filter row m = t - j, so every A fragment read from the slab is used for
+// up to R MFMAs and the slab is filled (R+9)/R times per output row instead of 10 times.  B fragments (packed four k-steps
+// per lane: [m][n][2][64 lanes][4]) and A fragments are fetched one cell column ahead of the MFMAs that consume them; the
+// next feature row is loaded into registers while the current one is multiplied.  Each accumulator still receives its
+// terms in (m, n, p) order  =>  bit-identical to the oracle's chain.
+template <int R>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base,
+                     const float4* __restrict__ Bg4, ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
+{
+    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11, NT = FR + R - 1;
+    constexpr int NST = (SEG * 8 + 63) / 64;
+    constexpr int RSRC_FLAGS = 0x00020000;          // raw buffer, 32-bit data format (out-of-range lanes read 0)
+    extern __shared__ __attribute__((aligned(16))) float s_seg[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = ml_level(st, blockIdx.x);
+    const LvDesc d = lv[l];
+    const int local = blockIdx.x - st.b0[l];
+    const int bx = local % d.score_bx;
+    const int by = (local / d.score_bx) % d.score_by;
+    const int b = __builtin_amdgcn_readfirstlane(local / (d.score_bx * d.score_by));
+    const int fh = d.fh, fw = d.fw;
+    const int r_top = (by * 4 + wave) * R, c_base = bx * WCOLS;
+    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
+    if (r_top + FR / 2 >= r1) return;               // wave-uniform
+    float* seg = s_seg + (size_t)wave * SEG * PITCH;
+    const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride + (size_t)c_base * PVF_FHOG_STRIDE;
+    const int seg_cells = (fw - c_base < SEG) ? fw - c_base : SEG;
+    const int i = lane & 15, kq = lane >> 4;
+    const int lane16 = lane * 16;
+    f32x4 acc[R][MT];
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool two_tiles = (c_base + 48 + FC / 2 < c1);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)Bg4, 0, FR * NK * 2 * 64 * 16, RSRC_FLAGS);
+    u32x4 sv[NST];
+    // the segment of one feature row is one linear run of seg_cells * 128 bytes: lane + 64 u -> 16 bytes at 16 * (lane + 64 u)
+    auto load_row = [&](int fr) {
+        const int bytes = (fr < fh) ? seg_cells * PVF_FHOG_STRIDE * 4 : 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + (size_t)fr * fw * PVF_FHOG_STRIDE), 0, bytes, RSRC_FLAGS);
+#pragma unroll
+        for (int u = 0; u < NST; ++u) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, u * 1024, 0);
+    };
+    auto fill_slab = [&]() {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int idx = lane + 64 * u;
+            if (idx < SEG * 8) {
+                const int cell = idx >> 3, q = idx & 7;
+                uint2* dd = reinterpret_cast<uint2*>(seg + cell * PITCH + 4 * q);
+                dd[0] = make_uint2(sv[u].x, sv[u].y);
+                dd[1] = make_uint2(sv[u].z, sv[u].w);
+            }
+        }
+    };
+    load_row(r_top);
+    fill_slab();
+    const float* a0 = seg + (3 * i) * PITCH + kq;
+    for (int t = 0; t < NT; ++t) {
+        if (t + 1 < NT) load_row(r_top + t + 1);
+        // filter row of output row j at this step (clamped: the fragments of an inactive row are loaded but never used)
+        int bo[R];
+        bool on[R];
+        bool all_on = two_tiles;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int m = t - j;
+            on[j] = (m >= 0 && m < FR);
+            all_on = all_on && on[j];
+            const int mc = m < 0 ? 0 : (m >= FR ? FR - 1 : m);
+            bo[j] = mc * NK * 2048;
+        }
+        u32x4 bn[R][2];
+        float an[8 * MT];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j], 0);
+            bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + 1024, 0);
+        }
+#pragma unroll
+        for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+            for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 4 * pq];
+#pragma unroll
+        for (int n = 0; n < NK; ++n) {
+            float ac[8 * MT];
+            float bc[R][8];
+#pragma unroll
+            for (int q = 0; q < 8 * MT; ++q) ac[q] = an[q];
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t b0 = bn[j][h].x, b1 = bn[j][h].y, b2 = bn[j][h].z, b3 = bn[j][h].w;   // scalars first: bit_cast of a vector element lvalue reads element 0
+                    bc[j][4 * h] = __uint_as_float(b0); bc[j][4 * h + 1] = __uint_as_float(b1);
+                    bc[j][4 * h + 2] = __uint_as_float(b2); bc[j][4 * h + 3] = __uint_as_float(b3);
+                }
+            if (n + 1 < NK) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + (n + 1) * 2048, 0);
+                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + (n + 1) * 2048 + 1024, 0);
+                }
+#pragma unroll
+                for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                    for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48 + n + 1) * PITCH + 4 * pq];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (all_on) {
+                // steady state: 2R independent accumulator chains interleaved
+#pragma unroll
+                for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                    for (int j = 0; j < R; ++j)
+#pragma unroll
+                        for (int tt = 0; tt < MT; ++tt)
+                            acc[j][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + tt], bc[j][pq], acc[j][tt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    if (!on[j]) continue;
+                    if (two_tiles) {
+#pragma unroll
+                        for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                            for (int tt = 0; tt < MT; ++tt)
+                                acc[j][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + tt], bc[j][pq], acc[j][tt], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int pq = 0; pq < 8; ++pq)
+                            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT], bc[j][pq], acc[j][0], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (t + 1 < NT) fill_slab();
+    }
+    const int jc = lane & 15;
+    if (jc < 15) {
+        const int s = jc / 5, f = jc % 5;
+        const float th = sp.thresh[f];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int r = r_top + j + FR / 2;
+            if (r >= r1) continue;
+#pragma unroll
+            for (int tt = 0; tt < MT; ++tt)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int pos = 4 * (lane >> 4) + reg;
+                    const int cc = c_base + tt * 48 + 3 * pos + s + FC / 2;
+                    const float v = acc[j][tt][reg];
+                    if (cc < c1 && v >= th) {
+                        const int idx = atomicAdd(&counts[b], 1);
+                        if (idx < sp.cap) {
+                            CandRec rec;
+                            rec.score = v - th; rec.filter = f; rec.level = l; rec.r = r; rec.c = cc;
+                            cands[(size_t)b * sp.cap + idx] = rec;
+                        }
+                    }
+                }
+        }
+    }
+}
+
+// output rows per wave of the scoring kernel (PVF_SCORE_ROWS = 1 selects the one-row kernel)
+static int score_rows_per_wave()
+{
+    static int r = -1;
+    if (r < 0) {
+        const char* e = getenv("PVF_SCORE_ROWS");
+        r = e ? atoi(e) : 4;
+        if (r != 1 && r != 2 && r != 4) r = 4;
+    }
+    return r;
+}
+
 struct MlPlan {
     int h = 0, w = 0, upsample = -1, B = 0;
     std::vector<LvDesc> lv;
@@ -1090,7 +1276,8 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         p.feat_floats += (size_t)d.feat_stride * B;
         d.grad_bx = (d.pitch / 4 + 255) / 256; d.hist_bx = (d.hc + 255) / 256; d.feat_bx = std::max((d.fw + 255) / 256, 0);
         const int out_r = d.fh - 9, out_c = d.fw - 9;
-        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + 3) / 4 : 0;
+        const int rows_per_block = 4 * score_rows_per_wave();
+        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + rows_per_block - 1) / rows_per_block : 0;
         p.grad.b0[l] = p.grad_blocks; p.grad_blocks += d.grad_bx * d.rows_t * B;
         p.hist.b0[l] = p.hist_blocks; p.hist_blocks += d.hist_bx * d.hr * B;
         p.feat.b0[l] = p.feat_blocks; p.feat_blocks += d.feat_bx * d.fh * B;
@@ -1154,18 +1341,38 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
     uint8_t* d_bin = c->s_grad.as<uint8_t>() + p->px_elems * 4;
     {
         ProfScope ps(c, "fhog");
-        hipLaunchKernelGGL(fhog_grad4_ml_k, dim3(p->grad_blocks), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_mag, d_bin, lut);
-        hipLaunchKernelGGL(fhog_hist_ml_k, dim3(p->hist_blocks), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_mag, d_bin, c->s_hist.as<float>(),
-                           c->s_norm.as<float>());
-        if (p->feat_blocks > 0)
+        {
+            ProfScope p1(c, "fhog_grad");
+            hipLaunchKernelGGL(fhog_grad4_ml_k, dim3(p->grad_blocks), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_mag, d_bin, lut);
+        }
+        {
+            ProfScope p2(c, "fhog_hist");
+            hipLaunchKernelGGL(fhog_hist_ml_k, dim3(p->hist_blocks), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_mag, d_bin, c->s_hist.as<float>(),
+                               c->s_norm.as<float>());
+        }
+        if (p->feat_blocks > 0) {
+            ProfScope p3(c, "fhog_feat");
             hipLaunchKernelGGL(fhog_feat_ml_k, dim3(p->feat_blocks), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_hist.as<float>(),
                                c->s_norm.as<float>(), c->s_feat.as<float>(), (m.frows - 1) / 2, (m.fcols - 1) / 2);
+        }
     }
     if (p->score_blocks > 0) {
         ProfScope ps(c, "score");
         const size_t lds = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
-        hipLaunchKernelGGL(score_mfma_ml_k, dim3(p->score_blocks), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), m.d_bmfma,
-                           sp0, d_counts, d_cands);
+        const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
+        switch (score_rows_per_wave()) {
+        case 4:
+            hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(p->score_blocks), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
+                               sp0, d_counts, d_cands);
+            break;
+        case 2:
+            hipLaunchKernelGGL(score_mfma_rows_ml_k<2>, dim3(p->score_blocks), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
+                               sp0, d_counts, d_cands);
+            break;
+        default:
+            hipLaunchKernelGGL(score_mfma_ml_k, dim3(p->score_blocks), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), m.d_bmfma,
+                               sp0, d_counts, d_cands);
+        }
     }
 }
 

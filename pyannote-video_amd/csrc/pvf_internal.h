@@ -98,6 +98,7 @@ struct DetectorModel {
     std::vector<float> thresh;
     float* d_w = nullptr;    // [nf][frows][fcols][32]
     float* d_wt = nullptr;   // [frows][fcols][32][8] filter-minor copy (unused by the current kernels)
+    float* d_bmfma4 = nullptr; // same fragments, [10][12][2][64][4] (four k-steps per lane) for score_mfma_rows_ml_k
     float* d_bmfma = nullptr; // [10][12][8][64] B fragments of score_mfma_k (3 shifts x 5 filters per 16-column tile)
 };
 
