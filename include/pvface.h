@@ -124,6 +124,9 @@ int32_t pvf_prof_get(pvf_handle ctx, const char* family, double* total_ms, int64
 /* ---- stage access used by the parity tests ------------------------------------------------------------ */
 int32_t pvf_debug_pyramid_level(pvf_handle ctx, pvf_handle frame, int32_t upsample, int32_t level,
                                 uint8_t* out, int32_t* h, int32_t* w);               /* out may be NULL: dims only */
+/* features of one pyramid level exactly as the batched detector computes them (all levels per launch); out [fh][fw][32] or NULL */
+int32_t pvf_debug_level_features(pvf_handle ctx, pvf_handle frame, int32_t upsample, int32_t level,
+                                 float* out, int32_t* fh, int32_t* fw);
 int32_t pvf_debug_fhog(pvf_handle ctx, const uint8_t* img, int32_t h, int32_t w, int32_t cell, int32_t pad_r,
                        int32_t pad_c, float* out, int32_t* fh, int32_t* fw);          /* out [fh][fw][32] */
 int32_t pvf_debug_detect_raw(pvf_handle ctx, pvf_handle frame, int32_t upsample, double adjust, float* scores,

@@ -82,6 +82,18 @@ extern "C" int32_t pvf_debug_pyramid_level(pvf_handle h, pvf_handle frame, int32
     API_END
 }
 
+extern "C" int32_t pvf_debug_level_features(pvf_handle h, pvf_handle frame, int32_t upsample, int32_t level, float* out, int32_t* fh, int32_t* fw)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    std::vector<float> buf;
+    int a = 0, b = 0;
+    det_level_features(c, c->frame(frame), upsample, level, out ? &buf : nullptr, &a, &b);
+    *fh = a; *fw = b;
+    if (out) memcpy(out, buf.data(), buf.size() * sizeof(float));
+    API_END
+}
+
 extern "C" int32_t pvf_debug_fhog(pvf_handle h, const uint8_t* img, int32_t ih, int32_t iw, int32_t cell, int32_t pad_r, int32_t pad_c,
                                   float* out, int32_t* fh, int32_t* fw)
 {

@@ -281,6 +281,8 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
     for (auto& kv : c->frames) if (kv.second.owned) (void)hipFree((void*)kv.second.d);
     for (auto& kv : c->trackers) if (kv.second->d_state) (void)hipFree(kv.second->d_state);
     for (auto p : c->tracker_pool) (void)hipFree(p);
+    if (c->d_orient_lut) (void)hipFree(c->d_orient_lut);
+    if (c->d_grad_lut) (void)hipFree(c->d_grad_lut);
     (void)hipStreamDestroy(c->stream);
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     g_ctxs.erase(h);

@@ -75,6 +75,99 @@ static void launch_resize(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* 
                        x_scale, y_scale);
 }
 
+// K1, v3 (batched detector): same arithmetic, memory access reshaped.  The v2 form issued 6 byte loads per new source row and
+// 3 byte stores per pixel -- 9 vector-memory instructions per pixel made it texture-addresser bound (TA busy 75 %).  Here a
+// lane fetches its two neighbouring source pixels (6 bytes) with ONE aligned 12-byte load + a byte funnel shift, and the 64
+// pixels of a wave leave as 48 aligned dwords: each lane packs its 3 result bytes, lanes 0..47 collect the two packed pixels
+// their dword straddles through the LDS crossbar (ds_bpermute) and store once.  Needs 4-byte aligned output rows
+// (level images of the batched path have a padded row pitch) and wave-aligned 64-pixel segments.
+template <int RS>
+__global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
+                                                     size_t in_stride, int in_rb, int ih, int iw, uint8_t* __restrict__ out,
+                                                     size_t out_stride, int out_rb, int oh, int ow, double x_scale, double y_scale)
+{
+    const int lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * 256 + (threadIdx.x & ~63);    // first column of this wave's segment
+    const int r0 = blockIdx.y * RS, b = blockIdx.z;
+    if (c0 >= ow) return;                                      // wave-uniform
+    const int c = min(c0 + lane, ow - 1);                      // lanes past the row end recompute the last column (never stored)
+    const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
+    uint8_t* ob = out + (size_t)b * out_stride + (size_t)c0 * 3;
+    const double x = c * x_scale;
+    const int left = (int)floor(x);
+    const bool has_right = (left + 1 <= iw - 1);
+    const double lr = x - left, lr1 = 1 - lr;
+    const int ol = left * 3;
+    // output dword d of the segment (lane d < 48) straddles packed pixels a = 4d / 3 and a + 1, starting at byte 4d - 3a of pixel a
+    const int pa_lane = (4 * lane) / 3, phase = 4 * lane - 3 * pa_lane;
+    const int bp0 = 4 * min(pa_lane, 63), bp1 = 4 * min(pa_lane + 1, 63);
+    const int seg_bytes = min(ow - c0, 64) * 3;
+    const bool stores = (4 * lane < seg_bytes);
+    int s0 = -1, s1 = -1;              // cached source rows
+    double h0[3], h1[3];
+    auto hblend = [&](int srow, double* hh) {
+        const uint8_t* a = in + (size_t)srow * in_rb + ol;
+        uint32_t lo, hi;
+        const unsigned sh = (unsigned)(uintptr_t)a & 3u;
+        const uint8_t* pa = a - sh;
+        if (srow == ih - 1 && pa + 12 > in + (size_t)ih * in_rb) {
+            // last pixels of the last source row: stay inside the frame (it may end on a page boundary)
+            uint32_t t[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) t[k] = (has_right || k < 3) ? a[k] : 0;
+            lo = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
+            hi = t[4] | (t[5] << 8);
+        } else {
+            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(pa), w1 = *reinterpret_cast<const uint32_t*>(pa + 4),
+                           w2 = *reinterpret_cast<const uint32_t*>(pa + 8);
+            lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
+            hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        }
+        const double tl0 = (double)(lo & 0xffu), tl1 = (double)((lo >> 8) & 0xffu), tl2 = (double)((lo >> 16) & 0xffu);
+        double tr0 = (double)(lo >> 24), tr1 = (double)(hi & 0xffu), tr2 = (double)((hi >> 8) & 0xffu);
+        if (!has_right) { tr0 = tl0; tr1 = tl1; tr2 = tl2; }
+        hh[0] = lr1 * tl0 + lr * tr0;
+        hh[1] = lr1 * tl1 + lr * tr1;
+        hh[2] = lr1 * tl2 + lr * tr2;
+    };
+    const int r_end = min(r0 + RS, oh);
+    for (int r = r0; r < r_end; ++r) {
+        const double y = r * y_scale;
+        const int top = (int)floor(y);
+        const int bottom = min(top + 1, ih - 1);
+        const double tb = y - top, tb1 = 1 - tb;
+        if (s1 == top) { s0 = s1; h0[0] = h1[0]; h0[1] = h1[1]; h0[2] = h1[2]; s1 = -1; }
+        if (s0 != top) { hblend(top, h0); s0 = top; }
+        if (s1 != bottom) {
+            if (bottom == top) { h1[0] = h0[0]; h1[1] = h0[1]; h1[2] = h0[2]; }
+            else hblend(bottom, h1);
+            s1 = bottom;
+        }
+        uint32_t P = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double v = tb1 * h0[k] + tb * h1[k];
+            P |= (uint32_t)(uint8_t)(v + 0.5) << (8 * k);
+        }
+        const uint32_t Pa = (uint32_t)__builtin_amdgcn_ds_bpermute(bp0, (int)P), Pb = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)P);
+        const uint32_t dw = __builtin_amdgcn_alignbyte(Pb >> 8, Pa | (Pb << 24), (unsigned)phase);
+        if (stores) *reinterpret_cast<uint32_t*>(ob + (size_t)r * out_rb + 4 * lane) = dw;
+    }
+}
+
+static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* in_base, size_t in_stride, int in_rb, int ih, int iw,
+                               uint8_t* out, size_t out_stride, int out_rb, int oh, int ow, int batch)
+{
+    const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
+    const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
+    PVF_REQUIRE(x_scale <= 2.0, "resize: more than 2x horizontal decimation is not used on this path");
+    PVF_REQUIRE(out_rb % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)out & 3) == 0 && out_rb >= (ow * 3 + 3) / 4 * 4, "resize: output rows must be 4-byte aligned");
+    constexpr int RS = 16;
+    dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
+    hipLaunchKernelGGL((resize_rows_k<RS>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb,
+                       oh, ow, x_scale, y_scale);
+}
+
 static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
 {
     const double right = ((iw - 1) + 1.25) * 2.0;
@@ -94,6 +187,10 @@ static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
 // which makes the table bit-identical to evaluating the chain per pixel.
 static const float h_dirx[9] = {1.0000f, 0.9397f, 0.7660f, 0.500f, 0.1736f, -0.1736f, -0.5000f, -0.7660f, -0.9397f};
 static const float h_diry[9] = {0.0000f, 0.3420f, 0.6428f, 0.8660f, 0.9848f, 0.9848f, 0.8660f, 0.6428f, 0.3420f};
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4u __attribute__((aligned(4)));
 
 const uint8_t* orientation_lut(Ctx* c)
 {
@@ -116,6 +213,58 @@ const uint8_t* orientation_lut(Ctx* c)
     HIP_CHECK(hipMalloc((void**)&c->d_orient_lut, lut.size()));
     HIP_CHECK(hipMemcpy(c->d_orient_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
     return c->d_orient_lut;
+}
+
+// The same table in 8 x 8 tiles (one 64-byte line each): with Y = by + 255, X = bx + 255 the entry sits at
+// (Y >> 3) << 12 | (X >> 3) << 6 | (Y & 7) << 3 | (X & 7).  Neighbouring pixels mostly have small, similar gradients, so a
+// wave's 64 look-ups touch a handful of lines instead of one line per table row (the row-major form cost ~50 L1 accesses
+// per gather and made the gradient pass texture-addresser bound).
+const uint8_t* orientation_lut_tiled(Ctx* c)
+{
+    if (c->d_grad_lut) return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
+    orientation_lut(c);
+    std::vector<uint8_t> ol((size_t)511 * 511);
+    HIP_CHECK(hipMemcpy(ol.data(), c->d_orient_lut, ol.size(), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> lut((size_t)64 * 64 * 64, 0);
+    for (int Y = 0; Y < 511; ++Y)
+        for (int X = 0; X < 511; ++X)
+            lut[((size_t)(Y >> 3) << 12) | ((size_t)(X >> 3) << 6) | ((Y & 7) << 3) | (X & 7)] = ol[(size_t)Y * 511 + X];
+    HIP_CHECK(hipMalloc((void**)&c->d_grad_lut, lut.size()));
+    HIP_CHECK(hipMemcpy(c->d_grad_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
+    return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
+}
+
+// correctly rounded sqrt of a non-negative integer-valued float < 2^24: the hardware estimate (<= 1 ulp) stepped to the
+// neighbour the exact residuals ask for.  Same result as sqrtf(); skips its denormal scaling and class checks.
+__device__ __forceinline__ float sqrt_exact_small(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
+    float r = (rm <= 0.0f) ? sm : s;
+    r = (rp > 0.0f) ? sp : r;
+    return r;
+}
+
+// colour channel with the largest |g|^2 (first wins); magnitude by arithmetic, orientation bin from the tiled table
+__device__ __forceinline__ void grad_lookup(const int u[3], const int d[3], const int l[3], const int r[3],
+                                            const uint8_t* __restrict__ lut_t, float* v, int* o)
+{
+    int bx = r[0] - l[0], by = d[0] - u[0];
+    int bv = bx * bx + by * by;
+    int bi = by * 512 + bx;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+        const int cx = r[k] - l[k], cy = d[k] - u[k];
+        const int cv = cx * cx + cy * cy;
+        const int ci = cy * 512 + cx;
+        if (cv > bv) { bv = cv; bi = ci; }
+    }
+    const unsigned P = (unsigned)(bi + 255 * 512 + 255);           // Y << 9 | X
+    const unsigned off = (P & 0x3F007u) | ((P & 0x1F8u) << 3) | ((P >> 6) & 0x38u);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lut_t, 0, 64 * 64 * 64, 0x00020000);
+    *o = (int)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
+    *v = sqrt_exact_small((float)bv);
 }
 
 __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, const uint8_t* __restrict__ row_c,
@@ -550,7 +699,6 @@ __global__ void __launch_bounds__(256) score_k(const float* __restrict__ feat, s
 // One wave = one output row x 96 columns (two 16-position tiles); its feature row segment lives in a wave-private LDS slab
 // (34-float cell pitch: conflict-free ds_read_b32 for lanes 3 cells apart), B fragments stream from L2.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ feat, size_t feat_stride, int fh, int fw,
                                                     const float* __restrict__ Bg, ScoreParams sp, int* __restrict__ counts,
@@ -762,7 +910,7 @@ static void run_pyramid(Ctx* c, const std::vector<Frame>& frames, int upsample, 
 // =====================================================================================================
 #define ML_MAX 32
 struct LvDesc {
-    int h, w;                                   // level image
+    int h, w, rb;                               // level image, row pitch in bytes (multiple of 64)
     int cells_nr, cells_nc, hr, hc, visible_nr, visible_nc;
     int rows_t, pitch;                          // gradient planes
     int fh, fw, hog_nr, hog_nc;                 // features
@@ -774,6 +922,12 @@ struct LvDesc {
 };
 struct MlStarts { int nl; int b0[ML_MAX + 1]; };
 
+// Logical block id of the multi-level kernels.  A contiguous-range-per-XCD order (so that vertically adjacent tiles meet in one
+// L2) was measured 5-8 % SLOWER for the histogram / feature / scoring kernels (the ranges differ in cost per block, and the
+// re-reads it saves are served by the MALL anyway), so blocks keep the hardware's round-robin order.
+__device__ __forceinline__ int ml_block(const MlStarts& st) { return (int)blockIdx.x; }
+static inline int ml_grid(int total) { return total; }
+
 __device__ __forceinline__ int ml_level(const MlStarts& st, int g)
 {
     int l = 0;
@@ -781,135 +935,221 @@ __device__ __forceinline__ int ml_level(const MlStarts& st, int g)
     return l;
 }
 
-__global__ void __launch_bounds__(256) fhog_grad4_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
-                                                       float* __restrict__ mag_base, uint8_t* __restrict__ bin_base,
-                                                       const uint8_t* __restrict__ lut)
+// v3 of the gradient pass: one lane owns 4 pixel columns x GR rows.  The 20-byte neighbourhood of a row is loaded once
+// (5 unaligned dwords) and serves as the "down" row of the row above, the centre row, and the "up" row of the row below,
+// so an interior row costs 5 loads instead of 11 and the level lookup / index arithmetic is paid once per GR rows.
+#define GRAD_ROWS 8
+__global__ void __launch_bounds__(256) fhog_grad4r_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
+                                                        float* __restrict__ mag_base, uint8_t* __restrict__ bin_base,
+                                                        const uint8_t* __restrict__ lut2)
 {
-    constexpr int C = 8;
-    const int l = ml_level(st, blockIdx.x);
+    constexpr int C = 8, GR = GRAD_ROWS;
+    const int g = ml_block(st);
+    if (g >= st.b0[st.nl]) return;
+    const int l = ml_level(st, g);
     const LvDesc d = lv[l];
-    const int local = blockIdx.x - st.b0[l];
+    const int local = g - st.b0[l];
+    const int nyb = (d.rows_t + GR - 1) / GR;
     const int qb = local % d.grad_bx;
-    const int yy = (local / d.grad_bx) % d.rows_t;
-    const int b = local / (d.grad_bx * d.rows_t);
+    const int yb = (local / d.grad_bx) % nyb;
+    const int b = local / (d.grad_bx * nyb);
     const int xx = 4 * (qb * 256 + threadIdx.x);
     if (xx >= d.pitch) return;
-    const int y = yy - 3 * C / 2, x0 = xx - 3 * C / 2;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    int o[4] = {0, 0, 0, 0};
-    if (y >= 1 && y < d.visible_nr && x0 + 3 >= 1 && x0 < d.visible_nc) {
-        const uint8_t* im = img_base + d.img_off + (size_t)b * d.img_stride;
-        const int rb = d.w * 3;
-        const uint8_t* rc = im + (size_t)y * rb;
-        const uint8_t* ru = rc - rb;
-        const uint8_t* rd = rc + rb;
-        if (x0 >= 1 && x0 + 4 <= d.visible_nc && x0 + 6 <= d.w) {
-            uint32_t wc[5], wu[3], wd[3];
-            const uint8_t* pc = rc + 3 * x0 - 3;
+    const int x0 = xx - 3 * C / 2;
+    const int yy0 = yb * GR;
+    const int rb = d.rb;
+    const uint8_t* im = img_base + d.img_off + (size_t)b * d.img_stride;
+    float* mg = mag_base + d.px_off + (size_t)b * d.px_stride + xx;
+    uint8_t* bn = bin_base + d.px_off + (size_t)b * d.px_stride + xx;
+    const bool col_any = (x0 + 3 >= 1 && x0 < d.visible_nc);
+    const bool col_fast = (x0 >= 1 && x0 + 4 <= d.visible_nc && x0 + 6 <= d.w);
+    if (col_fast) {
+        // all GR + 2 image rows of this lane are requested up front (one latency per block, not one per row); a row outside
+        // the image is never used.  The bin look-ups of row r are in flight while row r + 1 is computed; row r is stored then.
+        uint32_t w[GR + 2][5];
+        const uint8_t* pc = im + 3 * x0 - 3;
+        const int yfirst = yy0 - 3 * C / 2;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) wc[k] = *reinterpret_cast<const uint32_t*>(pc + 4 * k);
+        for (int k = 0; k < GR + 2; ++k) {
+            const int y = yfirst - 1 + k;
+            if (y >= 0 && y < d.h) {
+                const uint8_t* p = pc + (size_t)y * rb;
+                // aligned dwords + a byte funnel shift (the misalignment is the same for every lane of a row): unaligned
+                // 16-byte loads measured 20 % slower for the whole kernel
+                const unsigned sh = (unsigned)(uintptr_t)p & 3u;
+                const uint8_t* pa = p - sh;
+                const u32x4 q = *reinterpret_cast<const u32x4u*>(pa);
+                const uint32_t a0 = q.x, a1 = q.y, a2 = q.z, a3 = q.w;
+                const uint32_t a4 = *reinterpret_cast<const uint32_t*>(pa + 16), a5 = *reinterpret_cast<const uint32_t*>(pa + 20);
+                w[k][0] = __builtin_amdgcn_alignbyte(a1, a0, sh); w[k][1] = __builtin_amdgcn_alignbyte(a2, a1, sh);
+                w[k][2] = __builtin_amdgcn_alignbyte(a3, a2, sh); w[k][3] = __builtin_amdgcn_alignbyte(a4, a3, sh);
+                w[k][4] = __builtin_amdgcn_alignbyte(a5, a4, sh);
+            } else {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                wu[k] = *reinterpret_cast<const uint32_t*>(ru + 3 * x0 + 4 * k);
-                wd[k] = *reinterpret_cast<const uint32_t*>(rd + 3 * x0 + 4 * k);
+                for (int j = 0; j < 5; ++j) w[k][j] = 0;
             }
+        }
 #define BYTE_OF(w, i) (int)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
+        float pv[4] = {0.f, 0.f, 0.f, 0.f};
+        int po[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                int u[3], dd[3], ll[3], r[3];
+        for (int r = 0; r <= GR; ++r) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            int o[4] = {0, 0, 0, 0};
+            if (r < GR) {
+                const int y = yfirst + r;
+                if (yy0 + r < d.rows_t && y >= 1 && y < d.visible_nr) {            // block-uniform
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    u[k] = BYTE_OF(wu, 3 * p + k); dd[k] = BYTE_OF(wd, 3 * p + k);
-                    ll[k] = BYTE_OF(wc, 3 * p + k); r[k] = BYTE_OF(wc, 3 * p + 6 + k);
+                    for (int p = 0; p < 4; ++p) {
+                        int u[3], dd[3], ll[3], rr[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            u[k] = BYTE_OF(w[r], 3 * p + 3 + k); dd[k] = BYTE_OF(w[r + 2], 3 * p + 3 + k);
+                            ll[k] = BYTE_OF(w[r + 1], 3 * p + k); rr[k] = BYTE_OF(w[r + 1], 3 * p + 6 + k);
+                        }
+                        grad_lookup(u, dd, ll, rr, lut2, &v[p], &o[p]);
+                    }
                 }
-                grad_from_bytes(u, dd, ll, r, lut, &v[p], &o[p]);
             }
+            if (r >= 1 && yy0 + r - 1 < d.rows_t) {
+                const size_t idx = (size_t)(yy0 + r - 1) * d.pitch;
+                *reinterpret_cast<float4*>(mg + idx) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+                *reinterpret_cast<uint32_t*>(bn + idx) = (uint32_t)po[0] | ((uint32_t)po[1] << 8) | ((uint32_t)po[2] << 16) | ((uint32_t)po[3] << 24);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { pv[p] = v[p]; po[p] = o[p]; }
+        }
 #undef BYTE_OF
-        } else {
+        return;
+    }
+    for (int r = 0; r < GR; ++r) {
+        const int yy = yy0 + r, y = yy - 3 * C / 2;
+        if (yy >= d.rows_t) break;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        int o[4] = {0, 0, 0, 0};
+        if (col_any && y >= 1 && y < d.visible_nr) {
+            const uint8_t* rc = im + (size_t)y * rb;
+            const uint8_t* ru = rc - rb;
+            const uint8_t* rd = rc + rb;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 const int x = x0 + p;
                 if (x >= 1 && x < d.visible_nc) {
-                    int u[3], dd[3], ll[3], r[3];
+                    int u[3], dd[3], ll[3], rr[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { u[k] = ru[3 * x + k]; dd[k] = rd[3 * x + k]; ll[k] = rc[3 * x - 3 + k]; r[k] = rc[3 * x + 3 + k]; }
-                    grad_from_bytes(u, dd, ll, r, lut, &v[p], &o[p]);
+                    for (int k = 0; k < 3; ++k) { u[k] = ru[3 * x + k]; dd[k] = rd[3 * x + k]; ll[k] = rc[3 * x - 3 + k]; rr[k] = rc[3 * x + 3 + k]; }
+                    grad_lookup(u, dd, ll, rr, lut2, &v[p], &o[p]);
                 }
             }
         }
+        const size_t idx = (size_t)yy * d.pitch;
+        *reinterpret_cast<float4*>(mg + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint32_t*>(bn + idx) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
     }
-    const size_t idx = (size_t)d.px_off + (size_t)b * d.px_stride + (size_t)yy * d.pitch + xx;
-    *reinterpret_cast<float4*>(mag_base + idx) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<uint32_t*>(bin_base + idx) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
 }
 
-__global__ void __launch_bounds__(256) fhog_hist_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ mag_base,
-                                                      const uint8_t* __restrict__ bin_base, float* __restrict__ hist_base,
-                                                      float* __restrict__ norm_base)
+// v3 of the histogram pass: one lane owns HK vertically consecutive cells of one cell column and walks the 8 (HK + 1) pixel rows
+// they cover ONCE, top to bottom.  A row in band g feeds the lower half of cell g - 1 and the upper half of cell g, so every cell
+// still receives its votes in row-major order of its own 16 x 16 window (the order dlib's scatter loop produces), while the
+// (magnitude, bin) planes are read (HK + 1) / HK times instead of twice.  Two accumulator sets in LDS alternate between cells.
+#define HIST_CELLS 4
+__global__ void __launch_bounds__(256) fhog_hist4_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ mag_base,
+                                                       const uint8_t* __restrict__ bin_base, float* __restrict__ hist_base,
+                                                       float* __restrict__ norm_base)
 {
-    constexpr int C = 8, NV = 2 * C / 4;
-    __shared__ float acc[18][256];
-    const int l = ml_level(st, blockIdx.x);
+    constexpr int C = 8, HK = HIST_CELLS, NV = 2 * C / 4;
+    __shared__ float acc[2][18][256];
+    const int g0 = ml_block(st);
+    if (g0 >= st.b0[st.nl]) return;
+    const int l = ml_level(st, g0);
     const LvDesc d = lv[l];
-    const int local = blockIdx.x - st.b0[l];
+    const int local = g0 - st.b0[l];
+    const int nyb = (d.hr + HK - 1) / HK;
     const int xb = local % d.hist_bx;
-    const int hy = (local / d.hist_bx) % d.hr;
-    const int b = local / (d.hist_bx * d.hr);
+    const int yb = (local / d.hist_bx) % nyb;
+    const int b = local / (d.hist_bx * nyb);
     const int hx = xb * 256 + threadIdx.x;
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int o = 0; o < 18; ++o) acc[o][tid] = 0.0f;
+    for (int o = 0; o < 18; ++o) { acc[0][o][tid] = 0.0f; acc[1][o][tid] = 0.0f; }
     if (hx >= d.hc) return;
-    const float* mg = mag_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx;
-    const uint8_t* bn = bin_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx;
+    const int hy0 = yb * HK;
+    const int ncell = (d.hr - hy0 < HK) ? d.hr - hy0 : HK;       // cells of this lane that exist (block-uniform)
+    const float* mg = mag_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx + (size_t)(C * hy0) * d.pitch;
+    const uint8_t* bn = bin_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx + (size_t)(C * hy0) * d.pitch;
     float4 pv[2][NV];
     uint32_t pb[2][4];
-    auto load_row = [&](int wy, float4* dv, uint32_t* db) {
-        const size_t row = (size_t)(C * hy + wy) * d.pitch;
+    auto load_row = [&](int r, float4* dv, uint32_t* db) {
+        const size_t row = (size_t)r * d.pitch;
 #pragma unroll
         for (int q = 0; q < NV; ++q) dv[q] = *reinterpret_cast<const float4*>(mg + row + 4 * q);
         const uint4 t = *reinterpret_cast<const uint4*>(bn + row);
         db[0] = t.x; db[1] = t.y; db[2] = t.z; db[3] = t.w;
     };
-    load_row(0, pv[0], pb[0]);
+    auto finish = [&](int j) {                                     // cell j of this lane is complete: write it out, clear its set
+        const int hy = hy0 + j, set = j & 1;
+        float* h = hist_base + d.hist_off + (size_t)b * d.hist_stride + ((size_t)hy * d.hc + hx) * 18;
+        float e = 0.0f;
 #pragma unroll
-    for (int wy = 0; wy < 2 * C; ++wy) {
-        const int cur = wy & 1;
-        if (wy + 1 < 2 * C) load_row(wy + 1, pv[cur ^ 1], pb[cur ^ 1]);
-        const int i = wy % C;
-        const float fy = ((float)i + 0.5f) / (float)C;
-        const float wyv = (wy < C) ? fy : 1.0f - fy;
-        float v[2 * C];
-#pragma unroll
-        for (int q = 0; q < NV; ++q) { v[4 * q] = pv[cur][q].x; v[4 * q + 1] = pv[cur][q].y; v[4 * q + 2] = pv[cur][q].z; v[4 * q + 3] = pv[cur][q].w; }
-#pragma unroll
-        for (int wx = 0; wx < 2 * C; ++wx) {
-            const int j = wx % C;
-            const float fx = ((float)j + 0.5f) / (float)C;
-            const float wxv = (wx < C) ? fx : 1.0f - fx;
-            const int o = (int)((pb[cur][wx >> 2] >> (8 * (wx & 3))) & 0xffu);
-            acc[o][tid] = acc[o][tid] + (wyv * wxv) * v[wx];
+        for (int o = 0; o < 9; ++o) {
+            const float a0 = acc[set][o][tid], a1 = acc[set][o + 9][tid];
+            h[o] = a0; h[o + 9] = a1;
+            const float s2 = a0 + a1;
+            e = e + s2 * s2;
+            acc[set][o][tid] = 0.0f; acc[set][o + 9][tid] = 0.0f;
         }
-    }
-    float* h = hist_base + d.hist_off + (size_t)b * d.hist_stride + ((size_t)hy * d.hc + hx) * 18;
-    float e = 0.0f;
+        if (hy >= 1 && hy <= d.cells_nr && hx >= 1 && hx <= d.cells_nc)
+            norm_base[d.norm_off + (size_t)b * d.norm_stride + (size_t)(hy - 1) * d.cells_nc + (hx - 1)] = e;
+    };
+    const int nrows = C * (ncell + 1);
+    load_row(0, pv[0], pb[0]);
+    for (int g = 0; g <= ncell; ++g) {
+        const bool lower = (g >= 1);            // rows of this band are the lower half of cell g - 1
+        const bool upper = (g < ncell);         // ... and the upper half of cell g
+        float* accl = &acc[(g + 1) & 1][0][tid];
+        float* accu = &acc[g & 1][0][tid];
 #pragma unroll
-    for (int o = 0; o < 9; ++o) {
-        const float a0 = acc[o][tid], a1 = acc[o + 9][tid];
-        h[o] = a0; h[o + 9] = a1;
-        const float s2 = a0 + a1;
-        e = e + s2 * s2;
+        for (int i = 0; i < C; ++i) {
+            const int cur = i & 1;
+            const int r = C * g + i;
+            if (r + 1 < nrows) load_row(r + 1, pv[cur ^ 1], pb[cur ^ 1]);
+            const float fy = ((float)i + 0.5f) / (float)C;
+            float v[2 * C];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) { v[4 * q] = pv[cur][q].x; v[4 * q + 1] = pv[cur][q].y; v[4 * q + 2] = pv[cur][q].z; v[4 * q + 3] = pv[cur][q].w; }
+            if (lower) {
+#pragma unroll
+                for (int wx = 0; wx < 2 * C; ++wx) {
+                    const int j = wx % C;
+                    const float fx = ((float)j + 0.5f) / (float)C;
+                    const float wxv = (wx < C) ? fx : 1.0f - fx;
+                    const int o = (int)((pb[cur][wx >> 2] >> (8 * (wx & 3))) & 0xffu);
+                    accl[o * 256] = accl[o * 256] + ((1.0f - fy) * wxv) * v[wx];
+                }
+            }
+            if (upper) {
+#pragma unroll
+                for (int wx = 0; wx < 2 * C; ++wx) {
+                    const int j = wx % C;
+                    const float fx = ((float)j + 0.5f) / (float)C;
+                    const float wxv = (wx < C) ? fx : 1.0f - fx;
+                    const int o = (int)((pb[cur][wx >> 2] >> (8 * (wx & 3))) & 0xffu);
+                    accu[o * 256] = accu[o * 256] + (fy * wxv) * v[wx];
+                }
+            }
+        }
+        if (lower) finish(g - 1);
     }
-    if (hy >= 1 && hy <= d.cells_nr && hx >= 1 && hx <= d.cells_nc)
-        norm_base[d.norm_off + (size_t)b * d.norm_stride + (size_t)(hy - 1) * d.cells_nc + (hx - 1)] = e;
 }
 
 __global__ void __launch_bounds__(256) fhog_feat_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ hist_base,
                                                       const float* __restrict__ norm_base, float* __restrict__ feat_base, int oy, int ox)
 {
-    const int l = ml_level(st, blockIdx.x);
+    const int g = ml_block(st);
+    if (g >= st.b0[st.nl]) return;
+    const int l = ml_level(st, g);
     const LvDesc d = lv[l];
-    const int local = blockIdx.x - st.b0[l];
+    const int local = g - st.b0[l];
     const int xb = local % d.feat_bx;
     const int py = (local / d.feat_bx) % d.fh;
     const int b = local / (d.feat_bx * d.fh);
@@ -936,114 +1176,6 @@ __global__ void __launch_bounds__(256) fhog_feat_ml_k(MlStarts st, const LvDesc*
     for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
 }
 
-// scoring of every level: same body as score_mfma_k, level geometry from the table
-__global__ void __launch_bounds__(256) score_mfma_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base,
-                                                       const float* __restrict__ Bg, ScoreParams sp, int* __restrict__ counts,
-                                                       CandRec* __restrict__ cands)
-{
-    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11;
-    extern __shared__ __attribute__((aligned(16))) float s_seg[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l = ml_level(st, blockIdx.x);
-    const LvDesc d = lv[l];
-    const int local = blockIdx.x - st.b0[l];
-    const int bx = local % d.score_bx;
-    const int by = (local / d.score_bx) % d.score_by;
-    const int b = local / (d.score_bx * d.score_by);
-    const int fh = d.fh, fw = d.fw;
-    const int r_top = by * 4 + wave, c_base = bx * WCOLS;
-    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
-    if (r_top + FR / 2 >= r1) return;
-    float* seg = s_seg + (size_t)wave * SEG * PITCH;
-    const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride;
-    const int i = lane & 15, kq = lane >> 4;
-    f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool two_tiles = (c_base + 48 + FC / 2 < c1);
-    for (int m = 0; m < FR; ++m) {
-        const int fr = r_top + m;
-        float bv[NK * 8];
-        const float* bp = Bg + (size_t)m * NK * 8 * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < NK * 8; ++q) bv[q] = bp[q * 64];
-        constexpr int NST = (SEG * 8 + 63) / 64;
-        float4 sv[NST];
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int idx = lane + 64 * u;
-            const int cell = idx >> 3, q = idx & 7;
-            const int x = c_base + cell;
-            sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < SEG * 8 && fr < fh && x < fw) sv[u] = reinterpret_cast<const float4*>(fb + ((size_t)fr * fw + x) * PVF_FHOG_STRIDE)[q];
-        }
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int idx = lane + 64 * u;
-            if (idx < SEG * 8) {
-                const int cell = idx >> 3, q = idx & 7;
-                float2* dd = reinterpret_cast<float2*>(seg + cell * PITCH + 4 * q);
-                dd[0] = make_float2(sv[u].x, sv[u].y);
-                dd[1] = make_float2(sv[u].z, sv[u].w);
-            }
-        }
-        const float* a0 = seg + (3 * i) * PITCH + kq;
-        float an[8 * MT];
-#pragma unroll
-        for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) an[pq * MT + t] = a0[(t * 48) * PITCH + 4 * pq];
-#pragma unroll
-        for (int n = 0; n < NK; ++n) {
-            float ac[8 * MT];
-#pragma unroll
-            for (int q = 0; q < 8 * MT; ++q) ac[q] = an[q];
-            if (n + 1 < NK) {
-#pragma unroll
-                for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) an[pq * MT + t] = a0[(t * 48 + n + 1) * PITCH + 4 * pq];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (two_tiles) {
-#pragma unroll
-                for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + t], bv[n * 8 + pq], acc[t], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int pq = 0; pq < 8; ++pq)
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT], bv[n * 8 + pq], acc[0], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    const int j = lane & 15;
-    if (j < 15) {
-        const int s = j / 5, f = j % 5;
-        const float th = sp.thresh[f];
-        const int r = r_top + FR / 2;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int pos = 4 * (lane >> 4) + reg;
-                const int cc = c_base + t * 48 + 3 * pos + s + FC / 2;
-                const float v = acc[t][reg];
-                if (cc < c1 && v >= th) {
-                    const int idx = atomicAdd(&counts[b], 1);
-                    if (idx < sp.cap) {
-                        CandRec rec;
-                        rec.score = v - th; rec.filter = f; rec.level = l; rec.r = r; rec.c = cc;
-                        cands[(size_t)b * sp.cap + idx] = rec;
-                    }
-                }
-            }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------
 // K3 v3: one wave owns R consecutive output rows x 96 columns and walks the R + 9 feature rows it needs ONCE.
 // Staged feature row t feeds output row j through filter row m = t - j, so every A fragment read from the slab is used for
@@ -1062,9 +1194,11 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
     extern __shared__ __attribute__((aligned(16))) float s_seg[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int l = ml_level(st, blockIdx.x);
+    const int g = ml_block(st);
+    if (g >= st.b0[st.nl]) return;
+    const int l = ml_level(st, g);
     const LvDesc d = lv[l];
-    const int local = blockIdx.x - st.b0[l];
+    const int local = g - st.b0[l];
     const int bx = local % d.score_bx;
     const int by = (local / d.score_bx) % d.score_by;
     const int b = __builtin_amdgcn_readfirstlane(local / (d.score_bx * d.score_by));
@@ -1216,14 +1350,14 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
     }
 }
 
-// output rows per wave of the scoring kernel (PVF_SCORE_ROWS = 1 selects the one-row kernel)
+// output rows per wave of the scoring kernel (PVF_SCORE_ROWS = 2 or 4)
 static int score_rows_per_wave()
 {
     static int r = -1;
     if (r < 0) {
         const char* e = getenv("PVF_SCORE_ROWS");
         r = e ? atoi(e) : 4;
-        if (r != 1 && r != 2 && r != 4) r = 4;
+        if (r != 2 && r != 4) r = 4;
     }
     return r;
 }
@@ -1250,7 +1384,7 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
     std::vector<LevelDims> dims = level_schedule(h, w, upsample, m, &p.ups);
     PVF_REQUIRE((int)dims.size() <= ML_MAX, "too many pyramid levels");
     auto al = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
-    for (size_t u = 0; u + 1 < p.ups.size(); ++u) p.up_bytes = std::max(p.up_bytes, al((size_t)p.ups[u].h * p.ups[u].w * 3, 16) * B);
+    for (size_t u = 0; u + 1 < p.ups.size(); ++u) p.up_bytes = std::max(p.up_bytes, (size_t)p.ups[u].h * al((size_t)p.ups[u].w * 3, 64) * B);
     p.grad.nl = p.hist.nl = p.feat.nl = p.score.nl = (int)dims.size();
     for (size_t l = 0; l < dims.size(); ++l) {
         LvDesc d;
@@ -1264,7 +1398,8 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         const bool feat_ok = d.hog_nr > 0 && d.hog_nc > 0;
         d.fh = feat_ok ? d.hog_nr + m.frows - 1 : 0; d.fw = feat_ok ? d.hog_nc + m.fcols - 1 : 0;
         d.valid_score = (d.fh >= m.frows && d.fw >= m.fcols) ? 1 : 0;
-        d.img_off = (long long)p.img_bytes; d.img_stride = (long long)al((size_t)d.h * d.w * 3, 16);
+        d.rb = (int)al((size_t)d.w * 3, 64);
+        d.img_off = (long long)p.img_bytes; d.img_stride = (long long)d.h * d.rb;
         p.img_bytes += (size_t)d.img_stride * B;
         d.px_off = (long long)p.px_elems; d.px_stride = (long long)d.rows_t * d.pitch;
         p.px_elems += (size_t)d.px_stride * B;
@@ -1278,8 +1413,8 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         const int out_r = d.fh - 9, out_c = d.fw - 9;
         const int rows_per_block = 4 * score_rows_per_wave();
         d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + rows_per_block - 1) / rows_per_block : 0;
-        p.grad.b0[l] = p.grad_blocks; p.grad_blocks += d.grad_bx * d.rows_t * B;
-        p.hist.b0[l] = p.hist_blocks; p.hist_blocks += d.hist_bx * d.hr * B;
+        p.grad.b0[l] = p.grad_blocks; p.grad_blocks += d.grad_bx * ((d.rows_t + GRAD_ROWS - 1) / GRAD_ROWS) * B;
+        p.hist.b0[l] = p.hist_blocks; p.hist_blocks += d.hist_bx * ((d.hr + HIST_CELLS - 1) / HIST_CELLS) * B;
         p.feat.b0[l] = p.feat_blocks; p.feat_blocks += d.feat_bx * d.fh * B;
         p.score.b0[l] = p.score_blocks; p.score_blocks += d.score_bx * d.score_by * B;
         p.lv.push_back(d);
@@ -1307,32 +1442,34 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
     ProfScope ps(c, "pyramid");
     auto al = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
     const uint8_t* cur = nullptr;
-    int ch = h, cw = w;
+    int ch = h, cw = w, crb = w * 3;
     size_t cstride = 0;
     for (size_t u = 0; u < p->ups.size(); ++u) {
         const bool last = (u + 1 == p->ups.size());
         uint8_t* dst = last ? base + p->lv[0].img_off : up_tmp;
-        const size_t dstride = last ? (size_t)p->lv[0].img_stride : al((size_t)p->ups[u].h * p->ups[u].w * 3, 16);
-        launch_resize(c, cur ? nullptr : d_ptrs, cur, cstride, ch, cw, dst, dstride, p->ups[u].h, p->ups[u].w, B);
-        cur = dst; cstride = dstride; ch = p->ups[u].h; cw = p->ups[u].w;
+        const int drb = (int)al((size_t)p->ups[u].w * 3, 64);
+        const size_t dstride = (size_t)p->ups[u].h * drb;
+        launch_resize_rows(c, cur ? nullptr : d_ptrs, cur, cstride, crb, ch, cw, dst, dstride, drb, p->ups[u].h, p->ups[u].w, B);
+        cur = dst; cstride = dstride; crb = drb; ch = p->ups[u].h; cw = p->ups[u].w;
     }
     if (!cur) {
         for (int b = 0; b < B; ++b)
-            HIP_CHECK(hipMemcpyAsync(base + p->lv[0].img_off + (size_t)b * p->lv[0].img_stride, frames[b].d, (size_t)h * w * 3,
-                                     hipMemcpyDeviceToDevice, c->stream));
+            HIP_CHECK(hipMemcpy2DAsync(base + p->lv[0].img_off + (size_t)b * p->lv[0].img_stride, (size_t)p->lv[0].rb, frames[b].d, (size_t)w * 3,
+                                       (size_t)w * 3, (size_t)h, hipMemcpyDeviceToDevice, c->stream));
     }
     for (size_t l = 1; l < p->lv.size(); ++l)
-        launch_resize(c, nullptr, base + p->lv[l - 1].img_off, (size_t)p->lv[l - 1].img_stride, p->lv[l - 1].h, p->lv[l - 1].w,
-                      base + p->lv[l].img_off, (size_t)p->lv[l].img_stride, p->lv[l].h, p->lv[l].w, B);
+        launch_resize_rows(c, nullptr, base + p->lv[l - 1].img_off, (size_t)p->lv[l - 1].img_stride, p->lv[l - 1].rb, p->lv[l - 1].h, p->lv[l - 1].w,
+                           base + p->lv[l].img_off, (size_t)p->lv[l].img_stride, p->lv[l].rb, p->lv[l].h, p->lv[l].w, B);
     return p;
 }
 
-static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsample, const ScoreParams& sp0, int* d_counts, CandRec* d_cands)
+// pyramid + FHOG features of every level of the batch (s_feat at plan->lv[l].feat_off); returns the plan
+static MlPlan* ml_features(Ctx* c, const std::vector<Frame>& frames, int upsample)
 {
     const DetectorModel& m = c->det;
     const int B = (int)frames.size();
     MlPlan* p = ml_build_pyramid(c, frames, upsample);
-    const uint8_t* lut = orientation_lut(c);
+    const uint8_t* lut2 = orientation_lut_tiled(c);
     c->s_grad.ensure(p->px_elems * 5 + 256);
     c->s_hist.ensure(p->hist_floats * sizeof(float) + 64);
     c->s_norm.ensure(p->norm_floats * sizeof(float) + 64);
@@ -1343,36 +1480,37 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
         ProfScope ps(c, "fhog");
         {
             ProfScope p1(c, "fhog_grad");
-            hipLaunchKernelGGL(fhog_grad4_ml_k, dim3(p->grad_blocks), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_mag, d_bin, lut);
+            hipLaunchKernelGGL(fhog_grad4r_ml_k, dim3(ml_grid(p->grad_blocks)), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_mag, d_bin, lut2);
         }
         {
             ProfScope p2(c, "fhog_hist");
-            hipLaunchKernelGGL(fhog_hist_ml_k, dim3(p->hist_blocks), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_mag, d_bin, c->s_hist.as<float>(),
+            hipLaunchKernelGGL(fhog_hist4_ml_k, dim3(ml_grid(p->hist_blocks)), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_mag, d_bin, c->s_hist.as<float>(),
                                c->s_norm.as<float>());
         }
         if (p->feat_blocks > 0) {
             ProfScope p3(c, "fhog_feat");
-            hipLaunchKernelGGL(fhog_feat_ml_k, dim3(p->feat_blocks), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_hist.as<float>(),
+            hipLaunchKernelGGL(fhog_feat_ml_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_hist.as<float>(),
                                c->s_norm.as<float>(), c->s_feat.as<float>(), (m.frows - 1) / 2, (m.fcols - 1) / 2);
         }
     }
+    return p;
+}
+
+static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsample, const ScoreParams& sp0, int* d_counts, CandRec* d_cands)
+{
+    const DetectorModel& m = c->det;
+    const int B = (int)frames.size();
+    MlPlan* p = ml_features(c, frames, upsample);
     if (p->score_blocks > 0) {
         ProfScope ps(c, "score");
         const size_t lds = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
         const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
-        switch (score_rows_per_wave()) {
-        case 4:
-            hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(p->score_blocks), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
+        if (score_rows_per_wave() == 2)
+            hipLaunchKernelGGL(score_mfma_rows_ml_k<2>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
                                sp0, d_counts, d_cands);
-            break;
-        case 2:
-            hipLaunchKernelGGL(score_mfma_rows_ml_k<2>, dim3(p->score_blocks), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
+        else
+            hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
                                sp0, d_counts, d_cands);
-            break;
-        default:
-            hipLaunchKernelGGL(score_mfma_ml_k, dim3(p->score_blocks), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), m.d_bmfma,
-                               sp0, d_counts, d_cands);
-        }
     }
 }
 
@@ -1385,7 +1523,25 @@ void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vec
     *oh = p->lv[level].h; *ow = p->lv[level].w;
     if (out) {
         out->resize((size_t)(*oh) * (*ow) * 3);
-        HIP_CHECK(hipMemcpyAsync(out->data(), c->s_pyr.as<uint8_t>() + p->lv[level].img_off, out->size(), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpy2DAsync(out->data(), (size_t)(*ow) * 3, c->s_pyr.as<uint8_t>() + p->lv[level].img_off, (size_t)p->lv[level].rb,
+                                   (size_t)(*ow) * 3, (size_t)(*oh), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
+// features of one pyramid level as the batched detector computes them (parity tests of the multi-level FHOG kernels)
+void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::vector<float>* out, int* fh, int* fw)
+{
+    PVF_REQUIRE(c->det.loaded, "detector not loaded");
+    std::vector<Frame> fr{f};
+    MlPlan* p = ml_features(c, fr, upsample);
+    PVF_REQUIRE(level >= 0 && level < (int)p->lv.size(), "pyramid level out of range");
+    const LvDesc& d = p->lv[level];
+    *fh = d.fh; *fw = d.fw;
+    if (out) {
+        out->resize((size_t)d.fh * d.fw * PVF_FHOG_STRIDE);
+        if (!out->empty())
+            HIP_CHECK(hipMemcpyAsync(out->data(), c->s_feat.as<float>() + d.feat_off, out->size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_CHECK(hipStreamSynchronize(c->stream));
 }

@@ -185,6 +185,7 @@ struct Ctx {
     HostBuf h_cand, h_misc;
     int n_cu = 256;
     uint8_t* d_orient_lut = nullptr; // 511x511 orientation bins (detect.hip)
+    void* d_grad_lut = nullptr;          // orientation bins in 8 x 8 tiles (64^3 bytes): orientation_lut_tiled()
 
     Frame& frame(uint64_t id)
     {
@@ -216,6 +217,7 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
                    std::vector<std::vector<RawDet>>& raw_sorted);
 void det_nms(const DetectorModel& m, const std::vector<RawDet>& sorted, std::vector<RawDet>& out);
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* h, int* w);
+void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::vector<float>* out, int* fh, int* fw);
 void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, int pad_c, std::vector<float>& out, int* fh, int* fw);
 // device fhog used by dsst.hip too: img u8 [n][h][w][3] -> feat [n][fh][fw][32]
 void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat,

@@ -170,6 +170,16 @@ class Context(object):
         check(self._l.pvf_debug_pyramid_level(self._h, f.handle, upsample, level, ptr(out), C.byref(oh), C.byref(ow)))
         return out
 
+    def level_features(self, frame, upsample, level):
+        """FHOG features [fh][fw][32] of one pyramid level as the batched detector computes them (parity tests)."""
+        f = self.stage(frame)
+        fh, fw = C.c_int32(0), C.c_int32(0)
+        check(self._l.pvf_debug_level_features(self._h, f.handle, upsample, level, None, C.byref(fh), C.byref(fw)))
+        out = np.zeros((fh.value, fw.value, 32), np.float32)
+        if out.size:
+            check(self._l.pvf_debug_level_features(self._h, f.handle, upsample, level, ptr(out), C.byref(fh), C.byref(fw)))
+        return out
+
     def fhog(self, img, cell, pad_r, pad_c):
         img = np.ascontiguousarray(img, np.uint8)
         fh, fw = C.c_int32(0), C.c_int32(0)

@@ -46,6 +46,20 @@ def test_fhog_bit_exact(ctx, oracle, small_video, cell, pad, shape):
     assert bad == 0, "fhog cell %d: %d of %d floats differ (max abs %g)" % (cell, bad, a.size, np.abs(a - b).max())
 
 
+def test_batched_detector_level_features_bit_exact(ctx, oracle, small_video):
+    """the all-levels-per-launch FHOG kernels (what detect_batch runs) against the oracle, every cell of several levels"""
+    f = small_video.frame(3)
+    for level in (0, 1, 4, 9):
+        img = ctx.pyramid_level(f, 1, level)
+        a = ctx.level_features(f, 1, level)
+        b = oracle.fhog(img, 8, 10, 10)
+        assert a.shape == b.shape, (level, a.shape, b.shape)
+        bad = int((a.view(np.uint32) != b.view(np.uint32)).sum())
+        if bad:
+            _dump("level_feat_mismatch_%d" % level, gpu=a, cpu=b)
+        assert bad == 0, "level %d: %d of %d feature floats differ" % (level, bad, a.size)
+
+
 def test_detector_raw_and_boxes_bit_exact(ctx, oracle, small_video):
     det = _detector(oracle)
     for i in (0, 7):
