@@ -76,28 +76,59 @@ static void launch_resize(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* 
 }
 
 // K1, v3 (batched detector): same arithmetic, memory access reshaped.  The v2 form issued 6 byte loads per new source row and
-// 3 byte stores per pixel -- 9 vector-memory instructions per pixel made it texture-addresser bound (TA busy 75 %).  Here a
-// lane fetches its two neighbouring source pixels (6 bytes) with ONE aligned 12-byte load + a byte funnel shift, and the 64
-// pixels of a wave leave as 48 aligned dwords: each lane packs its 3 result bytes, lanes 0..47 collect the two packed pixels
-// their dword straddles through the LDS crossbar (ds_bpermute) and store once.  Needs 4-byte aligned output rows
-// (level images of the batched path have a padded row pitch) and wave-aligned 64-pixel segments.
+// 3 byte stores per pixel -- 9 vector-memory instructions per pixel made it texture-addresser bound (TA busy 75 %), and every
+// source row fetch exposed a full memory latency.  Here a wave first requests EVERY source row its RS output rows need (one
+// coalesced dword per lane and row: the 64 columns of a wave span < 256 source bytes for scales <= 1.25) and parks them in LDS;
+// after that single wait the strip runs on LDS + VALU only.  A lane picks its two neighbouring source pixels (6 bytes) from
+// three LDS dwords with a byte funnel shift; the 64 result pixels of a wave leave as 48 aligned dwords: each lane packs its 3
+// bytes, lanes 0..47 collect the two packed pixels their dword straddles through the LDS crossbar (ds_bpermute) and store once.
+// Needs 4-byte aligned output rows (level images of the batched path have a padded row pitch).
+#define RESIZE_MAXS 22
 template <int RS>
 __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
                                                      size_t in_stride, int in_rb, int ih, int iw, uint8_t* __restrict__ out,
                                                      size_t out_stride, int out_rb, int oh, int ow, double x_scale, double y_scale)
 {
+    constexpr int MAXS = RESIZE_MAXS;
+    __shared__ uint32_t s_rows[4][MAXS][64];
     const int lane = threadIdx.x & 63;
-    const int c0 = blockIdx.x * 256 + (threadIdx.x & ~63);    // first column of this wave's segment
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = blockIdx.x * 256 + wave * 64;               // first column of this wave's segment
     const int r0 = blockIdx.y * RS, b = blockIdx.z;
     if (c0 >= ow) return;                                      // wave-uniform
     const int c = min(c0 + lane, ow - 1);                      // lanes past the row end recompute the last column (never stored)
     const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
+    const uint8_t* in_end = in + (size_t)ih * in_rb;
     uint8_t* ob = out + (size_t)b * out_stride + (size_t)c0 * 3;
     const double x = c * x_scale;
     const int left = (int)floor(x);
+    const int left0 = __builtin_amdgcn_readfirstlane(left);    // lane 0 holds column c0: the smallest source column of the wave
     const bool has_right = (left + 1 <= iw - 1);
     const double lr = x - left, lr1 = 1 - lr;
-    const int ol = left * 3;
+    const int r_end = min(r0 + RS, oh);
+    const int s_first = (int)floor(r0 * y_scale);
+    const int s_last = min((int)floor((r_end - 1) * y_scale) + 1, ih - 1);
+    // stage the source rows: dword `lane` of the 256-byte window that starts at the aligned address below the wave's first pixel.
+    // Branch-free so that all loads are in flight together: a dword that lies wholly past the frame is redirected to the frame's
+    // last word (never used; an aligned dword cannot straddle a page, so the word holding the last byte is always readable).
+    {
+        typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
+        const uintptr_t last_word = ((uintptr_t)in_end - 1) & ~(uintptr_t)3;
+        const int nrows = s_last - s_first + 1;
+        uint32_t t[MAXS];
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) {
+            t[k] = 0;
+            if (k < nrows) {                                   // wave-uniform
+                const uintptr_t a = (uintptr_t)(in + (size_t)(s_first + k) * in_rb + 3 * left0);
+                uintptr_t q = (a & ~(uintptr_t)3) + 4 * lane;
+                q = q < last_word ? q : last_word;
+                t[k] = *(gptr_t)q;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) s_rows[wave][k][lane] = t[k];
+    }
     // output dword d of the segment (lane d < 48) straddles packed pixels a = 4d / 3 and a + 1, starting at byte 4d - 3a of pixel a
     const int pa_lane = (4 * lane) / 3, phase = 4 * lane - 3 * pa_lane;
     const int bp0 = 4 * min(pa_lane, 63), bp1 = 4 * min(pa_lane + 1, 63);
@@ -106,23 +137,11 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     int s0 = -1, s1 = -1;              // cached source rows
     double h0[3], h1[3];
     auto hblend = [&](int srow, double* hh) {
-        const uint8_t* a = in + (size_t)srow * in_rb + ol;
-        uint32_t lo, hi;
-        const unsigned sh = (unsigned)(uintptr_t)a & 3u;
-        const uint8_t* pa = a - sh;
-        if (srow == ih - 1 && pa + 12 > in + (size_t)ih * in_rb) {
-            // last pixels of the last source row: stay inside the frame (it may end on a page boundary)
-            uint32_t t[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) t[k] = (has_right || k < 3) ? a[k] : 0;
-            lo = t[0] | (t[1] << 8) | (t[2] << 16) | (t[3] << 24);
-            hi = t[4] | (t[5] << 8);
-        } else {
-            const uint32_t w0 = *reinterpret_cast<const uint32_t*>(pa), w1 = *reinterpret_cast<const uint32_t*>(pa + 4),
-                           w2 = *reinterpret_cast<const uint32_t*>(pa + 8);
-            lo = __builtin_amdgcn_alignbyte(w1, w0, sh);
-            hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-        }
+        const uint8_t* a0 = in + (size_t)srow * in_rb + 3 * left0;
+        const unsigned off = ((unsigned)(uintptr_t)a0 & 3u) + 3u * (unsigned)(left - left0);     // byte offset of this lane's pixel in the window
+        const uint32_t* w = &s_rows[wave][srow - s_first][off >> 2];
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+        const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, off & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, off & 3u);
         const double tl0 = (double)(lo & 0xffu), tl1 = (double)((lo >> 8) & 0xffu), tl2 = (double)((lo >> 16) & 0xffu);
         double tr0 = (double)(lo >> 24), tr1 = (double)(hi & 0xffu), tr2 = (double)((hi >> 8) & 0xffu);
         if (!has_right) { tr0 = tl0; tr1 = tl1; tr2 = tl2; }
@@ -130,7 +149,6 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
         hh[1] = lr1 * tl1 + lr * tr1;
         hh[2] = lr1 * tl2 + lr * tr2;
     };
-    const int r_end = min(r0 + RS, oh);
     for (int r = r0; r < r_end; ++r) {
         const double y = r * y_scale;
         const int top = (int)floor(y);
@@ -160,9 +178,9 @@ static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint
 {
     const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
     const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
-    PVF_REQUIRE(x_scale <= 2.0, "resize: more than 2x horizontal decimation is not used on this path");
-    PVF_REQUIRE(out_rb % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)out & 3) == 0 && out_rb >= (ow * 3 + 3) / 4 * 4, "resize: output rows must be 4-byte aligned");
     constexpr int RS = 16;
+    PVF_REQUIRE(x_scale <= 1.25 && (RS - 1) * y_scale + 3 <= RESIZE_MAXS, "resize_rows: scale outside the pyramid's range (2x up, 6/5 down)");
+    PVF_REQUIRE(out_rb % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)out & 3) == 0 && out_rb >= (ow * 3 + 3) / 4 * 4, "resize: output rows must be 4-byte aligned");
     dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
     hipLaunchKernelGGL((resize_rows_k<RS>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb,
                        oh, ow, x_scale, y_scale);
