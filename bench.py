@@ -69,7 +69,7 @@ def main():
     times = [t_off + video.timestamp(i) for i in range(args.frames)]
     shots = [(t_off + a, t_off + b) for a, b in video.shots()]
 
-    ctx = Context(device=local_rank, priority=1)   # tracker / extract stream: latency-bound, high priority
+    ctx = Context(device=local_rank)
     frames = [ctx.wrap_torch(frames_t[i]) for i in range(args.frames)]
     pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap)
 
@@ -82,7 +82,7 @@ def main():
         tm["cluster_s"] = time.perf_counter() - t0
         return res, labels, tm
 
-    ctxs = [ctx] + ([pipe.det_ctx] if pipe.det_ctx is not None else [])
+    ctxs = [ctx]
 
     def barrier():
         for c in ctxs:

@@ -72,6 +72,9 @@ int32_t pvf_detect_batch(pvf_handle ctx, const pvf_handle* frames, int32_t n_fra
 /* ---- S2 correlation tracker ------------------------------------------------------------------------ */
 /* ref: tracking.py:250  dlib.correlation_tracker() */
 int32_t pvf_tracker_create(pvf_handle ctx, pvf_handle* trk);
+/* n trackers at once / n trackers back to the pool: the batched host path creates and kills a few thousand per shot */
+int32_t pvf_tracker_create_many(pvf_handle ctx, int32_t n, pvf_handle* trks);
+int32_t pvf_tracker_destroy_many(pvf_handle ctx, const pvf_handle* trks, int32_t n);
 int32_t pvf_tracker_destroy(pvf_handle ctx, pvf_handle trk);
 /* ref: tracking.py:251  tracker.start_track(frame, dlib.drectangle(*detection)) ; box = (l,t,r,b) doubles */
 int32_t pvf_tracker_start(pvf_handle ctx, pvf_handle trk, pvf_handle frame, const double box[4]);

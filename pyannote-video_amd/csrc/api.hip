@@ -109,18 +109,46 @@ extern "C" int32_t pvf_debug_fhog(pvf_handle h, const uint8_t* img, int32_t ih, 
 }
 
 // ---- S2 -------------------------------------------------------------------------------------------
-extern "C" int32_t pvf_tracker_create(pvf_handle h, pvf_handle* trk)
+static pvf_handle tracker_new(Ctx* c)
 {
-    API_BEGIN
-    Ctx* c = enter(h);
     std::unique_ptr<Tracker> t(new Tracker());
     if (!c->tracker_pool.empty()) { t->d_state = c->tracker_pool.back(); c->tracker_pool.pop_back(); }
     else HIP_CHECK(hipMalloc((void**)&t->d_state, TRK_DOUBLES * sizeof(double)));
     const uint64_t id = c->next_id++;
     c->trackers[id] = std::move(t);
-    *trk = id;
+    return id;
+}
+
+extern "C" int32_t pvf_tracker_create(pvf_handle h, pvf_handle* trk)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    *trk = tracker_new(c);
     API_END
 }
+
+extern "C" int32_t pvf_tracker_create_many(pvf_handle h, int32_t n, pvf_handle* trks)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    PVF_REQUIRE(n >= 0, "negative count");
+    for (int i = 0; i < n; ++i) trks[i] = tracker_new(c);
+    API_END
+}
+
+extern "C" int32_t pvf_tracker_destroy_many(pvf_handle h, const pvf_handle* trks, int32_t n)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    for (int i = 0; i < n; ++i) {
+        auto it = c->trackers.find(trks[i]);
+        PVF_REQUIRE(it != c->trackers.end(), "unknown tracker handle");
+        c->tracker_pool.push_back(it->second->d_state);
+        c->trackers.erase(it);
+    }
+    API_END
+}
+
 extern "C" int32_t pvf_tracker_destroy(pvf_handle h, pvf_handle trk)
 {
     API_BEGIN

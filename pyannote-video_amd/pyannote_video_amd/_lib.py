@@ -40,6 +40,8 @@ _SIGS = {
     "pvf_detect_batch": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_double, P, P, P, C.c_int32]),
     "pvf_tracker_create": (C.c_int32, [H, P]),
     "pvf_tracker_destroy": (C.c_int32, [H, H]),
+    "pvf_tracker_create_many": (C.c_int32, [H, C.c_int32, P]),
+    "pvf_tracker_destroy_many": (C.c_int32, [H, P, C.c_int32]),
     "pvf_tracker_start": (C.c_int32, [H, H, H, P]),
     "pvf_tracker_update": (C.c_int32, [H, H, H, P]),
     "pvf_tracker_position": (C.c_int32, [H, H, P]),

@@ -9,6 +9,7 @@ with the inter-stage text formats applied in memory (3-decimal boxes + int() tru
 results equal what the file-based flow produces.  The video is staged once; the reference decodes it twice.
 """
 import time as _time
+import os
 import numpy as np
 from . import formats
 from .face_tracking import FaceTracking
@@ -64,18 +65,116 @@ def faces_per_frame(rows, frame_times, frame_width, frame_height, drop_last=True
     return out
 
 
+class ExtractStream(object):
+    """`extract` (pyannote-face.py:121-175, 425-466) fed shot by shot while later shots are still being detected.
+
+    The reference reads the finished track file and walks frames and timestamp groups in step (faces_per_frame above).  Shots
+    are disjoint in time and arrive in order, so the same walk can be resumed whenever a shot's tracks exist: groups are
+    appended to a queue, the frame pointer only moves while a group is available, and the newest group is held back until a
+    later one arrives because the reference's generator never yields the last group of the file.  The faces that become
+    available are aligned and embedded immediately."""
+
+    def __init__(self, ctx, frames, frame_times, frame_width, frame_height):
+        self.ctx, self.frames, self.times = ctx, frames, frame_times
+        self.w, self.h = frame_width, frame_height
+        self.tracks, self.rows = [], []
+        self.groups, self.gi, self.fi = [], 0, 0
+        self.face_boxes, self.face_T, self.face_id = [], [], []
+        self.pts, self.emb = [], []
+        self.emitted = []     # (frame index, T) of every group handed on, in order
+
+    def _emit(self, available):
+        """faces of the groups that may be handed on now: (frames, boxes)"""
+        face_frames, boxes = [], []
+        times = self.times
+        while self.fi < len(times) and self.gi < available:
+            T, g = self.groups[self.gi]
+            if T > times[self.fi]:
+                self.fi += 1
+                continue
+            for ident, box in g:
+                face_frames.append(self.frames[self.fi]); boxes.append(box)
+                self.face_T.append(T); self.face_id.append(ident)
+            self.emitted.append((self.fi, T))
+            self.gi += 1
+            self.fi += 1
+        self.face_boxes.extend(boxes)
+        return face_frames, boxes
+
+    def compute(self, work):
+        """GPU part: landmarks + embeddings of one batch of faces returned by prepare(); batches must arrive in order"""
+        face_frames, boxes = work
+        if boxes:
+            pts = self.ctx.landmarks(face_frames, boxes)
+            self.pts.append(pts)
+            self.emb.append(self.ctx.embed(face_frames, pts))
+
+    def prepare(self, tracks):
+        """host part for the normalised tracks of the next shot (in shot order): the track-file rows, their timestamp groups,
+        and the faces that can be extracted now"""
+        base = len(self.tracks)
+        rows = []
+        for k, track in enumerate(tracks):
+            for t, box, status in track:
+                rows.append((formats.quantise_time(t), base + k, tuple(np.float32("%.3f" % v) for v in box), status))
+        rows.sort(key=lambda r: r[0])
+        self.tracks.extend(tracks)
+        self.rows.extend(rows)
+        k, n = 0, len(rows)
+        while k < n:
+            T = rows[k][0]
+            g = []
+            while k < n and rows[k][0] == T:
+                _, ident, box, _ = rows[k]
+                g.append((ident, (int(box[0] * self.w), int(box[1] * self.h), int(box[2] * self.w), int(box[3] * self.h))))
+                k += 1
+            if self.groups and self.groups[-1][0] == T:
+                self.groups[-1][1].extend(g)      # cannot happen for disjoint shots; keeps the grouping rule exact anyway
+            else:
+                self.groups.append((T, g))
+        return self._emit(len(self.groups) - 1)
+
+    def feed(self, tracks):
+        self.compute(self.prepare(tracks))
+
+    def finish(self, drop_last=True):
+        self.compute(self._emit(len(self.groups) - (1 if drop_last else 0)))
+        self.rows.sort(key=lambda r: r[0])
+        pts = np.concatenate(self.pts) if self.pts else np.zeros((0, 68, 2), np.int32)
+        emb = np.concatenate(self.emb) if self.emb else np.zeros((0, 128), np.float32)
+        return pts, emb
+
+
+class _LaneBackend(object):
+    """what the lanes of the tracking thread see of the tracker context while the GPU thread owns it: on-demand updates
+    take the context lock, killed trackers are only queued (the GPU thread destroys them between its batches)"""
+
+    def __init__(self, backend, lock, dead):
+        self.backend, self.lock, self.dead = backend, lock, dead
+
+    def update_many(self, handles, frames):
+        with self.lock:
+            return self.backend.update_many(handles, frames)
+
+    def start_many(self, frames, boxes):
+        with self.lock:
+            return self.backend.start_many(frames, boxes)
+
+    def release(self, handle):
+        self.dead.append(handle)
+
+
 class FacePipeline(object):
     def __init__(self, ctx, landmarks, embedding, detect_min_size=0.0, detect_every=0.0,
                  track_min_overlap_ratio=CLI_MIN_OVERLAP_RATIO, track_min_confidence=CLI_MIN_CONFIDENCE,
                  track_max_gap=CLI_MAX_GAP, threshold=0.6, detect_batch_size=8, overlap=True):
         self.ctx = ctx
-        # The detector is throughput-bound (big kernels), the trackers are latency-bound (many tiny dependent launches):
-        # a second context (own HIP stream + scratch) lets a host thread run detection ahead, shot by shot, while the
-        # main thread tracks the previous shot.  Both streams share the GPU; results are identical to the serial order.
-        self.det_ctx = None
-        if overlap:
-            from .runtime import Context
-            self.det_ctx = Context(device=ctx.device, priority=-1)
+        # overlap=True: ONE host thread feeds the GPU with large batches in a fixed order -- detect shot k, bulk tracker work of
+        # shot k, align + embed the faces of shot k-1 -- while the caller's thread runs the host state machine (association,
+        # graph, merging) of shot k one step behind.  Every kernel runs uncontended on one stream; the Python work hides
+        # behind the GPU work.  (Several streams with a detector thread running ahead were measured slower: the small
+        # tracker batches they need fill the GPU badly and the threads fight over the interpreter lock.)
+        self.overlap = overlap
         self.detect_batch_size = detect_batch_size
         ctx.load_shape_predictor(landmarks)
         ctx.load_embedder(embedding)
@@ -86,60 +185,111 @@ class FacePipeline(object):
         self.clustering = FaceClustering(threshold=threshold, ctx=ctx)
         self.detect_every = detect_every
 
-    def _track_overlapped(self, shot_inputs, backend):
-        """detector thread (second context) runs ahead shot by shot; the caller's thread tracks shot k as soon as its
-        detections exist.  ctypes releases the GIL inside every library call."""
+    def _run_pipelined(self, shot_inputs, backend, ex, normalize, mark):
+        """GPU thread: detect(k), speculate(k), extract(k-1) ...; this thread: lanes + merging of shot k as soon as its detections
+        and bulk tracker results exist.  ctypes releases the GIL inside every library call."""
         import threading
-        dctx = self.det_ctx
+        import queue
         n = len(shot_inputs)
-        dets = [None] * n
-        ready = [threading.Event() for _ in range(n)]
-        err = []
+        ready, done = queue.Queue(), queue.Queue()
+        lock = threading.Lock()
+        dead = []
         bs = max(1, int(self.detect_batch_size))
+        ctx = self.ctx
+        trace = [(_time.perf_counter(), "begin")] if os.environ.get("PVF_TRACE") else None
 
-        def worker():
+        def note(*ev):
+            if trace is not None:
+                trace.append((_time.perf_counter(),) + ev)
+
+        def release_dead():
+            batch = []
+            while dead:
+                batch.append(dead.pop())
+            if batch:
+                backend.release_many(batch)
+
+        def gpu_thread():
+            extracted = 0
             try:
                 for k, (cache, flags) in enumerate(shot_inputs):
-                    out = [[] for _ in cache]
+                    dets = [[] for _ in cache]
                     idx = [i for i, f in enumerate(flags) if f]
-                    shared = {i: dctx.share(cache[i][1]) if hasattr(cache[i][1], "handle") else cache[i][1] for i in idx}
                     for o in range(0, len(idx), bs):
                         chunk = idx[o:o + bs]
-                        res = dctx.detect_batch([shared[i] for i in chunk], 1)
+                        with lock:
+                            res = ctx.detect_batch([cache[i][1] for i in chunk], 1)
                         for i, (boxes, _) in zip(chunk, res):
-                            out[i] = [tuple(b) for b in boxes]
-                    dets[k] = out
-                    ready[k].set()
-            except BaseException as e:   # surface in the caller's thread
-                err.append(e)
-                for ev in ready:
-                    ev.set()
+                            dets[i] = [tuple(b) for b in boxes]
+                    note("detected", k)
+                    # faces of the shots the tracking thread has finished meanwhile (it is idle now, so the host side of these
+                    # calls does not fight its state machine for the interpreter)
+                    while extracted < n:
+                        try:
+                            work = done.get_nowait()
+                        except queue.Empty:
+                            break
+                        with lock:
+                            ex.compute(work)
+                        extracted += 1
+                        note("extracted", extracted - 1)
+                    det_at = {t: d for (t, _), d in zip(cache, dets)}
+                    with lock:
+                        release_dead()
+                        plan_f = backend.speculate(cache, det_at)
+                        plan_b = backend.speculate(list(reversed(cache)), det_at)
+                    note("speculated", k)
+                    ready.put((k, dets, (plan_f, plan_b)))
+                while extracted < n:
+                    work = done.get()
+                    if work is None:
+                        return
+                    with lock:
+                        ex.compute(work)
+                    extracted += 1
+                    note("extracted", extracted - 1)
+                with lock:
+                    release_dead()
+            except BaseException as e:
+                ready.put(e)
 
-        th = threading.Thread(target=worker, name="pvface-detector")
+        import sys
+        old_interval = sys.getswitchinterval()
+        # the GPU thread re-takes the interpreter lock after every library call; with the default 5 ms switch interval each of
+        # those hand-overs can stall the GPU queue for milliseconds while this thread runs the tracking state machine
+        sys.setswitchinterval(1e-4)
+        th = threading.Thread(target=gpu_thread, name="pvface-gpu")
         th.start()
-        from .tracking_by_detection import LaneScheduler
-        sched = LaneScheduler(backend)
-        jobs = [None] * n
-        nxt = 0
+        lane_backend = _LaneBackend(backend, lock, dead)
+        ok = False
         try:
-            while nxt < n or len(sched):
-                # admit every shot whose detections exist; block only when there is nothing to track
-                while nxt < n and (ready[nxt].is_set() or len(sched) == 0):
-                    ready[nxt].wait()
-                    if err:
-                        raise err[0]
-                    cache, flags = shot_inputs[nxt]
-                    jobs[nxt] = self.tracking.begin_shot(cache, flags, dets[nxt], backend)
-                    for lane in jobs[nxt]["lanes"]:
-                        sched.add(lane)
-                    nxt += 1
-                if len(sched):
-                    sched.round()
+            for k, (cache, flags) in enumerate(shot_inputs):
+                item = ready.get()
+                if isinstance(item, BaseException):
+                    raise item
+                _, dets, plans = item
+                job = self.tracking.begin_shot(cache, flags, dets, lane_backend, plans)
+                self.tracking._run_lanes(job["lanes"], lane_backend)
+                tracks = self.tracking.finish_shot(job)
+                note("tracked", k)
+                if k == n - 1:
+                    mark["tracked"] = _time.perf_counter()
+                done.put(ex.prepare(normalize(tracks)))
+            ok = True
         finally:
+            if not ok:
+                done.put(None)
             th.join()
-        if err:
-            raise err[0]
-        return [self.tracking.finish_shot(j) for j in jobs]
+            sys.setswitchinterval(old_interval)
+        if not ready.empty():
+            item = ready.get()
+            if isinstance(item, BaseException):
+                raise item
+        if trace is not None:
+            import json
+            note("finish")
+            with open(os.environ["PVF_TRACE"], "w") as f:
+                json.dump(trace, f)
 
     def run(self, frames, times, frame_rate, shots, timings=None, cluster=True, last_shard=True):
         """frames: list of DeviceFrame (or numpy arrays), one size; times: their timestamps; shots: [(start, end)].
@@ -156,27 +306,25 @@ class FacePipeline(object):
             flags = [(i % every == 0) for i in range(i0, i1)]
             shot_inputs.append((cache, flags))
         backend = HipTrackers(self.ctx)
-        if self.det_ctx is None:
-            per_shot = self.tracking.process_shots(shot_inputs, backend)
+        ex = ExtractStream(self.ctx, frames, times, w, h)
+        mark = {}
+
+        def normalize(shot_tracks):
+            return [self.tracking._normalize_track(tr, w, h) for tr in shot_tracks]
+
+        if not self.overlap:
+            for k, shot_tracks in enumerate(self.tracking.process_shots(shot_inputs, backend)):
+                if k == len(shot_inputs) - 1:
+                    mark["tracked"] = _time.perf_counter()
+                ex.feed(normalize(shot_tracks))
         else:
-            per_shot = self._track_overlapped(shot_inputs, backend)
-        tracks = [self.tracking._normalize_track(tr, w, h) for shot in per_shot for tr in shot]
-        tm["track_s"] = _time.perf_counter() - t0
-        t1 = _time.perf_counter()
-        # track.txt in memory, then extract's view of it
-        rows = []
-        for identifier, track in enumerate(tracks):
-            for t, box, status in track:
-                rows.append((formats.quantise_time(t), identifier, tuple(np.float32("%.3f" % v) for v in box), status))
-        rows.sort(key=lambda r: r[0])
-        per_frame = faces_per_frame(rows, times, w, h, drop_last=last_shard)
-        face_frames, face_boxes, face_T, face_id = [], [], [], []
-        for fi, T, g in per_frame:
-            for ident, box in g:
-                face_frames.append(frames[fi]); face_boxes.append(box); face_T.append(T); face_id.append(ident)
-        pts = self.ctx.landmarks(face_frames, face_boxes)
-        emb = self.ctx.embed(face_frames, pts)
-        tm["extract_s"] = _time.perf_counter() - t1
+            self._run_pipelined(shot_inputs, backend, ex, normalize, mark)
+        pts, emb = ex.finish(drop_last=last_shard)
+        tracks, rows = ex.tracks, ex.rows
+        face_boxes, face_T, face_id = ex.face_boxes, ex.face_T, ex.face_id
+        t1 = mark.get("tracked", _time.perf_counter())
+        tm["track_s"] = t1 - t0                                  # until the last shot's tracks exist (earlier shots already extracted)
+        tm["extract_s"] = _time.perf_counter() - t1              # what is left of extraction after that
         t2 = _time.perf_counter()
         face_T = np.asarray(face_T, np.float64)
         face_id = np.asarray(face_id, np.int64)

@@ -195,6 +195,17 @@ class Context(object):
         check(self._l.pvf_tracker_create(self._h, C.byref(h)))
         return h.value
 
+    def tracker_create_many(self, n):
+        self.ensure_tracker_tables()
+        out = np.zeros(int(n), np.uint64)
+        if n:
+            check(self._l.pvf_tracker_create_many(self._h, int(n), ptr(out)))
+        return [int(v) for v in out]
+
+    def tracker_destroy_many(self, trks):
+        if self._h is not None and len(trks):
+            check(self._l.pvf_tracker_destroy_many(self._h, ptr(handles(trks)), len(trks)))
+
     def tracker_destroy(self, trk):
         if self._h is not None:
             check(self._l.pvf_tracker_destroy(self._h, trk))

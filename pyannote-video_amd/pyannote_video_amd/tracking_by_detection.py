@@ -55,7 +55,7 @@ class HipTrackers(object):
         self.ctx = ctx
 
     def start_many(self, frames, boxes):
-        hs = [self.ctx.tracker_create() for _ in boxes]
+        hs = self.ctx.tracker_create_many(len(boxes))
         self.ctx.tracker_start_many(hs, frames, boxes)
         return hs
 
@@ -64,6 +64,9 @@ class HipTrackers(object):
 
     def release(self, handle):
         self.ctx.tracker_destroy(handle)
+
+    def release_many(self, handles):
+        self.ctx.tracker_destroy_many(handles)
 
     def speculate(self, cache, detections_at, chunk=1024):
         """Issue EVERY start_track of a lane and the first update of every started tracker as large batches.
@@ -230,13 +233,15 @@ class TrackingByDetection(object):
         return match
 
     # ---- one pass over one shot, written as a coroutine that asks for batched tracker work -------------------
-    def _lane(self, cache, detections_at, direction, edges, backend=None):
+    def _lane(self, cache, detections_at, direction, edges, backend=None, plan=None):
         """cache: [(t, frame)] in processing order; detections_at: {t: [box]}; edges: list receiving
         (u, v, confidence) in the order the reference calls add_edge (tracking.py:214-259).
         A coroutine: it yields ('update', handles, frames) / ('start', frames, boxes) and receives the results, so that a
-        scheduler can batch the requests of many lanes.  With a speculating backend (HipTrackers.speculate) the starts and
-        first updates were already issued in bulk and only trackers that survive an association need on-demand updates."""
-        plan = backend.speculate(cache, detections_at) if (backend is not None and hasattr(backend, 'speculate')) else None
+        scheduler can batch the requests of many lanes.  With a speculating backend (HipTrackers.speculate), or a `plan` that
+        was computed ahead by another thread, the starts and first updates were already issued in bulk and only trackers that
+        survive an association need on-demand updates."""
+        if plan is None and backend is not None and hasattr(backend, 'speculate'):
+            plan = backend.speculate(cache, detections_at)
         release = backend.release if backend is not None else None
         trackers = {}      # identifier -> backend handle  (dict order == creation order, like the reference's dict)
         position = {}      # identifier -> (l,t,r,b) doubles after the last update
@@ -380,8 +385,9 @@ class TrackingByDetection(object):
                 out[i] = [tuple(d) for d in self.detect_func(cache[i][1])]
         return out
 
-    def begin_shot(self, cache, flags, dets=None, backend=None):
-        """graph with the detections of one shot + its two lane coroutines (not started)"""
+    def begin_shot(self, cache, flags, dets=None, backend=None, plans=None):
+        """graph with the detections of one shot + its two lane coroutines (not started); plans = (forward, backward) results of
+        HipTrackers.speculate computed ahead (backward: on the reversed cache)"""
         if dets is None:
             dets = self._detect_shot(cache, flags)
         g = nx.DiGraph()
@@ -392,7 +398,8 @@ class TrackingByDetection(object):
                 g.add_edge(t, (t, box, DETECTION))
             det_at[t] = d
         ef, eb = [], []
-        lanes = [self._lane(cache, det_at, FORWARD, ef, backend), self._lane(list(reversed(cache)), det_at, BACKWARD, eb, backend)]
+        pf, pb = plans if plans is not None else (None, None)
+        lanes = [self._lane(cache, det_at, FORWARD, ef, backend, pf), self._lane(list(reversed(cache)), det_at, BACKWARD, eb, backend, pb)]
         return {"graph": g, "ef": ef, "eb": eb, "lanes": lanes}
 
     def finish_shot(self, job):

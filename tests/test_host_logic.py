@@ -173,3 +173,51 @@ def test_text_quantisation_helpers():
     line = list(formats.track_lines(3, [(1.23456, box, 'detection')]))[0]
     assert line == '1.235 3 0.123 0.500 0.988 0.750 detection\n'
     assert formats.quantise_track_box(box, 1920, 1080) == (int(np.float32('0.123') * 1920), 540, int(np.float32('0.988') * 1920), 810)
+
+
+class _FakeExtractCtx(object):
+    def landmarks(self, frames, boxes):
+        return np.array([[[b[0] + f, b[1] + f]] * 68 for f, b in zip(frames, boxes)], np.int32).reshape(-1, 68, 2)
+
+    def embed(self, frames, pts):
+        return np.array([[float(f) + p[0, 0] * 1e-3] * 128 for f, p in zip(frames, pts)], np.float32).reshape(-1, 128)
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("drop_last", [True, False])
+def test_extract_stream_equals_whole_file_walk(seed, drop_last):
+    """shot-by-shot extraction == the reference's walk over the finished track file (including its lagging frame pointer and
+    the group it never yields)"""
+    from pyannote_video_amd import pipeline, formats
+    rng = np.random.default_rng(seed)
+    fps = 25.0
+    n_frames = 90
+    # frame times that do not always survive the 3-decimal quantisation (so that groups can lag behind frames)
+    times = [i / fps + (1e-4 if i % 7 == 3 else 0.0) for i in range(n_frames)]
+    shots = [(0, 30), (30, 52), (52, 90)]
+    per_shot = []
+    for a, b in shots:
+        tracks = []
+        for _ in range(int(rng.integers(0, 4))):
+            i0 = int(rng.integers(a, b - 2)); i1 = int(rng.integers(i0 + 1, b))
+            box = rng.uniform(0.1, 0.6, 2)
+            tracks.append([(times[i], (box[0], box[1], box[0] + 0.2, box[1] + 0.3), "detection") for i in range(i0, i1)])
+        per_shot.append(tracks)
+    W, H = 640, 360
+    frames = list(range(n_frames))
+    ex = pipeline.ExtractStream(_FakeExtractCtx(), frames, times, W, H)
+    for tracks in per_shot:
+        ex.feed(tracks)
+    pts, emb = ex.finish(drop_last=drop_last)
+    # whole-file form
+    rows = []
+    for identifier, track in enumerate(t for tracks in per_shot for t in tracks):
+        for t, box, status in track:
+            rows.append((formats.quantise_time(t), identifier, tuple(np.float32("%.3f" % v) for v in box), status))
+    rows.sort(key=lambda r: r[0])
+    ref = pipeline.faces_per_frame(rows, times, W, H, drop_last=drop_last)
+    assert ex.emitted == [(fi, T) for fi, T, _ in ref]
+    assert ex.face_id == [ident for _, _, g in ref for ident, _ in g]
+    assert ex.face_boxes == [box for _, _, g in ref for _, box in g]
+    assert ex.rows == rows
+    assert len(emb) == len(ex.face_id) == len(pts)
