@@ -146,7 +146,7 @@ def main():
     score_ms = fam["score"]["ms"]
     launches = max(fam["score"]["launches"], 1)
     achieved = (flop_per_frame * n_score_frames / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
-    roofline = {"kernel": "score_k (HOG filter scoring, 5 filters x 3100 MAC per position)", "bound": "mfma",
+    roofline = {"kernel": "score_mfma_rows_ml_k<4> (HOG filter scoring of every pyramid level of a 32-frame batch, 5 filters x 3100 MAC per position)", "bound": "mfma",
                 "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_ms": round(score_ms / launches, 4),
@@ -159,7 +159,7 @@ def main():
         if pm["detect_batch"] == args.detect_batch and pm["frame"] == "%dx%d" % (args.width, args.height):
             roofline["traffic"] = pm["traffic_bytes_per_launch"]
             roofline["traffic_source"] = pm["source"]
-            roofline["algorithmic_bytes_per_launch"] = sum(g[2] * g[3] for g in geo) * 128.0 * args.detect_batch / max(len(geo), 1)
+            roofline["algorithmic_bytes_per_launch"] = sum(g[2] * g[3] for g in geo) * 128.0 * args.detect_batch   # features read once
     except Exception:
         pass
 
