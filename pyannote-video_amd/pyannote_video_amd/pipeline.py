@@ -222,17 +222,22 @@ class FacePipeline(object):
                         for i, (boxes, _) in zip(chunk, res):
                             dets[i] = [tuple(b) for b in boxes]
                     note("detected", k)
+
+                    def drain():
+                        nonlocal extracted
+                        while extracted < n:
+                            try:
+                                work = done.get_nowait()
+                            except queue.Empty:
+                                break
+                            with lock:
+                                ex.compute(work)
+                            extracted += 1
+                            note("extracted", extracted - 1)
+
                     # faces of the shots the tracking thread has finished meanwhile (it is idle now, so the host side of these
-                    # calls does not fight its state machine for the interpreter)
-                    while extracted < n:
-                        try:
-                            work = done.get_nowait()
-                        except queue.Empty:
-                            break
-                        with lock:
-                            ex.compute(work)
-                        extracted += 1
-                        note("extracted", extracted - 1)
+                    # calls does not compete with its state machine for the interpreter; measured better than after speculate)
+                    drain()
                     det_at = {t: d for (t, _), d in zip(cache, dets)}
                     with lock:
                         release_dead()
