@@ -68,6 +68,10 @@ int32_t pvf_detect(pvf_handle ctx, pvf_handle frame, int32_t upsample, double ad
 int32_t pvf_detect_batch(pvf_handle ctx, const pvf_handle* frames, int32_t n_frames, int32_t upsample,
                          double adjust_threshold, pvf_rect_i32* out, float* scores, int32_t* counts,
                          int32_t cap_per_frame);
+/* many frames of one size, processed `batch` at a time with the host post-processing of a batch hidden behind the kernels of
+ * the next one; results identical to pvf_detect_batch on each batch (what the pipeline calls once per shot) */
+int32_t pvf_detect_many(pvf_handle ctx, const pvf_handle* frames, int32_t n_frames, int32_t batch, int32_t upsample,
+                        double adjust_threshold, pvf_rect_i32* out, float* scores, int32_t* counts, int32_t cap);
 
 /* ---- S2 correlation tracker ------------------------------------------------------------------------ */
 /* ref: tracking.py:250  dlib.correlation_tracker() */

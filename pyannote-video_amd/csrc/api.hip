@@ -41,6 +41,30 @@ extern "C" int32_t pvf_detect_batch(pvf_handle h, const pvf_handle* frames, int3
     API_END
 }
 
+extern "C" int32_t pvf_detect_many(pvf_handle h, const pvf_handle* frames, int32_t n_frames, int32_t batch, int32_t upsample, double adjust,
+                                   pvf_rect_i32* out, float* scores, int32_t* counts, int32_t cap)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    PVF_REQUIRE(n_frames > 0 && batch > 0 && frames && out && counts && cap > 0, "pvf_detect_many: bad arguments");
+    PVF_REQUIRE(upsample >= 0 && upsample <= 2, "pvf_detect_many: upsample must be 0..2");
+    std::vector<Frame> fr(n_frames);
+    for (int i = 0; i < n_frames; ++i) fr[i] = c->frame(frames[i]);
+    std::vector<std::vector<RawDet>> raw;
+    det_run_many(c, fr, batch, upsample, adjust, raw);
+    std::vector<RawDet> kept;
+    for (int i = 0; i < n_frames; ++i) {
+        det_nms(c->det, raw[i], kept);
+        const int n = std::min<int>((int)kept.size(), cap);
+        counts[i] = n;
+        for (int k = 0; k < n; ++k) {
+            out[(size_t)i * cap + k] = pvf_rect_i32{kept[k].l, kept[k].t, kept[k].rr, kept[k].b};
+            if (scores) scores[(size_t)i * cap + k] = kept[k].score;
+        }
+    }
+    API_END
+}
+
 extern "C" int32_t pvf_detect(pvf_handle h, pvf_handle frame, int32_t upsample, double adjust, pvf_rect_i32* out, float* scores,
                               int32_t cap, int32_t* n)
 {

@@ -281,6 +281,7 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
     for (auto& kv : c->frames) if (kv.second.owned) (void)hipFree((void*)kv.second.d);
     for (auto& kv : c->trackers) if (kv.second->d_state) (void)hipFree(kv.second->d_state);
     for (auto p : c->tracker_pool) (void)hipFree(p);
+    for (int k = 0; k < 2; ++k) if (c->det_ev[k]) (void)hipEventDestroy(c->det_ev[k]);
     if (c->d_orient_lut) (void)hipFree(c->d_orient_lut);
     if (c->d_grad_lut) (void)hipFree(c->d_grad_lut);
     (void)hipStreamDestroy(c->stream);

@@ -865,14 +865,18 @@ static std::vector<LevelDims> level_schedule(int h, int w, int upsample, const D
     return out;
 }
 
+// table of frame pointers for the kernels of one batch.  Two tables alternate (det_slot): the pinned host copy of a batch must
+// survive until its asynchronous upload has run, and det_run_many has the next batch in flight before it collects this one.
 static void upload_frame_ptrs(Ctx* c, const std::vector<Frame>& frames, const uint8_t*** d_ptrs)
 {
-    c->s_misc.ensure(frames.size() * sizeof(void*));
-    c->h_misc.ensure(frames.size() * sizeof(void*));
-    const uint8_t** hp = c->h_misc.as<const uint8_t*>();
+    DevBuf& d = c->s_fptr[c->det_slot & 1];
+    HostBuf& h = c->h_fptr[c->det_slot & 1];
+    d.ensure(frames.size() * sizeof(void*));
+    h.ensure(frames.size() * sizeof(void*));
+    const uint8_t** hp = h.as<const uint8_t*>();
     for (size_t i = 0; i < frames.size(); ++i) hp[i] = frames[i].d;
-    HIP_CHECK(hipMemcpyAsync(c->s_misc.p, hp, frames.size() * sizeof(void*), hipMemcpyHostToDevice, c->stream));
-    *d_ptrs = c->s_misc.as<const uint8_t*>();
+    HIP_CHECK(hipMemcpyAsync(d.p, hp, frames.size() * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+    *d_ptrs = d.as<const uint8_t*>();
 }
 
 // builds level `want_level` (or all levels when want_level < 0, calling per_level after each one); images ping-pong in s_pyr
@@ -1573,6 +1577,8 @@ static bool raw_less(const RawDet& x, const RawDet& y)
     return x.c < y.c;
 }
 
+static void decode_candidates(const DetectorModel& m, int upsample, const CandRec* q, int n, std::vector<RawDet>& v);
+
 void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, double adjust, std::vector<std::vector<RawDet>>& raw_sorted)
 {
     const DetectorModel& m = c->det;
@@ -1644,7 +1650,6 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     raw_sorted.assign(B, {});
-    const int bw = m.fcols - 2 * m.padding, bh = m.frows - 2 * m.padding;
     for (int b = 0; b < B; ++b) {
         const int n = h_counts[b];
         if (n > cap) throw PvfError("detector: candidate buffer overflow (threshold far too low for this input)");
@@ -1653,22 +1658,101 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
                                  c->stream));
     }
     HIP_CHECK(hipStreamSynchronize(c->stream));
-    for (int b = 0; b < B; ++b) {
-        const int n = h_counts[b];
-        auto& v = raw_sorted[b];
-        v.resize(n);
-        for (int i = 0; i < n; ++i) {
-            const CandRec& q = h_cands[(size_t)b * cap + i];
-            long rect[4];
-            const long cl = q.c - bw / 2, ct = q.r - bh / 2;
-            fhog_to_image(cl, ct, m.cell, m.frows, m.fcols, &rect[0], &rect[1]);
-            fhog_to_image(cl + bw - 1, ct + bh - 1, m.cell, m.frows, m.fcols, &rect[2], &rect[3]);
-            for (int k = 0; k < q.level; ++k) rect_up6(rect);
-            for (int u = 0; u < upsample; ++u) rect_down2i(rect);
-            v[i] = RawDet{q.score, q.filter, q.level, q.r, q.c, (int32_t)rect[0], (int32_t)rect[1], (int32_t)rect[2], (int32_t)rect[3]};
-        }
-        std::sort(v.begin(), v.end(), raw_less);
+    for (int b = 0; b < B; ++b) decode_candidates(m, upsample, h_cands + (size_t)b * cap, h_counts[b], raw_sorted[b]);
+}
+
+// ---- many batches with the host work of batch j hidden behind the kernels of batch j + 1 ------------------------------------
+// Per batch the host has to wait for the candidate counts, copy the candidates, map them to image rectangles and sort them;
+// done batch by batch that leaves the GPU idle for ~1 ms out of every ~13.  Here the kernels of the next batch are queued
+// before the results of the current one are collected.  Scratch (pyramid, planes, features) is shared: stream order keeps
+// batch j + 1 from touching it before batch j is done; only the candidate buffers and the frame-pointer tables alternate.
+static const int DET_PREFETCH = 512;      // candidates per frame copied back unconditionally (more are fetched on demand)
+
+static void decode_candidates(const DetectorModel& m, int upsample, const CandRec* q, int n, std::vector<RawDet>& v)
+{
+    const int bw = m.fcols - 2 * m.padding, bh = m.frows - 2 * m.padding;
+    v.resize(n);
+    for (int i = 0; i < n; ++i) {
+        long rect[4];
+        const long cl = q[i].c - bw / 2, ct = q[i].r - bh / 2;
+        fhog_to_image(cl, ct, m.cell, m.frows, m.fcols, &rect[0], &rect[1]);
+        fhog_to_image(cl + bw - 1, ct + bh - 1, m.cell, m.frows, m.fcols, &rect[2], &rect[3]);
+        for (int k = 0; k < q[i].level; ++k) rect_up6(rect);
+        for (int u = 0; u < upsample; ++u) rect_down2i(rect);
+        v[i] = RawDet{q[i].score, q[i].filter, q[i].level, q[i].r, q[i].c, (int32_t)rect[0], (int32_t)rect[1], (int32_t)rect[2], (int32_t)rect[3]};
     }
+    std::sort(v.begin(), v.end(), raw_less);
+}
+
+void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsample, double adjust,
+                  std::vector<std::vector<RawDet>>& raw_sorted)
+{
+    const DetectorModel& m = c->det;
+    PVF_REQUIRE(m.loaded, "detector not loaded");
+    PVF_REQUIRE(!frames.empty() && batch > 0, "no frames");
+    const int N = (int)frames.size();
+    raw_sorted.assign(N, {});
+    static const bool per_level = getenv("PVF_PER_LEVEL") != nullptr;
+    if (!(m.n_filters == 5 && m.d_bmfma && !per_level) || N <= batch) {
+        for (int o = 0; o < N; o += batch) {                   // plain batch-by-batch form
+            std::vector<Frame> fr(frames.begin() + o, frames.begin() + std::min(N, o + batch));
+            std::vector<std::vector<RawDet>> part;
+            det_run_batch(c, fr, upsample, adjust, part);
+            for (size_t i = 0; i < part.size(); ++i) raw_sorted[o + i] = std::move(part[i]);
+        }
+        return;
+    }
+    const int cap = 8192, PF = DET_PREFETCH;
+    ScoreParams sp;
+    for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
+    sp.n_filters = m.n_filters; sp.cap = cap;
+    const size_t cnt_bytes = (((size_t)batch * sizeof(int) + 63) / 64) * 64;
+    for (int k = 0; k < 2; ++k) {
+        c->s_cand2[k].ensure(cnt_bytes + (size_t)batch * cap * sizeof(CandRec));
+        c->h_cand2[k].ensure(cnt_bytes + (size_t)batch * PF * sizeof(CandRec));
+        if (!c->det_ev[k]) HIP_CHECK(hipEventCreateWithFlags(&c->det_ev[k], hipEventDisableTiming));
+    }
+    auto submit = [&](int o, int slot) {
+        std::vector<Frame> fr(frames.begin() + o, frames.begin() + std::min(N, o + batch));
+        const int B = (int)fr.size();
+        int* d_counts = c->s_cand2[slot].as<int>();
+        CandRec* d_cands = reinterpret_cast<CandRec*>(c->s_cand2[slot].as<uint8_t>() + cnt_bytes);
+        HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), c->stream));
+        c->det_slot = slot;
+        det_run_batch_ml(c, fr, upsample, sp, d_counts, d_cands);
+        HIP_CHECK(hipGetLastError());
+        uint8_t* hb = c->h_cand2[slot].as<uint8_t>();
+        HIP_CHECK(hipMemcpyAsync(hb, d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpy2DAsync(hb + cnt_bytes, (size_t)PF * sizeof(CandRec), d_cands, (size_t)cap * sizeof(CandRec),
+                                   (size_t)PF * sizeof(CandRec), (size_t)B, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipEventRecord(c->det_ev[slot], c->stream));
+    };
+    auto collect = [&](int o, int slot) {
+        const int B = std::min(N, o + batch) - o;
+        HIP_CHECK(hipEventSynchronize(c->det_ev[slot]));
+        const uint8_t* hb = c->h_cand2[slot].as<uint8_t>();
+        const int* h_counts = reinterpret_cast<const int*>(hb);
+        const CandRec* h_cands = reinterpret_cast<const CandRec*>(hb + cnt_bytes);
+        const CandRec* d_cands = reinterpret_cast<const CandRec*>(c->s_cand2[slot].as<uint8_t>() + cnt_bytes);
+        std::vector<CandRec> big;
+        for (int b = 0; b < B; ++b) {
+            const int n = h_counts[b];
+            if (n > cap) throw PvfError("detector: candidate buffer overflow (threshold far too low for this input)");
+            if (n <= PF) { decode_candidates(m, upsample, h_cands + (size_t)b * PF, n, raw_sorted[o + b]); continue; }
+            big.resize(n);                                      // rare: more candidates than were copied back ahead
+            HIP_CHECK(hipMemcpyAsync(big.data(), d_cands + (size_t)b * cap, (size_t)n * sizeof(CandRec), hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            decode_candidates(m, upsample, big.data(), n, raw_sorted[o + b]);
+        }
+    };
+    submit(0, 0);
+    int slot = 0;
+    for (int o = 0; o < N; o += batch) {
+        if (o + batch < N) submit(o + batch, slot ^ 1);
+        collect(o, slot);
+        slot ^= 1;
+    }
+    c->det_slot = 0;
 }
 
 static bool boxes_overlap(const RawDet& a, const RawDet& b, double iou, double covered)

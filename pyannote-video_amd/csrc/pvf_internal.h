@@ -183,6 +183,11 @@ struct Ctx {
     // scratch (grow only)
     DevBuf s_grad, s_pyr, s_hist, s_norm, s_feat, s_cand, s_misc, s_chip, s_chip_pyr, s_act0, s_act1, s_act2, s_trk0, s_trk1, s_trk2, s_clu0, s_clu1;
     HostBuf h_cand, h_misc;
+    // det_run_many: alternating candidate buffers / frame-pointer tables / completion events of the two batches in flight
+    DevBuf s_cand2[2], s_fptr[2];
+    HostBuf h_cand2[2], h_fptr[2];
+    hipEvent_t det_ev[2] = {nullptr, nullptr};
+    int det_slot = 0;
     int n_cu = 256;
     uint8_t* d_orient_lut = nullptr; // 511x511 orientation bins (detect.hip)
     void* d_grad_lut = nullptr;          // orientation bins in 8 x 8 tiles (64^3 bytes): orientation_lut_tiled()
@@ -215,6 +220,8 @@ void pvf_set_error(const char* msg);
 struct RawDet { float score; int32_t filter, level, r, c, l, t, rr, b; };
 void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, double adjust,
                    std::vector<std::vector<RawDet>>& raw_sorted);
+void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsample, double adjust,
+                  std::vector<std::vector<RawDet>>& raw_sorted);
 void det_nms(const DetectorModel& m, const std::vector<RawDet>& sorted, std::vector<RawDet>& out);
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* h, int* w);
 void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::vector<float>* out, int* fh, int* fw);

@@ -38,6 +38,7 @@ _SIGS = {
     "pvf_frame_device_ptr": (C.c_int32, [H, H, P]),
     "pvf_detect": (C.c_int32, [H, H, C.c_int32, C.c_double, P, P, C.c_int32, P]),
     "pvf_detect_batch": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_double, P, P, P, C.c_int32]),
+    "pvf_detect_many": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int32, C.c_double, P, P, P, C.c_int32]),
     "pvf_tracker_create": (C.c_int32, [H, P]),
     "pvf_tracker_destroy": (C.c_int32, [H, H]),
     "pvf_tracker_create_many": (C.c_int32, [H, C.c_int32, P]),

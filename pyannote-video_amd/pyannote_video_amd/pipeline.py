@@ -215,11 +215,10 @@ class FacePipeline(object):
                 for k, (cache, flags) in enumerate(shot_inputs):
                     dets = [[] for _ in cache]
                     idx = [i for i, f in enumerate(flags) if f]
-                    for o in range(0, len(idx), bs):
-                        chunk = idx[o:o + bs]
+                    if idx:
                         with lock:
-                            res = ctx.detect_batch([cache[i][1] for i in chunk], 1)
-                        for i, (boxes, _) in zip(chunk, res):
+                            res = ctx.detect_many([cache[i][1] for i in idx], bs, 1)
+                        for i, (boxes, _) in zip(idx, res):
                             dets[i] = [tuple(b) for b in boxes]
                     note("detected", k)
 
@@ -323,7 +322,14 @@ class FacePipeline(object):
                     mark["tracked"] = _time.perf_counter()
                 ex.feed(normalize(shot_tracks))
         else:
-            self._run_pipelined(shot_inputs, backend, ex, normalize, mark)
+            import gc
+            was_enabled = gc.isenabled()
+            gc.disable()      # a full collection in the middle of a shot stalls both threads for tens of milliseconds
+            try:
+                self._run_pipelined(shot_inputs, backend, ex, normalize, mark)
+            finally:
+                if was_enabled:
+                    gc.enable()
         pts, emb = ex.finish(drop_last=last_shard)
         tracks, rows = ex.tracks, ex.rows
         face_boxes, face_T, face_id = ex.face_boxes, ex.face_T, ex.face_id

@@ -149,6 +149,19 @@ class Context(object):
         check(self._l.pvf_detect_batch(self._h, ptr(hs), n, int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
         return [([tuple(int(v) for v in out[i, k]) for k in range(counts[i])], scores[i, :counts[i]].copy()) for i in range(n)]
 
+    def detect_many(self, frames, batch, upsample=1, adjust_threshold=0.0, cap=64):
+        """any number of frames of one size, `batch` at a time, host post-processing overlapped with the next batch's kernels"""
+        fr = [self.stage(f) for f in frames]
+        hs = handles([f.handle for f in fr])
+        n = len(fr)
+        out = np.zeros((n, cap, 4), np.int32)
+        scores = np.zeros((n, cap), np.float32)
+        counts = np.zeros(n, np.int32)
+        check(self._l.pvf_detect_many(self._h, ptr(hs), n, int(batch), int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
+        if int(counts.max(initial=0)) >= cap:     # a frame filled its slots: repeat with room for every detection
+            return self.detect_many(frames, batch, upsample, adjust_threshold, cap * 8)
+        return [([tuple(int(v) for v in out[i, k]) for k in range(counts[i])], scores[i, :counts[i]].copy()) for i in range(n)]
+
     def detect(self, frame, upsample=1, adjust_threshold=0.0):
         return self.detect_batch([frame], upsample, adjust_threshold)[0]
 

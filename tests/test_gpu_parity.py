@@ -86,6 +86,15 @@ def test_detect_batch_equals_single(ctx, small_video):
     assert single == batch
 
 
+def test_detect_many_pipelined_equals_single(ctx, small_video):
+    frames = [small_video.frame(i) for i in range(7)]
+    single = [ctx.detect(f, 1) for f in frames]
+    many = ctx.detect_many(frames, 3, 1)             # batches of 3, 3, 1 with two in flight
+    assert [b for b, _ in many] == [b for b, _ in single]
+    for (_, sa), (_, sb) in zip(many, single):
+        assert np.array_equal(sa, sb)
+
+
 def test_chips_bit_exact(ctx, oracle, small_video):
     f = small_video.frame(2)
     cases = [((100.5, 60.25, 180.75, 140.0), 1.0, 0.0, 64, 64),        # mild scale
