@@ -68,7 +68,7 @@ class HipTrackers(object):
     def release_many(self, handles):
         self.ctx.tracker_destroy_many(handles)
 
-    def speculate(self, cache, detections_at, chunk=1024):
+    def speculate(self, cache, detections_at, chunk=4096):
         """Issue EVERY start_track of a lane and the first update of every started tracker as large batches.
 
         In the reference loop (tracking.py:199-259) a tracker started on the detections of frame i is unconditionally
