@@ -91,6 +91,14 @@ int32_t pvf_tracker_start_many(pvf_handle ctx, const pvf_handle* trks, const pvf
                                const double* boxes /* n*4 */, int32_t n);
 int32_t pvf_tracker_update_many(pvf_handle ctx, const pvf_handle* trks, const pvf_handle* frames, int32_t n,
                                 double* psr /* n */, double* boxes_out /* n*4, may be NULL */);
+/* update() without the model update: same confidence and position as pvf_tracker_update_many, filters untouched.  The batched
+ * host path kills most trackers right after their first update (tracking.py:219-224: a tracker matched to a new detection is
+ * dropped), so it defers the filter update and only pays for it -- pvf_tracker_commit_many, with the SAME frames -- for the
+ * trackers that live on.  After the commit the tracker state is bit-identical to an immediate update.  A tracker with an
+ * uncommitted deferred update refuses further updates. */
+int32_t pvf_tracker_update_many_deferred(pvf_handle ctx, const pvf_handle* trks, const pvf_handle* frames, int32_t n,
+                                         double* psr, double* boxes_out);
+int32_t pvf_tracker_commit_many(pvf_handle ctx, const pvf_handle* trks, const pvf_handle* frames, int32_t n);
 
 /* ---- S3 rectangles + association (host; tiny, order-sensitive) --------------------------------------- */
 /* ref: tracking.py:129-134 _match on dlib.drectangle (width = r-l; empty -> area 0), :160-168 overlap matrix */

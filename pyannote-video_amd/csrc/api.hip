@@ -208,6 +208,29 @@ extern "C" int32_t pvf_tracker_start(pvf_handle h, pvf_handle trk, pvf_handle fr
 {
     return pvf_tracker_start_many(h, &trk, &frame, box, 1);
 }
+extern "C" int32_t pvf_tracker_update_many_deferred(pvf_handle h, const pvf_handle* trks, const pvf_handle* frames, int32_t n, double* psr,
+                                                    double* boxes_out)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    std::vector<Tracker*> t(n);
+    std::vector<Frame> f(n);
+    for (int i = 0; i < n; ++i) { t[i] = &c->tracker(trks[i]); f[i] = c->frame(frames[i]); }
+    dsst_update_many(c, t, f, psr, boxes_out, 1);
+    API_END
+}
+
+extern "C" int32_t pvf_tracker_commit_many(pvf_handle h, const pvf_handle* trks, const pvf_handle* frames, int32_t n)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    std::vector<Tracker*> t(n);
+    std::vector<Frame> f(n);
+    for (int i = 0; i < n; ++i) { t[i] = &c->tracker(trks[i]); f[i] = c->frame(frames[i]); }
+    dsst_update_many(c, t, f, nullptr, nullptr, 2);
+    API_END
+}
+
 extern "C" int32_t pvf_tracker_update(pvf_handle h, pvf_handle trk, pvf_handle frame, double* psr)
 {
     return pvf_tracker_update_many(h, &trk, &frame, 1, psr, nullptr);

@@ -463,7 +463,7 @@ __global__ void __launch_bounds__(256) scale_start_k(const TrkJob* __restrict__ 
 }
 
 __global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ Fs, const double* __restrict__ tw32,
-                                                      double ln_alpha, double* __restrict__ results)
+                                                      double ln_alpha, double* __restrict__ results, int update_model)
 {
     __shared__ double2 Gs[NSC];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -503,8 +503,9 @@ __global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__
         st[TRK_POS] = r[0]; st[TRK_POS + 1] = r[1]; st[TRK_POS + 2] = r[2]; st[TRK_POS + 3] = r[3];
         results[(size_t)b * 8 + 1] = r[0]; results[(size_t)b * 8 + 2] = r[1]; results[(size_t)b * 8 + 3] = r[2]; results[(size_t)b * 8 + 4] = r[3];
         results[(size_t)b * 8 + 7] = pos;
-        scale_target_seq(Gs, pos, tw32);
+        if (update_model) scale_target_seq(Gs, pos, tw32);
     }
+    if (!update_model) return;                  // deferred update: position and confidence only, filters untouched
     __syncthreads();
     for (int e = tid; e < SDIM * NSC; e += 256) {
         const int k = e & 31;
@@ -522,6 +523,13 @@ __global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__
         }
         st[TRK_BS + tid] = bq;
     }
+}
+
+// commit of a deferred update: put the position the update started from back into the tracker state
+__global__ void restore_pos_k(const TrkJob* __restrict__ jobs, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * 4) jobs[i >> 2].state[TRK_POS + (i & 3)] = jobs[i >> 2].box[i & 3];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -616,6 +624,7 @@ void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<F
     for (int i = 0; i < n; ++i) {
         memcpy(t[i]->pos, boxes + 4 * i, 4 * sizeof(double));
         t[i]->started = true;
+        t[i]->pending = false;
     }
     std::vector<TrkJob> jobs; std::vector<ChipJob> cj;
     DsstBuffers b = prepare(c, t, f, boxes, jobs, cj);
@@ -634,25 +643,42 @@ void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<F
     HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 
-void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, double* psr, double* boxes_out)
+// mode 0: dlib's update().  mode 1 (deferred): the same response, peak, position and confidence, but the translation and
+// scale filters are left as they were and the tracker remembers where it started from -- most trackers of the batched host path
+// are killed right after their first update (their face was detected again), so the model update would be thrown away.
+// mode 2 (commit): for a tracker that survived a deferred update, redo that update in full on the same frame; the state is
+// then bit-identical to what mode 0 would have left (same inputs, same arithmetic).
+void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, double* psr, double* boxes_out, int mode)
 {
     const int n = (int)t.size();
     if (n == 0) return;
     ensure_fft_lds();
-    for (int i = 0; i < n; ++i) PVF_REQUIRE(t[i]->started, "tracker.update before start_track");
+    for (int i = 0; i < n; ++i) {
+        PVF_REQUIRE(t[i]->started, "tracker.update before start_track");
+        if (mode == 2) {
+            PVF_REQUIRE(t[i]->pending, "commit of a tracker that has no deferred update");
+            memcpy(t[i]->pos, t[i]->prev_pos, sizeof t[i]->pos);
+            t[i]->pending = false;
+        } else {
+            PVF_REQUIRE(!t[i]->pending, "tracker has a deferred update: commit it (with the frame it was computed on) first");
+        }
+        if (mode == 1) memcpy(t[i]->prev_pos, t[i]->pos, sizeof t[i]->pos);
+    }
     std::vector<TrkJob> jobs; std::vector<ChipJob> cj;
     DsstBuffers b = prepare(c, t, f, nullptr, jobs, cj);
+    if (mode == 2) hipLaunchKernelGGL(restore_pos_k, dim3((4 * n + 255) / 256), dim3(256), 0, c->stream, b.jobs, n);
     translation_features(c, b, cj, n);
     {
         ProfScope ps(c, "dsst");
         hipLaunchKernelGGL(corr_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G0);
         hipLaunchKernelGGL(peak_k, dim3(n), dim3(256), LDS_FFT, c->stream, b.jobs, b.G0, c->ttab.d_tw64, b.results, b.G1);
-        hipLaunchKernelGGL(filter_update_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G1);
+        if (mode != 1) hipLaunchKernelGGL(filter_update_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G1);
     }
     scale_features(c, b, n);
     {
         ProfScope ps(c, "dsst");
-        hipLaunchKernelGGL(scale_update_k, dim3(n), dim3(256), 0, c->stream, b.jobs, b.Fs, c->ttab.d_tw32, c->ttab.ln_alpha, b.results);
+        hipLaunchKernelGGL(scale_update_k, dim3(n), dim3(256), 0, c->stream, b.jobs, b.Fs, c->ttab.d_tw32, c->ttab.ln_alpha, b.results,
+                           mode != 1 ? 1 : 0);
     }
     HIP_CHECK(hipGetLastError());
     c->h_misc.ensure((size_t)n * 8 * sizeof(double));
@@ -660,8 +686,9 @@ void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<
     HIP_CHECK(hipMemcpyAsync(hr, b.results, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; ++i) {
-        psr[i] = hr[8 * i];
+        if (psr) psr[i] = hr[8 * i];
         for (int k = 0; k < 4; ++k) t[i]->pos[k] = hr[8 * i + 1 + k];
         if (boxes_out) memcpy(boxes_out + 4 * i, t[i]->pos, 4 * sizeof(double));
+        if (mode == 1) t[i]->pending = true;
     }
 }

@@ -144,7 +144,9 @@ struct TrackerTables {
 struct Tracker {
     double* d_state = nullptr; // A[32*64*64*2] B[64*64] As[512*32*2] Bs[32] pos[4]
     double pos[4] = {0, 0, 0, 0};
+    double prev_pos[4] = {0, 0, 0, 0};   // position before a deferred update (dsst_update_many mode 1)
     bool started = false;
+    bool pending = false;                // deferred update not committed yet
 };
 constexpr size_t TRK_A = 0;
 constexpr size_t TRK_B = TRK_A + (size_t)32 * 64 * 64 * 2;
@@ -241,7 +243,7 @@ void face_chip_details(const EmbedModel& m, const int32_t* pts68, ChipDetails* o
 void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out);
 // tracker (dsst.hip)
 void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes);
-void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, double* psr, double* boxes_out);
+void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, double* psr, double* boxes_out, int mode = 0);
 // association (assoc.cpp part of api)
 void overlap_matrix_host(const double* a, int na, const double* b, int nb, double ratio, double* out);
 void munkres_host(const double* cost, int n, int32_t* row_to_col);

@@ -48,6 +48,8 @@ _SIGS = {
     "pvf_tracker_position": (C.c_int32, [H, H, P]),
     "pvf_tracker_start_many": (C.c_int32, [H, P, P, P, C.c_int32]),
     "pvf_tracker_update_many": (C.c_int32, [H, P, P, C.c_int32, P, P]),
+    "pvf_tracker_update_many_deferred": (C.c_int32, [H, P, P, C.c_int32, P, P]),
+    "pvf_tracker_commit_many": (C.c_int32, [H, P, P, C.c_int32]),
     "pvf_overlap_matrix": (C.c_int32, [P, C.c_int32, P, C.c_int32, C.c_double, P]),
     "pvf_munkres": (C.c_int32, [P, C.c_int32, P]),
     "pvf_landmarks": (C.c_int32, [H, P, P, C.c_int32, P]),

@@ -156,6 +156,10 @@ class _LaneBackend(object):
         with self.lock:
             return self.backend.update_many(handles, frames)
 
+    def commit_many(self, handles, frames):
+        with self.lock:
+            self.backend.commit_many(handles, frames)
+
     def start_many(self, frames, boxes):
         with self.lock:
             return self.backend.start_many(frames, boxes)

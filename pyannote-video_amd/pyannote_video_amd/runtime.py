@@ -230,15 +230,23 @@ class Context(object):
         b = np.ascontiguousarray(boxes, np.float64).reshape(-1, 4)
         check(self._l.pvf_tracker_start_many(self._h, ptr(handles(trks)), ptr(handles([f.handle for f in fr])), ptr(b), len(trks)))
 
-    def tracker_update_many(self, trks, frames):
+    def tracker_update_many(self, trks, frames, defer=False):
+        """defer=True: confidence and position only, the filter update is left to tracker_commit_many (same frames)"""
         n = len(trks)
         if not n:
             return np.zeros(0), np.zeros((0, 4))
         fr = [self.stage(f) for f in frames]
         psr = np.zeros(n, np.float64)
         boxes = np.zeros((n, 4), np.float64)
-        check(self._l.pvf_tracker_update_many(self._h, ptr(handles(trks)), ptr(handles([f.handle for f in fr])), n, ptr(psr), ptr(boxes)))
+        fn = self._l.pvf_tracker_update_many_deferred if defer else self._l.pvf_tracker_update_many
+        check(fn(self._h, ptr(handles(trks)), ptr(handles([f.handle for f in fr])), n, ptr(psr), ptr(boxes)))
         return psr, boxes
+
+    def tracker_commit_many(self, trks, frames):
+        n = len(trks)
+        if n:
+            fr = [self.stage(f) for f in frames]
+            check(self._l.pvf_tracker_commit_many(self._h, ptr(handles(trks)), ptr(handles([f.handle for f in fr])), n))
 
     def tracker_position(self, trk):
         b = np.zeros(4, np.float64)

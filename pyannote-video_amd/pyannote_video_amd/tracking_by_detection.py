@@ -59,8 +59,12 @@ class HipTrackers(object):
         self.ctx.tracker_start_many(hs, frames, boxes)
         return hs
 
-    def update_many(self, handles, frames):
-        return self.ctx.tracker_update_many(handles, frames)
+    def update_many(self, handles, frames, defer=False):
+        return self.ctx.tracker_update_many(handles, frames, defer)
+
+    def commit_many(self, handles, frames):
+        """filter update of trackers whose last (deferred) update ran on `frames`"""
+        self.ctx.tracker_commit_many(handles, frames)
 
     def release(self, handle):
         self.ctx.tracker_destroy(handle)
@@ -74,7 +78,12 @@ class HipTrackers(object):
         In the reference loop (tracking.py:199-259) a tracker started on the detections of frame i is unconditionally
         updated on frame i+1 (:202-203) before anything can kill it, so these two operations never depend on the
         association logic; each tracker's arithmetic is independent of the batch it runs in, so the results are the
-        ones the frame-by-frame order produces.  Returns {t: (handles, psr or None, boxes or None)}."""
+        ones the frame-by-frame order produces.  Returns {t: (handles, psr or None, boxes or None)}.
+
+        Backends with `commit_many` run these first updates WITHOUT the filter update (a tracker that is matched to a
+        detection on that frame is dropped, tracking.py:219-224, which is the common case); the lane commits it for the
+        trackers that live on, before their next update."""
+        defer = hasattr(self, 'commit_many')
         flat_f, flat_b, owner = [], [], []
         for i, (t, frame) in enumerate(cache):
             for d in detections_at.get(t, []):
@@ -91,7 +100,10 @@ class HipTrackers(object):
         pos = np.zeros((n, 4), np.float64)
         for o in range(0, len(upd), chunk):
             ks = upd[o:o + chunk]
-            p, b = self.update_many([hs[k] for k in ks], [cache[owner[k] + 1][1] for k in ks])
+            if defer:
+                p, b = self.update_many([hs[k] for k in ks], [cache[owner[k] + 1][1] for k in ks], True)
+            else:
+                p, b = self.update_many([hs[k] for k in ks], [cache[owner[k] + 1][1] for k in ks])
             psr[ks] = p
             pos[ks] = b
         plan, k = {}, 0
@@ -165,6 +177,11 @@ class LaneScheduler(object):
                 n = len(r[1])
                 replies[k] = (psr[o:o + n], boxes[o:o + n])
                 o += n
+        cm = [(k, r) for k, r in pending.items() if r[0] == 'commit']
+        if cm:
+            backend.commit_many([h for _, r in cm for h in r[1]], [f for _, r in cm for f in r[2]])
+            for k, _ in cm:
+                replies[k] = None
         st = [(k, r) for k, r in pending.items() if r[0] == 'start']
         if st:
             fr = [f for _, r in st for f in r[1]]
@@ -248,11 +265,14 @@ class TrackingByDetection(object):
         confidences = {}
         previous = {}
         cached = {}        # identifier -> (psr, box) of a first update computed ahead
+        uncommitted = {}   # identifier -> frame of its deferred first update (filters not updated yet)
+        deferring = plan is not None and backend is not None and hasattr(backend, 'commit_many')
         new_identifier = 0
 
         def kill(identifier):
             h = trackers.pop(identifier)
             cached.pop(identifier, None)
+            uncommitted.pop(identifier, None)
             if release is not None:
                 release(h)
             return h
@@ -262,11 +282,16 @@ class TrackingByDetection(object):
             if ids:
                 need = [i for i in ids if i not in cached]
                 fresh = {}
+                late = [i for i in need if i in uncommitted]
+                if late:      # survivors of a deferred first update: bring their filters up to date before updating again
+                    yield ('commit', [trackers[i] for i in late], [uncommitted.pop(i) for i in late])
                 if need:
                     psr, boxes = yield ('update', [trackers[i] for i in need], [frame] * len(need))
                     for k, identifier in enumerate(need):
                         fresh[identifier] = (float(psr[k]), tuple(float(v) for v in boxes[k]))
                 for identifier in ids:
+                    if deferring and identifier in cached:
+                        uncommitted[identifier] = frame
                     conf, pos = cached.pop(identifier) if identifier in cached else fresh[identifier]
                     confidences[identifier] = conf
                     position[identifier] = pos

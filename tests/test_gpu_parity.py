@@ -180,6 +180,41 @@ def test_tracker_bit_exact(ctx, oracle, small_video):
         ctx.tracker_destroy(t)
 
 
+def test_tracker_deferred_update_and_commit_bit_exact(ctx, oracle, small_video):
+    """update without the model update + commit on the same frame == immediate update (outputs and filter state), and both
+    equal the oracle's tracker"""
+    from pyannote_video_amd import models, _lib
+    tabs = models.dsst_tables()
+    f0 = small_video.frame(0)
+    boxes = ctx.detect(f0, 1)[0]
+    dbox = [tuple(float(v) for v in b) for b in boxes]
+    n = len(dbox)
+    ref = [oracle.Tracker(tabs) for _ in dbox]
+    for r, b in zip(ref, dbox):
+        r.start_track(f0, b)
+    trk = ctx.tracker_create_many(n)
+    ctx.tracker_start_many(trk, [f0] * n, dbox)
+    f1, f2, f3 = small_video.frame(1), small_video.frame(2), small_video.frame(3)
+    psr, pos = ctx.tracker_update_many(trk, [f1] * n, defer=True)
+    want = [(r.update(f1), r.get_position()) for r in ref]
+    assert [(psr[k], tuple(pos[k])) for k in range(n)] == want
+    _, A0, B0 = ctx.tracker_state(trk[0])
+    with pytest.raises(_lib.PvfError):                       # an uncommitted tracker refuses the next update
+        ctx.tracker_update_many(trk[:1], [f2])
+    ctx.tracker_commit_many(trk, [f1] * n)
+    _, A1, B1 = ctx.tracker_state(trk[0])
+    Ar, Br = ref[0].debug_state()
+    assert not np.array_equal(A0, A1)                        # the deferred call had left the filters alone
+    assert np.array_equal(A1, Ar) and np.array_equal(B1, Br)
+    assert ctx.tracker_position(trk[0]) == ref[0].get_position()
+    for f in (f2, f3):
+        psr, pos = ctx.tracker_update_many(trk, [f] * n)
+        for k, r in enumerate(ref):
+            assert psr[k] == r.update(f)
+            assert tuple(pos[k]) == r.get_position()
+    ctx.tracker_destroy_many(trk)
+
+
 def test_pair_mean_dist_and_hac(ctx, oracle):
     rng = np.random.default_rng(5)
     K, T = 9, 60

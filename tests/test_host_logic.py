@@ -221,3 +221,68 @@ def test_extract_stream_equals_whole_file_walk(seed, drop_last):
     assert ex.face_boxes == [box for _, _, g in ref for _, box in g]
     assert ex.rows == rows
     assert len(emb) == len(ex.face_id) == len(pts)
+
+
+class ModelScriptTracker(ScriptTracker):
+    """a scripted tracker with a 'model' (age) that every full update advances and that feeds back into the confidence, so a
+    forgotten or misplaced commit of a deferred update changes the tracks"""
+    def __init__(self):
+        ScriptTracker.__init__(self)
+        self.age = 0
+
+    def update(self, frame):
+        conf = ScriptTracker.update(self, frame)
+        conf = conf - 0.7 * (self.age % 4)
+        self.age += 1
+        return conf
+
+
+class ModelRefTracker(ModelScriptTracker):
+    def get_position(self):
+        return self.box
+
+
+class DeferringObjectTrackers(SpeculatingObjectTrackers):
+    """per-object trackers behind the deferred-update interface of the GPU backend (update_many(defer=True) / commit_many)"""
+    def __init__(self, factory):
+        SpeculatingObjectTrackers.__init__(self, factory)
+        self.pending = {}
+        self.commits = 0
+
+    def update_many(self, handles, frames, defer=False):
+        import copy
+        if not defer:
+            assert not any(id(h) in self.pending for h in handles), "update of a tracker with an uncommitted deferred update"
+            return ObjectTrackers.update_many(self, handles, frames)
+        psr, pos = [], []
+        for h, f in zip(handles, frames):
+            probe = copy.deepcopy(h)
+            psr.append(probe.update(f))
+            p = probe.get_position()
+            pos.append((p.left(), p.top(), p.right(), p.bottom()))
+            self.pending[id(h)] = (f, h)
+        return np.array(psr, np.float64), np.array(pos, np.float64).reshape(-1, 4)
+
+    def commit_many(self, handles, frames):
+        for h, f in zip(handles, frames):
+            g, _ = self.pending.pop(id(h))
+            assert g is f, "commit with a different frame than the deferred update ran on"
+            h.update(f)
+            self.commits += 1
+
+    def release(self, handle):
+        self.pending.pop(id(handle), None)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_deferred_first_updates_with_commit_equal_sequential_reference(seed):
+    from oracle import ref_flow
+    frames, dets = scenario(400 + seed, n=60, p_miss=0.4)
+    times = [i / 25.0 for i in range(len(frames))]
+    cache = list(zip(times, frames))
+    backend = DeferringObjectTrackers(ModelScriptTracker)
+    tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0, trackers=backend)
+    got = tbd.process_shots([(cache, [True] * len(cache), dets)], backend)[0]
+    ref = ref_flow.track_shot(cache, dets, ModelRefTracker, 10., 0.5, 1.0)
+    assert got == ref
+    assert backend.commits > 0          # the scenario has survivors, i.e. the commit path ran
