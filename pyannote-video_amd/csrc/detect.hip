@@ -301,6 +301,24 @@ __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, co
     *bo = lut[(by + 255) * 511 + (bx + 255)];
 }
 
+// The per-image FHOG kernels below run on 1-D grids over (image, row, column): the images they see in production are the
+// trackers' chips (23 x 23 scale samples, 64 x 64 translation windows), whose rows would fill 2-25 % of a 256-lane block each.
+__device__ __forceinline__ bool flat_index(int nx, int ny, int nb, int* x, int* y, int* b)
+{
+    const unsigned g = blockIdx.x * 256u + threadIdx.x;
+    const unsigned t = g / (unsigned)nx;
+    *x = (int)(g - t * (unsigned)nx);
+    *b = (int)(t / (unsigned)ny);
+    *y = (int)(t - (unsigned)*b * (unsigned)ny);
+    return *b < nb;
+}
+static inline dim3 flat_grid(int nx, int ny, int nb)
+{
+    const size_t total = (size_t)nx * ny * nb;
+    PVF_REQUIRE(total < ((size_t)1 << 31), "fhog: too many work items for one launch");
+    return dim3((unsigned)((total + 255) / 256));
+}
+
 // Pass 1: per pixel (orientation bin, gradient magnitude) into planes shifted by 3C/2 so that histogram cell (hy,hx) owns rows
 // yy in [C*hy, C*hy+2C) and columns xx in [C*hx, C*hx+2C)  (yy = y + 3C/2, xx = x + 3C/2; pitch = multiple of 16 floats).
 // One lane = 4 consecutive pixels of one row; interior quads fetch their 3 x 18-byte neighbourhood with
@@ -323,12 +341,11 @@ __device__ __forceinline__ void grad_from_bytes(const int u[3], const int d[3], 
 template <int C>
 __global__ void __launch_bounds__(256) fhog_grad4_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
                                                     int visible_nc, float* __restrict__ mag, uint8_t* __restrict__ bin, size_t px_stride,
-                                                    int rows_t, int pitch, const uint8_t* __restrict__ lut)
+                                                    int rows_t, int pitch, const uint8_t* __restrict__ lut, int n_img)
 {
-    const int q = blockIdx.x * 256 + threadIdx.x;       // quad index within the row
-    const int yy = blockIdx.y, b = blockIdx.z;
+    int q, yy, b;                                       // quad index within the row, plane row, image
+    if (!flat_index(pitch / 4, rows_t, n_img, &q, &yy, &b)) return;
     const int xx = 4 * q;
-    if (xx >= pitch) return;
     const int y = yy - 3 * C / 2, x0 = xx - 3 * C / 2;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     int o[4] = {0, 0, 0, 0};
@@ -383,15 +400,15 @@ __global__ void __launch_bounds__(256) fhog_grad4_k(const uint8_t* __restrict__ 
 template <int C>
 __global__ void __launch_bounds__(256) fhog_hist_k(const float* __restrict__ mag, const uint8_t* __restrict__ bin, size_t px_stride, int pitch,
                                                    float* __restrict__ hist, size_t hist_stride, int hr, int hc,
-                                                   float* __restrict__ norm, size_t norm_stride, int cells_nr, int cells_nc)
+                                                   float* __restrict__ norm, size_t norm_stride, int cells_nr, int cells_nc, int n_img)
 {
     __shared__ float acc[18][256];
-    const int hx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int hy = blockIdx.y, b = blockIdx.z;
+    int hx, hy, b;
+    const bool valid = flat_index(hc, hr, n_img, &hx, &hy, &b);
     const int tid = threadIdx.x;
 #pragma unroll
     for (int o = 0; o < 18; ++o) acc[o][tid] = 0.0f;
-    if (hx < hc) {
+    if (valid) {
         const float* mg = mag + (size_t)b * px_stride + (size_t)C * hx;
         const uint8_t* bn = bin + (size_t)b * px_stride + (size_t)C * hx;
         constexpr int NV = 2 * C / 4;            // float4 loads per row
@@ -485,11 +502,10 @@ __device__ __forceinline__ void cell_features(const float* h, const float* n, fl
 
 __global__ void __launch_bounds__(256) fhog_feat_k(const float* __restrict__ hist, size_t hist_stride, int hc, const float* __restrict__ norm,
                                                    size_t norm_stride, int cells_nc, float* __restrict__ feat, size_t feat_stride, int fw,
-                                                   int hog_nr, int hog_nc, int oy, int ox)
+                                                   int hog_nr, int hog_nc, int oy, int ox, int fh, int n_img)
 {
-    const int px = blockIdx.x * blockDim.x + threadIdx.x;      // padded output coordinates
-    const int py = blockIdx.y, b = blockIdx.z;
-    if (px >= fw) return;
+    int px, py, b;                                             // padded output coordinates, image
+    if (!flat_index(fw, fh, n_img, &px, &py, &b)) return;
     const int x = px - ox, y = py - oy;
     if (x < 0 || y < 0 || x >= hog_nc || y >= hog_nr) {
         float4* z = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)py * fw + px) * PVF_FHOG_STRIDE);
@@ -514,11 +530,11 @@ __global__ void __launch_bounds__(256) fhog_feat_k(const float* __restrict__ his
 
 // cell size 1 (correlation tracker translation chip): every pixel is a cell
 __global__ void __launch_bounds__(256) fhog1_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw,
-                                                    float* __restrict__ norm, uint8_t* __restrict__ angle, size_t px_stride, const uint8_t* __restrict__ lut)
+                                                    float* __restrict__ norm, uint8_t* __restrict__ angle, size_t px_stride, const uint8_t* __restrict__ lut,
+                                                    int n_img)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y, b = blockIdx.z;
-    if (x >= iw) return;
+    int x, y, b;
+    if (!flat_index(iw, ih, n_img, &x, &y, &b)) return;
     float v = 0.0f;
     int o = 0;
     if (y >= 1 && y < ih - 1 && x >= 1 && x < iw - 1) {
@@ -531,11 +547,10 @@ __global__ void __launch_bounds__(256) fhog1_grad_k(const uint8_t* __restrict__ 
 
 __global__ void __launch_bounds__(256) fhog1_feat_k(const float* __restrict__ norm, const uint8_t* __restrict__ angle, size_t px_stride,
                                                     int iw, float* __restrict__ feat, size_t feat_stride, int fw, int hog_nr, int hog_nc,
-                                                    int oy, int ox)
+                                                    int oy, int ox, int fh, int n_img)
 {
-    const int px = blockIdx.x * blockDim.x + threadIdx.x;
-    const int py = blockIdx.y, b = blockIdx.z;
-    if (px >= fw) return;
+    int px, py, b;
+    if (!flat_index(fw, fh, n_img, &px, &py, &b)) return;
     const int x = px - ox, y = py - oy;
     if (x < 0 || y < 0 || x >= hog_nc || y >= hog_nr) {
         float4* z = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)py * fw + px) * PVF_FHOG_STRIDE);
@@ -588,11 +603,9 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
         const size_t px = (size_t)h * w;
         norm.ensure(px * n * sizeof(float));
         hist.ensure(px * n);
-        dim3 g1((w + 255) / 256, h, n);
-        hipLaunchKernelGGL(fhog1_grad_k, g1, dim3(256), 0, c->stream, d_img, img_stride, h, w, norm.as<float>(), hist.as<uint8_t>(), px, lut);
-        dim3 g2((fw + 255) / 256, fh, n);
-        hipLaunchKernelGGL(fhog1_feat_k, g2, dim3(256), 0, c->stream, norm.as<float>(), hist.as<uint8_t>(), px, w, d_feat, feat_stride, fw,
-                           h - 2, w - 2, oy, ox);
+        hipLaunchKernelGGL(fhog1_grad_k, flat_grid(w, h, n), dim3(256), 0, c->stream, d_img, img_stride, h, w, norm.as<float>(), hist.as<uint8_t>(), px, lut, n);
+        hipLaunchKernelGGL(fhog1_feat_k, flat_grid(fw, fh, n), dim3(256), 0, c->stream, norm.as<float>(), hist.as<uint8_t>(), px, w, d_feat, feat_stride, fw,
+                           h - 2, w - 2, oy, ox, fh, n);
         return;
     }
     PVF_REQUIRE(cell == 8 || cell == 4, "fhog: cell size 1, 4 or 8");
@@ -608,21 +621,19 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
     grad.ensure(px_stride * n * 5 + 256);
     float* d_mag = grad.as<float>();
     uint8_t* d_bin = grad.as<uint8_t>() + px_stride * n * 4;
-    dim3 g4((pitch / 4 + 255) / 256, rows_t, n);
-    dim3 gh((hc + 255) / 256, hr, n);
+    const dim3 g4 = flat_grid(pitch / 4, rows_t, n), gh = flat_grid(hc, hr, n);
     if (cell == 8) {
-        hipLaunchKernelGGL((fhog_grad4_k<8>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
+        hipLaunchKernelGGL((fhog_grad4_k<8>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
         hipLaunchKernelGGL((fhog_hist_k<8>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
-                           norm.as<float>(), norm_stride, cells_nr, cells_nc);
+                           norm.as<float>(), norm_stride, cells_nr, cells_nc, n);
     } else {
-        hipLaunchKernelGGL((fhog_grad4_k<4>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut);
+        hipLaunchKernelGGL((fhog_grad4_k<4>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
         hipLaunchKernelGGL((fhog_hist_k<4>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
-                           norm.as<float>(), norm_stride, cells_nr, cells_nc);
+                           norm.as<float>(), norm_stride, cells_nr, cells_nc, n);
     }
     const int hog_nr = cells_nr - 2, hog_nc = cells_nc - 2;
-    dim3 gf((fw + 255) / 256, fh, n);
-    hipLaunchKernelGGL(fhog_feat_k, gf, dim3(256), 0, c->stream, hist.as<float>(), hist_stride, hc, norm.as<float>(), norm_stride, cells_nc,
-                       d_feat, feat_stride, fw, hog_nr, hog_nc, oy, ox);
+    hipLaunchKernelGGL(fhog_feat_k, flat_grid(fw, fh, n), dim3(256), 0, c->stream, hist.as<float>(), hist_stride, hc, norm.as<float>(), norm_stride, cells_nc,
+                       d_feat, feat_stride, fw, hog_nr, hog_nc, oy, ox, fh, n);
 }
 
 void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, int pad_c, std::vector<float>& out, int* fh, int* fw)
