@@ -239,8 +239,11 @@ class FacePipeline(object):
                             note("extracted", extracted - 1)
 
                     # faces of the shots the tracking thread has finished meanwhile (it is idle now, so the host side of these
-                    # calls does not compete with its state machine for the interpreter; measured better than after speculate)
-                    drain()
+                    # calls does not compete with its state machine for the interpreter; measured better than after speculate).
+                    # For the last shot the order is swapped: its state machine then runs while these faces are embedded
+                    # instead of leaving the GPU idle at the very end.
+                    if k < n - 1:
+                        drain()
                     det_at = {t: d for (t, _), d in zip(cache, dets)}
                     with lock:
                         release_dead()
@@ -248,6 +251,8 @@ class FacePipeline(object):
                         plan_b = backend.speculate(list(reversed(cache)), det_at)
                     note("speculated", k)
                     ready.put((k, dets, (plan_f, plan_b)))
+                    if k == n - 1:
+                        drain()
                 while extracted < n:
                     work = done.get()
                     if work is None:
