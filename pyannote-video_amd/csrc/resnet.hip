@@ -106,23 +106,48 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
         }
     }
     const int Kpad = (a.K + KC - 1) / KC * KC;
-    for (int k0 = 0; k0 < Kpad; k0 += KC) {
-        // ---- stage A
-        if (!GENERIC) {
-            const int tap = k0 / a.Cin, c0 = k0 % a.Cin;
-            const int r = tap / a.ksz, s = tap % a.ksz;
+    // fast path: the global loads of K-chunk k0 + KC are issued before the MFMAs of chunk k0 and land in LDS after them, so
+    // a block no longer waits for memory between its two barriers
+    float4 va[A_F4], vb[B_F4];
+    auto fetch = [&](int k0) {
+        const int tap = k0 / a.Cin, c0 = k0 % a.Cin;
+        const int r = tap / a.ksz, s = tap % a.ksz;
 #pragma unroll
-            for (int q = 0; q < A_F4; ++q) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int iy = pa_y[q] + r, ix = pa_x[q] + s;
-                if (pa_ok[q] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                    v = *reinterpret_cast<const float4*>(a.in + (((size_t)pa_b[q] * a.H + iy) * a.W + ix) * a.Cin + c0 + 4 * pa_j[q]);
-                const int kk = 4 * pa_j[q];
-                As[(kk + 0) * PA + pa_i[q]] = v.x;
-                As[(kk + 1) * PA + pa_i[q]] = v.y;
-                As[(kk + 2) * PA + pa_i[q]] = v.z;
-                As[(kk + 3) * PA + pa_i[q]] = v.w;
-            }
+        for (int q = 0; q < A_F4; ++q) {
+            va[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int iy = pa_y[q] + r, ix = pa_x[q] + s;
+            if (pa_ok[q] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                va[q] = *reinterpret_cast<const float4*>(a.in + (((size_t)pa_b[q] * a.H + iy) * a.W + ix) * a.Cin + c0 + 4 * pa_j[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < B_F4; ++q) {
+            const int idx = tid + q * 256;          // over KC * BN/4
+            const int kk = idx / (BN / 4), j4 = idx % (BN / 4);
+            const int k = k0 + kk;
+            vb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < a.K) vb[q] = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + n0 + 4 * j4);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int q = 0; q < A_F4; ++q) {
+            const int kk = 4 * pa_j[q];
+            As[(kk + 0) * PA + pa_i[q]] = va[q].x;
+            As[(kk + 1) * PA + pa_i[q]] = va[q].y;
+            As[(kk + 2) * PA + pa_i[q]] = va[q].z;
+            As[(kk + 3) * PA + pa_i[q]] = va[q].w;
+        }
+#pragma unroll
+        for (int q = 0; q < B_F4; ++q) {
+            const int idx = tid + q * 256;
+            const int kk = idx / (BN / 4), j4 = idx % (BN / 4);
+            *reinterpret_cast<float4*>(&Bs[kk * PB + 4 * j4]) = vb[q];
+        }
+    };
+    if (!GENERIC) fetch(0);
+    for (int k0 = 0; k0 < Kpad; k0 += KC) {
+        if (!GENERIC) {
+            park();
         } else {
             for (int idx = tid; idx < BM * KC; idx += 256) {
                 const int i = idx / KC, kk = idx % KC;
@@ -142,18 +167,18 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
                 }
                 As[kk * PA + i] = v;
             }
-        }
-        // ---- stage B
 #pragma unroll
-        for (int q = 0; q < B_F4; ++q) {
-            const int idx = tid + q * 256;          // over KC * BN/4
-            const int kk = idx / (BN / 4), j4 = idx % (BN / 4);
-            const int k = k0 + kk;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < a.K) v = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + n0 + 4 * j4);
-            *reinterpret_cast<float4*>(&Bs[kk * PB + 4 * j4]) = v;
+            for (int q = 0; q < B_F4; ++q) {
+                const int idx = tid + q * 256;          // over KC * BN/4
+                const int kk = idx / (BN / 4), j4 = idx % (BN / 4);
+                const int k = k0 + kk;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < a.K) v = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + n0 + 4 * j4);
+                *reinterpret_cast<float4*>(&Bs[kk * PB + 4 * j4]) = v;
+            }
         }
         __syncthreads();
+        if (!GENERIC && k0 + KC < Kpad) fetch(k0 + KC);
         const int ai = wm * 32 + (lane & 31), bj = wn * 32 + (lane & 31), kh = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
