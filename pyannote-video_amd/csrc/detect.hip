@@ -972,8 +972,16 @@ __device__ __forceinline__ int ml_level(const MlStarts& st, int g)
 // (5 unaligned dwords) and serves as the "down" row of the row above, the centre row, and the "up" row of the row below,
 // so an interior row costs 5 loads instead of 11 and the level lookup / index arithmetic is paid once per GR rows.
 #define GRAD_ROWS 8
+// (magnitude, bin) of a pixel in ONE dword.  A magnitude is 0 or sqrt of an integer in [1, 130050], i.e. in [1, 361): scaled by
+// 2^-126 (exact, still a normal number) its exponent field is 1..9, so the sign bit and the top four exponent bits are zero and
+// hold the 5-bit orientation bin.  The histogram pass undoes it with one AND and one exact multiply.  4 bytes per pixel instead
+// of 5 and one store / one load stream instead of two.
+__device__ __forceinline__ uint32_t pack_mag_bin(float mag, int bin) { return __float_as_uint(mag * 0x1p-126f) | ((uint32_t)bin << 27); }
+__device__ __forceinline__ float packed_mag(uint32_t w) { return __uint_as_float(w & 0x07FFFFFFu) * 0x1p+126f; }
+__device__ __forceinline__ int packed_bin(uint32_t w) { return (int)(w >> 27); }
+
 __global__ void __launch_bounds__(256) fhog_grad4r_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
-                                                        float* __restrict__ mag_base, uint8_t* __restrict__ bin_base,
+                                                        uint32_t* __restrict__ px_base,
                                                         const uint8_t* __restrict__ lut2)
 {
     constexpr int C = 8, GR = GRAD_ROWS;
@@ -992,8 +1000,7 @@ __global__ void __launch_bounds__(256) fhog_grad4r_ml_k(MlStarts st, const LvDes
     const int yy0 = yb * GR;
     const int rb = d.rb;
     const uint8_t* im = img_base + d.img_off + (size_t)b * d.img_stride;
-    float* mg = mag_base + d.px_off + (size_t)b * d.px_stride + xx;
-    uint8_t* bn = bin_base + d.px_off + (size_t)b * d.px_stride + xx;
+    uint32_t* pxo = px_base + d.px_off + (size_t)b * d.px_stride + xx;
     const bool col_any = (x0 + 3 >= 1 && x0 < d.visible_nc);
     const bool col_fast = (x0 >= 1 && x0 + 4 <= d.visible_nc && x0 + 6 <= d.w);
     if (col_fast) {
@@ -1046,8 +1053,8 @@ __global__ void __launch_bounds__(256) fhog_grad4r_ml_k(MlStarts st, const LvDes
             }
             if (r >= 1 && yy0 + r - 1 < d.rows_t) {
                 const size_t idx = (size_t)(yy0 + r - 1) * d.pitch;
-                *reinterpret_cast<float4*>(mg + idx) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-                *reinterpret_cast<uint32_t*>(bn + idx) = (uint32_t)po[0] | ((uint32_t)po[1] << 8) | ((uint32_t)po[2] << 16) | ((uint32_t)po[3] << 24);
+                *reinterpret_cast<uint4*>(pxo + idx) = make_uint4(pack_mag_bin(pv[0], po[0]), pack_mag_bin(pv[1], po[1]), pack_mag_bin(pv[2], po[2]),
+                                                                  pack_mag_bin(pv[3], po[3]));
             }
 #pragma unroll
             for (int p = 0; p < 4; ++p) { pv[p] = v[p]; po[p] = o[p]; }
@@ -1076,8 +1083,7 @@ __global__ void __launch_bounds__(256) fhog_grad4r_ml_k(MlStarts st, const LvDes
             }
         }
         const size_t idx = (size_t)yy * d.pitch;
-        *reinterpret_cast<float4*>(mg + idx) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<uint32_t*>(bn + idx) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+        *reinterpret_cast<uint4*>(pxo + idx) = make_uint4(pack_mag_bin(v[0], o[0]), pack_mag_bin(v[1], o[1]), pack_mag_bin(v[2], o[2]), pack_mag_bin(v[3], o[3]));
     }
 }
 
@@ -1086,8 +1092,8 @@ __global__ void __launch_bounds__(256) fhog_grad4r_ml_k(MlStarts st, const LvDes
 // still receives its votes in row-major order of its own 16 x 16 window (the order dlib's scatter loop produces), while the
 // (magnitude, bin) planes are read (HK + 1) / HK times instead of twice.  Two accumulator sets in LDS alternate between cells.
 #define HIST_CELLS 4
-__global__ void __launch_bounds__(256) fhog_hist4_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ mag_base,
-                                                       const uint8_t* __restrict__ bin_base, float* __restrict__ hist_base,
+__global__ void __launch_bounds__(256) fhog_hist4_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint32_t* __restrict__ px_base,
+                                                       float* __restrict__ hist_base,
                                                        float* __restrict__ norm_base)
 {
     constexpr int C = 8, HK = HIST_CELLS, NV = 2 * C / 4;
@@ -1108,16 +1114,12 @@ __global__ void __launch_bounds__(256) fhog_hist4_ml_k(MlStarts st, const LvDesc
     if (hx >= d.hc) return;
     const int hy0 = yb * HK;
     const int ncell = (d.hr - hy0 < HK) ? d.hr - hy0 : HK;       // cells of this lane that exist (block-uniform)
-    const float* mg = mag_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx + (size_t)(C * hy0) * d.pitch;
-    const uint8_t* bn = bin_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx + (size_t)(C * hy0) * d.pitch;
-    float4 pv[2][NV];
-    uint32_t pb[2][4];
-    auto load_row = [&](int r, float4* dv, uint32_t* db) {
+    const uint32_t* pxi = px_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx + (size_t)(C * hy0) * d.pitch;
+    uint4 pw[2][NV];
+    auto load_row = [&](int r, uint4* dw) {
         const size_t row = (size_t)r * d.pitch;
 #pragma unroll
-        for (int q = 0; q < NV; ++q) dv[q] = *reinterpret_cast<const float4*>(mg + row + 4 * q);
-        const uint4 t = *reinterpret_cast<const uint4*>(bn + row);
-        db[0] = t.x; db[1] = t.y; db[2] = t.z; db[3] = t.w;
+        for (int q = 0; q < NV; ++q) dw[q] = *reinterpret_cast<const uint4*>(pxi + row + 4 * q);
     };
     auto finish = [&](int j) {                                     // cell j of this lane is complete: write it out, clear its set
         const int hy = hy0 + j, set = j & 1;
@@ -1135,7 +1137,7 @@ __global__ void __launch_bounds__(256) fhog_hist4_ml_k(MlStarts st, const LvDesc
             norm_base[d.norm_off + (size_t)b * d.norm_stride + (size_t)(hy - 1) * d.cells_nc + (hx - 1)] = e;
     };
     const int nrows = C * (ncell + 1);
-    load_row(0, pv[0], pb[0]);
+    load_row(0, pw[0]);
     for (int g = 0; g <= ncell; ++g) {
         const bool lower = (g >= 1);            // rows of this band are the lower half of cell g - 1
         const bool upper = (g < ncell);         // ... and the upper half of cell g
@@ -1145,18 +1147,23 @@ __global__ void __launch_bounds__(256) fhog_hist4_ml_k(MlStarts st, const LvDesc
         for (int i = 0; i < C; ++i) {
             const int cur = i & 1;
             const int r = C * g + i;
-            if (r + 1 < nrows) load_row(r + 1, pv[cur ^ 1], pb[cur ^ 1]);
+            if (r + 1 < nrows) load_row(r + 1, pw[cur ^ 1]);
             const float fy = ((float)i + 0.5f) / (float)C;
             float v[2 * C];
+            int ob[2 * C];
 #pragma unroll
-            for (int q = 0; q < NV; ++q) { v[4 * q] = pv[cur][q].x; v[4 * q + 1] = pv[cur][q].y; v[4 * q + 2] = pv[cur][q].z; v[4 * q + 3] = pv[cur][q].w; }
+            for (int q = 0; q < NV; ++q) {
+                const uint32_t w4[4] = {pw[cur][q].x, pw[cur][q].y, pw[cur][q].z, pw[cur][q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[4 * q + e] = packed_mag(w4[e]); ob[4 * q + e] = packed_bin(w4[e]); }
+            }
             if (lower) {
 #pragma unroll
                 for (int wx = 0; wx < 2 * C; ++wx) {
                     const int j = wx % C;
                     const float fx = ((float)j + 0.5f) / (float)C;
                     const float wxv = (wx < C) ? fx : 1.0f - fx;
-                    const int o = (int)((pb[cur][wx >> 2] >> (8 * (wx & 3))) & 0xffu);
+                    const int o = ob[wx];
                     accl[o * 256] = accl[o * 256] + ((1.0f - fy) * wxv) * v[wx];
                 }
             }
@@ -1166,7 +1173,7 @@ __global__ void __launch_bounds__(256) fhog_hist4_ml_k(MlStarts st, const LvDesc
                     const int j = wx % C;
                     const float fx = ((float)j + 0.5f) / (float)C;
                     const float wxv = (wx < C) ? fx : 1.0f - fx;
-                    const int o = (int)((pb[cur][wx >> 2] >> (8 * (wx & 3))) & 0xffu);
+                    const int o = ob[wx];
                     accu[o * 256] = accu[o * 256] + (fy * wxv) * v[wx];
                 }
             }
@@ -1503,21 +1510,20 @@ static MlPlan* ml_features(Ctx* c, const std::vector<Frame>& frames, int upsampl
     const int B = (int)frames.size();
     MlPlan* p = ml_build_pyramid(c, frames, upsample);
     const uint8_t* lut2 = orientation_lut_tiled(c);
-    c->s_grad.ensure(p->px_elems * 5 + 256);
+    c->s_grad.ensure(p->px_elems * 4 + 256);
     c->s_hist.ensure(p->hist_floats * sizeof(float) + 64);
     c->s_norm.ensure(p->norm_floats * sizeof(float) + 64);
     c->s_feat.ensure(p->feat_floats * sizeof(float) + 64);
-    float* d_mag = c->s_grad.as<float>();
-    uint8_t* d_bin = c->s_grad.as<uint8_t>() + p->px_elems * 4;
+    uint32_t* d_px = c->s_grad.as<uint32_t>();
     {
         ProfScope ps(c, "fhog");
         {
             ProfScope p1(c, "fhog_grad");
-            hipLaunchKernelGGL(fhog_grad4r_ml_k, dim3(ml_grid(p->grad_blocks)), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_mag, d_bin, lut2);
+            hipLaunchKernelGGL(fhog_grad4r_ml_k, dim3(ml_grid(p->grad_blocks)), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_px, lut2);
         }
         {
             ProfScope p2(c, "fhog_hist");
-            hipLaunchKernelGGL(fhog_hist4_ml_k, dim3(ml_grid(p->hist_blocks)), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_mag, d_bin, c->s_hist.as<float>(),
+            hipLaunchKernelGGL(fhog_hist4_ml_k, dim3(ml_grid(p->hist_blocks)), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_px, c->s_hist.as<float>(),
                                c->s_norm.as<float>());
         }
         if (p->feat_blocks > 0) {
