@@ -104,6 +104,10 @@ int32_t pvf_tracker_commit_many(pvf_handle ctx, const pvf_handle* trks, const pv
 /* ref: tracking.py:129-134 _match on dlib.drectangle (width = r-l; empty -> area 0), :160-168 overlap matrix */
 int32_t pvf_overlap_matrix(const double* a, int32_t na, const double* b, int32_t nb, double ratio, double* out);
 /* ref: tracking.py:121,172  Munkres().compute(cost) on the square n x n matrix -> column of each row */
+/* _associate (tracking.py:136-182) in one call: gated overlaps, square padding, cost = max - overlap, Munkres, and only the pairs
+ * with a positive overlap.  trackers / detections: [n][4] doubles (l,t,r,b); det_of_tracker[t] = detection index or -1. */
+int32_t pvf_associate(const double* trackers, int32_t n_trackers, const double* detections, int32_t n_detections,
+                      double min_overlap_ratio, int32_t* det_of_tracker);
 int32_t pvf_munkres(const double* cost, int32_t n, int32_t* row_to_col);
 
 /* ---- S4 landmarks + embedding ---------------------------------------------------------------------- */

@@ -391,6 +391,35 @@ extern "C" int32_t pvf_overlap_matrix(const double* a, int32_t na, const double*
     overlap_matrix_host(a, na, b, nb, ratio, out);
     API_END
 }
+// _associate of the reference in one call (tracking.py:136-182): gated overlap matrix, padded to square, cost = max - overlap,
+// Munkres, and the pairs whose overlap is positive.  det_of_tracker[t] = matched detection index or -1.
+extern "C" int32_t pvf_associate(const double* trackers, int32_t n_trackers, const double* detections, int32_t n_detections, double ratio,
+                                 int32_t* det_of_tracker)
+{
+    API_BEGIN
+    PVF_REQUIRE(n_trackers >= 0 && n_detections >= 0 && det_of_tracker, "pvf_associate: bad arguments");
+    for (int t = 0; t < n_trackers; ++t) det_of_tracker[t] = -1;
+    if (n_trackers < 1 || n_detections < 1) return 0;
+    const int n = std::max(n_trackers, n_detections);
+    std::vector<double> ov((size_t)n_trackers * n_detections), area((size_t)n * n, 0.0), cost((size_t)n * n);
+    overlap_matrix_host(trackers, n_trackers, detections, n_detections, ratio, ov.data());
+    double mx = 0.0;                                           // np.max over the padded matrix (it contains zeros)
+    for (int t = 0; t < n_trackers; ++t)
+        for (int d = 0; d < n_detections; ++d) {
+            const double v = ov[(size_t)t * n_detections + d];
+            area[(size_t)t * n + d] = v;
+            if (v > mx) mx = v;
+        }
+    for (size_t i = 0; i < cost.size(); ++i) cost[i] = mx - area[i];
+    std::vector<int32_t> r2c(n);
+    munkres_host(cost.data(), n, r2c.data());
+    for (int t = 0; t < n_trackers; ++t) {
+        const int d = r2c[t];
+        if (d < n_detections && area[(size_t)t * n + d] > 0.0) det_of_tracker[t] = d;
+    }
+    API_END
+}
+
 extern "C" int32_t pvf_munkres(const double* cost, int32_t n, int32_t* row_to_col)
 {
     API_BEGIN

@@ -52,6 +52,7 @@ _SIGS = {
     "pvf_tracker_commit_many": (C.c_int32, [H, P, P, C.c_int32]),
     "pvf_overlap_matrix": (C.c_int32, [P, C.c_int32, P, C.c_int32, C.c_double, P]),
     "pvf_munkres": (C.c_int32, [P, C.c_int32, P]),
+    "pvf_associate": (C.c_int32, [P, C.c_int32, P, C.c_int32, C.c_double, P]),
     "pvf_landmarks": (C.c_int32, [H, P, P, C.c_int32, P]),
     "pvf_embed": (C.c_int32, [H, P, P, C.c_int32, P]),
     "pvf_embed_chips": (C.c_int32, [H, P, C.c_int32, P]),
@@ -113,6 +114,15 @@ def overlap_matrix(a, b, ratio):
     out = np.zeros((len(a), len(b)), np.float64)
     check(lib().pvf_overlap_matrix(ptr(a), len(a), ptr(b), len(b), float(ratio), ptr(out)))
     return out
+
+
+def associate(trackers, detections, ratio):
+    """[(tracker row, detection index)] of the reference's _associate, tracker rows ascending"""
+    a = np.ascontiguousarray(trackers, np.float64).reshape(-1, 4)
+    b = np.ascontiguousarray(detections, np.float64).reshape(-1, 4)
+    out = np.empty(len(a), np.int32)
+    check(lib().pvf_associate(ptr(a), len(a), ptr(b), len(b), float(ratio), ptr(out)))
+    return [(t, int(d)) for t, d in enumerate(out) if d >= 0]
 
 
 def munkres(cost):

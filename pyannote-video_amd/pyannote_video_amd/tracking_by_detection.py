@@ -233,21 +233,10 @@ class TrackingByDetection(object):
 
     def _associate(self, positions, detections):
         """positions: [(identifier, (l,t,r,b))] in tracker order. Returns {detection index: identifier} (tracking.py:136-182)."""
-        n_trackers, n_detections = len(positions), len(detections)
-        if n_trackers < 1 or n_detections < 1:
+        if len(positions) < 1 or len(detections) < 1:
             return dict()
-        n = max(n_trackers, n_detections)
-        overlap_area = np.zeros((n, n))
-        overlap_area[:n_trackers, :n_detections] = _lib.overlap_matrix(
-            [p for _, p in positions], [tuple(float(v) for v in d) for d in detections], self.track_min_overlap_ratio)
-        match = {}
-        mapping = _lib.munkres(np.max(overlap_area) - overlap_area)
-        for t, d in mapping:
-            if t >= n_trackers or d >= n_detections:
-                continue
-            if overlap_area[t, d] > 0.:
-                match[d] = positions[t][0]
-        return match
+        pairs = _lib.associate([p for _, p in positions], detections, self.track_min_overlap_ratio)
+        return {d: positions[t][0] for t, d in pairs}
 
     # ---- one pass over one shot, written as a coroutine that asks for batched tracker work -------------------
     def _lane(self, cache, detections_at, direction, edges, backend=None, plan=None):

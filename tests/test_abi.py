@@ -45,3 +45,21 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert not re.search(r"pvo_[a-z0-9_]+\s*\(", src) and "libpvo" not in src, f   # comments may cite oracle files
+
+
+def test_associate_equals_overlap_plus_munkres_composition():
+    """pvf_associate == the reference's _associate written out with the two host helpers (tracking.py:136-182)"""
+    from pyannote_video_amd import _lib
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        nt, nd = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        def boxes(n):
+            c = rng.uniform(50, 400, (n, 2)); s = rng.uniform(20, 120, (n, 1))
+            return [tuple(float(v) for v in (c[i, 0] - s[i, 0], c[i, 1] - s[i, 0], c[i, 0] + s[i, 0], c[i, 1] + s[i, 0])) for i in range(n)]
+        T, D = boxes(nt), boxes(nd)
+        ratio = float(rng.choice([0.2, 0.5]))
+        n = max(nt, nd)
+        area = np.zeros((n, n))
+        area[:nt, :nd] = _lib.overlap_matrix(T, D, ratio)
+        want = [(t, d) for t, d in _lib.munkres(np.max(area) - area) if t < nt and d < nd and area[t, d] > 0.]
+        assert _lib.associate(T, D, ratio) == want
