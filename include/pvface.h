@@ -79,6 +79,10 @@ int32_t pvf_tracker_create(pvf_handle ctx, pvf_handle* trk);
 /* n trackers at once / n trackers back to the pool: the batched host path creates and kills a few thousand per shot */
 int32_t pvf_tracker_create_many(pvf_handle ctx, int32_t n, pvf_handle* trks);
 int32_t pvf_tracker_destroy_many(pvf_handle ctx, const pvf_handle* trks, int32_t n);
+/* n new trackers that are exact copies (filters, position) of started trackers without a pending deferred update.  The two
+ * passes over a shot (tracking.py:184-259 forward, then backward) start one tracker per detection from the same frame and box:
+ * the second pass clones instead of recomputing the same filters. */
+int32_t pvf_tracker_clone_many(pvf_handle ctx, const pvf_handle* src, int32_t n, pvf_handle* dst);
 int32_t pvf_tracker_destroy(pvf_handle ctx, pvf_handle trk);
 /* ref: tracking.py:251  tracker.start_track(frame, dlib.drectangle(*detection)) ; box = (l,t,r,b) doubles */
 int32_t pvf_tracker_start(pvf_handle ctx, pvf_handle trk, pvf_handle frame, const double box[4]);

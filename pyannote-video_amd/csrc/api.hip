@@ -160,6 +160,18 @@ extern "C" int32_t pvf_tracker_create_many(pvf_handle h, int32_t n, pvf_handle* 
     API_END
 }
 
+extern "C" int32_t pvf_tracker_clone_many(pvf_handle h, const pvf_handle* src, int32_t n, pvf_handle* dst)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    PVF_REQUIRE(n >= 0, "negative count");
+    std::vector<Tracker*> s(n), d(n);
+    for (int i = 0; i < n; ++i) s[i] = &c->tracker(src[i]);
+    for (int i = 0; i < n; ++i) { dst[i] = tracker_new(c); d[i] = &c->tracker(dst[i]); }
+    dsst_clone_many(c, s, d);
+    API_END
+}
+
 extern "C" int32_t pvf_tracker_destroy_many(pvf_handle h, const pvf_handle* trks, int32_t n)
 {
     API_BEGIN

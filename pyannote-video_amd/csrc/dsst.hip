@@ -525,6 +525,37 @@ __global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__
     }
 }
 
+// copies of freshly started trackers (both passes of a shot start one tracker per detection from the same frame and box, so the
+// second pass clones the first pass's trackers instead of computing the same filters again)
+__global__ void __launch_bounds__(256) clone_state_k(const double* const* __restrict__ src, double* const* __restrict__ dst)
+{
+    const double2* s = reinterpret_cast<const double2*>(src[blockIdx.y]);
+    double2* d = reinterpret_cast<double2*>(dst[blockIdx.y]);
+    constexpr int N2 = (int)(TRK_DOUBLES / 2);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < N2; i += gridDim.x * 256) d[i] = s[i];
+}
+
+void dsst_clone_many(Ctx* c, const std::vector<Tracker*>& src, const std::vector<Tracker*>& dst)
+{
+    const int n = (int)src.size();
+    if (n == 0) return;
+    static_assert(TRK_DOUBLES % 2 == 0, "tracker state is copied as double2");
+    c->s_misc.ensure((size_t)2 * n * sizeof(void*));
+    c->h_misc.ensure((size_t)2 * n * sizeof(void*));
+    double** hp = c->h_misc.as<double*>();
+    for (int i = 0; i < n; ++i) {
+        PVF_REQUIRE(src[i]->started && !src[i]->pending, "clone: source tracker must be started and have no deferred update");
+        hp[i] = src[i]->d_state; hp[n + i] = dst[i]->d_state;
+        memcpy(dst[i]->pos, src[i]->pos, sizeof src[i]->pos);
+        dst[i]->started = true; dst[i]->pending = false;
+    }
+    HIP_CHECK(hipMemcpyAsync(c->s_misc.p, hp, (size_t)2 * n * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+    ProfScope ps(c, "dsst");
+    hipLaunchKernelGGL(clone_state_k, dim3(64, n), dim3(256), 0, c->stream, c->s_misc.as<const double*>(), c->s_misc.as<double*>() + n);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+
 // commit of a deferred update: put the position the update started from back into the tracker state
 __global__ void restore_pos_k(const TrkJob* __restrict__ jobs, int n)
 {

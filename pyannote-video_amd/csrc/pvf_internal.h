@@ -243,6 +243,7 @@ void face_chip_details(const EmbedModel& m, const int32_t* pts68, ChipDetails* o
 void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out);
 // tracker (dsst.hip)
 void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes);
+void dsst_clone_many(Ctx* c, const std::vector<Tracker*>& src, const std::vector<Tracker*>& dst);
 void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, double* psr, double* boxes_out, int mode = 0);
 // association (assoc.cpp part of api)
 void overlap_matrix_host(const double* a, int na, const double* b, int nb, double ratio, double* out);

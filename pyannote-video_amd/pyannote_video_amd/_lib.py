@@ -43,6 +43,7 @@ _SIGS = {
     "pvf_tracker_destroy": (C.c_int32, [H, H]),
     "pvf_tracker_create_many": (C.c_int32, [H, C.c_int32, P]),
     "pvf_tracker_destroy_many": (C.c_int32, [H, P, C.c_int32]),
+    "pvf_tracker_clone_many": (C.c_int32, [H, P, C.c_int32, P]),
     "pvf_tracker_start": (C.c_int32, [H, H, H, P]),
     "pvf_tracker_update": (C.c_int32, [H, H, H, P]),
     "pvf_tracker_position": (C.c_int32, [H, H, P]),

@@ -247,8 +247,11 @@ class FacePipeline(object):
                     det_at = {t: d for (t, _), d in zip(cache, dets)}
                     with lock:
                         release_dead()
-                        plan_f = backend.speculate(cache, det_at)
-                        plan_b = backend.speculate(list(reversed(cache)), det_at)
+                        if hasattr(backend, "speculate_pair"):
+                            plan_f, plan_b = backend.speculate_pair(cache, det_at)
+                        else:
+                            plan_f = backend.speculate(cache, det_at)
+                            plan_b = backend.speculate(list(reversed(cache)), det_at)
                     note("speculated", k)
                     ready.put((k, dets, (plan_f, plan_b)))
                     if k == n - 1:

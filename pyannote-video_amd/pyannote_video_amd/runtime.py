@@ -215,6 +215,12 @@ class Context(object):
             check(self._l.pvf_tracker_create_many(self._h, int(n), ptr(out)))
         return [int(v) for v in out]
 
+    def tracker_clone_many(self, trks):
+        out = np.zeros(len(trks), np.uint64)
+        if len(trks):
+            check(self._l.pvf_tracker_clone_many(self._h, ptr(handles(trks)), len(trks), ptr(out)))
+        return [int(v) for v in out]
+
     def tracker_destroy_many(self, trks):
         if self._h is not None and len(trks):
             check(self._l.pvf_tracker_destroy_many(self._h, ptr(handles(trks)), len(trks)))

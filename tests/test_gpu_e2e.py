@@ -36,6 +36,25 @@ def test_pipeline_matches_oracle_flow(ctx, oracle, small_video, model_paths):
     assert ref_flow.cluster(em, 0.6) == res["labels"]
 
 
+def test_pipeline_with_sparse_detection_matches_oracle_flow(ctx, oracle, small_video, model_paths):
+    """detection every 3rd frame: trackers have to live between detections, i.e. the deferred first updates of the bulk path are
+    committed and followed by on-demand updates; tracks must still equal the sequential oracle flow"""
+    from pyannote_video_amd import models, pipeline
+    from oracle import ref_flow
+    v = small_video
+    frames_np = [v.frame(i) for i in range(v.n_frames)]
+    times = [v.timestamp(i) for i in range(v.n_frames)]
+    every = 3.0 / v.frame_rate
+    pipe = pipeline.FacePipeline(ctx, model_paths[0], model_paths[1], detect_every=every, detect_batch_size=4)
+    res = pipe.run([ctx.upload(f) for f in frames_np], times, v.frame_rate, v.shots(), cluster=False)
+    det = oracle.Detector(models.load_container(models.DEFAULT_DETECTOR))
+    tabs = models.dsst_tables()
+    ref_tracks = ref_flow.track_video(frames_np, times, v.shots(), det, lambda: oracle.Tracker(tabs), v.frame_rate,
+                                      detect_every=every, min_conf=10., ratio=0.5, max_gap=1.0)
+    assert any("forward" in st or "backward" in st for tr in ref_tracks for _, _, st in tr)
+    assert res["tracks"] == ref_tracks
+
+
 def test_reference_api_surface(ctx, small_video, model_paths):
     """Face / FaceTracking / FaceClustering used the way scripts/pyannote-face.py uses them (:247-267, :281-311)"""
     from pyannote_video_amd import Face, FaceTracking, FaceClustering

@@ -215,6 +215,30 @@ def test_tracker_deferred_update_and_commit_bit_exact(ctx, oracle, small_video):
     ctx.tracker_destroy_many(trk)
 
 
+def test_tracker_clone_bit_exact(ctx, oracle, small_video):
+    """a cloned tracker behaves exactly like the one it was copied from (and like the oracle's)"""
+    from pyannote_video_amd import models
+    tabs = models.dsst_tables()
+    f0, f1 = small_video.frame(4), small_video.frame(3)
+    boxes = ctx.detect(f0, 1)[0]
+    dbox = [tuple(float(v) for v in b) for b in boxes]
+    n = len(dbox)
+    trk = ctx.tracker_create_many(n)
+    ctx.tracker_start_many(trk, [f0] * n, dbox)
+    twin = ctx.tracker_clone_many(trk)
+    _, A0, B0 = ctx.tracker_state(trk[0])
+    _, A1, B1 = ctx.tracker_state(twin[0])
+    assert np.array_equal(A0, A1) and np.array_equal(B0, B1)
+    assert [ctx.tracker_position(t) for t in twin] == [ctx.tracker_position(t) for t in trk]
+    pa, ba = ctx.tracker_update_many(trk, [f1] * n)
+    pb, bb = ctx.tracker_update_many(twin, [f1] * n)
+    assert np.array_equal(pa, pb) and np.array_equal(ba, bb)
+    ref = oracle.Tracker(tabs)
+    ref.start_track(f0, dbox[0])
+    assert ref.update(f1) == pb[0] and ref.get_position() == tuple(bb[0])
+    ctx.tracker_destroy_many(trk + twin)
+
+
 def test_pair_mean_dist_and_hac(ctx, oracle):
     rng = np.random.default_rng(5)
     K, T = 9, 60
