@@ -162,14 +162,16 @@ static void load_embedder(Ctx* c, const char* path)
         ConvLayer L{cin, cout, k, stride, pad, nullptr, nullptr, nullptr, nullptr};
         const size_t nw = (size_t)cout * cin * k * k;
         PVF_REQUIRE(p + nw + 3 * (size_t)cout <= end, "emb.blob too short");
-        std::vector<float> wt(nw);
-        // [cout][cin][r][s] -> [(r*k+s)*cin + c][cout]
+        // [cout][cin][r][s] -> [(r*k+s)*cp + c][cout]; the 3-channel input layer is stored with a fourth, all-zero channel
+        // (cp = 4) so that the kernel stages one pixel tap with one 16-byte load: x + 0 * w is exact, the chain is unchanged
+        const int cp = (cin == 3) ? 4 : cin;
+        std::vector<float> wt((size_t)k * k * cp * cout, 0.0f);
         for (int o = 0; o < cout; ++o)
             for (int ci = 0; ci < cin; ++ci)
                 for (int r = 0; r < k; ++r)
                     for (int s = 0; s < k; ++s)
-                        wt[((size_t)(r * k + s) * cin + ci) * cout + o] = p[(((size_t)o * cin + ci) * k + r) * k + s];
-        L.d_w = upload<float>(wt.data(), nw);
+                        wt[((size_t)(r * k + s) * cp + ci) * cout + o] = p[(((size_t)o * cin + ci) * k + r) * k + s];
+        L.d_w = upload<float>(wt.data(), wt.size());
         p += nw;
         L.d_bias = upload<float>(p, cout); p += cout;
         L.d_gamma = upload<float>(p, cout); p += cout;

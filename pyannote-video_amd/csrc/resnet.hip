@@ -44,13 +44,13 @@ void face_chip_details(const EmbedModel& m, const int32_t* pts, ChipDetails* out
 }
 
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) prep_input_k(const uint8_t* __restrict__ chips, float* __restrict__ out, size_t n)
+// chips u8 [n][3] -> network input f32 [n][4] (fourth channel 0, see the weight layout in ctx.hip)
+__global__ void __launch_bounds__(256) prep_input_k(const uint8_t* __restrict__ chips, float4* __restrict__ out, size_t n_px)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % 3);
-    const float avg = c == 0 ? 122.782f : (c == 1 ? 117.001f : 104.298f);
-    out[i] = ((float)chips[i] - avg) / 256.0f;
+    if (i >= n_px) return;
+    const uint8_t* q = chips + 3 * i;
+    out[i] = make_float4(((float)q[0] - 122.782f) / 256.0f, ((float)q[1] - 117.001f) / 256.0f, ((float)q[2] - 104.298f) / 256.0f, 0.0f);
 }
 
 struct ConvArgs {
@@ -66,7 +66,7 @@ struct ConvArgs {
 };
 
 // BM = 32*WM output pixels, BN = 32*WN output channels, KC = 32 per stage
-template <int WM, int WN, bool GENERIC>
+template <int WM, int WN>
 __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
 {
     constexpr int BM = 32 * WM, BN = 32 * WN, KC = 32;
@@ -87,22 +87,20 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     constexpr int B_F4 = KC * BN / 4 / 256;
     int pa_b[A_F4], pa_y[A_F4], pa_x[A_F4], pa_i[A_F4], pa_j[A_F4];
     bool pa_ok[A_F4];
-    if (!GENERIC) {
 #pragma unroll
-        for (int q = 0; q < A_F4; ++q) {
-            const int idx = tid + q * 256;     // over BM * 8
-            const int i = idx >> 3, j = idx & 7;
-            const long m = m0 + i;
-            pa_i[q] = i; pa_j[q] = j;
-            pa_ok[q] = false; pa_b[q] = 0; pa_y[q] = 0; pa_x[q] = 0;
-            if (m < M) {
-                const int ox = (int)(m % a.OW);
-                const long t = m / a.OW;
-                const int oy = (int)(t % a.OH);
-                pa_b[q] = (int)(t / a.OH);
-                pa_ok[q] = (oy < a.AH && ox < a.AW);
-                pa_y[q] = oy * a.stride - a.pad; pa_x[q] = ox * a.stride - a.pad;
-            }
+    for (int q = 0; q < A_F4; ++q) {
+        const int idx = tid + q * 256;     // over BM * 8
+        const int i = idx >> 3, j = idx & 7;
+        const long m = m0 + i;
+        pa_i[q] = i; pa_j[q] = j;
+        pa_ok[q] = false; pa_b[q] = 0; pa_y[q] = 0; pa_x[q] = 0;
+        if (m < M) {
+            const int ox = (int)(m % a.OW);
+            const long t = m / a.OW;
+            const int oy = (int)(t % a.OH);
+            pa_b[q] = (int)(t / a.OH);
+            pa_ok[q] = (oy < a.AH && ox < a.AW);
+            pa_y[q] = oy * a.stride - a.pad; pa_x[q] = ox * a.stride - a.pad;
         }
     }
     const int Kpad = (a.K + KC - 1) / KC * KC;
@@ -110,14 +108,20 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     // a block no longer waits for memory between its two barriers
     float4 va[A_F4], vb[B_F4];
     auto fetch = [&](int k0) {
-        const int tap = k0 / a.Cin, c0 = k0 % a.Cin;
-        const int r = tap / a.ksz, s = tap % a.ksz;
+        // one float4 = 4 consecutive input channels of one filter tap.  Cin >= 32: the whole chunk lies in one tap;
+        // Cin == 4 (the padded RGB input): every float4 is a tap of its own
+        const bool one_tap = (a.Cin >= KC);
+        const int tap0 = k0 / a.Cin, c00 = k0 - tap0 * a.Cin;
 #pragma unroll
         for (int q = 0; q < A_F4; ++q) {
             va[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kq = k0 + 4 * pa_j[q];
+            int tap = tap0, c0 = c00 + 4 * pa_j[q];
+            if (!one_tap) { tap = kq / a.Cin; c0 = kq - tap * a.Cin; }
+            const int r = tap / a.ksz, s = tap - r * a.ksz;
             const int iy = pa_y[q] + r, ix = pa_x[q] + s;
-            if (pa_ok[q] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                va[q] = *reinterpret_cast<const float4*>(a.in + (((size_t)pa_b[q] * a.H + iy) * a.W + ix) * a.Cin + c0 + 4 * pa_j[q]);
+            if (kq < a.K && pa_ok[q] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                va[q] = *reinterpret_cast<const float4*>(a.in + (((size_t)pa_b[q] * a.H + iy) * a.W + ix) * a.Cin + c0);
         }
 #pragma unroll
         for (int q = 0; q < B_F4; ++q) {
@@ -144,41 +148,11 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
             *reinterpret_cast<float4*>(&Bs[kk * PB + 4 * j4]) = vb[q];
         }
     };
-    if (!GENERIC) fetch(0);
+    fetch(0);
     for (int k0 = 0; k0 < Kpad; k0 += KC) {
-        if (!GENERIC) {
-            park();
-        } else {
-            for (int idx = tid; idx < BM * KC; idx += 256) {
-                const int i = idx / KC, kk = idx % KC;
-                const int k = k0 + kk;
-                const long m = m0 + i;
-                float v = 0.0f;
-                if (k < a.K && m < M) {
-                    const int ox = (int)(m % a.OW);
-                    const long t = m / a.OW;
-                    const int oy = (int)(t % a.OH);
-                    const int b = (int)(t / a.OH);
-                    const int tap = k / a.Cin, ci = k % a.Cin;
-                    const int r = tap / a.ksz, s = tap % a.ksz;
-                    const int iy = oy * a.stride - a.pad + r, ix = ox * a.stride - a.pad + s;
-                    if (oy < a.AH && ox < a.AW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                        v = a.in[(((size_t)b * a.H + iy) * a.W + ix) * a.Cin + ci];
-                }
-                As[kk * PA + i] = v;
-            }
-#pragma unroll
-            for (int q = 0; q < B_F4; ++q) {
-                const int idx = tid + q * 256;          // over KC * BN/4
-                const int kk = idx / (BN / 4), j4 = idx % (BN / 4);
-                const int k = k0 + kk;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < a.K) v = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + n0 + 4 * j4);
-                *reinterpret_cast<float4*>(&Bs[kk * PB + 4 * j4]) = v;
-            }
-        }
+        park();
         __syncthreads();
-        if (!GENERIC && k0 + KC < Kpad) fetch(k0 + KC);
+        if (k0 + KC < Kpad) fetch(k0 + KC);
         const int ai = wm * 32 + (lane & 31), bj = wn * 32 + (lane & 31), kh = lane >> 5;
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 2) {
@@ -252,14 +226,12 @@ __global__ void __launch_bounds__(256) head_k(const float* __restrict__ x, int H
 static void launch_conv(Ctx* c, const ConvArgs& a)
 {
     const long M = (long)a.B * a.OH * a.OW;
-    if (a.Cin % 32 != 0) {
-        PVF_REQUIRE(a.Cout == 32, "generic conv path expects 32 output channels");
-        hipLaunchKernelGGL((conv_mfma_k<4, 1, true>), dim3((unsigned)((M + 127) / 128), 1), dim3(256), 0, c->stream, a);
-    } else if (a.Cout == 32) {
-        hipLaunchKernelGGL((conv_mfma_k<4, 1, false>), dim3((unsigned)((M + 127) / 128), 1), dim3(256), 0, c->stream, a);
+    PVF_REQUIRE(a.Cin % 32 == 0 || a.Cin == 4, "conv: input channels must be 4 (padded RGB) or a multiple of 32");
+    if (a.Cout == 32) {
+        hipLaunchKernelGGL((conv_mfma_k<4, 1>), dim3((unsigned)((M + 127) / 128), 1), dim3(256), 0, c->stream, a);
     } else {
         PVF_REQUIRE(a.Cout % 64 == 0, "conv: Cout must be 32 or a multiple of 64");
-        hipLaunchKernelGGL((conv_mfma_k<2, 2, false>), dim3((unsigned)((M + 63) / 64), a.Cout / 64), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((conv_mfma_k<2, 2>), dim3((unsigned)((M + 63) / 64), a.Cout / 64), dim3(256), 0, c->stream, a);
     }
 }
 
@@ -273,7 +245,7 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
     const int h1 = 1 + (S - 7) / 2;       // 72
     const int hp = 1 + (h1 - 3) / 2;      // 35
     const size_t big = (size_t)MAXB * h1 * h1 * 32;
-    c->s_act0.ensure(std::max(big, (size_t)MAXB * S * S * 3) * sizeof(float));
+    c->s_act0.ensure(std::max(big, (size_t)MAXB * S * S * 4) * sizeof(float));
     c->s_act1.ensure(big * sizeof(float));
     c->s_act2.ensure((size_t)MAXB * hp * hp * 32 * sizeof(float) + (size_t)MAXB * 128 * sizeof(float));
     for (int b0 = 0; b0 < n; b0 += MAXB) {
@@ -282,13 +254,14 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
         float* x = c->s_act0.as<float>();
         float* y = c->s_act1.as<float>();
         float* z = c->s_act2.as<float>();
-        const size_t nin = (size_t)B * S * S * 3;
-        hipLaunchKernelGGL(prep_input_k, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, c->stream, d_chips + (size_t)b0 * S * S * 3, x, nin);
+        const size_t nin = (size_t)B * S * S;
+        hipLaunchKernelGGL(prep_input_k, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, c->stream, d_chips + (size_t)b0 * S * S * 3,
+                           reinterpret_cast<float4*>(x), nin);
         // conv1 -> y ; maxpool -> z
         ConvArgs a;
         memset(&a, 0, sizeof a);
         const ConvLayer& L0 = e.convs[0];
-        a.in = x; a.B = B; a.H = S; a.W = S; a.Cin = 3; a.w = L0.d_w; a.K = 7 * 7 * 3; a.bias = L0.d_bias; a.gamma = L0.d_gamma; a.beta = L0.d_beta;
+        a.in = x; a.B = B; a.H = S; a.W = S; a.Cin = 4; a.w = L0.d_w; a.K = 7 * 7 * 4; a.bias = L0.d_bias; a.gamma = L0.d_gamma; a.beta = L0.d_beta;
         a.out = y; a.OH = h1; a.OW = h1; a.Cout = 32; a.AH = h1; a.AW = h1; a.ksz = 7; a.stride = 2; a.pad = 0; a.relu = 1; a.skip_mode = 0;
         launch_conv(c, a);
         const size_t npool = (size_t)B * hp * hp * 32;
