@@ -134,6 +134,13 @@ int32_t pvf_pair_mean_dist(pvf_handle ctx, const double* X, int32_t N, int32_t d
 /* ref: clustering.py:116-119,138-148  FaceClustering(threshold)(starting_point, features): average-linkage HAC from the
  * track partition, stop when the closest pair's mean distance exceeds `threshold`;
  * labels[t] = smallest track index of t's cluster; merge_log optional [(T-1)*4] = (a, b, dist, new_size) */
+/* The two halves of pvf_cluster_tracks for several GPUs sharing one global clustering (dist.py): rows [track0, track1) of the
+ * track-pair mean-distance matrix D (T x T, row-major; other rows are left untouched) from the gathered embeddings, and the
+ * agglomeration of a complete D.  Every entry of D is produced by the same sequential chain as in the single call. */
+int32_t pvf_pair_mean_dist_rows(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
+                                int32_t track0, int32_t track1, double* D);
+int32_t pvf_cluster_dist(pvf_handle ctx, const double* D, const int32_t* row_start, int32_t T, double threshold,
+                         int32_t* labels, double* merge_log, int32_t* n_merges);
 int32_t pvf_cluster_tracks(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start,
                            int32_t T, double threshold, int32_t* labels, double* merge_log, int32_t* n_merges);
 

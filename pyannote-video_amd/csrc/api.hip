@@ -529,6 +529,29 @@ extern "C" int32_t pvf_pair_mean_dist(pvf_handle h, const double* X, int32_t N, 
     API_END
 }
 
+extern "C" int32_t pvf_pair_mean_dist_rows(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
+                                           int32_t track0, int32_t track1, double* D)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    pair_mean_dist_dev(c, X, N, dim, row_start, T, D, nullptr, track0, track1);
+    API_END
+}
+
+extern "C" int32_t pvf_cluster_dist(pvf_handle h, const double* D, const int32_t* row_start, int32_t T, double threshold, int32_t* labels,
+                                    double* merge_log, int32_t* n_merges)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    PVF_REQUIRE(T > 0 && D && row_start && labels, "pvf_cluster_dist: bad arguments");
+    c->s_clu1.ensure((size_t)T * T * sizeof(double) + (size_t)T * 64 + 4096);
+    double* dD = c->s_clu1.as<double>();
+    HIP_CHECK(hipMemcpyAsync(dD, D, (size_t)T * T * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int n = hac_dev(c, dD, row_start, T, threshold, labels, merge_log);
+    if (n_merges) *n_merges = n;
+    API_END
+}
+
 extern "C" int32_t pvf_cluster_tracks(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
                                       double threshold, int32_t* labels, double* merge_log, int32_t* n_merges)
 {

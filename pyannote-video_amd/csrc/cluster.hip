@@ -19,12 +19,12 @@ __global__ void __launch_bounds__(256) transpose_k(const double* __restrict__ X,
 // then one lane per track continues that track's running sum over the chunk in row order (a single sequential chain).
 #define PD_CHUNK 2048
 __global__ void __launch_bounds__(256) row_track_sums_k(const double* __restrict__ X, const double* __restrict__ Xt, int N, int dim,
-                                                        const int32_t* __restrict__ row_start, int T, double* __restrict__ S)
+                                                        const int32_t* __restrict__ row_start, int T, double* __restrict__ S, int a0)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[]; // xa[dim] + dist[PD_CHUNK]
     double* xa = sm;
     double* dist = sm + dim;
-    const int a = blockIdx.x, tid = threadIdx.x;
+    const int a = a0 + blockIdx.x, tid = threadIdx.x;
     for (int k = tid; k < dim; k += 256) xa[k] = X[(size_t)a * dim + k];
     for (int j = tid; j < T; j += 256) S[(size_t)a * T + j] = 0.0;
     __syncthreads();
@@ -49,10 +49,10 @@ __global__ void __launch_bounds__(256) row_track_sums_k(const double* __restrict
 }
 
 __global__ void __launch_bounds__(256) track_pair_mean_k(const double* __restrict__ S, const int32_t* __restrict__ row_start, int T,
-                                                         double* __restrict__ D)
+                                                         double* __restrict__ D, int t0)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = blockIdx.y;
+    const int i = t0 + blockIdx.y;
     if (j >= T) return;
     if (i == j) { D[(size_t)i * T + j] = 0.0; return; }
     double sum = 0;
@@ -61,8 +61,14 @@ __global__ void __launch_bounds__(256) track_pair_mean_k(const double* __restric
     D[(size_t)i * T + j] = sum / cnt;
 }
 
-void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* row_start, int T, double* h_D, double** d_D_keep)
+// D rows of the tracks [t0, t1) only (all columns): the unit of work when several GPUs split the pairwise distances of one
+// global clustering -- a track's rows all live in one contiguous block, so every entry of D is still produced by one sequential
+// chain, the same one the single-GPU call runs.  h_D / d_D_keep address the full T x T matrix (rows outside the range untouched).
+void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* row_start, int T, double* h_D, double** d_D_keep,
+                        int t0, int t1)
 {
+    if (t1 < 0) t1 = T;
+    PVF_REQUIRE(0 <= t0 && t0 <= t1 && t1 <= T, "pair_mean_dist: bad track range");
     PVF_REQUIRE(N > 0 && T > 0 && dim > 0 && dim <= 4096, "pair_mean_dist: bad sizes");
     PVF_REQUIRE(row_start[0] == 0 && row_start[T] == N, "pair_mean_dist: row_start must cover [0, N)");
     const size_t xb = (size_t)N * dim * sizeof(double);
@@ -80,11 +86,15 @@ void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* 
     {
         ProfScope ps(c, "pdist");
         hipLaunchKernelGGL(transpose_k, dim3((unsigned)(((size_t)N * dim + 255) / 256)), dim3(256), 0, c->stream, dX, N, dim, dXt);
-        hipLaunchKernelGGL(row_track_sums_k, dim3(N), dim3(256), (dim + PD_CHUNK) * sizeof(double), c->stream, dX, dXt, N, dim, dR, T, dS);
-        hipLaunchKernelGGL(track_pair_mean_k, dim3((T + 255) / 256, T), dim3(256), 0, c->stream, dS, dR, T, dD);
+        const int a0 = row_start[t0], a1 = row_start[t1];
+        if (a1 > a0)
+            hipLaunchKernelGGL(row_track_sums_k, dim3(a1 - a0), dim3(256), (dim + PD_CHUNK) * sizeof(double), c->stream, dX, dXt, N, dim, dR, T, dS, a0);
+        if (t1 > t0)
+            hipLaunchKernelGGL(track_pair_mean_k, dim3((T + 255) / 256, t1 - t0), dim3(256), 0, c->stream, dS, dR, T, dD, t0);
     }
     HIP_CHECK(hipGetLastError());
-    if (h_D) HIP_CHECK(hipMemcpyAsync(h_D, dD, db, hipMemcpyDeviceToHost, c->stream));
+    if (h_D && t1 > t0)
+        HIP_CHECK(hipMemcpyAsync(h_D + (size_t)t0 * T, dD + (size_t)t0 * T, (size_t)(t1 - t0) * T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (d_D_keep) *d_D_keep = dD;
 }

@@ -249,5 +249,6 @@ void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<
 void overlap_matrix_host(const double* a, int na, const double* b, int nb, double ratio, double* out);
 void munkres_host(const double* cost, int n, int32_t* row_to_col);
 // clustering (cluster.hip)
-void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* row_start, int T, double* h_D, double** d_D_keep);
+void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* row_start, int T, double* h_D, double** d_D_keep,
+                        int t0 = 0, int t1 = -1);
 int hac_dev(Ctx* c, double* d_D, const int32_t* row_start, int T, double threshold, int32_t* labels, double* merge_log);

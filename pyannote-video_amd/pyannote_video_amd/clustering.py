@@ -61,6 +61,7 @@ class FaceClustering(object):
         self.ctx = ctx
         self.logger = logger
         self.history = None
+        self.shard = None      # dist.DistanceShard when the pairwise distances are split over the ranks of a job
 
     def cluster_arrays(self, track_ids, row_track, X):
         """labels for `track_ids` (sorted unique ints) given per-row track ids; X float64 [N, dim]"""
@@ -72,7 +73,15 @@ class FaceClustering(object):
         Xs = np.ascontiguousarray(X[rows], np.float64)
         counts = np.array([(rt == t).sum() for t in track_ids], np.int64)
         row_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-        labels, log = ctx.cluster_tracks(Xs, row_start, self.threshold)
+        if self.shard is None:
+            labels, log = ctx.cluster_tracks(Xs, row_start, self.threshold)
+        else:
+            # several GPUs, every one holding all rows: each computes the distance-matrix rows of its share of the tracks
+            # (balanced by row count), the rows are exchanged, and every rank agglomerates the same complete matrix
+            T = len(track_ids)
+            t0, t1 = self.shard.track_range(row_start)
+            D = self.shard.assemble(ctx.pair_mean_dist_rows(Xs, row_start, t0, t1), row_start)
+            labels, log = ctx.cluster_dist(D, row_start, self.threshold)
         self.history = [(int(track_ids[int(a)]), int(track_ids[int(b)]), float(d)) for a, b, d, _ in log]
         return [int(track_ids[int(l)]) for l in labels]
 

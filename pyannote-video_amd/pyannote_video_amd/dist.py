@@ -60,10 +60,56 @@ def gather_rows(face_T, face_id, X, n_tracks, device=None):
     return np.concatenate(Ts), np.concatenate(ids), np.ascontiguousarray(np.concatenate(Xs)), offsets
 
 
+class DistanceShard(object):
+    """Splits the N x N pairwise distances of the global clustering over the ranks: every rank already holds all gathered rows,
+    computes the rows of the T x T track-pair matrix for a contiguous share of the tracks (balanced by row count, so by work),
+    and one all-gather of those rows (T x T doubles in total) gives every rank the complete matrix.  Without it each rank would
+    repeat the whole O(N^2) step, which grows with the square of the number of GPUs under weak scaling."""
+
+    def __init__(self, rank, world, device=None):
+        self.rank, self.world, self.device = rank, world, device
+
+    def bounds(self, row_start):
+        n = int(row_start[-1])
+        T = len(row_start) - 1
+        cuts = [0]
+        for r in range(1, self.world):
+            target = n * r / float(self.world)
+            t = cuts[-1]
+            while t < T and row_start[t + 1] <= target:
+                t += 1
+            cuts.append(t)
+        cuts.append(T)
+        return cuts
+
+    def track_range(self, row_start):
+        cuts = self.bounds(row_start)
+        return cuts[self.rank], cuts[self.rank + 1]
+
+    def assemble(self, D_mine, row_start):
+        import torch
+        import torch.distributed as dist
+        T = D_mine.shape[0]
+        cuts = self.bounds(row_start)
+        dev = self.device if self.device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = torch.from_numpy(np.ascontiguousarray(D_mine)).to(dev)
+        parts = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t)
+        D = np.zeros((T, T), np.float64)
+        for r in range(self.world):
+            a, b = cuts[r], cuts[r + 1]
+            if b > a:
+                D[a:b] = parts[r][a:b].cpu().numpy()
+        return D
+
+
 def global_cluster(clustering, face_T, face_id, X):
     """single global clustering on the gathered rows (computed identically on every rank)"""
     if len(face_T) == 0:
         return {}
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and clustering.shard is None:
+        clustering.shard = DistanceShard(dist.get_rank(), dist.get_world_size())
     sp, data = clustering.model.preprocess((face_T, face_id, X))
     res = clustering(sp, features=data)
     return {int(track): int(label) for _, track, label in res.itertracks(yield_label=True)}

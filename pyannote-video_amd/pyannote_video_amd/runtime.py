@@ -329,6 +329,25 @@ class Context(object):
         check(self._l.pvf_cluster_tracks(self._h, ptr(X), X.shape[0], X.shape[1], ptr(rs), T, float(threshold), ptr(labels), ptr(log), C.byref(n)))
         return labels, log[:n.value]
 
+    def pair_mean_dist_rows(self, X, row_start, track0, track1):
+        """rows [track0, track1) of the T x T track-pair mean-distance matrix (the other rows are zero)"""
+        X = np.ascontiguousarray(X, np.float64)
+        rs = np.ascontiguousarray(row_start, np.int32)
+        T = len(rs) - 1
+        D = np.zeros((T, T), np.float64)
+        check(self._l.pvf_pair_mean_dist_rows(self._h, ptr(X), X.shape[0], X.shape[1], ptr(rs), T, int(track0), int(track1), ptr(D)))
+        return D
+
+    def cluster_dist(self, D, row_start, threshold):
+        D = np.ascontiguousarray(D, np.float64)
+        rs = np.ascontiguousarray(row_start, np.int32)
+        T = len(rs) - 1
+        labels = np.zeros(T, np.int32)
+        log = np.zeros((max(T - 1, 1), 4), np.float64)
+        n = C.c_int32(0)
+        check(self._l.pvf_cluster_dist(self._h, ptr(D), ptr(rs), T, float(threshold), ptr(labels), ptr(log), C.byref(n)))
+        return labels, log[:n.value]
+
     # ---- measurement
     def prof_enable(self, on=True):
         check(self._l.pvf_prof_enable(self._h, 1 if on else 0))

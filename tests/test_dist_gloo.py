@@ -58,3 +58,18 @@ def test_shard_planner_contiguous_and_balanced():
     plan = pd.shard_shots(uneven, 2)
     assert plan == [(0, 3), (3, 5)] or plan == [(0, 2), (2, 5)]
     assert all(e > s for s, e in pd.shard_shots(shots[:3], 3))
+
+
+def test_distance_shard_bounds_cover_and_balance():
+    from pyannote_video_amd.dist import DistanceShard
+    rng = np.random.default_rng(2)
+    for trial in range(50):
+        T = int(rng.integers(1, 40)); world = int(rng.integers(1, 9))
+        sizes = rng.integers(1, 30, T)
+        rs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        cuts = DistanceShard(0, world).bounds(rs)
+        assert cuts[0] == 0 and cuts[-1] == T and len(cuts) == world + 1
+        assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+        assert [DistanceShard(r, world).track_range(rs) for r in range(world)] == list(zip(cuts, cuts[1:]))
+        rows = [int(rs[b] - rs[a]) for a, b in zip(cuts, cuts[1:])]
+        assert max(rows) <= rs[-1] / world + sizes.max()          # no share exceeds the even split by more than one track

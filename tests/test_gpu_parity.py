@@ -263,3 +263,18 @@ def test_pair_mean_dist_and_hac(ctx, oracle):
     for t in range(T):
         assert ident[labels[t]] == ident[t]
     assert len(set(labels.tolist())) == len(set(ident.tolist()))
+    # the split form used by several GPUs: row ranges of D stitched together == the whole D, bit for bit; HAC from that D
+    from pyannote_video_amd.dist import DistanceShard
+    for world in (2, 3):
+        Dsum = np.zeros_like(D)
+        covered = []
+        for r in range(world):
+            t0, t1 = DistanceShard(r, world).track_range(rs)
+            covered.append((t0, t1))
+            part = ctx.pair_mean_dist_rows(X, rs, t0, t1)
+            assert not part[:t0].any() and not part[t1:].any()
+            Dsum[t0:t1] = part[t0:t1]
+        assert covered[0][0] == 0 and covered[-1][1] == T and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        assert np.array_equal(Dsum, D)
+        l2, log2 = ctx.cluster_dist(Dsum, rs, 0.6)
+        assert np.array_equal(l2, labels) and np.array_equal(log2, log)
