@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--shots", type=int, default=4)
     ap.add_argument("--detect-batch", type=int, default=32)
     ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle sample (0 = skip)")
-    ap.add_argument("--no-overlap", action="store_true", help="run detector and trackers on one stream (clean per-kernel timings)")
+    ap.add_argument("--no-overlap", action="store_true", help="no GPU-feeding thread: every stage runs in the caller's thread, shot after shot")
     ap.add_argument("--small-models", action="store_true", help="debug only: reduced landmark model")
     args = ap.parse_args()
 
