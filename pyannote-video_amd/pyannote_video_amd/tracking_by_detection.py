@@ -270,6 +270,20 @@ class TrackingByDetection(object):
             overlap = 0.
         return overlap
 
+    def _no_match(self, p1, p2):
+        """_match(drectangle(*p1), drectangle(*p2)) == 0 without building the rectangle objects (same float arithmetic:
+        intersection corners by max / min, empty rectangles have zero area, the two gating comparisons of tracking.py:129-134)"""
+        l1, t1, r1, b1 = float(p1[0]), float(p1[1]), float(p1[2]), float(p1[3])
+        l2, t2, r2, b2 = float(p2[0]), float(p2[1]), float(p2[2]), float(p2[3])
+        il, it, ir, ib = max(l1, l2), max(t1, t2), min(r1, r2), min(b1, b2)
+        overlap = 0.0 if (il > ir or it > ib) else (ir - il) * (ib - it)
+        a1 = 0.0 if (l1 > r1 or t1 > b1) else (r1 - l1) * (b1 - t1)
+        a2 = 0.0 if (l2 > r2 or t2 > b2) else (r2 - l2) * (b2 - t2)
+        ratio = self.track_min_overlap_ratio
+        if overlap < ratio * a1 or overlap < ratio * a2:
+            return True
+        return overlap == 0
+
     def _associate(self, positions, detections):
         """positions: [(identifier, (l,t,r,b))] in tracker order. Returns {detection index: identifier} (tracking.py:136-182)."""
         if len(positions) < 1 or len(detections) < 1:
@@ -373,7 +387,7 @@ class TrackingByDetection(object):
             group = list(group)
             error = False
             for (_, pos1, _), (_, pos2, _) in itertools.combinations(group, 2):
-                if self._match(drectangle(*pos1), drectangle(*pos2)) == 0:
+                if self._no_match(pos1, pos2):
                     error = True
                     break
             status = "+".join(sorted((status for _, _, status in group), key=lambda s: _STATUS_ORDER[s]))
@@ -401,7 +415,7 @@ class TrackingByDetection(object):
             tj = tracks[j][0][0]
             if (tj < ti) or (tj - ti > self.track_max_gap):
                 continue
-            if self._match(drectangle(*tracks[i][-1][1]), drectangle(*tracks[j][0][1])):
+            if not self._no_match(tracks[i][-1][1], tracks[j][0][1]):
                 graph.add_edge(i, j)
         merged_tracks = []
         for group in nx.connected_components(graph):

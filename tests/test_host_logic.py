@@ -286,3 +286,20 @@ def test_deferred_first_updates_with_commit_equal_sequential_reference(seed):
     ref = ref_flow.track_shot(cache, dets, ModelRefTracker, 10., 0.5, 1.0)
     assert got == ref
     assert backend.commits > 0          # the scenario has survivors, i.e. the commit path ran
+
+
+def test_inline_overlap_gate_equals_rectangle_form():
+    """_no_match (used by _fix / _fill_gaps) == (_match(drectangle, drectangle) == 0) on random, touching, empty and nested boxes"""
+    from pyannote_video_amd.shim import drectangle
+    rng = np.random.default_rng(9)
+    for ratio in (0.0, 0.3, 0.5, 1.0):
+        tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=ratio)
+        for _ in range(3000):
+            a = rng.integers(-5, 40, 4).astype(float) * rng.choice([1.0, 0.5])
+            b = rng.integers(-5, 40, 4).astype(float) * rng.choice([1.0, 0.5])
+            if rng.random() < 0.3:
+                b = a + rng.integers(-2, 3, 4)
+            if rng.random() < 0.7:
+                a[2:] = np.maximum(a[2:], a[:2]); b[2:] = np.maximum(b[2:], b[:2])
+            want = tbd._match(drectangle(*a), drectangle(*b)) == 0
+            assert tbd._no_match(tuple(a), tuple(b)) == want, (ratio, a, b)
