@@ -135,3 +135,21 @@ def test_hac_matches_numpy_restatement(oracle):
     labels, _ = oracle.hac(oracle.pair_mean_dist(X, rs), sizes, 0.6)
     assert {t: int(labels[t]) for t in range(T)} == ref
     assert len(set(ref.values())) == K
+
+
+def test_score_level_matches_float64_window_sums(oracle):
+    """filter scoring (spatially_filter_image convention: output at the window centre) against a float64 numpy window sum"""
+    from pyannote_video_amd import models
+    m = models.load_container(models.DEFAULT_DETECTOR)
+    det = oracle.Detector(m)
+    w = np.asarray(m["det.w"], np.float64).reshape(-1, 10, 10, 32)
+    rng = np.random.default_rng(11)
+    fh, fw = 23, 31
+    feat = (rng.random((fh, fw, 32)) * 0.4).astype(np.float32)
+    feat[:, :, 31] = 0.0
+    for f in range(w.shape[0]):
+        got = det.score_level(feat, f)
+        for r in range(5, fh - 4):
+            for c in range(5, fw - 4):
+                want = float((feat[r - 5:r + 5, c - 5:c + 5, :31].astype(np.float64) * w[f, :, :, :31]).sum())
+                assert abs(got[r, c] - want) <= 2e-4 * max(1.0, abs(want)), (f, r, c, got[r, c], want)
