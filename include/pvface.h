@@ -39,10 +39,14 @@ int32_t pvf_sync(pvf_handle ctx);
 /* ---- models --------------------------------------------------------------------------------------- */
 /* ref: face.py:54  dlib.get_frontal_face_detector()  (path == NULL: detector shipped with the package) */
 int32_t pvf_load_detector(pvf_handle ctx, const char* path);
-/* ref: face.py:58  dlib.shape_predictor(landmarks) */
+/* ref: face.py:58  dlib.shape_predictor(landmarks); README.md:29-30, scripts/pyannote-face.py:37,451-452 pass dlib's own
+ * `shape_predictor_68_face_landmarks.dat` by path: accepted as is (dlib::serialize stream), as is the `.pvfm` container */
 int32_t pvf_load_shape_predictor(pvf_handle ctx, const char* path);
-/* ref: face.py:62  dlib.face_recognition_model_v1(embedding) */
+/* ref: face.py:62  dlib.face_recognition_model_v1(embedding); `dlib_face_recognition_resnet_model_v1.dat` or `.pvfm` */
 int32_t pvf_load_embedder(pvf_handle ctx, const char* path);
+/* host only (no GPU needed): one named tensor of a model file exactly as the two loaders above parse it
+ * (kind 1 = shape predictor, 2 = embedder; names "sp.*" / "emb.*"); out == NULL returns the size in *nbytes */
+int32_t pvf_model_tensor(const char* path, int32_t kind, const char* name, void* out, int64_t cap_bytes, int64_t* nbytes);
 /* constant tables of dlib.correlation_tracker's default constructor (ref: tracking.py:250), computed once on the host:
  * mask64[64*64], mask_scale[32], tw64[32*2] (cos,sin 2*pi*k/64), tw32[16*2] */
 int32_t pvf_set_tracker_tables(pvf_handle ctx, const double* mask64, const double* mask_scale, const double* tw64,

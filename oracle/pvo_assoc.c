@@ -1,8 +1,11 @@
 /*
  * pvo_assoc.c -- ORACLE (test infrastructure): tracker/detection association.
  *   reference: pyannote/video/tracking.py:129-134 (_match on dlib.drectangle), :136-182 (_associate, Munkres)
- * PARITY UNPINNED for munkres tie behaviour ([EXT] munkres >= 1.0.7, classic 6-step Kuhn-Munkres, row-major zero search);
- * optimal cost is pinned against scipy.optimize.linear_sum_assignment in tests/.
+ * munkres: PINNED against the package itself (munkres 1.1.4, setup.py:51 asks for >= 1.0.7; its source is on disk in this
+ * container at /opt/conda/lib/python3.9/site-packages/munkres.py and is loaded by tests/test_reference_pins.py), ties
+ * included.  The step order below restates Munkres.__step1..6 literally, including step 4's resumed cyclic search
+ * (__find_a_zero(i0, j0)), which returns the LAST uncovered zero of the first row that has one.  The optimal cost is
+ * additionally pinned against scipy.optimize.linear_sum_assignment.
  */
 #include "pvo.h"
 #include <stdlib.h>
@@ -55,16 +58,23 @@ void pvo_munkres(const double* cost, int n, int32_t* row_to_col)
                     if (marked[i * n + j] == 1 && !cc[j]) { cc[j] = 1; ++count; }
             step = count >= n ? 7 : 4;
         } else if (step == 4) {
+            int i0 = 0, j0 = 0;                       /* the search resumes where the previous primed zero was found */
             for (;;) {
-                int row = -1, col = -1;
-                for (int i = 0; i < n && row < 0; ++i)
-                    for (int j = 0; j < n; ++j)
-                        if (C[i * n + j] == 0 && !rc[i] && !cc[j]) { row = i; col = j; break; }
+                int row = -1, col = -1, i = i0, done = 0;
+                while (!done) {
+                    int j = j0;
+                    do {                              /* no early exit: the last uncovered zero of the row wins */
+                        if (C[i * n + j] == 0 && !rc[i] && !cc[j]) { row = i; col = j; done = 1; }
+                        j = (j + 1) % n;
+                    } while (j != j0);
+                    i = (i + 1) % n;
+                    if (i == i0) done = 1;
+                }
                 if (row < 0) { step = 6; break; }
                 marked[row * n + col] = 2;
                 int star = -1;
                 for (int j = 0; j < n; ++j) if (marked[row * n + j] == 1) { star = j; break; }
-                if (star >= 0) { rc[row] = 1; cc[star] = 0; }
+                if (star >= 0) { rc[row] = 1; cc[star] = 0; i0 = row; j0 = star; }
                 else { z0r = row; z0c = col; step = 5; break; }
             }
         } else if (step == 5) {

@@ -179,7 +179,8 @@ def extract(track_lines, frames, times, landmarks, embed):
         t = yield
         faces, current = [], None
         for T, ident, (l, tp, r, b) in rows:
-            box = (int(l * w), int(tp * h), int(r * w), int(b * h))
+            # iterrows() over the mixed-dtype frame yields Python floats: the products are float64 (pyannote-face.py:142-145)
+            box = (int(float(l) * w), int(float(tp) * h), int(float(r) * w), int(float(b) * h))
             if T == current or current is None:
                 faces.append((ident, box))
                 current = T

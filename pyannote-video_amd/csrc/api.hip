@@ -283,8 +283,14 @@ void overlap_matrix_host(const double* a, int na, const double* b, int nb, doubl
         }
 }
 
-// Kuhn-Munkres in the six-step formulation the `munkres` package uses (row-major search for uncovered zeros),
-// so that ties between equally good assignments resolve the way the reference's host code resolves them.
+// Kuhn-Munkres exactly as `munkres` 1.1.4 runs it (reference tracking.py:35,121,172 -> Munkres().compute(cost)): the same six
+// steps on the same matrix in the same scan orders, because among equally good assignments the step order decides which one
+// comes out (and with it the track ids).  Two details of that package are easy to miss and are kept:
+//   - step 4 resumes its search for an uncovered zero at the row of the last primed zero and at the column of that row's
+//     starred zero, wrapping around cyclically (Munkres.__step4 / __find_a_zero(i0, j0));
+//   - inside the first row that has an uncovered zero the search does not stop at the first hit: it keeps scanning the row
+//     (cyclically from j0) and returns the LAST uncovered zero of that row.
+// Pinned against the package itself in tests/test_reference_pins.py (ties included).
 namespace {
 struct Hungarian {
     int n;
@@ -294,7 +300,7 @@ struct Hungarian {
     int z0r = 0, z0c = 0;
     explicit Hungarian(const double* cost, int n_) : n(n_), C(cost, cost + (size_t)n_ * n_), mark((size_t)n_ * n_, 0), rowc(n_, 0), colc(n_, 0), path(4 * n_ + 8, 0) {}
     void clear_covers() { std::fill(rowc.begin(), rowc.end(), 0); std::fill(colc.begin(), colc.end(), 0); }
-    int reduce_rows()
+    int reduce_rows()                                       // __step1
     {
         for (int i = 0; i < n; ++i) {
             double mn = C[(size_t)i * n];
@@ -303,7 +309,7 @@ struct Hungarian {
         }
         return 2;
     }
-    int star_initial()
+    int star_initial()                                      // __step2
     {
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j)
@@ -311,7 +317,7 @@ struct Hungarian {
         clear_covers();
         return 3;
     }
-    int cover_starred()
+    int cover_starred()                                     // __step3
     {
         int count = 0;
         for (int i = 0; i < n; ++i)
@@ -319,24 +325,41 @@ struct Hungarian {
                 if (mark[(size_t)i * n + j] == 1 && !colc[j]) { colc[j] = 1; ++count; }
         return count >= n ? 7 : 4;
     }
-    int prime_zeros()
+    // __find_a_zero(i0, j0): rows cyclically from i0; in the first row holding an uncovered zero, the last such zero in the
+    // cyclic column order that starts at j0
+    void find_a_zero(int i0, int j0, int* row, int* col) const
     {
-        for (;;) {
-            int row = -1, col = -1;
-            for (int i = 0; i < n && row < 0; ++i) {
-                if (rowc[i]) continue;
-                for (int j = 0; j < n; ++j)
-                    if (!colc[j] && C[(size_t)i * n + j] == 0) { row = i; col = j; break; }
+        *row = -1; *col = -1;
+        int i = i0;
+        bool done = false;
+        while (!done) {
+            int j = j0;
+            for (;;) {
+                if (C[(size_t)i * n + j] == 0 && !rowc[i] && !colc[j]) { *row = i; *col = j; done = true; }
+                j = (j + 1) % n;
+                if (j == j0) break;
             }
-            if (row < 0) return 6;
+            i = (i + 1) % n;
+            if (i == i0) done = true;
+        }
+    }
+    int prime_zeros()                                       // __step4
+    {
+        int row = 0, col = 0;
+        for (;;) {
+            int r, cc;
+            find_a_zero(row, col, &r, &cc);
+            if (r < 0) return 6;
+            row = r; col = cc;
             mark[(size_t)row * n + col] = 2;
             int star = -1;
             for (int j = 0; j < n; ++j) if (mark[(size_t)row * n + j] == 1) { star = j; break; }
             if (star < 0) { z0r = row; z0c = col; return 5; }
-            rowc[row] = 1; colc[star] = 0;
+            col = star;
+            rowc[row] = 1; colc[col] = 0;
         }
     }
-    int augment()
+    int augment()                                           // __step5
     {
         int count = 0;
         path[0] = z0r; path[1] = z0c;
@@ -357,7 +380,7 @@ struct Hungarian {
         for (auto& m : mark) if (m == 2) m = 0;
         return 3;
     }
-    int shift_costs()
+    int shift_costs()                                       // __step6 (+= then -= on an element that gets both, like the package)
     {
         double mn = 0; bool have = false;
         for (int i = 0; i < n; ++i)

@@ -122,7 +122,7 @@ static void load_detector(Ctx* c, const char* path)
 
 static void load_shape(Ctx* c, const char* path)
 {
-    auto m = pvf_read_container(path);
+    auto m = pvf_read_model(path, 1);
     const int32_t* q = need(m, "sp.meta").i32();
     ShapeModel& s = c->shape;
     s.n_cascades = q[0]; s.n_trees = q[1]; s.n_parts = q[2]; s.n_pix = q[3]; s.depth = q[4];
@@ -146,7 +146,7 @@ static const int UNITS[14][3] = {{32, 32, 0}, {32, 32, 0}, {32, 32, 0}, {32, 64,
 
 static void load_embedder(Ctx* c, const char* path)
 {
-    auto m = pvf_read_container(path);
+    auto m = pvf_read_model(path, 2);
     EmbedModel& e = c->emb;
     e.chip_size = need(m, "emb.meta").i32()[0];
     e.chip_padding = need(m, "emb.padding").f64()[0];
@@ -325,6 +325,21 @@ extern "C" int32_t pvf_load_embedder(pvf_handle h, const char* path)
     HIP_CHECK(hipSetDevice(c->device));
     PVF_REQUIRE(path != nullptr, "path is NULL");
     load_embedder(c, path);
+    API_END
+}
+
+// host only: one tensor of a model file as the loaders see it (`.pvfm` container or dlib `.dat`); out == NULL: size only
+extern "C" int32_t pvf_model_tensor(const char* path, int32_t kind, const char* name, void* out, int64_t cap_bytes, int64_t* nbytes)
+{
+    API_BEGIN
+    PVF_REQUIRE(path && name && nbytes, "pvf_model_tensor: bad arguments");
+    auto m = pvf_read_model(path, kind);
+    const Tensor& t = need(m, name);
+    *nbytes = (int64_t)t.data.size();
+    if (out) {
+        PVF_REQUIRE(cap_bytes >= (int64_t)t.data.size(), "pvf_model_tensor: buffer too small");
+        memcpy(out, t.data.data(), t.data.size());
+    }
     API_END
 }
 

@@ -78,6 +78,8 @@ struct Tensor {
     const double* f64() const { return reinterpret_cast<const double*>(data.data()); }
 };
 std::map<std::string, Tensor> pvf_read_container(const char* path);
+// `.pvfm` container or dlib `.dat` stream (dlibdat.hip); kind 1 = shape predictor, 2 = embedder
+std::map<std::string, Tensor> pvf_read_model(const char* path, int kind);
 
 struct Frame {
     const uint8_t* d = nullptr; // device, HWC RGB contiguous

@@ -31,6 +31,7 @@ _SIGS = {
     "pvf_load_detector": (C.c_int32, [H, C.c_char_p]),
     "pvf_load_shape_predictor": (C.c_int32, [H, C.c_char_p]),
     "pvf_load_embedder": (C.c_int32, [H, C.c_char_p]),
+    "pvf_model_tensor": (C.c_int32, [C.c_char_p, C.c_int32, C.c_char_p, P, C.c_int64, P]),
     "pvf_set_tracker_tables": (C.c_int32, [H, P, P, P, P, C.c_double, C.c_double]),
     "pvf_frame_upload": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int64, P]),
     "pvf_frame_wrap_device": (C.c_int32, [H, P, C.c_int32, C.c_int32, P]),
@@ -111,6 +112,15 @@ def device_count():
 
 
 # ---- host-only helpers (usable without a GPU) ---------------------------------------------------------
+def model_tensor(path, kind, name, dtype):
+    """one tensor of a model file as the C loaders parse it (kind 1 = shape predictor, 2 = embedder)"""
+    n = C.c_int64(0)
+    check(lib().pvf_model_tensor(str(path).encode(), int(kind), name.encode(), None, 0, C.byref(n)))
+    out = np.zeros(n.value // np.dtype(dtype).itemsize, dtype)
+    check(lib().pvf_model_tensor(str(path).encode(), int(kind), name.encode(), ptr(out), out.nbytes, C.byref(n)))
+    return out
+
+
 def overlap_matrix(a, b, ratio):
     a = np.ascontiguousarray(a, np.float64).reshape(-1, 4)
     b = np.ascontiguousarray(b, np.float64).reshape(-1, 4)

@@ -28,10 +28,17 @@ def write_tracks(path, tracks):
             f.flush()
 
 
+def denormalise(box, frame_width, frame_height):
+    """float32 normalised box (as parsed from track.txt) -> integer pixel rectangle of `getFaceGenerator` (:142-145).
+    The reference iterates `tracking.iterrows()` over a mixed-dtype frame, so pandas hands the float32 columns back as
+    Python floats and `left * frame_width` runs in float64 (0.175 * 640 -> 111, not the float32 product 112)."""
+    return (int(float(box[0]) * frame_width), int(float(box[1]) * frame_height),
+            int(float(box[2]) * frame_width), int(float(box[3]) * frame_height))
+
+
 def quantise_track_box(box, frame_width, frame_height):
     """(l,t,r,b) normalised -> integer pixel rectangle exactly as `extract` rebuilds it from track.txt"""
-    q = [np.float32("%.3f" % v) for v in box]
-    return (int(q[0] * frame_width), int(q[1] * frame_height), int(q[2] * frame_width), int(q[3] * frame_height))
+    return denormalise([np.float32("%.3f" % v) for v in box], frame_width, frame_height)
 
 
 def quantise_time(t):

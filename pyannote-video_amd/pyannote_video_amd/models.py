@@ -202,3 +202,417 @@ def ensure_synthetic_models(directory, small=False):
     if not os.path.exists(ep):
         save_container(ep, make_embedder())
     return lp, ep
+
+
+# ---------------------------------------------------------------------------------------------
+# dlib `.dat` files (dlib::serialize streams).  The reference hands dlib model files to the library by path
+# (README.md:29-30, face.py:58,62, scripts/pyannote-face.py:37,451-452):
+#     shape_predictor_68_face_landmarks.dat          -> dlib.shape_predictor
+#     dlib_face_recognition_resnet_model_v1.dat      -> dlib.face_recognition_model_v1
+# [EXT] The stream layout below restates dlib's serialize.h / shape_predictor.h / dnn/{core,layers,tensor}.h from their
+# published form; dlib's source and the real files are not available in this environment, so the reader is exercised by
+# round-tripping through the writer below (tests/test_dlib_dat.py) and against the C++ reader of libpvface (csrc/dlibdat.hip).
+#
+#   integer      1 control byte (low nibble = n payload bytes, 0x80 = negative) + n little-endian magnitude bytes
+#   float/double two integers: mantissa (int64) and exponent (int16), value = mantissa * 2**exponent
+#                (exponent 32000 / 32001 / 32002 = +inf / -inf / nan)
+#   matrix<T>    integers -nr, -nc, then nr*nc elements row-major
+#   std::vector  integer size, then the items;   std::string  integer size, then the bytes
+#   tensor       int version(2), 4 integers (n, k, nr, nc), then n*k*nr*nc raw little-endian IEEE floats
+class DlibWriter(object):
+    def __init__(self):
+        self.parts = []
+
+    def int(self, v):
+        v = int(v)
+        neg = 0x80 if v < 0 else 0
+        v = abs(v)
+        payload = bytearray()
+        while True:
+            payload.append(v & 0xFF)
+            v >>= 8
+            if v == 0:
+                break
+        self.parts.append(bytes([len(payload) | neg]) + bytes(payload))
+
+    def float(self, v, digits=24):
+        v = float(np.float32(v)) if digits == 24 else float(v)      # a C++ float has 24 significant bits: the mantissa is exact
+        if np.isinf(v):
+            self.int(0); self.int(32000 if v > 0 else 32001); return
+        if np.isnan(v):
+            self.int(0); self.int(32002); return
+        m, e = np.frexp(v)
+        mant = int(m * float(1 << digits))
+        exp = int(e) - digits
+        for _ in range(8):
+            if mant & 0xFF or mant == 0:
+                break
+            mant >>= 8
+            exp += 8
+        self.int(mant); self.int(exp)
+
+    def double(self, v):
+        self.float(v, digits=53)
+
+    def string(self, s):
+        b = s.encode() if isinstance(s, str) else bytes(s)
+        self.int(len(b)); self.parts.append(b)
+
+    def matrix_f32(self, a):
+        a = np.asarray(a, np.float32)
+        a = a.reshape(a.shape[0], -1) if a.ndim > 1 else a.reshape(-1, 1)
+        self.int(-a.shape[0]); self.int(-a.shape[1])
+        for v in a.reshape(-1):
+            self.float(v)
+
+    def tensor(self, a):
+        a = np.ascontiguousarray(a, np.float32)
+        dims = list(a.shape) + [1] * (4 - a.ndim) if a.size else [0, 0, 0, 0]
+        self.int(2)
+        for d in dims:
+            self.int(d)
+        self.parts.append(a.astype("<f4").tobytes())
+
+    def bytes(self):
+        return b"".join(self.parts)
+
+
+class DlibReader(object):
+    def __init__(self, data):
+        self.b = memoryview(data)
+        self.o = 0
+
+    def int(self):
+        c = self.b[self.o]
+        n, neg = c & 0x0F, c & 0x80
+        if n == 0 or n > 8 or (c & 0x70):
+            raise IOError("dlib stream: bad integer control byte 0x%02x at offset %d" % (c, self.o))
+        v = int.from_bytes(self.b[self.o + 1:self.o + 1 + n], "little")
+        self.o += 1 + n
+        return -v if neg else v
+
+    def float(self):
+        m, e = self.int(), self.int()
+        if e == 32000:
+            return float("inf")
+        if e == 32001:
+            return float("-inf")
+        if e == 32002:
+            return float("nan")
+        return float(np.ldexp(float(m), e))
+
+    def string(self):
+        n = self.int()
+        s = bytes(self.b[self.o:self.o + n])
+        self.o += n
+        return s
+
+    def matrix_f32(self):
+        nr, nc = -self.int(), -self.int()
+        if nr < 0 or nc < 0:
+            raise IOError("dlib stream: matrix header expected at offset %d" % self.o)
+        out = np.empty(nr * nc, np.float32)
+        for i in range(nr * nc):
+            out[i] = self.float()
+        return out.reshape(nr, nc)
+
+    def tensor(self):
+        ver = self.int()
+        if ver != 2:
+            raise IOError("dlib stream: tensor version %d" % ver)
+        dims = [self.int() for _ in range(4)]
+        n = int(np.prod(dims))
+        a = np.frombuffer(self.b[self.o:self.o + 4 * n], "<f4").astype(np.float32).reshape(dims)
+        self.o += 4 * n
+        return a
+
+
+def _unpack_many(rd, count):
+    """`count` (mantissa, exponent) floats -> float32 array; the bulk of a shape predictor file (65 M leaf values)"""
+    out = np.empty(count, np.float32)
+    b, o = rd.b, rd.o
+    ldexp = np.ldexp
+    for i in range(count):
+        c = b[o]; n = c & 0x0F
+        m = int.from_bytes(b[o + 1:o + 1 + n], "little")
+        if c & 0x80:
+            m = -m
+        o += 1 + n
+        c = b[o]; n = c & 0x0F
+        e = int.from_bytes(b[o + 1:o + 1 + n], "little")
+        if c & 0x80:
+            e = -e
+        o += 1 + n
+        out[i] = ldexp(float(m), e) if e < 32000 else (np.inf if e == 32000 else (-np.inf if e == 32001 else np.nan))
+    rd.o = o
+    return out
+
+
+def write_dlib_shape_predictor(path, model):
+    """our tensors -> dlib::shape_predictor stream: int version(1); matrix<float,0,1> initial_shape;
+    vector<vector<regression_tree>> forests (tree = vector<split_feature{idx1, idx2, thresh}>, vector<matrix<float,0,1>> leaves);
+    vector<vector<unsigned long>> anchor_idx; vector<vector<vector<float,2>>> deltas"""
+    meta = model["sp.meta"]
+    nc, nt = int(meta[0]), int(meta[1])
+    w = DlibWriter()
+    w.int(1)
+    w.matrix_f32(model["sp.initial_shape"].reshape(-1, 1))
+    i1, i2, th, lv = model["sp.split_idx1"], model["sp.split_idx2"], model["sp.split_thresh"], model["sp.leaves"]
+    w.int(nc)
+    for c in range(nc):
+        w.int(nt)
+        for t in range(nt):
+            w.int(i1.shape[2])
+            for s in range(i1.shape[2]):
+                w.int(i1[c, t, s]); w.int(i2[c, t, s]); w.float(th[c, t, s])
+            w.int(lv.shape[2])
+            for l in range(lv.shape[2]):
+                w.matrix_f32(lv[c, t, l].reshape(-1, 1))
+    w.int(nc)
+    for c in range(nc):
+        a = model["sp.anchor_idx"][c]
+        w.int(len(a))
+        for v in a:
+            w.int(v)
+    w.int(nc)
+    for c in range(nc):
+        d = model["sp.deltas"][c]
+        w.int(len(d))
+        for x, y in d:
+            w.float(x); w.float(y)
+    with open(path, "wb") as f:
+        f.write(w.bytes())
+
+
+def read_dlib_shape_predictor(path):
+    """dlib::shape_predictor stream -> the tensors of our container (see write_dlib_shape_predictor for the layout)"""
+    with open(path, "rb") as f:
+        rd = DlibReader(f.read())
+    ver = rd.int()
+    if ver != 1:
+        raise IOError("%s: shape_predictor version %d (1 expected)" % (path, ver))
+    initial = rd.matrix_f32().reshape(-1)
+    nc = rd.int()
+    forests = []
+    for _ in range(nc):
+        nt = rd.int()
+        trees = []
+        for _ in range(nt):
+            ns = rd.int()
+            sp = np.empty((ns, 3), np.float64)
+            for s in range(ns):
+                sp[s, 0] = rd.int(); sp[s, 1] = rd.int(); sp[s, 2] = rd.float()
+            nl = rd.int()
+            leaves = []
+            for _ in range(nl):
+                nr, ncol = -rd.int(), -rd.int()
+                leaves.append(_unpack_many(rd, nr * ncol))
+            trees.append((sp, np.stack(leaves)))
+        forests.append(trees)
+    anchors = []
+    for _ in range(rd.int()):
+        anchors.append(np.array([rd.int() for _ in range(rd.int())], np.int32))
+    deltas = []
+    for _ in range(rd.int()):
+        n = rd.int()
+        deltas.append(_unpack_many(rd, 2 * n).reshape(n, 2))
+    nt, ns, nl = len(forests[0]), forests[0][0][0].shape[0], forests[0][0][1].shape[0]
+    depth = int(round(np.log2(nl)))
+    if (1 << depth) != nl or ns != nl - 1:
+        raise IOError("%s: regression trees are not complete binary trees" % path)
+    return {
+        "sp.meta": np.array([nc, nt, len(initial) // 2, len(anchors[0]), depth], np.int32),
+        "sp.initial_shape": initial.astype(np.float32),
+        "sp.anchor_idx": np.stack(anchors).astype(np.int32),
+        "sp.deltas": np.stack(deltas).astype(np.float32),
+        "sp.split_idx1": np.array([[t[0][:, 0] for t in trees] for trees in forests]).astype(np.int32),
+        "sp.split_idx2": np.array([[t[0][:, 1] for t in trees] for trees in forests]).astype(np.int32),
+        "sp.split_thresh": np.array([[t[0][:, 2] for t in trees] for trees in forests]).astype(np.float32),
+        "sp.leaves": np.array([[t[1] for t in trees] for trees in forests]).astype(np.float32),
+    }
+
+
+# [EXT] dlib's mean_face_shape_x / _y (image_transforms/interpolation.h, get_face_chip_details): compiled into dlib, not stored
+# in the model file, so a `.dat` embedder uses these recalled constants (51 points = landmarks 17..67).
+DLIB_MEAN_FACE_X = [
+    0.000213256, 0.0752622, 0.18113, 0.29077, 0.393397, 0.586856, 0.689483, 0.799124, 0.904991, 0.98004, 0.490127, 0.490127,
+    0.490127, 0.490127, 0.36688, 0.426036, 0.490127, 0.554217, 0.613373, 0.121737, 0.187122, 0.265825, 0.334606, 0.260918,
+    0.182743, 0.645647, 0.714428, 0.793132, 0.858516, 0.79751, 0.719335, 0.254149, 0.340985, 0.428858, 0.490127, 0.551395,
+    0.639268, 0.726104, 0.642159, 0.556721, 0.490127, 0.423532, 0.338094, 0.290379, 0.428096, 0.490127, 0.552157, 0.689874,
+    0.553364, 0.490127, 0.42689]
+DLIB_MEAN_FACE_Y = [
+    0.106454, 0.038915, 0.0187482, 0.0344891, 0.0773906, 0.0773906, 0.0344891, 0.0187482, 0.038915, 0.106454, 0.203352,
+    0.307009, 0.409805, 0.515625, 0.587326, 0.609345, 0.628106, 0.609345, 0.587326, 0.216423, 0.178758, 0.179852, 0.231733,
+    0.245099, 0.244077, 0.231733, 0.179852, 0.178758, 0.216423, 0.244077, 0.245099, 0.780233, 0.745405, 0.727388, 0.742578,
+    0.727388, 0.745405, 0.780233, 0.864805, 0.902192, 0.909281, 0.902192, 0.864805, 0.784792, 0.778746, 0.785343, 0.778746,
+    0.784792, 0.824182, 0.831803, 0.824182]
+
+# Layer walk of dlib's anet_type (face_recognition_model_v1), input side first -- the order in which a network stream holds the
+# layer `details` (add_layer serialises its sub-network before its own details):
+#   con(7x7/2) affine relu max_pool, then per residual unit: con affine relu con affine [avg_pool on down units] add_prev relu ...,
+#   avg_pool_everything, fc_no_bias(128), loss_metric
+def write_dlib_embedder(path, model):
+    """our blob -> a dlib network stream with anet_type's layer order.  Layer details are written exactly as dlib's layers
+    write them (tag string, params tensor, hyper-parameters); the add_layer bookkeeping around them (version, setup flags,
+    empty gradient / output tensors) follows dnn/core.h [EXT]."""
+    p = split_resnet_blob(model["emb.blob"])
+    empty = np.zeros((0,), np.float32)
+
+    def layer_tail(w):
+        w.int(1); w.int(1); w.int(0)          # this_layer_setup_called, gradient_input_is_stale, get_output_and_gradient_input_disabled
+        w.tensor(empty); w.tensor(empty)      # x_grad, cached_output
+        w.tensor(empty)                       # params_grad (version 2)
+
+    details = []    # innermost first
+
+    def affine(g, b):
+        def emit(w, g=g, b=b):
+            w.string("affine_")
+            w.tensor(np.concatenate([g.reshape(-1), b.reshape(-1)]))
+            w.int(1)                                                              # mode = CONV_MODE
+        details.append(emit)
+
+    def simple(tag, ints=()):
+        def emit(w, tag=tag, ints=ints):
+            w.string(tag)
+            for v in ints:
+                w.int(v)
+        details.append(emit)
+
+    def con_named(wname, bname, k, stride, pad):
+        wgt, bias = p[wname], p[bname]
+        def emit(w, wgt=wgt, bias=bias):
+            w.string("con_4")
+            w.tensor(np.concatenate([wgt.reshape(-1), bias.reshape(-1)]))
+            w.int(wgt.shape[0]); w.int(k); w.int(k); w.int(stride); w.int(stride); w.int(pad); w.int(pad)
+            w.double(1); w.double(1); w.double(1); w.double(0)
+        details.append(emit)
+
+    details.clear()
+    con_named("conv1.w", "conv1.b", 7, 2, 0)
+    affine(p["aff1.g"], p["aff1.b"])
+    simple("relu_")
+    simple("max_pool_2", (3, 3, 2, 2, 0, 0))
+    for u, (cin, n, down) in enumerate(RESNET_UNITS):
+        con_named("u%d.a.w" % u, "u%d.a.b" % u, 3, 2 if down else 1, 0 if down else 1)
+        affine(p["u%d.a.g" % u], p["u%d.a.beta" % u])
+        simple("relu_")
+        con_named("u%d.b.w" % u, "u%d.b.b" % u, 3, 1, 1)
+        affine(p["u%d.b.g" % u], p["u%d.b.beta" % u])
+        if down:
+            simple("avg_pool_2", (2, 2, 2, 2, 0, 0))
+        simple("add_prev_")
+        simple("relu_")
+    simple("avg_pool_2", (0, 0, 1, 1, 0, 0))
+    def fc(w):
+        w.string("fc_2")
+        w.int(128); w.int(0)                  # num_outputs, bias_mode = FC_NO_BIAS
+        w.tensor(p["fc.w"])
+        w.double(1); w.double(1); w.double(1); w.double(0)
+    details.append(fc)
+
+    w = DlibWriter()
+    w.int(1)                                  # add_loss_layer version
+    w.string("loss_metric_2"); w.float(0.04); w.float(0.6)
+    # nested add_layer records: one version integer per layer on the way in, details + bookkeeping on the way out
+    for _ in details:
+        w.int(2)
+    w.string("input_rgb_image_sized"); w.float(122.782); w.float(117.001); w.float(104.298); w.int(150); w.int(150)
+    for emit in details:
+        emit(w)
+        layer_tail(w)
+    with open(path, "wb") as f:
+        f.write(w.bytes())
+
+
+def _find_all(buf, pat):
+    out, o = [], buf.find(pat)
+    while o >= 0:
+        out.append(o)
+        o = buf.find(pat, o + 1)
+    return out
+
+
+def read_dlib_embedder(path):
+    """dlib network stream of anet_type -> our container tensors.
+
+    The nesting records around the layers (add_layer / add_tag_layer / add_skip_layer versions and flags) differ between
+    dlib releases, so the reader does not depend on them: it locates the self-delimiting `details` records of the layers
+    that carry parameters by their length-prefixed tag strings ("con_N", "affine_", "fc_N"), which appear input side first,
+    and reads the `params` tensor that follows each tag.  29 con + 29 affine + 1 fc records with anet_type's shapes are
+    required; anything else is an error."""
+    with open(path, "rb") as f:
+        data = f.read()
+
+    def tagged(prefix):
+        hits = []
+        for o in _find_all(data, prefix.encode()):
+            # the tag is a serialised std::string: [0x01][len][bytes]; accept "con_", "con_2" ... "con_9"
+            if o < 2 or data[o - 2] != 0x01:
+                continue
+            ln = data[o - 1]
+            if ln < len(prefix) or ln > len(prefix) + 2:
+                continue
+            tag = data[o:o + ln]
+            if not all(48 <= c <= 57 for c in tag[len(prefix):]):
+                continue
+            hits.append((o - 2, o + ln))
+        return hits
+
+    recs = sorted([(s, e, "con") for s, e in tagged("con_")] + [(s, e, "affine") for s, e in tagged("affine_")] +
+                  [(s, e, "fc") for s, e in tagged("fc_")])
+    cons, affs, fcs = [], [], []
+    for s, e, kind in recs:
+        rd = DlibReader(data)
+        rd.o = e
+        try:
+            if kind == "fc":
+                rd.int(); rd.int()            # num_outputs, bias_mode
+            t = rd.tensor()
+        except (IOError, IndexError, ValueError):
+            continue
+        if kind == "con":
+            nf = rd.int(); nr = rd.int(); ncol = rd.int(); sy = rd.int(); sx = rd.int()
+            cons.append((t.reshape(-1), nf, nr, ncol, sy, sx))
+        elif kind == "affine":
+            affs.append(t.reshape(-1))
+        else:
+            fcs.append(t.reshape(-1))
+    if len(cons) != 29 or len(affs) != 29 or len(fcs) != 1:
+        raise IOError("%s: expected 29 con, 29 affine and 1 fc record (anet_type), found %d / %d / %d" % (path, len(cons), len(affs), len(fcs)))
+    lay = resnet_param_layout()
+    shapes = dict(lay)
+    parts = {}
+    conv_names = ["conv1"] + [n for u in range(len(RESNET_UNITS)) for n in ("u%d.a" % u, "u%d.b" % u)]
+    for name, (flat, nf, nr, ncol, sy, sx), ab in zip(conv_names, cons, affs):
+        wshape = shapes[name + ".w"]
+        nw = int(np.prod(wshape))
+        if nf != wshape[0] or nr != wshape[2] or ncol != wshape[3] or flat.size != nw + nf or ab.size != 2 * nf:
+            raise IOError("%s: layer %s does not have anet_type's shape" % (path, name))
+        parts[name + ".w"] = flat[:nw].reshape(wshape)
+        parts[name + ".b"] = flat[nw:]
+        gname, bname = ("aff1.g", "aff1.b") if name == "conv1" else (name + ".g", name + ".beta")
+        parts[gname], parts[bname] = ab[:nf], ab[nf:]
+    if fcs[0].size != 256 * 128:
+        raise IOError("%s: fc layer is not 256 x 128" % path)
+    parts["fc.w"] = fcs[0].reshape(256, 128)
+    blob = np.concatenate([np.asarray(parts[name], np.float32).reshape(-1) for name, _ in lay])
+    return {
+        "emb.meta": np.array([150], np.int32),
+        "emb.padding": np.array([0.25], np.float64),
+        "emb.mean_shape": np.stack([np.asarray(DLIB_MEAN_FACE_X), np.asarray(DLIB_MEAN_FACE_Y)], 1).astype(np.float32),
+        "emb.blob": blob,
+    }
+
+
+def load_model_file(path, kind):
+    """tensors of a model file given by path: our `.pvfm` container or a dlib `.dat` stream (kind: 'shape_predictor' | 'embedder')"""
+    with open(path, "rb") as f:
+        magic = f.read(8)
+    if magic == b"PVFMODEL":
+        return load_container(path)
+    if kind == "shape_predictor":
+        return read_dlib_shape_predictor(path)
+    if kind == "embedder":
+        return read_dlib_embedder(path)
+    raise ValueError("unknown model kind %r" % kind)

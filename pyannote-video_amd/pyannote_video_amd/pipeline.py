@@ -47,8 +47,7 @@ def faces_per_frame(rows, frame_times, frame_width, frame_height, drop_last=True
         g = []
         while k < n and rows[k][0] == T:
             _, ident, box, _ = rows[k]
-            g.append((ident, (int(box[0] * frame_width), int(box[1] * frame_height),
-                              int(box[2] * frame_width), int(box[3] * frame_height))))
+            g.append((ident, formats.denormalise(box, frame_width, frame_height)))
             k += 1
         groups.append((T, g))
     if drop_last:
@@ -126,7 +125,7 @@ class ExtractStream(object):
             g = []
             while k < n and rows[k][0] == T:
                 _, ident, box, _ = rows[k]
-                g.append((ident, (int(box[0] * self.w), int(box[1] * self.h), int(box[2] * self.w), int(box[3] * self.h))))
+                g.append((ident, formats.denormalise(box, self.w, self.h)))
                 k += 1
             if self.groups and self.groups[-1][0] == T:
                 self.groups[-1][1].extend(g)      # cannot happen for disjoint shots; keeps the grouping rule exact anyway

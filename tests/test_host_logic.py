@@ -172,7 +172,10 @@ def test_text_quantisation_helpers():
     box = (0.123456, 0.5, 0.987654, 0.75)
     line = list(formats.track_lines(3, [(1.23456, box, 'detection')]))[0]
     assert line == '1.235 3 0.123 0.500 0.988 0.750 detection\n'
-    assert formats.quantise_track_box(box, 1920, 1080) == (int(np.float32('0.123') * 1920), 540, int(np.float32('0.988') * 1920), 810)
+    assert formats.quantise_track_box(box, 1920, 1080) == (int(float(np.float32('0.123')) * 1920), 540, int(float(np.float32('0.988')) * 1920), 810)
+    # the product runs in float64 on the float32-parsed value, as pandas' iterrows() hands it to the reference (pyannote-face.py:142);
+    # a float32 product would give 112 here
+    assert formats.quantise_track_box((0.175, 0.175, 0.175, 0.175), 640, 640) == (111, 111, 111, 111)
 
 
 class _FakeExtractCtx(object):
