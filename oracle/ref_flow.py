@@ -173,7 +173,8 @@ def extract(track_lines, frames, times, landmarks, embed):
     for line in track_lines:
         p = line.split()
         rows.append((float(p[0]), int(p[1]), [np.float32(v) for v in p[2:6]]))
-    rows.sort(key=lambda r: r[0])
+    # tracking.sort_values('t') (pyannote-face.py:130): pandas' default sort is numpy's unstable quicksort argsort
+    rows = [rows[i] for i in np.argsort(np.array([r[0] for r in rows], np.float64), kind="quicksort")]
 
     def generator():
         t = yield

@@ -27,13 +27,40 @@ def shard_shots(shot_ranges, world_size):
     return out
 
 
-def gather_rows(face_T, face_id, X, n_tracks, device=None):
-    """All-gather variable-length rows from every rank.  Returns (T, id_global, X) concatenated in rank order and the
-    per-rank track offsets.  Uses torch.distributed (backend nccl == RCCL on ROCm, gloo on CPU)."""
+def _gather_padded(loc, dev):
+    """all-gather of float64 [n_r, k] blocks of different n_r: one count exchange + one padded payload exchange"""
     import torch
     import torch.distributed as dist
+    world = dist.get_world_size()
+    cnt = torch.tensor([len(loc)], dtype=torch.int64, device=dev)
+    allc = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(allc, cnt)
+    rows = [int(c[0]) for c in allc]
+    pay = torch.zeros((max(max(rows), 1), loc.shape[1]), dtype=torch.float64, device=dev)
+    if len(loc):
+        pay[:len(loc)] = torch.from_numpy(np.ascontiguousarray(loc, np.float64)).to(dev)
+    allp = [torch.zeros_like(pay) for _ in range(world)]
+    dist.all_gather(allp, pay)
+    return [allp[r][:rows[r]].cpu().numpy() for r in range(world)]
+
+
+def gather_rows(face_T, face_id, X, n_tracks, device=None, file_T=None, file_id=None):
+    """All-gather variable-length rows from every rank.  Returns (T, id_global, X) concatenated in rank order and the
+    per-rank track offsets.  Uses torch.distributed (backend nccl == RCCL on ROCm, gloo on CPU).
+
+    file_T / file_id: this rank's share of the track table in file order (FacePipeline.run(..., reorder=False)["file_T"/"file_id"]).
+    When given, the shares are gathered too (a few bytes per row) and the rows are put into the order the reference's `extract`
+    writes them for the WHOLE video (formats.file_order: pandas' unstable sort of the complete table decides the order of the
+    faces of one frame), so a sharded run returns exactly the rows of a single-process run."""
+    import torch
+    import torch.distributed as dist
+    from . import formats
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        return np.asarray(face_T, np.float64), np.asarray(face_id, np.int64), np.asarray(X, np.float64), [0]
+        T, ids, Xa = np.asarray(face_T, np.float64), np.asarray(face_id, np.int64), np.asarray(X, np.float64)
+        if file_T is not None and len(T):
+            perm = formats.file_order(T, ids, file_T, file_id)
+            T, ids, Xa = T[perm], ids[perm], Xa[perm]
+        return T, ids, Xa, [0]
     world = dist.get_world_size()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
     counts = torch.tensor([len(face_T), int(n_tracks)], dtype=torch.int64, device=dev)
@@ -57,7 +84,15 @@ def gather_rows(face_T, face_id, X, n_tracks, device=None):
     for r in range(world):
         a = allp[r][:rows[r]].cpu().numpy()
         Ts.append(a[:, 0]); ids.append(a[:, 1].astype(np.int64) + offsets[r]); Xs.append(a[:, 2:])
-    return np.concatenate(Ts), np.concatenate(ids), np.ascontiguousarray(np.concatenate(Xs)), offsets
+    T, gid, Xa = np.concatenate(Ts), np.concatenate(ids), np.ascontiguousarray(np.concatenate(Xs))
+    if file_T is not None:
+        parts = _gather_padded(np.stack([np.asarray(file_T, np.float64), np.asarray(file_id, np.float64)], 1).reshape(-1, 2), dev)
+        fT = np.concatenate([p[:, 0] for p in parts])
+        fid = np.concatenate([p[:, 1].astype(np.int64) + offsets[r] for r, p in enumerate(parts)])
+        if len(T):
+            perm = formats.file_order(T, gid, fT, fid)
+            T, gid, Xa = T[perm], gid[perm], np.ascontiguousarray(Xa[perm])
+    return T, gid, Xa, offsets
 
 
 class DistanceShard(object):

@@ -45,8 +45,18 @@ def quantise_time(t):
     return float("%.3f" % t)
 
 
+def pandas_sort_order(times):
+    """Row order of `tracking.sort_values('t')` (pyannote-face.py:130) for the rows of a track file in file order.
+
+    pandas sorts one float column with numpy's default `argsort(kind='quicksort')`, which is NOT stable: rows that share a
+    timestamp (the faces of one frame) come out in an order that depends on the whole column and on numpy's sort kernel for
+    this CPU.  That order decides nothing but the order of the faces of one frame in landmarks.txt / embedding.txt; it is
+    replayed with the same numpy call so that the files match the reference's line for line on the machine they are made on."""
+    return np.argsort(np.asarray(times, np.float64), kind="quicksort")
+
+
 def read_tracks(path):
-    """[(T, identifier, (l,t,r,b) float32 normalised, status)] sorted by time (stable), like getFaceGenerator (:121-130)"""
+    """[(T, identifier, (l,t,r,b) float32 normalised, status)] in the order of getFaceGenerator's sorted table (:121-130)"""
     rows = []
     with open(path) as f:
         for line in f:
@@ -54,8 +64,17 @@ def read_tracks(path):
             if not p:
                 continue
             rows.append((float(p[0]), int(p[1]), tuple(np.float32(v) for v in p[2:6]), p[6]))
-    rows.sort(key=lambda r: r[0])   # pandas sort_values('t') default quicksort is not stable; ties keep file order here
-    return rows
+    return [rows[i] for i in pandas_sort_order([r[0] for r in rows])]
+
+
+def file_order(face_T, face_id, file_T, file_id):
+    """permutation that puts extracted faces (any order within a timestamp) into the order the reference's `extract` writes them:
+    the order of the (T, track) rows in the pandas-sorted track table.  file_T / file_id: the track file's rows in file order."""
+    rank = {}
+    for k, i in enumerate(pandas_sort_order(file_T)):
+        rank[(float(file_T[i]), int(file_id[i]))] = k
+    keys = [rank[(float(t), int(i))] for t, i in zip(face_T, face_id)]
+    return np.argsort(np.asarray(keys, np.int64), kind="stable")
 
 
 def landmark_line(T, identifier, pts, frame_width, frame_height):

@@ -77,6 +77,7 @@ class ExtractStream(object):
         self.ctx, self.frames, self.times = ctx, frames, frame_times
         self.w, self.h = frame_width, frame_height
         self.tracks, self.rows = [], []
+        self.file_T, self.file_id = [], []    # the track file's (T, track) column in file order (decides the row order of the outputs)
         self.groups, self.gi, self.fi = [], 0, 0
         self.face_boxes, self.face_T, self.face_id = [], [], []
         self.pts, self.emb = [], []
@@ -116,6 +117,8 @@ class ExtractStream(object):
         for k, track in enumerate(tracks):
             for t, box, status in track:
                 rows.append((formats.quantise_time(t), base + k, tuple(np.float32("%.3f" % v) for v in box), status))
+        self.file_T.extend(r[0] for r in rows)
+        self.file_id.extend(r[1] for r in rows)
         rows.sort(key=lambda r: r[0])
         self.tracks.extend(tracks)
         self.rows.extend(rows)
@@ -136,11 +139,21 @@ class ExtractStream(object):
     def feed(self, tracks):
         self.compute(self.prepare(tracks))
 
-    def finish(self, drop_last=True):
+    def finish(self, drop_last=True, reorder=True):
+        """reorder: put the faces of one timestamp into the order the reference's `extract` writes them (formats.file_order).
+        A shard of a longer video leaves that to the step that sees the whole track table (dist.gather_rows)."""
         self.compute(self._emit(len(self.groups) - (1 if drop_last else 0)))
-        self.rows.sort(key=lambda r: r[0])
         pts = np.concatenate(self.pts) if self.pts else np.zeros((0, 68, 2), np.int32)
         emb = np.concatenate(self.emb) if self.emb else np.zeros((0, 128), np.float32)
+        if reorder and len(self.face_T):
+            perm = formats.file_order(self.face_T, self.face_id, self.file_T, self.file_id)
+            self.face_T = [self.face_T[i] for i in perm]
+            self.face_id = [self.face_id[i] for i in perm]
+            self.face_boxes = [self.face_boxes[i] for i in perm]
+            pts, emb = pts[perm], emb[perm]
+        order = formats.pandas_sort_order(self.file_T)
+        by_key = {(r[0], r[1]): r for r in self.rows}
+        self.rows = [by_key[(self.file_T[i], self.file_id[i])] for i in order]
         return pts, emb
 
 
@@ -306,7 +319,7 @@ class FacePipeline(object):
             with open(os.environ["PVF_TRACE"], "w") as f:
                 json.dump(trace, f)
 
-    def run(self, frames, times, frame_rate, shots, timings=None, cluster=True, last_shard=True):
+    def run(self, frames, times, frame_rate, shots, timings=None, cluster=True, last_shard=True, reorder=True):
         """frames: list of DeviceFrame (or numpy arrays), one size; times: their timestamps; shots: [(start, end)].
         Returns dict(tracks, track_rows, faces, landmarks, embeddings, labels)."""
         tm = timings if timings is not None else {}
@@ -341,7 +354,7 @@ class FacePipeline(object):
             finally:
                 if was_enabled:
                     gc.enable()
-        pts, emb = ex.finish(drop_last=last_shard)
+        pts, emb = ex.finish(drop_last=last_shard, reorder=reorder)
         tracks, rows = ex.tracks, ex.rows
         face_boxes, face_T, face_id = ex.face_boxes, ex.face_T, ex.face_id
         t1 = mark.get("tracked", _time.perf_counter())
@@ -360,7 +373,8 @@ class FacePipeline(object):
         tm["cluster_s"] = _time.perf_counter() - t2
         tm["total_s"] = _time.perf_counter() - t0
         return {"tracks": tracks, "track_rows": rows, "face_T": face_T, "face_id": face_id, "face_boxes": face_boxes,
-                "landmarks": pts, "embeddings": emb, "X": Xq, "labels": labels, "shot_ranges": ranges}
+                "landmarks": pts, "embeddings": emb, "X": Xq, "labels": labels, "shot_ranges": ranges,
+                "file_T": np.asarray(ex.file_T, np.float64), "file_id": np.asarray(ex.file_id, np.int64)}
 
 
 def _noop():

@@ -47,6 +47,53 @@ def test_gather_rows_world2(tmp_path):
     assert r0["T0"] == t0[0] and r0["Tlast"] == t1[-1]
 
 
+ORDER_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "pyannote-video_amd"))
+import torch.distributed as dist
+from pyannote_video_amd import dist as pd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+table = json.loads(open(sys.argv[3]).read())[rank]                     # this rank's share of the track table, file order
+fT, fid = np.array(table["T"]), np.array(table["id"])
+order = np.random.default_rng(rank).permutation(len(fT))               # faces arrive in any order within the shard
+X = np.zeros((len(fT), 128)); X[:, 0] = fT[order]; X[:, 1] = fid[order]
+gT, gid, gX, offsets = pd.gather_rows(fT[order], fid[order], X, table["n_tracks"], file_T=fT, file_id=fid)
+open(sys.argv[2] + ".%d" % rank, "w").write(json.dumps({"T": gT.tolist(), "ids": gid.tolist(), "x0": gX[:, 0].tolist()}))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_gather_rows_restores_reference_row_order_world2(tmp_path):
+    """faces of one timestamp come out in the order pandas' (unstable) sort of the WHOLE track table gives (formats.file_order),
+    however the table was split over the ranks"""
+    import json
+    from pyannote_video_amd import formats
+    rng = np.random.default_rng(5)
+    shares, fT, fid, base = [], [], [], 0
+    for rank, (f0, f1) in enumerate([(0, 40), (40, 70)]):
+        T, ids = [], []
+        n_tracks = 5 + rank
+        for k in range(n_tracks):                                       # file order: track after track
+            a = int(rng.integers(f0, f1 - 3)); b = int(rng.integers(a + 2, f1))
+            T += [round(i / 25.0, 3) for i in range(a, b)]; ids += [k] * (b - a)
+        shares.append({"T": T, "id": ids, "n_tracks": n_tracks})
+        fT += T; fid += [i + base for i in ids]; base += n_tracks
+    (tmp_path / "table.json").write_text(json.dumps(shares))
+    script = tmp_path / "worker.py"
+    script.write_text(ORDER_WORKER)
+    out = str(tmp_path / "out")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29617", str(script), ROOT, out, str(tmp_path / "table.json")], env=dict(os.environ, MASTER_ADDR="127.0.0.1"),
+                          timeout=240)
+    r0, r1 = (json.loads(open(out + ".%d" % r).read()) for r in (0, 1))
+    want = formats.pandas_sort_order(fT)
+    assert r0 == r1
+    assert r0["T"] == [fT[i] for i in want] and r0["ids"] == [fid[i] for i in want]
+    assert r0["x0"] == r0["T"]                                          # the payload rows moved with their keys
+
+
 def test_shard_planner_contiguous_and_balanced():
     from pyannote_video_amd import dist as pd
     shots = [(i * 250, (i + 1) * 250) for i in range(32)]

@@ -31,8 +31,8 @@ ranges = pipeline.split_into_shots(times, v.shots())
 s0, s1 = pd.shard_shots(ranges, world)[rank]
 i0, i1 = ranges[s0][0], ranges[s1 - 1][1]
 frames = [ctx.upload(v.frame(i)) for i in range(i0, i1)]
-res = pipe.run(frames, times[i0:i1], v.frame_rate, v.shots()[s0:s1], cluster=False, last_shard=(rank == world - 1))
-T, ids, X, offsets = pd.gather_rows(res["face_T"], res["face_id"], res["X"], len(res["tracks"]))
+res = pipe.run(frames, times[i0:i1], v.frame_rate, v.shots()[s0:s1], cluster=False, last_shard=(rank == world - 1), reorder=False)
+T, ids, X, offsets = pd.gather_rows(res["face_T"], res["face_id"], res["X"], len(res["tracks"]), file_T=res["file_T"], file_id=res["file_id"])
 labels = pd.global_cluster(pipe.clustering, T, ids, X)
 out = {"rank": rank, "n_tracks": len(res["tracks"]), "offsets": offsets, "T": T.tolist(), "ids": ids.tolist(),
        "Xsum": float(np.abs(X).sum()), "labels": sorted(labels.items())}

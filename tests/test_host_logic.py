@@ -160,7 +160,7 @@ def test_extract_time_sync_equals_reference_generator():
         for identifier, track in enumerate(tracks):
             for t, box, status in track:
                 rows.append((formats.quantise_time(t), identifier, tuple(np.float32("%.3f" % v) for v in box), status))
-        rows.sort(key=lambda r: r[0])
+        rows = [rows[i] for i in formats.pandas_sort_order([r[0] for r in rows])]       # tracking.sort_values('t')
         got = [box for _, _, g in pipeline.faces_per_frame(rows, times, 200, 100) for _, box in g]
         assert got == seen
 
@@ -217,7 +217,7 @@ def test_extract_stream_equals_whole_file_walk(seed, drop_last):
     for identifier, track in enumerate(t for tracks in per_shot for t in tracks):
         for t, box, status in track:
             rows.append((formats.quantise_time(t), identifier, tuple(np.float32("%.3f" % v) for v in box), status))
-    rows.sort(key=lambda r: r[0])
+    rows = [rows[i] for i in formats.pandas_sort_order([r[0] for r in rows])]           # tracking.sort_values('t') of the whole file
     ref = pipeline.faces_per_frame(rows, times, W, H, drop_last=drop_last)
     assert ex.emitted == [(fi, T) for fi, T, _ in ref]
     assert ex.face_id == [ident for _, _, g in ref for ident, _ in g]
