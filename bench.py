@@ -35,7 +35,8 @@ def main():
     ap.add_argument("--faces", type=int, default=8)
     ap.add_argument("--shots", type=int, default=4)
     ap.add_argument("--detect-batch", type=int, default=32)
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the CPU-oracle sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the all-core CPU-oracle sample, centred on the first shot cut (0 = skip)")
+    ap.add_argument("--cpu-frames-1t", type=int, default=4, help="frames of the single-thread CPU-oracle sample (same centre)")
     ap.add_argument("--no-overlap", action="store_true", help="no GPU-feeding thread: every stage runs in the caller's thread, shot after shot")
     ap.add_argument("--small-models", action="store_true", help="debug only: reduced landmark model")
     args = ap.parse_args()
@@ -147,7 +148,7 @@ def main():
     score_ms = fam["score"]["ms"]
     launches = max(fam["score"]["launches"], 1)
     achieved = (flop_per_frame * n_score_frames / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
-    roofline = {"kernel": "score_mfma_rows_ml_k<4> (HOG filter scoring of every pyramid level of a 32-frame batch, 5 filters x 3100 MAC per position)", "bound": "mfma",
+    roofline = {"kernel": "score_sys_ml_k (HOG filter scoring of every pyramid level of a %d-frame batch, 5 filters x 3100 MAC per position)" % args.detect_batch, "bound": "mfma",
                 "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_ms": round(score_ms / launches, 4),
@@ -156,7 +157,7 @@ def main():
     # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read inside this process);
     # the committed measurement is attached when it was taken on this configuration.
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_score.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_score.json")))
         if pm["detect_batch"] == args.detect_batch and pm["frame"] == "%dx%d" % (args.width, args.height):
             roofline["traffic"] = pm["traffic_bytes_per_launch"]
             roofline["traffic_source"] = pm["source"]
@@ -164,9 +165,9 @@ def main():
     except Exception:
         pass
 
-    cpu = None
+    cpu, parity = None, None
     if world == 1 and args.cpu_frames > 0:
-        cpu = cpu_baseline(video, lp, ep, args.cpu_frames)
+        cpu, parity = cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args)
 
     n_clusters = len(set(labels.values()))
     out = {
@@ -182,6 +183,7 @@ def main():
                    "detect_batch": args.detect_batch},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "parity": parity,
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
         "kernel_families_ms": fam,
         "results": {"tracks": len(res["tracks"]), "faces_embedded": int(len(res["face_T"])), "clusters": n_clusters,
@@ -191,30 +193,81 @@ def main():
     print(json.dumps(out))
 
 
-def cpu_baseline(video, lp, ep, n_frames):
-    """The CPU oracle (a port: dlib itself is not installable here) on the first n frames of the same video, same models,
-    same flow (detect every frame, fwd+bwd tracking, landmarks, embedding, clustering)."""
+def cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args):
+    """Outside the timed region: the CPU oracle (a port: dlib itself is not installable here) on a bounded sample of the SAME video
+    -- a window of frames centred on the first shot cut, so that it holds a shot boundary -- timed with all host cores and with one
+    thread, and the product pipeline on the same window compared with it: the parity gate of this run."""
+    import concurrent.futures
     import numpy as np
     from pyannote_video_amd import models, pipeline
     from oracle import oracle, ref_flow
-    oracle.lib().pvo_set_threads(min(os.cpu_count() or 1, 32))   # more threads than rows per level only adds overhead
-    cores = oracle.lib().pvo_get_max_threads()
-    frames = [video.frame(i) for i in range(n_frames)]
-    times = [video.timestamp(i) for i in range(n_frames)]
+    nproc = os.cpu_count() or 1
+    cut = video.shot_bounds[1] if video.n_shots > 1 else video.n_frames // 2
     det = oracle.Detector(models.load_container(models.DEFAULT_DETECTOR))
-    sp = oracle.ShapePredictor(models.load_container(lp))
-    emb = oracle.Embedder(models.load_container(ep))
+    sp = oracle.ShapePredictor(models.load_model_file(lp, "shape_predictor"))
+    emb = oracle.Embedder(models.load_model_file(ep, "embedder"))
     tabs = models.dsst_tables()
-    t0 = time.perf_counter()
-    tracks = ref_flow.track_video(frames, times, [(0.0, 1e9)], det, lambda: oracle.Tracker(tabs), video.frame_rate,
-                                  min_conf=pipeline.CLI_MIN_CONFIDENCE, ratio=pipeline.CLI_MIN_OVERLAP_RATIO, max_gap=pipeline.CLI_MAX_GAP)
-    t_track = time.perf_counter() - t0
-    lm, em = ref_flow.extract(ref_flow.track_text(tracks), frames, times, sp, emb)
-    ref_flow.cluster(em, 0.6)
-    dt = time.perf_counter() - t0
-    return {"value": round(n_frames / dt, 4), "unit": "frames/s", "cores": int(cores), "kind": "port",
-            "sample": "first %d frames of the same 1080p video, whole flow (detect+track %.1fs of %.1fs); scoring loop OpenMP over "
-                      "%d threads, other stages 1 thread" % (n_frames, t_track, dt, cores)}
+
+    def window(n):
+        i0 = max(0, min(cut - n // 2, video.n_frames - n))
+        idx = list(range(i0, i0 + n))
+        shots = [(a, b) for a, b in video.shots() if b > video.timestamp(idx[0]) and a <= video.timestamp(idx[-1])]
+        return idx, [video.timestamp(i) for i in idx], shots
+
+    def note(msg):
+        if os.environ.get("PVF_VERBOSE"):
+            sys.stderr.write("[bench %.1fs] %s\n" % (time.perf_counter() - t_begin, msg))
+            sys.stderr.flush()
+    t_begin = time.perf_counter()
+
+    def oracle_flow(idx, times, shots, threads):
+        oracle.lib().pvo_set_threads(threads)
+        frames = [np.ascontiguousarray(frames_t[i].cpu().numpy()) for i in idx]      # the bytes the GPU path sees
+        pool = concurrent.futures.ThreadPoolExecutor(min(threads, 32)) if threads > 1 else None
+        note("oracle flow on %d frames, %d threads" % (len(idx), threads))
+        t0 = time.perf_counter()
+        tracks = ref_flow.track_video(frames, times, shots, det, lambda: oracle.Tracker(tabs), video.frame_rate,
+                                      min_conf=pipeline.CLI_MIN_CONFIDENCE, ratio=pipeline.CLI_MIN_OVERLAP_RATIO, max_gap=pipeline.CLI_MAX_GAP, pool=pool)
+        t_track = time.perf_counter() - t0
+        note("  detect + tracking done (%.1f s)" % t_track)
+        lm, em = ref_flow.extract(ref_flow.track_text(tracks), frames, times, sp, emb, pool=pool)
+        labels = ref_flow.cluster(em, 0.6)
+        dt = time.perf_counter() - t0
+        note("  whole flow done (%.1f s)" % dt)
+        if pool is not None:
+            pool.shutdown()
+        return tracks, lm, em, labels, dt, t_track
+
+    idx, times, shots = window(min(args.cpu_frames, video.n_frames))
+    tracks, lm, em, labels, dt, t_track = oracle_flow(idx, times, shots, nproc)
+    cpu = {"value": round(len(idx) / dt, 4), "unit": "frames/s", "cores": int(nproc), "kind": "port",
+           "sample": "frames %d..%d of the same 1080p video (a window around the shot cut at frame %d), whole flow: detect + fwd/bwd tracking %.1f s "
+                     "of %.1f s, then landmarks, embedding, clustering; OpenMP over pyramid rows, FHOG cell rows and scoring rows, trackers and "
+                     "faces of a frame in a thread pool" % (idx[0], idx[-1], cut, t_track, dt)}
+    if args.cpu_frames_1t > 0:
+        idx1, times1, shots1 = window(min(args.cpu_frames_1t, video.n_frames))
+        _, _, _, _, dt1, _ = oracle_flow(idx1, times1, shots1, 1)
+        cpu["single_thread"] = {"value": round(len(idx1) / dt1, 4), "unit": "frames/s", "cores": 1,
+                                "sample": "frames %d..%d, same flow, one thread (how the reference runs: one Python thread, single-threaded dlib)" % (idx1[0], idx1[-1])}
+    # ---- parity gate: the product on the same window (frames already in HBM) vs the oracle flow above
+    note("product pipeline on the parity window")
+    dev_frames = [ctx.wrap_torch(frames_t[i]) for i in idx]
+    res = pipe.run(dev_frames, times, video.frame_rate, shots)
+    ref_e = np.array([[float(x) for x in line.split()[2:]] for line in em]).reshape(-1, 128)
+    ref_pts = np.array([[float(x) for x in line.split()[2:]] for line in lm]).reshape(-1, 68, 2)
+    w, h = video.frame_size
+    ref_int = np.rint(ref_pts * np.array([w, h], np.float64)).astype(np.int64)      # 5 decimals of x / width resolve the integer point
+    same_rows = len(ref_e) == len(res["embeddings"]) and [int(l.split()[1]) for l in em] == res["face_id"].tolist()
+    parity = {
+        "sample": "product pipeline vs CPU oracle flow on frames %d..%d (1080p, full landmark model, detect batch %d)" % (idx[0], idx[-1], args.detect_batch),
+        "boxes": "exact" if res["tracks"] == tracks else "MISMATCH",           # every track row: time, detector / tracker box, status string
+        "track_ids": "exact" if [len(t) for t in res["tracks"]] == [len(t) for t in tracks] and same_rows else "MISMATCH",
+        "landmarks": "exact" if same_rows and np.array_equal(res["landmarks"].astype(np.int64), ref_int) else "MISMATCH",
+        "embed_l2_max": float(np.linalg.norm(ref_e - res["embeddings"].astype(np.float64), axis=1).max()) if same_rows and len(ref_e) else None,
+        "labels": "exact" if res["labels"] == labels else "MISMATCH",
+        "tracks": len(tracks), "faces": int(len(ref_e)),
+    }
+    return cpu, parity
 
 
 if __name__ == "__main__":

@@ -135,6 +135,10 @@ int32_t pvf_face_chips(pvf_handle ctx, const pvf_handle* frames, const int32_t* 
  * X float64 [N][dim], rows grouped by track, row_start[T+1]; D float64 [T][T] (positive distances) */
 int32_t pvf_pair_mean_dist(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start,
                            int32_t T, double* D);
+/* same with the pair distance chosen: metric 0 = Euclidean (the reference, clustering.py:101), 1 = cosine distance 1 - a.b / (|a| |b|)
+ * (BASELINE.json north_star's wording; 128-D rows).  pvf_cluster_dist agglomerates either matrix. */
+int32_t pvf_pair_mean_dist_metric(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start,
+                                  int32_t T, int32_t metric, double* D);
 /* ref: clustering.py:116-119,138-148  FaceClustering(threshold)(starting_point, features): average-linkage HAC from the
  * track partition, stop when the closest pair's mean distance exceeds `threshold`;
  * labels[t] = smallest track index of t's cluster; merge_log optional [(T-1)*4] = (a, b, dist, new_size) */

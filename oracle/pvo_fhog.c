@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 
 static const float DIRX[9] = {1.0000f, 0.9397f, 0.7660f, 0.500f, 0.1736f, -0.1736f, -0.5000f, -0.7660f, -0.9397f};
 static const float DIRY[9] = {0.0000f, 0.3420f, 0.6428f, 0.8660f, 0.9848f, 0.9848f, 0.8660f, 0.6428f, 0.3420f};
@@ -140,26 +141,42 @@ void pvo_fhog(const uint8_t* img, int ih, int iw, int cell, int pad_r, int pad_c
     const int visible_nr = (cells_nr * cell < ih ? cells_nr * cell : ih) - 1;
     const int visible_nc = (cells_nc * cell < iw ? cells_nc * cell : iw) - 1;
 
-    for (int y = 1; y < visible_nr; ++y) {
-        const float yp = ((float)y + 0.5f) / (float)cell - 0.5f;
-        const int iyp = (int)floorf(yp);
-        const float vy0 = yp - (float)iyp;
-        const float vy1 = 1.0f - vy0;
-        for (int x = 1; x < visible_nc; ++x) {
-            float gx, gy;
-            float v = gradient(img, iw, y, x, &gx, &gy);
-            const int bo = snap_orientation(gx, gy);
-            v = sqrtf(v);
-            const float xp = ((float)x + 0.5f) / (float)cell - 0.5f;
-            const int ixp = (int)floorf(xp);
-            const float vx0 = xp - (float)ixp;
-            const float vx1 = 1.0f - vx0;
-            hist[((size_t)(iyp + 1) * hc + (ixp + 1)) * 18 + bo] += (vy1 * vx1) * v;
-            hist[((size_t)(iyp + 2) * hc + (ixp + 1)) * 18 + bo] += (vy0 * vx1) * v;
-            hist[((size_t)(iyp + 1) * hc + (ixp + 2)) * 18 + bo] += (vy1 * vx0) * v;
-            hist[((size_t)(iyp + 2) * hc + (ixp + 2)) * 18 + bo] += (vy0 * vx0) * v;
+    /* dlib's loop visits the pixels in row-major order and scatters each vote into 4 cells, so a cell's bins are summed in
+     * row-major order of the pixels that vote for it.  For the all-core CPU baseline the histogram ROWS are dealt out to threads:
+     * each thread walks the pixel rows that vote into its rows, in the same order, and adds only to its own rows -- the sums are
+     * formed in exactly the sequential order, for any thread count (band = 1 reproduces the plain loop). */
+    const int n_bands = (ih * iw > 65536) ? omp_get_max_threads() : 1;
+    const int band_rows = (hr + n_bands - 1) / n_bands;
+    #pragma omp parallel for schedule(static) if (n_bands > 1)
+    for (int band = 0; band < n_bands; ++band) {
+        const int r_lo = band * band_rows, r_hi = (r_lo + band_rows < hr) ? r_lo + band_rows : hr;   /* histogram rows [r_lo, r_hi) */
+        if (r_lo >= r_hi) continue;
+        /* pixel row y votes into histogram rows iyp + 1 and iyp + 2 with iyp + 1 = (y + 4) / 8 (cell = 8); generic: compute and test */
+        for (int y = 1; y < visible_nr; ++y) {
+            const float yp = ((float)y + 0.5f) / (float)cell - 0.5f;
+            const int iyp = (int)floorf(yp);
+            const int ra = iyp + 1, rb2 = iyp + 2;
+            const int in_a = (ra >= r_lo && ra < r_hi), in_b = (rb2 >= r_lo && rb2 < r_hi);
+            if (!in_a && !in_b) continue;
+            const float vy0 = yp - (float)iyp;
+            const float vy1 = 1.0f - vy0;
+            for (int x = 1; x < visible_nc; ++x) {
+                float gx, gy;
+                float v = gradient(img, iw, y, x, &gx, &gy);
+                const int bo = snap_orientation(gx, gy);
+                v = sqrtf(v);
+                const float xp = ((float)x + 0.5f) / (float)cell - 0.5f;
+                const int ixp = (int)floorf(xp);
+                const float vx0 = xp - (float)ixp;
+                const float vx1 = 1.0f - vx0;
+                if (in_a) hist[((size_t)(iyp + 1) * hc + (ixp + 1)) * 18 + bo] += (vy1 * vx1) * v;
+                if (in_b) hist[((size_t)(iyp + 2) * hc + (ixp + 1)) * 18 + bo] += (vy0 * vx1) * v;
+                if (in_a) hist[((size_t)(iyp + 1) * hc + (ixp + 2)) * 18 + bo] += (vy1 * vx0) * v;
+                if (in_b) hist[((size_t)(iyp + 2) * hc + (ixp + 2)) * 18 + bo] += (vy0 * vx0) * v;
+            }
         }
     }
+    #pragma omp parallel for schedule(static) if (cells_nr * cells_nc > 4096)
     for (int r = 0; r < cells_nr; ++r)
         for (int c = 0; c < cells_nc; ++c) {
             const float* h = hist + ((size_t)(r + 1) * hc + (c + 1)) * 18;
@@ -169,6 +186,7 @@ void pvo_fhog(const uint8_t* img, int ih, int iw, int cell, int pad_r, int pad_c
         }
     const int hog_nr = cells_nr - 2, hog_nc = cells_nc - 2;
     const int oy = (pad_r - 1) / 2, ox = (pad_c - 1) / 2;
+    #pragma omp parallel for schedule(static) if (hog_nr * hog_nc > 4096)
     for (int y = 0; y < hog_nr; ++y)
         for (int x = 0; x < hog_nc; ++x) {
             float n[9];

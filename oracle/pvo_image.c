@@ -20,6 +20,8 @@ void pvo_resize_bilinear_rgb(const uint8_t* in, int ih, int iw, uint8_t* out, in
 {
     const double x_scale = (iw - 1) / (double)imax(ow - 1, 1);
     const double y_scale = (ih - 1) / (double)imax(oh - 1, 1);
+    /* rows are independent: OpenMP over rows for the all-core CPU baseline (pvo_set_threads); same bytes for any thread count */
+    #pragma omp parallel for schedule(static) if (oh * ow > 65536)
     for (int r = 0; r < oh; ++r) {
         const double y = r * y_scale;
         const int top = (int)floor(y);

@@ -61,13 +61,16 @@ def associate(trackers, detections, ratio):
     return out
 
 
-def one_pass(graph, cache, direction, tracker_factory, min_conf, ratio):
+def one_pass(graph, cache, direction, tracker_factory, min_conf, ratio, pool=None):
+    """pool: optional concurrent.futures executor -- the trackers of one frame are independent objects, so the all-core CPU
+    baseline updates / starts them concurrently (the C calls release the interpreter lock); results are identical"""
     seq = cache if direction == FWD else list(reversed(cache))
     trackers, conf, prev = {}, {}, {}
     next_id = 0
     for t, frame in seq:
-        for ident, trk in list(trackers.items()):
-            c = trk.update(frame)
+        items = list(trackers.items())
+        confs = list(pool.map(lambda it: it[1].update(frame), items)) if pool is not None else [trk.update(frame) for _, trk in items]
+        for (ident, trk), c in zip(items, confs):
             conf[ident] = c
             if c < min_conf:
                 del trackers[ident], conf[ident], prev[ident]
@@ -80,9 +83,11 @@ def one_pass(graph, cache, direction, tracker_factory, min_conf, ratio):
             node = (t, tuple(trk.get_position()), direction)
             graph.add_edge(prev[ident], node, confidence=conf[ident])
             prev[ident] = node
-        for det in detections:
+        def start(det):
             trk = tracker_factory()
             trk.start_track(frame, tuple(float(v) for v in det))
+            return trk
+        for det, trk in zip(detections, list(pool.map(start, detections)) if pool is not None else [start(d) for d in detections]):
             trackers[next_id] = trk
             prev[next_id] = (t, det, DET)
             next_id += 1
@@ -120,22 +125,22 @@ def fill_gaps(tracks, max_gap, ratio):
     return [[item for k in sorted(comp) for item in tracks[k]] for comp in nx.connected_components(g)]
 
 
-def track_shot(cache, detections, tracker_factory, min_conf=10., ratio=0.3, max_gap=0.):
+def track_shot(cache, detections, tracker_factory, min_conf=10., ratio=0.3, max_gap=0., pool=None):
     """cache [(t, frame)], detections [[box]] aligned with cache -> list of tracks sorted by (min_t, max_t)"""
     graph = nx.DiGraph()
     for (t, _), dets in zip(cache, detections):
         graph.add_node(t)
         for d in dets:
             graph.add_edge(t, (t, tuple(d), DET))
-    one_pass(graph, cache, FWD, tracker_factory, min_conf, ratio)
-    one_pass(graph, cache, BWD, tracker_factory, min_conf, ratio)
+    one_pass(graph, cache, FWD, tracker_factory, min_conf, ratio, pool)
+    one_pass(graph, cache, BWD, tracker_factory, min_conf, ratio, pool)
     graph.remove_nodes_from([n for n in list(graph) if not isinstance(n, tuple)])
     comps = nx.connected_components(graph.to_undirected(reciprocal=False))
     tracks = fill_gaps([fix(c, ratio) for c in comps], max_gap, ratio)
     return sorted(tracks, key=span)
 
 
-def track_video(frames, times, shots, detect, tracker_factory, frame_rate, detect_every=0., min_conf=10., ratio=0.3, max_gap=0.):
+def track_video(frames, times, shots, detect, tracker_factory, frame_rate, detect_every=0., min_conf=10., ratio=0.3, max_gap=0., pool=None):
     """-> normalised tracks in the order `pyannote-face.py track` enumerates them"""
     every = int(detect_every * frame_rate) if detect_every > 0 else 1
     every = max(every, 1)
@@ -144,7 +149,7 @@ def track_video(frames, times, shots, detect, tracker_factory, frame_rate, detec
     out, cache, dets, k = [], [], [], 0
 
     def flush():
-        for tr in track_shot(cache, dets, tracker_factory, min_conf, ratio, max_gap):
+        for tr in track_shot(cache, dets, tracker_factory, min_conf, ratio, max_gap, pool):
             out.append([(t, (l / w, tp / h, r / w, b / h), st) for t, (l, tp, r, b), st in tr])
     for i, (t, frame) in enumerate(zip(times, frames)):
         # time-driven segment generator: once t reaches the current segment's end, flush and move to the next segment
@@ -166,8 +171,9 @@ def track_text(tracks):
     return lines
 
 
-def extract(track_lines, frames, times, landmarks, embed):
-    """-> (landmark lines, embedding lines), literal text like the CLI writes"""
+def extract(track_lines, frames, times, landmarks, embed, pool=None):
+    """-> (landmark lines, embedding lines), literal text like the CLI writes.  pool: optional executor, faces of one frame are
+    independent (all-core CPU baseline)"""
     h, w = frames[0].shape[:2]
     rows = []
     for line in track_lines:
@@ -200,9 +206,10 @@ def extract(track_lines, frames, times, landmarks, embed):
     lm_lines, em_lines = [], []
     for t, frame in zip(times, frames):
         T, faces = gen.send(t)
-        for ident, box in faces:
-            pts = landmarks(frame, box)
-            e = embed(frame, pts)
+        def one(face):
+            pts = landmarks(frame, face[1])
+            return pts, embed(frame, pts)
+        for (ident, box), (pts, e) in zip(faces, list(pool.map(one, faces)) if pool is not None else [one(f) for f in faces]):
             lm_lines.append('%.3f %d' % (T, ident) + ''.join(' %.5f %.5f' % (x / w, y / h) for x, y in pts))
             em_lines.append('%.3f %d' % (T, ident) + ''.join(' %.5f' % float(v) for v in e))
     return lm_lines, em_lines

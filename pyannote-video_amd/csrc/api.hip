@@ -552,6 +552,15 @@ extern "C" int32_t pvf_pair_mean_dist(pvf_handle h, const double* X, int32_t N, 
     API_END
 }
 
+extern "C" int32_t pvf_pair_mean_dist_metric(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T, int32_t metric,
+                                              double* D)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    pair_mean_dist_dev(c, X, N, dim, row_start, T, D, nullptr, 0, -1, metric);
+    API_END
+}
+
 extern "C" int32_t pvf_pair_mean_dist_rows(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
                                            int32_t track0, int32_t track1, double* D)
 {

@@ -1,9 +1,11 @@
 // cluster.hip -- K10/K11: track-pair mean Euclidean distances and average-linkage agglomeration
 // (reference pyannote/video/face/clustering.py:100-112 pdist + block means, :116-119 merged similarity, :138-141 stop at 0.6).
-// float64 like scipy/numpy in the reference; the N x N matrix is never materialised:
-//   S[a][j] = sum_{b in track j} ||x_a - x_b||   (one lane per (row, track), X kept dimension-major so lanes coalesce)
-//   D[i][j] = sum_{a in track i} S[a][j] / (n_i n_j)
-// HAC keeps D in HBM with cached row minima; a merge costs O(T) plus re-scans of the rows whose minimum died.
+// float64 like scipy/numpy in the reference; neither the N x N matrix nor an N x T intermediate is materialised.
+//   128-D rows (the embeddings): 16 x 16 tiles of x_a . x_b on the f64 matrix cores (v_mfma_f64_16x16x4_f64), distance and the
+//   per-track-pair reduction inside the tile pass (pair_tiles_k below);
+//   other dimensions: the plain per-row kernels (row_track_sums_k / track_pair_mean_k) with an N x T scratch.
+// HAC keeps D in HBM with cached row minima; a merge costs O(T) plus re-scans of the rows whose minimum died.  Up to 10 240 tracks the
+// whole agglomeration is ONE persistent workgroup (row minima in LDS, no launches inside the loop).
 #include "pvf_internal.h"
 #include <cmath>
 
@@ -61,16 +63,275 @@ __global__ void __launch_bounds__(256) track_pair_mean_k(const double* __restric
     D[(size_t)i * T + j] = sum / cnt;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K10 on the f64 matrix cores.
+//
+// Rows are grouped into ROW BLOCKS of at most 16 consecutive rows: a track with >= 16 rows is cut into chunks of 16 (blocks that
+// hold nothing else), shorter tracks are packed whole, several to a block.  The blocking depends on the track sizes only, never on
+// which rank computes which rows, so every D entry is formed by the same additions wherever it is computed.
+// A wave owns one row block (its 16 x 128 values stay in registers as 32 A fragments) and sweeps a range of column blocks, which
+// its workgroup stages through LDS (one copy serves 4 row blocks).  Per 16 x 16 tile: 32 MFMAs give x_a . x_b,
+//   d = sqrt(|a|^2 + |b|^2 - 2 a.b)     (recomputed as sum (a_k - b_k)^2 where the Gram form would cancel; cosine: 1 - a.b / (|a| |b|)),
+// lane r adds the tile's row r to a running sum over b that restarts whenever a column track ends (sequential in b, across tiles),
+// and for every finished column track the sums of the rows of each row track are added in row order:
+//   whole row tracks  ->  D[i][j] = sum / (n_i n_j) written at once;   chunks of a long track -> P[chunk][j], summed in chunk order by
+// pair_chunks_k.  D[i][i] = 0 like scipy's squareform diagonal.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#define PT_PITCH 130                      // doubles per staged row: (2 j + k) mod 32 distinct bank pairs for the B fragment reads
+
+struct PtArgs {
+    const double* X; const double* nrm; int N, T;
+    const int* row_track; const int* row_last; const int* row_seg_len;   // per row: track, 1 on a track's last row, rows of its block segment if it starts one else 0
+    const int* blk_r0; const int* blk_nr; const int* blk_chunk;          // per block: first row, rows, chunk index (-1: packed whole tracks)
+    const int* range_b0;                                                   // column ranges: block index bounds [n_ranges + 1]
+    const int* row_start; double* D; double* P;
+    int n_blocks, n_ranges, t0, t1, metric;
+};
+
+__global__ void __launch_bounds__(256) row_norms_k(const double* __restrict__ X, int N, int dim, double* __restrict__ nrm)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= N) return;
+    double s = 0;
+    for (int k = 0; k < dim; ++k) { const double v = X[(size_t)a * dim + k]; s += v * v; }
+    nrm[a] = s;
+}
+
+__global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
+{
+    constexpr int DIM = 128, KS = DIM / 4;
+    __shared__ __attribute__((aligned(16))) double Bs[2][16 * PT_PITCH];
+    __shared__ double tileD[4][16][17];
+    __shared__ double colS[4][16][17];
+    __shared__ int colInfo[2][16][2];                 // per staged column: track (or -1 for padding), last-row flag
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ab = blockIdx.x * 4 + wave;             // row block of this wave
+    const bool have = ab < a.n_blocks;
+    const int cb0 = a.range_b0[blockIdx.y], cb1 = a.range_b0[blockIdx.y + 1];
+    const int ar0 = have ? a.blk_r0[ab] : 0, anr = have ? a.blk_nr[ab] : 0, achunk = have ? a.blk_chunk[ab] : -1;
+    // a wave whose rows all lie outside [t0, t1) has nothing to write (row tracks are contiguous in a block)
+    bool wanted = false;
+    if (have) { const int ta = a.row_track[ar0], tb = a.row_track[ar0 + anr - 1]; wanted = (tb >= a.t0 && ta < a.t1); }
+    const int i16 = lane & 15, k4 = lane >> 4;
+    double af[KS];
+    {
+        const bool ok = have && i16 < anr;
+        const double* xa = a.X + (size_t)(ar0 + (ok ? i16 : 0)) * DIM + k4;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[s] = ok ? xa[4 * s] : 0.0;
+    }
+    double na4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int row = k4 + 4 * r; na4[r] = (have && row < anr) ? a.nrm[ar0 + row] : 0.0; }
+    double run = 0.0;                                  // lane r < 16: running sum of row r over the columns of the current column track
+    // staging role: thread t moves 8 doubles (64 bytes) of row t >> 4
+    const int srow = tid >> 4, sch = tid & 15;
+    auto stage = [&](int cb, int buf) {
+        const int r0 = a.blk_r0[cb], nr = a.blk_nr[cb];
+        double v[8];
+        const bool ok = srow < nr;
+        const double* src = a.X + (size_t)(r0 + (ok ? srow : 0)) * DIM + 8 * sch;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ok ? src[q] : 0.0;
+        double* dst = &Bs[buf][srow * PT_PITCH + 8 * sch];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q] = v[q];
+        if (tid < 16) {
+            colInfo[buf][tid][0] = tid < nr ? a.row_track[r0 + tid] : -1;
+            colInfo[buf][tid][1] = tid < nr ? a.row_last[r0 + tid] : 0;
+        }
+    };
+    if (cb0 < cb1) stage(cb0, 0);
+    __syncthreads();
+    for (int cb = cb0; cb < cb1; ++cb) {
+        const int buf = (cb - cb0) & 1;
+        if (cb + 1 < cb1) stage(cb + 1, buf ^ 1);
+        if (wanted) {
+            const int br0 = a.blk_r0[cb];
+            f64x4 acc = (f64x4){0.0, 0.0, 0.0, 0.0};
+            const double* bp = &Bs[buf][i16 * PT_PITCH + k4];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bp[4 * s], acc, 0, 0, 0);
+            // C/D of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
+            const int ct = colInfo[buf][i16][0];
+            const double nb = ct >= 0 ? a.nrm[br0 + i16] : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = k4 + 4 * r;
+                double d = 0.0;
+                if (row < anr && ct >= 0) {
+                    const double g = acc[r], sum = na4[r] + nb;
+                    if (a.metric == 1) d = 1.0 - g / sqrt(na4[r] * nb);
+                    else {
+                        double d2 = sum - 2.0 * g;
+                        if (d2 < 1e-2 * sum) {         // the Gram form cancels for close rows: take the differences instead
+                            const double* xa = a.X + (size_t)(ar0 + row) * DIM;
+                            const double* xb = a.X + (size_t)(br0 + i16) * DIM;
+                            d2 = 0.0;
+                            for (int k = 0; k < DIM; ++k) { const double t = xa[k] - xb[k]; d2 += t * t; }
+                        }
+                        d = sqrt(d2 > 0.0 ? d2 : 0.0);
+                    }
+                }
+                tileD[wave][row][i16] = d;
+            }
+            __builtin_amdgcn_wave_barrier();        // tileD is written and read by different lanes of this wave (LDS is in order per wave)
+            // running sums over b, one lane per row; a finished column track leaves its sum in colS[row][column]
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (colInfo[buf][c][0] >= 0) {
+                        run += tileD[wave][lane][c];
+                        if (colInfo[buf][c][1]) { colS[wave][lane][c] = run; run = 0.0; }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // sums over the rows of each row track, in row order, for every finished column track
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q, r = idx >> 4, c = idx & 15;
+                const int len = (r < anr) ? a.row_seg_len[ar0 + r] : 0;
+                if (len > 0 && colInfo[buf][c][1]) {
+                    const int i = a.row_track[ar0 + r], j = colInfo[buf][c][0];
+                    if (i >= a.t0 && i < a.t1) {
+                        double s = 0.0;
+                        for (int rr = r; rr < r + len; ++rr) s += colS[wave][rr][c];
+                        if (achunk >= 0) a.P[(size_t)achunk * a.T + j] = s;
+                        else {
+                            const double cnt = (double)(a.row_start[i + 1] - a.row_start[i]) * (double)(a.row_start[j + 1] - a.row_start[j]);
+                            a.D[(size_t)i * a.T + j] = (i == j) ? 0.0 : s / cnt;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// long tracks: D[i][j] = (P[c0][j] + P[c0+1][j] + ...) / (n_i n_j), chunks in order
+__global__ void __launch_bounds__(256) pair_chunks_k(const double* __restrict__ P, const int* __restrict__ big_track, const int* __restrict__ big_c0,
+                                                     const int* __restrict__ big_nc, const int32_t* __restrict__ row_start, int T, double* __restrict__ D)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = big_track[blockIdx.y];
+    if (j >= T) return;
+    double s = 0.0;
+    for (int c = 0; c < big_nc[blockIdx.y]; ++c) s += P[(size_t)(big_c0[blockIdx.y] + c) * T + j];
+    const double cnt = (double)(row_start[i + 1] - row_start[i]) * (double)(row_start[j + 1] - row_start[j]);
+    D[(size_t)i * T + j] = (i == j) ? 0.0 : s / cnt;
+}
+
+static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* row_start, int T, double* h_D, double** d_D_keep, int t0, int t1,
+                                int metric)
+{
+    constexpr int DIM = 128;
+    // ---- blocking (host, O(N))
+    std::vector<int> row_track(N), row_last(N, 0), row_seg(N, 0), blk_r0, blk_nr, blk_chunk, big_track, big_c0, big_nc;
+    std::vector<int> blk_first_track;
+    int n_chunks = 0;
+    for (int t = 0; t < T; ++t) for (int r = row_start[t]; r < row_start[t + 1]; ++r) row_track[r] = t;
+    for (int t = 0; t < T; ++t) if (row_start[t + 1] > row_start[t]) row_last[row_start[t + 1] - 1] = 1;
+    int t = 0;
+    while (t < T) {
+        const int n = row_start[t + 1] - row_start[t];
+        if (n == 0) { ++t; continue; }
+        if (n >= 16) {
+            big_track.push_back(t); big_c0.push_back(n_chunks);
+            int k = 0;
+            for (int r = row_start[t]; r < row_start[t + 1]; r += 16, ++k) {
+                const int nr = std::min(16, row_start[t + 1] - r);
+                blk_r0.push_back(r); blk_nr.push_back(nr); blk_chunk.push_back(n_chunks + k); blk_first_track.push_back(t);
+                row_seg[r] = nr;
+            }
+            big_nc.push_back(k);
+            n_chunks += k;
+            ++t;
+        } else {
+            const int r0 = row_start[t];
+            int rows = 0;
+            blk_first_track.push_back(t);
+            while (t < T && rows + (row_start[t + 1] - row_start[t]) <= 16 && (row_start[t + 1] - row_start[t]) < 16) {
+                const int m = row_start[t + 1] - row_start[t];
+                if (m > 0) row_seg[row_start[t]] = m;
+                rows += m;
+                ++t;
+            }
+            blk_r0.push_back(r0); blk_nr.push_back(rows); blk_chunk.push_back(-1);
+        }
+    }
+    const int nb = (int)blk_r0.size();
+    // column ranges: about 4 x 256 workgroups in total, cut only where a block starts a new track (never inside a long track)
+    const int row_groups = (nb + 3) / 4;
+    int want_ranges = std::max(1, std::min(nb, (4 * 256 + row_groups - 1) / row_groups));
+    std::vector<int> range_b0{0};
+    for (int k = 1; k < want_ranges; ++k) {
+        int b = (int)((long long)nb * k / want_ranges);
+        while (b < nb && blk_chunk[b] >= 0 && b > 0 && blk_first_track[b] == blk_first_track[b - 1]) ++b;   // move past the chunks of one track
+        if (b > range_b0.back() && b < nb) range_b0.push_back(b);
+    }
+    range_b0.push_back(nb);
+    const int n_ranges = (int)range_b0.size() - 1;
+    // ---- device buffers
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t xb = al((size_t)N * DIM * 8), nbz = al((size_t)N * 8), ib = al((size_t)N * 4), bb = al((size_t)nb * 4), pb = al((size_t)std::max(n_chunks, 1) * T * 8);
+    const size_t rsb = al((size_t)(T + 1) * 4), rgb = al((size_t)(n_ranges + 1) * 4), bigb = al((size_t)std::max<size_t>(big_track.size(), 1) * 4);
+    c->s_clu0.ensure(xb + nbz + 3 * ib + 3 * bb + pb + rsb + rgb + 3 * bigb + 1024);
+    c->s_clu1.ensure((size_t)T * T * sizeof(double) + (size_t)T * 64 + 4096);
+    uint8_t* p = c->s_clu0.as<uint8_t>();
+    auto take = [&](size_t bytes) { uint8_t* q = p; p += bytes; return q; };
+    double* dX = (double*)take(xb); double* dN = (double*)take(nbz);
+    int* dRT = (int*)take(ib); int* dRL = (int*)take(ib); int* dRS = (int*)take(ib);
+    int* dB0 = (int*)take(bb); int* dBN = (int*)take(bb); int* dBC = (int*)take(bb);
+    double* dP = (double*)take(pb);
+    int* dRow = (int*)take(rsb); int* dRange = (int*)take(rgb);
+    int* dBigT = (int*)take(bigb); int* dBigC0 = (int*)take(bigb); int* dBigNc = (int*)take(bigb);
+    double* dD = c->s_clu1.as<double>();
+    auto up = [&](void* d, const void* h, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream)); };
+    up(dX, X, (size_t)N * DIM * 8);
+    up(dRT, row_track.data(), (size_t)N * 4); up(dRL, row_last.data(), (size_t)N * 4); up(dRS, row_seg.data(), (size_t)N * 4);
+    up(dB0, blk_r0.data(), (size_t)nb * 4); up(dBN, blk_nr.data(), (size_t)nb * 4); up(dBC, blk_chunk.data(), (size_t)nb * 4);
+    up(dRow, row_start, (size_t)(T + 1) * 4); up(dRange, range_b0.data(), (size_t)(n_ranges + 1) * 4);
+    up(dBigT, big_track.data(), big_track.size() * 4); up(dBigC0, big_c0.data(), big_c0.size() * 4); up(dBigNc, big_nc.data(), big_nc.size() * 4);
+    // the staging buffers above are std::vectors: the copies must have run before they go out of scope
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    {
+        ProfScope ps(c, "pdist");
+        hipLaunchKernelGGL(row_norms_k, dim3((N + 255) / 256), dim3(256), 0, c->stream, dX, N, DIM, dN);
+        PtArgs a;
+        a.X = dX; a.nrm = dN; a.N = N; a.T = T; a.row_track = dRT; a.row_last = dRL; a.row_seg_len = dRS;
+        a.blk_r0 = dB0; a.blk_nr = dBN; a.blk_chunk = dBC; a.range_b0 = dRange; a.row_start = dRow; a.D = dD; a.P = dP;
+        a.n_blocks = nb; a.n_ranges = n_ranges; a.t0 = t0; a.t1 = t1; a.metric = metric;
+        hipLaunchKernelGGL(pair_tiles_k, dim3(row_groups, n_ranges), dim3(256), 0, c->stream, a);
+        // long tracks of the requested range
+        std::vector<int> sel;
+        for (size_t k = 0; k < big_track.size(); ++k) if (big_track[k] >= t0 && big_track[k] < t1) sel.push_back((int)k);
+        if (!sel.empty()) {
+            const int k0 = sel.front(), nsel = (int)sel.size();     // long tracks inside [t0, t1) are consecutive entries
+            hipLaunchKernelGGL(pair_chunks_k, dim3((T + 255) / 256, nsel), dim3(256), 0, c->stream, dP, dBigT + k0, dBigC0 + k0, dBigNc + k0, dRow, T, dD);
+        }
+    }
+    HIP_CHECK(hipGetLastError());
+    if (h_D && t1 > t0)
+        HIP_CHECK(hipMemcpyAsync(h_D + (size_t)t0 * T, dD + (size_t)t0 * T, (size_t)(t1 - t0) * T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (d_D_keep) *d_D_keep = dD;
+}
+
 // D rows of the tracks [t0, t1) only (all columns): the unit of work when several GPUs split the pairwise distances of one
 // global clustering -- a track's rows all live in one contiguous block, so every entry of D is still produced by one sequential
 // chain, the same one the single-GPU call runs.  h_D / d_D_keep address the full T x T matrix (rows outside the range untouched).
 void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* row_start, int T, double* h_D, double** d_D_keep,
-                        int t0, int t1)
+                        int t0, int t1, int metric)
 {
     if (t1 < 0) t1 = T;
     PVF_REQUIRE(0 <= t0 && t0 <= t1 && t1 <= T, "pair_mean_dist: bad track range");
     PVF_REQUIRE(N > 0 && T > 0 && dim > 0 && dim <= 4096, "pair_mean_dist: bad sizes");
     PVF_REQUIRE(row_start[0] == 0 && row_start[T] == N, "pair_mean_dist: row_start must cover [0, N)");
+    PVF_REQUIRE(metric == 0 || metric == 1, "pair_mean_dist: metric 0 (euclidean) or 1 (cosine)");
+    if (dim == 128) { pair_mean_dist_mfma(c, X, N, row_start, T, h_D, d_D_keep, t0, t1, metric); return; }
+    PVF_REQUIRE(metric == 0, "pair_mean_dist: cosine is implemented for 128-D rows");
     const size_t xb = (size_t)N * dim * sizeof(double);
     const size_t sb = (size_t)N * T * sizeof(double), db = (size_t)T * T * sizeof(double), rb = (size_t)(T + 1) * sizeof(int32_t);
     c->s_clu0.ensure(2 * xb + sb + rb + 512);
@@ -203,6 +464,96 @@ __global__ void __launch_bounds__(256) hac_init_k(HacState h, const int32_t* __r
     h.alive[k] = 1; h.dirty[k] = 0; h.size[k] = (double)(row_start[k + 1] - row_start[k]);
 }
 
+// The whole agglomeration in ONE workgroup: row minima and their arguments live in LDS (12 bytes per track: up to 10 240 tracks), a merge
+// is argmin over LDS -> size-weighted update of row / column bi in HBM -> re-scan of the rows whose cached minimum died.  Same decisions
+// as the kernels above (first minimum in row-major order, rows re-scanned from scratch), no launch or host round trip inside the loop.
+#define HAC_PERSIST_MAX_T 10200          // 16 bytes of LDS per track + the reduction scratch <= 160 KiB
+// (value, index) minimum over the workgroup, smaller index on equal values: wave reduction by shuffles, 16 partial results through LDS
+__device__ __forceinline__ void block_argmin(double& v, int& i, double* wv, int* wi)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_down(v, off, 64);
+        const int oi = __shfl_down(i, off, 64);
+        if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                                     // the previous round's readers are done with wv / wi
+    if (lane == 0) { wv[wave] = v; wi[wave] = i; }
+    __syncthreads();
+    v = wv[0]; i = wi[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) {
+        const double ov = wv[w]; const int oi = wi[w];
+        if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+__global__ void __launch_bounds__(1024) hac_persist_k(HacState h)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const int T = h.T, tid = threadIdx.x;
+    double* rmin = reinterpret_cast<double*>(hsm);
+    int* rarg = reinterpret_cast<int*>(hsm + (size_t)T * 8);
+    int* dlist = rarg + T;                              // rows to re-scan after this merge
+    __shared__ double wv[16];
+    __shared__ int wi[16];
+    __shared__ int s_nd;
+    for (int r = tid; r < T; r += 1024) { rmin[r] = h.rmin[r]; rarg[r] = h.rarg[r]; }
+    __syncthreads();
+    int merges = 0;
+    while (merges < T - 1) {
+        double bv = INFINITY; int bi = 0x7fffffff;
+        for (int r = tid; r < T; r += 1024) {
+            const double v = rmin[r];
+            if (v < bv) { bv = v; bi = r; }             // ascending r per thread: first occurrence kept
+        }
+        block_argmin(bv, bi, wv, wi);
+        if (bi == 0x7fffffff || !(bv <= h.threshold)) break;      // uniform: every thread holds the same (bv, bi)
+        const int mi = bi, mj = rarg[bi];
+        const double szi = h.size[mi], szj = h.size[mj];
+        if (tid == 0) {
+            s_nd = 0;
+            h.log[4 * merges] = mi; h.log[4 * merges + 1] = mj; h.log[4 * merges + 2] = bv; h.log[4 * merges + 3] = szi + szj;
+        }
+        __syncthreads();                                 // sizes and rarg[bi] are read by everyone before anything changes
+        for (int k = tid; k < T; k += 1024) {
+            if (k == mi || k == mj || !h.alive[k]) continue;
+            const double v = (szi * h.D[(size_t)mi * T + k] + szj * h.D[(size_t)mj * T + k]) / (szi + szj);
+            h.D[(size_t)mi * T + k] = v;
+            h.D[(size_t)k * T + mi] = v;
+            if (k < mi) {
+                const int ra = rarg[k];
+                if (ra == mi || ra == mj) dlist[atomicAdd(&s_nd, 1)] = k;
+                else if (v < rmin[k] || (v == rmin[k] && mi < ra)) { rmin[k] = v; rarg[k] = mi; }
+            } else if (k < mj) {
+                if (rarg[k] == mj) dlist[atomicAdd(&s_nd, 1)] = k;
+            }
+        }
+        if (tid == 0) {
+            h.size[mi] = szi + szj; h.alive[mj] = 0;
+            rmin[mj] = INFINITY; rarg[mj] = 0x7fffffff;
+            dlist[atomicAdd(&s_nd, 1)] = mi;
+        }
+        __syncthreads();
+        const int nd = s_nd;
+        for (int q = 0; q < nd; ++q) {                   // re-scan row r: first minimum over the alive columns j > r
+            const int r = dlist[q];
+            double v0 = INFINITY; int j0 = 0x7fffffff;
+            for (int j = r + 1 + tid; j < T; j += 1024) {
+                if (!h.alive[j]) continue;
+                const double v = h.D[(size_t)r * T + j];
+                if (v < v0) { v0 = v; j0 = j; }
+            }
+            block_argmin(v0, j0, wv, wi);
+            if (tid == 0) { rmin[r] = v0; rarg[r] = j0; }
+        }
+        __syncthreads();
+        ++merges;
+    }
+    if (tid == 0) *h.n_merges = merges;
+}
+
 int hac_dev(Ctx* c, double* d_D, const int32_t* row_start, int T, double threshold, int32_t* labels, double* merge_log)
 {
     for (int i = 0; i < T; ++i) labels[i] = i;
@@ -230,6 +581,15 @@ int hac_dev(Ctx* c, double* d_D, const int32_t* row_start, int T, double thresho
     hipLaunchKernelGGL(hac_init_k, dim3((T + 255) / 256), dim3(256), 0, c->stream, h, dR);
     hipLaunchKernelGGL(hac_row_min_k, dim3(T), dim3(256), 0, c->stream, h, 0);
     double hbest[4];
+    if (T <= HAC_PERSIST_MAX_T) {
+        const size_t lds = (size_t)T * 16;               // rmin f64, rarg i32, re-scan list i32
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)hac_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, HAC_PERSIST_MAX_T * 16));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(hac_persist_k, dim3(1), dim3(1024), lds, c->stream, h);
+    } else
     for (int it = 0; it < T - 1; ++it) {
         hipLaunchKernelGGL(hac_argmin_k, dim3(1), dim3(1024), 0, c->stream, h);
         hipLaunchKernelGGL(hac_merge_k, dim3((T + 255) / 256), dim3(256), 0, c->stream, h);

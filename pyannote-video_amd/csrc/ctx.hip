@@ -78,7 +78,7 @@ static void load_detector(Ctx* c, const char* path)
     DetectorModel& d = c->det;
     d.n_filters = q[0]; d.frows = q[1]; d.fcols = q[2]; d.cell = q[3]; d.padding = q[4];
     d.win_w = q[5]; d.win_h = q[6]; d.min_w = q[7]; d.min_h = q[8]; d.max_levels = q[9];
-    PVF_REQUIRE(d.n_filters >= 1 && d.n_filters <= 8, "detector: 1..8 filters supported");
+    PVF_REQUIRE(d.n_filters == 5, "detector: dlib's frontal face detector has 5 filters; the scoring kernel packs 3 shifts x 5 filters per MFMA tile");
     PVF_REQUIRE(d.frows == 10 && d.fcols == 10 && d.cell == 8, "detector: 10x10 cells of 8 px supported");
     const Tensor& nms = need(m, "det.nms");
     d.nms_iou = nms.f64()[0]; d.nms_covered = nms.f64()[1];
@@ -87,15 +87,9 @@ static void load_detector(Ctx* c, const char* path)
     const Tensor& th = need(m, "det.thresh");
     d.thresh.assign(th.f32(), th.f32() + d.n_filters);
     if (d.d_w) (void)hipFree(d.d_w);
-    if (d.d_wt) (void)hipFree(d.d_wt);
     d.d_w = upload<float>(w.f32(), w.numel());
-    // filter-minor copy [m][n][p][8]
-    std::vector<float> wt((size_t)d.frows * d.fcols * 32 * 8, 0.0f);
-    for (int f = 0; f < d.n_filters; ++f)
-        for (int i = 0; i < d.frows * d.fcols * 32; ++i) wt[(size_t)i * 8 + f] = w.f32()[(size_t)f * d.frows * d.fcols * 32 + i];
-    d.d_wt = upload<float>(wt.data(), wt.size());
     if (d.d_bmfma) { (void)hipFree(d.d_bmfma); d.d_bmfma = nullptr; }
-    if (d.n_filters == 5) {
+    {
         // B fragments of score_mfma_k: index ((m*12 + n')*8 + pq)*64 + lane ; lane -> k = lane>>4 (plane 4pq+k), column j = lane&15 = 5*s + f
         std::vector<float> bm((size_t)10 * 12 * 8 * 64, 0.0f);
         for (int mm = 0; mm < 10; ++mm)
@@ -284,6 +278,7 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
     for (auto& kv : c->trackers) if (kv.second->d_state) (void)hipFree(kv.second->d_state);
     for (auto p : c->tracker_pool) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) if (c->det_ev[k]) (void)hipEventDestroy(c->det_ev[k]);
+    ml_plans_free(c);
     if (c->d_orient_lut) (void)hipFree(c->d_orient_lut);
     if (c->d_grad_lut) (void)hipFree(c->d_grad_lut);
     (void)hipStreamDestroy(c->stream);

@@ -1,7 +1,7 @@
 // detect.hip -- K1..K4: image pyramid, FHOG, filter scoring, NMS  (replaces dlib.get_frontal_face_detector()(rgb, 1);
 // reference pyannote/video/face/face.py:54,66).  All arithmetic follows the orders stated in oracle/pvo_fhog.c and
 // oracle/pvo_detect.c so that boxes are bit-identical; the code itself is written for gfx950 (wave64, LDS tiles).
-#include "pvf_internal.h"
+#include "fhog_dev.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -9,74 +9,12 @@
 // =====================================================================================================
 // K1: bilinear resize (pyramid_up / pyramid_down<6>), uint8 RGB HWC, double coordinates, (v + 0.5) truncation
 // =====================================================================================================
-// K1, lean form: one lane = one output column, walking RS consecutive output rows.  The horizontal blend of a source row,
+// One lane = one output column, walking RS consecutive output rows.  The horizontal blend of a source row,
 //   H_s = (1 - lr) * S[s][left] + lr * S[s][right],
-// depends only on (s, column), and consecutive output rows share source rows, so each H_s is evaluated once and kept in
-// registers (two-entry cache; the hit test depends on the row only => wave-uniform).  The value written is the same expression
-// as before:  v = (1 - tb) * H_top + tb * H_bottom ; out = (uint8)(v + 0.5).
-template <int RS>
-__global__ void __launch_bounds__(256) resize_strip_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
-                                                      size_t in_stride, int ih, int iw, uint8_t* __restrict__ out, size_t out_stride,
-                                                      int oh, int ow, double x_scale, double y_scale)
-{
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * RS, b = blockIdx.z;
-    if (c >= ow) return;
-    const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
-    uint8_t* ob = out + (size_t)b * out_stride;
-    const double x = c * x_scale;
-    const int left = (int)floor(x);
-    const int right = min(left + 1, iw - 1);
-    const double lr = x - left, lr1 = 1 - lr;
-    const int ol = left * 3, orr = right * 3;
-    int s0 = -1, s1 = -1;              // cached source rows
-    double h0[3], h1[3];
-    const int r_end = min(r0 + RS, oh);
-    for (int r = r0; r < r_end; ++r) {
-        const double y = r * y_scale;
-        const int top = (int)floor(y);
-        const int bottom = min(top + 1, ih - 1);
-        const double tb = y - top, tb1 = 1 - tb;
-        // make (s0 == top, s1 == bottom)
-        if (s1 == top) { s0 = s1; h0[0] = h1[0]; h0[1] = h1[1]; h0[2] = h1[2]; s1 = -1; }
-        if (s0 != top) {
-            const uint8_t* p = in + (size_t)top * iw * 3;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { const double tl = p[ol + k], tr = p[orr + k]; h0[k] = lr1 * tl + lr * tr; }
-            s0 = top;
-        }
-        if (s1 != bottom) {
-            if (bottom == top) { h1[0] = h0[0]; h1[1] = h0[1]; h1[2] = h0[2]; }
-            else {
-                const uint8_t* p = in + (size_t)bottom * iw * 3;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { const double bl = p[ol + k], br = p[orr + k]; h1[k] = lr1 * bl + lr * br; }
-            }
-            s1 = bottom;
-        }
-        uint8_t* o = ob + ((size_t)r * ow + c) * 3;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double v = tb1 * h0[k] + tb * h1[k];
-            o[k] = (uint8_t)(v + 0.5);
-        }
-    }
-}
-
-static void launch_resize(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* in_base, size_t in_stride, int ih, int iw,
-                          uint8_t* out, size_t out_stride, int oh, int ow, int batch)
-{
-    const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
-    const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
-    PVF_REQUIRE(x_scale <= 2.0, "resize: more than 2x horizontal decimation is not used on this path");
-    constexpr int RS = 16;
-    dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
-    hipLaunchKernelGGL((resize_strip_k<RS>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, ih, iw, out, out_stride, oh, ow,
-                       x_scale, y_scale);
-}
-
-// K1, v3 (batched detector): same arithmetic, memory access reshaped.  The v2 form issued 6 byte loads per new source row and
-// 3 byte stores per pixel -- 9 vector-memory instructions per pixel made it texture-addresser bound (TA busy 75 %), and every
+// depends only on (s, column) and consecutive output rows share source rows, so each H_s is evaluated once and kept in registers
+// (two-entry cache; the hit test depends on the row only => wave-uniform); the value written is
+//   v = (1 - tb) * H_top + tb * H_bottom ; out = (uint8)(v + 0.5)      (oracle/pvo_image.c).
+// Byte-sized loads and stores (9 vector-memory instructions per pixel) made an earlier form texture-addresser bound and every
 // source row fetch exposed a full memory latency.  Here a wave first requests EVERY source row its RS output rows need (one
 // coalesced dword per lane and row: the 64 columns of a wave span < 256 source bytes for scales <= 1.25) and parks them in LDS;
 // after that single wait the strip runs on LDS + VALU only.  A lane picks its two neighbouring source pixels (6 bytes) from
@@ -195,642 +133,10 @@ static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
 }
 
 // =====================================================================================================
-// K2: FHOG.  gradient -> (orientation bin, magnitude) per pixel; histogram cells gather their 2C x 2C window in
-// row-major pixel order (== the order dlib's scatter loop adds in); 4-way block normalisation -> 31 features.
-// =====================================================================================================
-
-// Orientation snap of dlib's FHOG: arg-max over 9 directions of +-dot(direction, gradient), first maximum wins.
-// The gradient of a uint8 image is a pair of integers in [-255,255]^2, so the bin is a pure function of 511x511 inputs:
-// it is tabulated once on the host with exactly these float operations (mul, mul, add, strict compares; no contraction),
-// which makes the table bit-identical to evaluating the chain per pixel.
-static const float h_dirx[9] = {1.0000f, 0.9397f, 0.7660f, 0.500f, 0.1736f, -0.1736f, -0.5000f, -0.7660f, -0.9397f};
-static const float h_diry[9] = {0.0000f, 0.3420f, 0.6428f, 0.8660f, 0.9848f, 0.9848f, 0.8660f, 0.6428f, 0.3420f};
-
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 u32x4u __attribute__((aligned(4)));
-
-const uint8_t* orientation_lut(Ctx* c)
-{
-    if (c->d_orient_lut) return c->d_orient_lut;
-    std::vector<uint8_t> lut((size_t)511 * 511);
-    for (int by = -255; by <= 255; ++by)
-        for (int bx = -255; bx <= 255; ++bx) {
-            const volatile float gx = (float)bx, gy = (float)by;
-            float best_dot = 0.0f;
-            int best_o = 0;
-            for (int o = 0; o < 9; ++o) {
-                const volatile float a = gx * h_dirx[o];
-                const volatile float b = gy * h_diry[o];
-                const float dot = a + b;
-                if (dot > best_dot) { best_dot = dot; best_o = o; }
-                else if (-dot > best_dot) { best_dot = -dot; best_o = o + 9; }
-            }
-            lut[(size_t)(by + 255) * 511 + (bx + 255)] = (uint8_t)best_o;
-        }
-    HIP_CHECK(hipMalloc((void**)&c->d_orient_lut, lut.size()));
-    HIP_CHECK(hipMemcpy(c->d_orient_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
-    return c->d_orient_lut;
-}
-
-// The same table in 8 x 8 tiles (one 64-byte line each): with Y = by + 255, X = bx + 255 the entry sits at
-// (Y >> 3) << 12 | (X >> 3) << 6 | (Y & 7) << 3 | (X & 7).  Neighbouring pixels mostly have small, similar gradients, so a
-// wave's 64 look-ups touch a handful of lines instead of one line per table row (the row-major form cost ~50 L1 accesses
-// per gather and made the gradient pass texture-addresser bound).
-const uint8_t* orientation_lut_tiled(Ctx* c)
-{
-    if (c->d_grad_lut) return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
-    orientation_lut(c);
-    std::vector<uint8_t> ol((size_t)511 * 511);
-    HIP_CHECK(hipMemcpy(ol.data(), c->d_orient_lut, ol.size(), hipMemcpyDeviceToHost));
-    std::vector<uint8_t> lut((size_t)64 * 64 * 64, 0);
-    for (int Y = 0; Y < 511; ++Y)
-        for (int X = 0; X < 511; ++X)
-            lut[((size_t)(Y >> 3) << 12) | ((size_t)(X >> 3) << 6) | ((Y & 7) << 3) | (X & 7)] = ol[(size_t)Y * 511 + X];
-    HIP_CHECK(hipMalloc((void**)&c->d_grad_lut, lut.size()));
-    HIP_CHECK(hipMemcpy(c->d_grad_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
-    return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
-}
-
-// correctly rounded sqrt of a non-negative integer-valued float < 2^24: the hardware estimate (<= 1 ulp) stepped to the
-// neighbour the exact residuals ask for.  Same result as sqrtf(); skips its denormal scaling and class checks.
-__device__ __forceinline__ float sqrt_exact_small(float x)
-{
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
-    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
-    float r = (rm <= 0.0f) ? sm : s;
-    r = (rp > 0.0f) ? sp : r;
-    return r;
-}
-
-// colour channel with the largest |g|^2 (first wins); magnitude by arithmetic, orientation bin from the tiled table
-__device__ __forceinline__ void grad_lookup(const int u[3], const int d[3], const int l[3], const int r[3],
-                                            const uint8_t* __restrict__ lut_t, float* v, int* o)
-{
-    int bx = r[0] - l[0], by = d[0] - u[0];
-    int bv = bx * bx + by * by;
-    int bi = by * 512 + bx;
-#pragma unroll
-    for (int k = 1; k < 3; ++k) {
-        const int cx = r[k] - l[k], cy = d[k] - u[k];
-        const int cv = cx * cx + cy * cy;
-        const int ci = cy * 512 + cx;
-        if (cv > bv) { bv = cv; bi = ci; }
-    }
-    const unsigned P = (unsigned)(bi + 255 * 512 + 255);           // Y << 9 | X
-    const unsigned off = (P & 0x3F007u) | ((P & 0x1F8u) << 3) | ((P >> 6) & 0x38u);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lut_t, 0, 64 * 64 * 64, 0x00020000);
-    *o = (int)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
-    *v = sqrt_exact_small((float)bv);
-}
-
-__device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, const uint8_t* __restrict__ row_c,
-                                           const uint8_t* __restrict__ row_d, int x3, const uint8_t* __restrict__ lut, float* v2, int* bo)
-{
-    // row_* point at the byte rows; x3 = 3*x (pixel x of the centre row); colour channel with the largest |g|^2, first wins
-    int bx = (int)row_c[x3 + 3] - (int)row_c[x3 - 3], by = (int)row_d[x3] - (int)row_u[x3];
-    int bv = bx * bx + by * by;
-#pragma unroll
-    for (int k = 1; k < 3; ++k) {
-        const int cx = (int)row_c[x3 + 3 + k] - (int)row_c[x3 - 3 + k], cy = (int)row_d[x3 + k] - (int)row_u[x3 + k];
-        const int cv = cx * cx + cy * cy;
-        if (cv > bv) { bv = cv; bx = cx; by = cy; }
-    }
-    *v2 = (float)bv;
-    *bo = lut[(by + 255) * 511 + (bx + 255)];
-}
-
-// The per-image FHOG kernels below run on 1-D grids over (image, row, column): the images they see in production are the
-// trackers' chips (23 x 23 scale samples, 64 x 64 translation windows), whose rows would fill 2-25 % of a 256-lane block each.
-__device__ __forceinline__ bool flat_index(int nx, int ny, int nb, int* x, int* y, int* b)
-{
-    const unsigned g = blockIdx.x * 256u + threadIdx.x;
-    const unsigned t = g / (unsigned)nx;
-    *x = (int)(g - t * (unsigned)nx);
-    *b = (int)(t / (unsigned)ny);
-    *y = (int)(t - (unsigned)*b * (unsigned)ny);
-    return *b < nb;
-}
-static inline dim3 flat_grid(int nx, int ny, int nb)
-{
-    const size_t total = (size_t)nx * ny * nb;
-    PVF_REQUIRE(total < ((size_t)1 << 31), "fhog: too many work items for one launch");
-    return dim3((unsigned)((total + 255) / 256));
-}
-
-// Pass 1: per pixel (orientation bin, gradient magnitude) into planes shifted by 3C/2 so that histogram cell (hy,hx) owns rows
-// yy in [C*hy, C*hy+2C) and columns xx in [C*hx, C*hx+2C)  (yy = y + 3C/2, xx = x + 3C/2; pitch = multiple of 16 floats).
-// One lane = 4 consecutive pixels of one row; interior quads fetch their 3 x 18-byte neighbourhood with
-// 11 (unaligned) dword loads and pick the bytes with constant shifts; results leave as one float4 + one packed dword.
-__device__ __forceinline__ void grad_from_bytes(const int u[3], const int d[3], const int l[3], const int r[3],
-                                                const uint8_t* __restrict__ lut, float* v, int* o)
-{
-    int bx = r[0] - l[0], by = d[0] - u[0];
-    int bv = bx * bx + by * by;
-#pragma unroll
-    for (int k = 1; k < 3; ++k) {
-        const int cx = r[k] - l[k], cy = d[k] - u[k];
-        const int cv = cx * cx + cy * cy;
-        if (cv > bv) { bv = cv; bx = cx; by = cy; }
-    }
-    *v = sqrtf((float)bv);
-    *o = lut[(by + 255) * 511 + (bx + 255)];
-}
-
-template <int C>
-__global__ void __launch_bounds__(256) fhog_grad4_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw, int visible_nr,
-                                                    int visible_nc, float* __restrict__ mag, uint8_t* __restrict__ bin, size_t px_stride,
-                                                    int rows_t, int pitch, const uint8_t* __restrict__ lut, int n_img)
-{
-    int q, yy, b;                                       // quad index within the row, plane row, image
-    if (!flat_index(pitch / 4, rows_t, n_img, &q, &yy, &b)) return;
-    const int xx = 4 * q;
-    const int y = yy - 3 * C / 2, x0 = xx - 3 * C / 2;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    int o[4] = {0, 0, 0, 0};
-    if (y >= 1 && y < visible_nr && x0 + 3 >= 1 && x0 < visible_nc) {
-        const uint8_t* im = img + (size_t)b * img_stride;
-        const int rb = iw * 3;
-        const uint8_t* rc = im + (size_t)y * rb;
-        const uint8_t* ru = rc - rb;
-        const uint8_t* rd = rc + rb;
-        if (x0 >= 1 && x0 + 4 <= visible_nc && x0 + 6 <= iw) {
-            uint32_t wc[5], wu[3], wd[3];
-            const uint8_t* pc = rc + 3 * x0 - 3;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) wc[k] = *reinterpret_cast<const uint32_t*>(pc + 4 * k);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                wu[k] = *reinterpret_cast<const uint32_t*>(ru + 3 * x0 + 4 * k);
-                wd[k] = *reinterpret_cast<const uint32_t*>(rd + 3 * x0 + 4 * k);
-            }
-#define BYTE_OF(w, i) (int)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                int u[3], d[3], l[3], r[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    u[k] = BYTE_OF(wu, 3 * p + k); d[k] = BYTE_OF(wd, 3 * p + k);
-                    l[k] = BYTE_OF(wc, 3 * p + k); r[k] = BYTE_OF(wc, 3 * p + 6 + k);
-                }
-                grad_from_bytes(u, d, l, r, lut, &v[p], &o[p]);
-            }
-#undef BYTE_OF
-        } else {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int x = x0 + p;
-                if (x >= 1 && x < visible_nc) {
-                    int u[3], d[3], l[3], r[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { u[k] = ru[3 * x + k]; d[k] = rd[3 * x + k]; l[k] = rc[3 * x - 3 + k]; r[k] = rc[3 * x + 3 + k]; }
-                    grad_from_bytes(u, d, l, r, lut, &v[p], &o[p]);
-                }
-            }
-        }
-    }
-    const size_t idx = (size_t)b * px_stride + (size_t)yy * pitch + xx;
-    *reinterpret_cast<float4*>(mag + idx) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<uint32_t*>(bin + idx) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
-}
-
-// Pass 2: one lane per histogram cell walks its 2C x 2C window in row-major order (== the order dlib's scatter loop adds in),
-// adding each vote to the bin's running sum kept in LDS (acc[bin][lane]: conflict-free).  Rows are read with 16-byte loads.
-template <int C>
-__global__ void __launch_bounds__(256) fhog_hist_k(const float* __restrict__ mag, const uint8_t* __restrict__ bin, size_t px_stride, int pitch,
-                                                   float* __restrict__ hist, size_t hist_stride, int hr, int hc,
-                                                   float* __restrict__ norm, size_t norm_stride, int cells_nr, int cells_nc, int n_img)
-{
-    __shared__ float acc[18][256];
-    int hx, hy, b;
-    const bool valid = flat_index(hc, hr, n_img, &hx, &hy, &b);
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int o = 0; o < 18; ++o) acc[o][tid] = 0.0f;
-    if (valid) {
-        const float* mg = mag + (size_t)b * px_stride + (size_t)C * hx;
-        const uint8_t* bn = bin + (size_t)b * px_stride + (size_t)C * hx;
-        constexpr int NV = 2 * C / 4;            // float4 loads per row
-        float4 pv[2][NV];
-        uint32_t pb[2][4];
-        auto load_row = [&](int wy, float4* dv, uint32_t* db) {
-            const size_t row = (size_t)(C * hy + wy) * pitch;
-#pragma unroll
-            for (int q = 0; q < NV; ++q) dv[q] = *reinterpret_cast<const float4*>(mg + row + 4 * q);
-            if (C == 8) {
-                const uint4 t = *reinterpret_cast<const uint4*>(bn + row);
-                db[0] = t.x; db[1] = t.y; db[2] = t.z; db[3] = t.w;
-            } else {
-                const uint2 t = *reinterpret_cast<const uint2*>(bn + row);
-                db[0] = t.x; db[1] = t.y; db[2] = 0; db[3] = 0;
-            }
-        };
-        load_row(0, pv[0], pb[0]);
-#pragma unroll
-        for (int wy = 0; wy < 2 * C; ++wy) {
-            const int cur = wy & 1;
-            if (wy + 1 < 2 * C) load_row(wy + 1, pv[cur ^ 1], pb[cur ^ 1]);   // next row is in flight while this one is accumulated
-            const int i = wy % C;
-            const float fy = ((float)i + 0.5f) / (float)C;
-            const float wyv = (wy < C) ? fy : 1.0f - fy;
-            float v[2 * C];
-#pragma unroll
-            for (int q = 0; q < NV; ++q) { v[4 * q] = pv[cur][q].x; v[4 * q + 1] = pv[cur][q].y; v[4 * q + 2] = pv[cur][q].z; v[4 * q + 3] = pv[cur][q].w; }
-#pragma unroll
-            for (int wx = 0; wx < 2 * C; ++wx) {
-                const int j = wx % C;
-                const float fx = ((float)j + 0.5f) / (float)C;
-                const float wxv = (wx < C) ? fx : 1.0f - fx;
-                const int o = (int)((pb[cur][wx >> 2] >> (8 * (wx & 3))) & 0xffu);
-                acc[o][tid] = acc[o][tid] + (wyv * wxv) * v[wx];
-            }
-        }
-        float* h = hist + (size_t)b * hist_stride + ((size_t)hy * hc + hx) * 18;
-        float e = 0.0f;
-#pragma unroll
-        for (int o = 0; o < 9; ++o) {
-            const float a0 = acc[o][tid], a1 = acc[o + 9][tid];
-            h[o] = a0; h[o + 9] = a1;
-            const float s2 = a0 + a1;
-            e = e + s2 * s2;
-        }
-        if (hy >= 1 && hy <= cells_nr && hx >= 1 && hx <= cells_nc)
-            norm[(size_t)b * norm_stride + (size_t)(hy - 1) * cells_nc + (hx - 1)] = e;
-    }
-}
-
-__device__ __forceinline__ void cell_features(const float* h, const float* n, float* o)
-{
-    const float eps = 0.0001f;
-    const float z1[4] = {n[4], n[1], n[3], n[0]};
-    const float z2[4] = {n[5], n[2], n[4], n[1]};
-    const float z3[4] = {n[7], n[4], n[6], n[3]};
-    const float z4[4] = {n[8], n[5], n[7], n[4]};
-    float nn[4], nv[4], t[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        nn[k] = 0.2f * sqrtf((((z1[k] + z2[k]) + z3[k]) + z4[k]) + eps);
-        nv[k] = 0.1f / nn[k];
-    }
-#pragma unroll
-    for (int g = 0; g < 18; g += 3) {
-        float hh[3][4];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) hh[j][k] = fminf(h[g + j], nn[k]) * nv[k];
-            o[g + j] = (hh[j][0] + hh[j][1]) + (hh[j][2] + hh[j][3]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) t[k] = t[k] + ((hh[0][k] + hh[1][k]) + hh[2][k]);
-    }
-    const float tscale = (float)(2 * 0.2357);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] = t[k] * tscale;
-#pragma unroll
-    for (int g = 0; g < 9; ++g) {
-        const float s = h[g] + h[g + 9];
-        float hh[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) hh[k] = fminf(s, nn[k]) * nv[k];
-        o[18 + g] = (hh[0] + hh[1]) + (hh[2] + hh[3]);
-    }
-    o[27] = t[0]; o[28] = t[1]; o[29] = t[2]; o[30] = t[3];
-    o[31] = 0.0f;
-}
-
-__global__ void __launch_bounds__(256) fhog_feat_k(const float* __restrict__ hist, size_t hist_stride, int hc, const float* __restrict__ norm,
-                                                   size_t norm_stride, int cells_nc, float* __restrict__ feat, size_t feat_stride, int fw,
-                                                   int hog_nr, int hog_nc, int oy, int ox, int fh, int n_img)
-{
-    int px, py, b;                                             // padded output coordinates, image
-    if (!flat_index(fw, fh, n_img, &px, &py, &b)) return;
-    const int x = px - ox, y = py - oy;
-    if (x < 0 || y < 0 || x >= hog_nc || y >= hog_nr) {
-        float4* z = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)py * fw + px) * PVF_FHOG_STRIDE);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    float n[9], h[18], o[32];
-    const float* nb = norm + (size_t)b * norm_stride;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) n[i * 3 + j] = nb[(size_t)(y + i) * cells_nc + (x + j)];
-    const float* hp = hist + (size_t)b * hist_stride + ((size_t)(y + 2) * hc + (x + 2)) * 18;
-#pragma unroll
-    for (int k = 0; k < 18; ++k) h[k] = hp[k];
-    cell_features(h, n, o);
-    float4* dst = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)(y + oy) * fw + (x + ox)) * PVF_FHOG_STRIDE);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-}
-
-// cell size 1 (correlation tracker translation chip): every pixel is a cell
-__global__ void __launch_bounds__(256) fhog1_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw,
-                                                    float* __restrict__ norm, uint8_t* __restrict__ angle, size_t px_stride, const uint8_t* __restrict__ lut,
-                                                    int n_img)
-{
-    int x, y, b;
-    if (!flat_index(iw, ih, n_img, &x, &y, &b)) return;
-    float v = 0.0f;
-    int o = 0;
-    if (y >= 1 && y < ih - 1 && x >= 1 && x < iw - 1) {
-        const uint8_t* im = img + (size_t)b * img_stride;
-        pixel_grad(im + (size_t)(y - 1) * iw * 3, im + (size_t)y * iw * 3, im + (size_t)(y + 1) * iw * 3, x * 3, lut, &v, &o);
-    }
-    norm[(size_t)b * px_stride + (size_t)y * iw + x] = v;
-    angle[(size_t)b * px_stride + (size_t)y * iw + x] = (uint8_t)o;
-}
-
-__global__ void __launch_bounds__(256) fhog1_feat_k(const float* __restrict__ norm, const uint8_t* __restrict__ angle, size_t px_stride,
-                                                    int iw, float* __restrict__ feat, size_t feat_stride, int fw, int hog_nr, int hog_nc,
-                                                    int oy, int ox, int fh, int n_img)
-{
-    int px, py, b;
-    if (!flat_index(fw, fh, n_img, &px, &py, &b)) return;
-    const int x = px - ox, y = py - oy;
-    if (x < 0 || y < 0 || x >= hog_nc || y >= hog_nr) {
-        float4* z = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)py * fw + px) * PVF_FHOG_STRIDE);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    float n[9], h[18], o[32];
-    const float* nb = norm + (size_t)b * px_stride;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) n[i * 3 + j] = nb[(size_t)(y + i) * iw + (x + j)];
-    const int a = angle[(size_t)b * px_stride + (size_t)(y + 1) * iw + (x + 1)];
-    const float mag = sqrtf(n[4]);
-#pragma unroll
-    for (int k = 0; k < 18; ++k) h[k] = (k == a) ? mag : 0.0f;
-    cell_features(h, n, o);
-    float4* dst = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)(y + oy) * fw + (x + ox)) * PVF_FHOG_STRIDE);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-}
-
-void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw)
-{
-    int hog_nr, hog_nc;
-    if (cell == 1) { hog_nr = ih - 2; hog_nc = iw - 2; }
-    else {
-        const int cells_nr = (int)((double)ih / (double)cell + 0.5);
-        const int cells_nc = (int)((double)iw / (double)cell + 0.5);
-        hog_nr = cells_nr - 2; hog_nc = cells_nc - 2;
-    }
-    if (hog_nr <= 0 || hog_nc <= 0) { *fh = 0; *fw = 0; return; }
-    *fh = hog_nr + pad_r - 1;
-    *fw = hog_nc + pad_c - 1;
-}
-
-void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat, DevBuf& hist, DevBuf& norm,
-                 size_t img_stride_in)
-{
-    DevBuf& grad = c->s_grad;
-    const uint8_t* lut = orientation_lut(c);
-    int fh, fw;
-    fhog_dims(h, w, cell, pad_r, pad_c, &fh, &fw);
-    PVF_REQUIRE(fh > 0 && fw > 0, "fhog: image too small");
-    const size_t feat_stride = (size_t)fh * fw * PVF_FHOG_STRIDE;
-    const int oy = (pad_r - 1) / 2, ox = (pad_c - 1) / 2;
-    const size_t img_stride = img_stride_in ? img_stride_in : (size_t)h * w * 3;
-    if (cell == 1) {
-        const size_t px = (size_t)h * w;
-        norm.ensure(px * n * sizeof(float));
-        hist.ensure(px * n);
-        hipLaunchKernelGGL(fhog1_grad_k, flat_grid(w, h, n), dim3(256), 0, c->stream, d_img, img_stride, h, w, norm.as<float>(), hist.as<uint8_t>(), px, lut, n);
-        hipLaunchKernelGGL(fhog1_feat_k, flat_grid(fw, fh, n), dim3(256), 0, c->stream, norm.as<float>(), hist.as<uint8_t>(), px, w, d_feat, feat_stride, fw,
-                           h - 2, w - 2, oy, ox, fh, n);
-        return;
-    }
-    PVF_REQUIRE(cell == 8 || cell == 4, "fhog: cell size 1, 4 or 8");
-    const int cells_nr = (int)((double)h / (double)cell + 0.5), cells_nc = (int)((double)w / (double)cell + 0.5);
-    const int hr = cells_nr + 2, hc = cells_nc + 2;
-    const int visible_nr = std::min(cells_nr * cell, h) - 1, visible_nc = std::min(cells_nc * cell, w) - 1;
-    const size_t hist_stride = (size_t)hr * hc * 18, norm_stride = (size_t)cells_nr * cells_nc;
-    hist.ensure(hist_stride * n * sizeof(float));
-    norm.ensure(norm_stride * n * sizeof(float));
-    // pass 1: (bin, magnitude) planes in the cell-blocked layout; pass 2: per-cell ordered accumulation + cell energy
-    const int rows_t = cell * (hr + 1), pitch = (cell * (hc + 1) + 15) / 16 * 16;
-    const size_t px_stride = (size_t)rows_t * pitch;            // multiple of 16 => every row / batch plane stays 16-byte aligned
-    grad.ensure(px_stride * n * 5 + 256);
-    float* d_mag = grad.as<float>();
-    uint8_t* d_bin = grad.as<uint8_t>() + px_stride * n * 4;
-    const dim3 g4 = flat_grid(pitch / 4, rows_t, n), gh = flat_grid(hc, hr, n);
-    if (cell == 8) {
-        hipLaunchKernelGGL((fhog_grad4_k<8>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
-        hipLaunchKernelGGL((fhog_hist_k<8>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
-                           norm.as<float>(), norm_stride, cells_nr, cells_nc, n);
-    } else {
-        hipLaunchKernelGGL((fhog_grad4_k<4>), g4, dim3(256), 0, c->stream, d_img, img_stride, h, w, visible_nr, visible_nc, d_mag, d_bin, px_stride, rows_t, pitch, lut, n);
-        hipLaunchKernelGGL((fhog_hist_k<4>), gh, dim3(256), 0, c->stream, d_mag, d_bin, px_stride, pitch, hist.as<float>(), hist_stride, hr, hc,
-                           norm.as<float>(), norm_stride, cells_nr, cells_nc, n);
-    }
-    const int hog_nr = cells_nr - 2, hog_nc = cells_nc - 2;
-    hipLaunchKernelGGL(fhog_feat_k, flat_grid(fw, fh, n), dim3(256), 0, c->stream, hist.as<float>(), hist_stride, hc, norm.as<float>(), norm_stride, cells_nc,
-                       d_feat, feat_stride, fw, hog_nr, hog_nc, oy, ox, fh, n);
-}
-
-void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, int pad_c, std::vector<float>& out, int* fh, int* fw)
-{
-    fhog_dims(h, w, cell, pad_r, pad_c, fh, fw);
-    PVF_REQUIRE(*fh > 0 && *fw > 0, "fhog: image too small");
-    c->s_pyr.ensure((size_t)h * w * 3);
-    HIP_CHECK(hipMemcpyAsync(c->s_pyr.p, himg, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream));
-    const size_t nf = (size_t)(*fh) * (*fw) * PVF_FHOG_STRIDE;
-    c->s_feat.ensure(nf * sizeof(float));
-    fhog_device(c, c->s_pyr.as<uint8_t>(), 1, h, w, cell, pad_r, pad_c, c->s_feat.as<float>(), c->s_hist, c->s_norm, 0);
-    out.resize(nf);
-    HIP_CHECK(hipMemcpyAsync(out.data(), c->s_feat.p, nf * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
-}
-
-// =====================================================================================================
-// K3: filter scoring.  score[f](r,c) = fmaf chain over (m, n, p) -- identical order to the oracle.
-// v1: VALU, one output position per lane, features staged in LDS with a 36-float cell pitch (conflict-free b128 reads),
-// weights come through the scalar unit (uniform addresses).
+// K3: filter scoring.  score[f](r,c) = fmaf chain over (m, n, p) -- identical order to the oracle (oracle/pvo_detect.c).
 // =====================================================================================================
 struct ScoreParams { float thresh[8]; int n_filters; int level; int cap; };
 struct CandRec { float score; int32_t filter, level, r, c; };
-
-template <int NF>
-__global__ void __launch_bounds__(256) score_k(const float* __restrict__ feat, size_t feat_stride, int fh, int fw,
-                                               const float* __restrict__ w, ScoreParams sp, int* __restrict__ counts,
-                                               CandRec* __restrict__ cands)
-{
-    constexpr int TR = 8, TC = 32, FR = 10, FC = 10, PITCH = 36;
-    constexpr int LR = TR + FR - 1, LC = TC + FC - 1;
-    extern __shared__ __attribute__((aligned(16))) float s_f[]; // [LR][LC][PITCH]
-    const int b = blockIdx.z;
-    const int r_base = blockIdx.y * TR, c_base = blockIdx.x * TC; // top-left of the feature window of this tile
-    const float* fb = feat + (size_t)b * feat_stride;
-    for (int i = threadIdx.x; i < LR * LC * 8; i += blockDim.x) {
-        const int cell = i >> 3, q = i & 7;
-        const int ly = cell / LC, lx = cell % LC;
-        const int y = r_base + ly, x = c_base + lx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y < fh && x < fw) v = reinterpret_cast<const float4*>(fb + ((size_t)y * fw + x) * PVF_FHOG_STRIDE)[q];
-        reinterpret_cast<float4*>(s_f + (size_t)cell * PITCH)[q] = v;
-    }
-    __syncthreads();
-    const int ty = threadIdx.x / TC, tx = threadIdx.x % TC;
-    float acc[NF];
-#pragma unroll
-    for (int f = 0; f < NF; ++f) acc[f] = 0.0f;
-    for (int m = 0; m < FR; ++m)
-        for (int n = 0; n < FC; ++n) {
-            const float* fp = s_f + ((size_t)(ty + m) * LC + (tx + n)) * PITCH;
-            const float* wp = w + ((size_t)m * FC + n) * PVF_FHOG_STRIDE;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = reinterpret_cast<const float4*>(fp)[q];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const float* wf = wp + (size_t)f * FR * FC * PVF_FHOG_STRIDE + 4 * q;
-                    acc[f] = fmaf(v.x, wf[0], acc[f]);
-                    acc[f] = fmaf(v.y, wf[1], acc[f]);
-                    acc[f] = fmaf(v.z, wf[2], acc[f]);
-                    if (q < 7) acc[f] = fmaf(v.w, wf[3], acc[f]);
-                }
-            }
-        }
-    // output position (centre convention of spatially_filter_image): r = top + FR/2, c = left + FC/2
-    const int r = r_base + ty + FR / 2, cc = c_base + tx + FC / 2;
-    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
-    if (r < r1 && cc < c1) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            if (acc[f] >= sp.thresh[f]) {
-                const int idx = atomicAdd(&counts[b], 1);
-                if (idx < sp.cap) {
-                    CandRec rec;
-                    rec.score = acc[f] - sp.thresh[f];
-                    rec.filter = f; rec.level = sp.level; rec.r = r; rec.c = cc;
-                    cands[(size_t)b * sp.cap + idx] = rec;
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K3 on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, same k-ordered fmaf chain as the VALU form).
-// N = 5 filters would use 5 of 16 MFMA columns, so three neighbouring output columns share one tile:
-//   column j = 5*s + f  (s = 0..2 shift, f = filter)  ->  15 of 16 columns carry work, K grows from 10 to 12 cells per row.
-//   A[i][k]  = F[r + m][c0 + 3 i + n'][p]          i = 16 window positions spaced 3 cells apart, k = (n', p), n' in [0,12)
-//   B[k][j]  = W[f][m][n' - s][p]  (0 outside the 10-cell filter row): zero terms are exact no-ops in the chain, the
-//   non-zero ones arrive in (m, n, p) order  =>  bit-identical to the oracle's chain.  Useful MACs / issued = 75.7 %.
-// One wave = one output row x 96 columns (two 16-position tiles); its feature row segment lives in a wave-private LDS slab
-// (34-float cell pitch: conflict-free ds_read_b32 for lanes 3 cells apart), B fragments stream from L2.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__global__ void __launch_bounds__(256) score_mfma_k(const float* __restrict__ feat, size_t feat_stride, int fh, int fw,
-                                                    const float* __restrict__ Bg, ScoreParams sp, int* __restrict__ counts,
-                                                    CandRec* __restrict__ cands)
-{
-    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11;
-    extern __shared__ __attribute__((aligned(16))) float s_seg[]; // [4 waves][SEG][PITCH]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.z;
-    const int r_top = blockIdx.y * 4 + wave, c_base = blockIdx.x * WCOLS;
-    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
-    if (r_top + FR / 2 >= r1) return;               // wave-uniform
-    float* seg = s_seg + (size_t)wave * SEG * PITCH;
-    const float* fb = feat + (size_t)b * feat_stride;
-    const int i = lane & 15, kq = lane >> 4;
-    f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool two_tiles = (c_base + 48 + FC / 2 < c1);   // wave-uniform: ragged row ends run one 48-column tile only
-    for (int m = 0; m < FR; ++m) {
-        const int fr = r_top + m;
-        // issue every load of this filter row up front: 96 B fragments (L2) + the feature row segment, then fill the slab
-        float bv[NK * 8];
-        const float* bp = Bg + (size_t)m * NK * 8 * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < NK * 8; ++q) bv[q] = bp[q * 64];
-        constexpr int NST = (SEG * 8 + 63) / 64;
-        float4 sv[NST];
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int idx = lane + 64 * u;
-            const int cell = idx >> 3, q = idx & 7;
-            const int x = c_base + cell;
-            sv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < SEG * 8 && fr < fh && x < fw) sv[u] = reinterpret_cast<const float4*>(fb + ((size_t)fr * fw + x) * PVF_FHOG_STRIDE)[q];
-        }
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int idx = lane + 64 * u;
-            if (idx < SEG * 8) {
-                const int cell = idx >> 3, q = idx & 7;
-                float2* d = reinterpret_cast<float2*>(seg + cell * PITCH + 4 * q);
-                d[0] = make_float2(sv[u].x, sv[u].y);
-                d[1] = make_float2(sv[u].z, sv[u].w);
-            }
-        }
-        const float* a0 = seg + (3 * i) * PITCH + kq;
-        // A fragments are fetched one cell column (8 k-steps x MT tiles) ahead of the MFMAs that consume them
-        float an[8 * MT];
-#pragma unroll
-        for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) an[pq * MT + t] = a0[(t * 48) * PITCH + 4 * pq];
-#pragma unroll
-        for (int n = 0; n < NK; ++n) {
-            float ac[8 * MT];
-#pragma unroll
-            for (int q = 0; q < 8 * MT; ++q) ac[q] = an[q];
-            if (n + 1 < NK) {
-#pragma unroll
-                for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) an[pq * MT + t] = a0[(t * 48 + n + 1) * PITCH + 4 * pq];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (two_tiles) {
-#pragma unroll
-                for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-                    for (int t = 0; t < MT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + t], bv[n * 8 + pq], acc[t], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int pq = 0; pq < 8; ++pq)
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT], bv[n * 8 + pq], acc[0], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // C/D layout of the 16x16 MFMA: column j = lane & 15, row = 4 * (lane >> 4) + reg
-    const int j = lane & 15;
-    if (j < 15) {
-        const int s = j / 5, f = j % 5;
-        const float th = sp.thresh[f];
-        const int r = r_top + FR / 2;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int pos = 4 * (lane >> 4) + reg;
-                const int cc = c_base + t * 48 + 3 * pos + s + FC / 2;
-                const float v = acc[t][reg];
-                if (cc < c1 && v >= th) {
-                    const int idx = atomicAdd(&counts[b], 1);
-                    if (idx < sp.cap) {
-                        CandRec rec;
-                        rec.score = v - th; rec.filter = f; rec.level = sp.level; rec.r = r; rec.c = cc;
-                        cands[(size_t)b * sp.cap + idx] = rec;
-                    }
-                }
-            }
-    }
-}
 
 // =====================================================================================================
 // host side: level schedule, rectangle mapping, canonical sort, NMS
@@ -890,50 +196,6 @@ static void upload_frame_ptrs(Ctx* c, const std::vector<Frame>& frames, const ui
     *d_ptrs = d.as<const uint8_t*>();
 }
 
-// builds level `want_level` (or all levels when want_level < 0, calling per_level after each one); images ping-pong in s_pyr
-template <class F>
-static void run_pyramid(Ctx* c, const std::vector<Frame>& frames, int upsample, int want_level, F&& per_level)
-{
-    const DetectorModel& m = c->det;
-    const int B = (int)frames.size();
-    const int h = frames[0].h, w = frames[0].w;
-    for (auto& f : frames) PVF_REQUIRE(f.h == h && f.w == w, "batched frames must share one size");
-    std::vector<LevelDims> ups;
-    std::vector<LevelDims> lv = level_schedule(h, w, upsample, m, &ups);
-    auto padded = [](int hh, int ww) { return ((size_t)hh * ww * 3 + 15) & ~(size_t)15; };
-    const size_t max_img = padded(lv[0].h, lv[0].w);
-    c->s_pyr.ensure(2 * max_img * B + 64);
-    uint8_t* buf[2] = {c->s_pyr.as<uint8_t>(), c->s_pyr.as<uint8_t>() + max_img * B};
-    const uint8_t** d_ptrs = nullptr;
-    upload_frame_ptrs(c, frames, &d_ptrs);
-    int cur = 0;
-    const uint8_t* cur_img = nullptr; // null => original frames via pointers
-    int ch = h, cw = w;
-    {
-        ProfScope ps(c, "pyramid");
-        for (size_t u = 0; u < ups.size(); ++u) {
-            launch_resize(c, cur_img ? nullptr : d_ptrs, cur_img, padded(ch, cw), ch, cw, buf[cur], padded(ups[u].h, ups[u].w),
-                          ups[u].h, ups[u].w, B);
-            cur_img = buf[cur]; cur ^= 1; ch = ups[u].h; cw = ups[u].w;
-        }
-    }
-    if (!cur_img) {
-        // no upsampling: copy frames into the ping-pong buffer so that every level has the same batched layout
-        for (int b = 0; b < B; ++b)
-            HIP_CHECK(hipMemcpyAsync(buf[cur] + (size_t)b * padded(h, w), frames[b].d, (size_t)h * w * 3, hipMemcpyDeviceToDevice, c->stream));
-        cur_img = buf[cur]; cur ^= 1;
-    }
-    for (int l = 0; l < (int)lv.size(); ++l) {
-        if (l > 0) {
-            ProfScope ps(c, "pyramid");
-            launch_resize(c, nullptr, cur_img, padded(ch, cw), ch, cw, buf[cur], padded(lv[l].h, lv[l].w), lv[l].h, lv[l].w, B);
-            cur_img = buf[cur]; cur ^= 1; ch = lv[l].h; cw = lv[l].w;
-        }
-        if (want_level < 0 || want_level == l) per_level(l, cur_img, ch, cw);
-        if (want_level == l) break;
-    }
-}
-
 // =====================================================================================================
 // All pyramid levels in one launch per stage.  HBM is large (288 GB): the whole pyramid of a batch stays resident
 // (81 MB of images + 136 MB of gradient planes + 33 MB of histograms + 58 MB of features per 1080p frame), so after the
@@ -949,6 +211,8 @@ struct LvDesc {
     int fh, fw, hog_nr, hog_nc;                 // features
     int grad_bx, hist_bx, feat_bx, score_bx, score_by;
     int valid_score;
+    int strips, chunks, chunk_rows, fused_tasks;  // fused FHOG: 64-lane strips of 61 feature columns x chunks of chunk_rows feature rows
+    int sys_bx;                                 // systolic scoring: 96-column tiles
     long long img_off, img_stride;              // bytes
     long long px_off, px_stride;                // elements
     long long hist_off, hist_stride, norm_off, norm_stride, feat_off, feat_stride;   // floats
@@ -1217,6 +481,379 @@ __global__ void __launch_bounds__(256) fhog_feat_ml_k(MlStarts st, const LvDesc*
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K2 fused: image rows -> 31-plane features in ONE pass; gradients and cell histograms never leave the chip.
+//
+// A wave owns a strip of 64 histogram columns (lane L <-> histogram column hx0 + L) and walks a chunk of the level top to bottom,
+// one pixel row at a time.  Per row a lane
+//   - holds the image rows y-1, y, y+1 of its own 8 pixel columns in registers (each row is loaded once, 32 bytes per lane, a
+//     further row is in flight) and turns them into 8 (magnitude, bin) pairs;
+//   - fetches the 8 pairs of the lane to its right (DPP wave shift): together they are the 16 columns of its cell's window;
+//   - adds the 16 votes to the bins of the cell whose UPPER half the row lies in and of the cell whose LOWER half it lies in.
+// A cell therefore receives its votes in row-major order of its own 16 x 16 window -- the order dlib's scatter loop produces
+// (oracle/pvo_fhog.c) -- while every pixel's gradient is computed exactly once.  The bins live in LDS, [bin][lane] (conflict-free), in
+// two arrays for even and odd cell rows: a vote is a ds_read / v_add / ds_write on the lane's own word, the chains of the two cells
+// a row votes into are independent, and LDS executes a wave's accesses in order, so no wait sits between one vote's write and
+// the next vote's read.  (ds_add_f32 gives the same sums -- it is an IEEE add -- but the LDS atomic unit retires so few lanes per
+// clock that the kernel ran 5 x slower with it: measured 713 us per 1080p frame.)  When a cell is complete its 18 bins move into registers;
+// a finished cell row's features (4-way block normalisation over the 3 x 3 neighbourhood of cell energies: rows from the two
+// previous cell rows kept in registers, columns from the neighbouring lanes) are written straight to the feature map.
+// HBM traffic: the level images once (83 MB per 1080p frame) + the features once (58 MB), against 472 MB for the three-pass
+// form (109 MB/frame gradient plane written and read 1.25 x, 33 MB histogram round trip).
+//
+// Strip geometry: feature column x needs the histograms x+1 .. x+3, so a strip of 64 lanes yields 61 feature columns
+// (lane 63 only supplies gradients to lane 62; lanes 0 and 62 only supply cell energies).  Row chunks of `chunk_rows` feature
+// rows re-walk 24 + 2 pixel rows of their upper neighbour (3 cell rows of histogram context).
+#define FUSED_OUT 61
+template <bool DPP>
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v, int next_addr)
+{
+    if (DPP) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(next_addr, (int)v);
+}
+template <bool DPP>
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v, int prev_addr)
+{
+    if (DPP) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(prev_addr, (int)v);
+}
+
+typedef __attribute__((address_space(3))) float lds_float;
+
+template <bool DPP, int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) fhog_fused_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
+                                                       float* __restrict__ feat_base, const uint8_t* __restrict__ lut2, int oy, int ox)
+{
+    constexpr int RSRC_FLAGS = 0x00020000;
+    // the bins of the two cell rows a pixel row votes into: two arrays, so that the compiler knows their updates never alias
+    __shared__ float s_even[4][18][64];                            // cell rows with even index
+    __shared__ float s_odd[4][18][64];                             // cell rows with odd index
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = ml_block(st);
+    if (g >= st.b0[st.nl]) return;
+    const int l = ml_level(st, g);
+    const LvDesc d = lv[l];
+    const int task = (g - st.b0[l]) * 4 + wave;
+    if (task >= d.fused_tasks) return;                             // wave-uniform
+    const int sx = task % d.strips;
+    const int t2 = task / d.strips;
+    const int cy = t2 % d.chunks;
+    const int b = t2 / d.chunks;
+    const int y0 = cy * d.chunk_rows;                              // first feature (hog) row of this chunk
+    const int R = min(d.chunk_rows, d.hog_nr - y0);
+    const int hx = FUSED_OUT * sx + 1 + lane;                      // histogram column of this lane
+    const int x_first = 8 * hx - 12;                               // image column of its first pixel
+    const uint8_t* im = img_base + d.img_off + (size_t)b * d.img_stride;
+    const int rb = d.rb;
+    // validity of the lane's 8 pixel columns: gradients exist for 1 <= x < visible_nc (oracle/pvo_fhog.c)
+    unsigned xmask = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) if (x_first + p >= 1 && x_first + p < d.visible_nc) xmask |= 1u << p;
+    // byte offsets of the two 16-byte halves of the lane's 32-byte window in an image row (8-aligned).  Columns left of the image
+    // give negative offsets, which are huge as unsigned: out of range for the row's buffer descriptor => zeros.  Both offsets go
+    // through the VGPR: the range check does not see an SGPR offset, so -16 + an SGPR 16 would be rejected although it is byte 0.
+    const int voff = 3 * x_first - 4, voff2 = voff + 16;
+    const int next_addr = ((lane + 1) & 63) * 4, prev_addr = ((lane + 63) & 63) * 4;
+    float* accE = &s_even[wave][0][lane];                          // bin k of this lane: accE[64 * k]
+    float* accO = &s_odd[wave][0][lane];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accO[64 * k] = 0.0f; }
+
+    // image rows as 8 dwords per lane: bytes [3 x_first - 4, 3 x_first + 28) -- pixel p, channel k at byte 4 + 3 p + k;
+    // a row outside the image, or bytes outside a row, read as 0 (such pixels are never valid)
+    uint32_t rw[4][8];
+    auto load_row = [&](int yi, uint32_t* dst) {
+        const int bytes = (yi >= 0 && yi < d.h) ? rb : 0;           // wave-uniform
+        const int yc = min(max(yi, 0), d.h - 1);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(im + (size_t)yc * rb), 0, bytes, RSRC_FLAGS);
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+        const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, voff2, 0, 0);
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = c.x; dst[5] = c.y; dst[6] = c.z; dst[7] = c.w;
+    };
+    const int g_first = y0 + 1, g_last = y0 + R + 3;               // bands (= cell rows whose upper half they hold)
+    const int y_begin = 8 * g_first - 12;
+    load_row(y_begin - 1, rw[0]);
+    load_row(y_begin, rw[1]);
+    load_row(y_begin + 1, rw[2]);
+
+    float hprev[18];
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) hprev[k] = 0.f;
+
+#define BYTE_OF(w, i) (int)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
+    // One band = 8 pixel rows: the upper half of cell row gb (bins in accU) and the lower half of cell row gb - 1 (bins in accL).
+    // The first band's lower half (cell row y0) and the last band's upper half (cell row y0 + R + 3) belong to cells this chunk
+    // does not need; they are accumulated all the same (no branches in the vote loop): the first is read and dropped, the last
+    // is never read.
+    auto band = [&](int gb, float* accU, float* accL) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int y = 8 * gb + i - 12;
+            uint32_t* up = rw[i & 3];
+            uint32_t* ce = rw[(i + 1) & 3];
+            uint32_t* dn = rw[(i + 2) & 3];
+            load_row(y + 2, rw[(i + 3) & 3]);                      // next step's lower row, in flight during this step
+            if (y >= 1 && y < d.visible_nr) {                      // wave-uniform; other rows hold no gradients (nothing to add)
+                float m[8];
+                int bo[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    int u3[3], d3[3], l3[3], r3[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        u3[k] = BYTE_OF(up, 4 + 3 * p + k); d3[k] = BYTE_OF(dn, 4 + 3 * p + k);
+                        l3[k] = BYTE_OF(ce, 1 + 3 * p + k); r3[k] = BYTE_OF(ce, 7 + 3 * p + k);
+                    }
+                    float v; int o;
+                    grad_lookup(u3, d3, l3, r3, lut2, &v, &o);
+                    const bool ok = (xmask >> p) & 1u;
+                    m[p] = ok ? v : 0.0f;
+                    bo[p] = o << 6;                                // float offset of the bin's row of 64 lanes
+                }
+                const float fy = ((float)i + 0.5f) / 8.0f;
+                // the 16 columns of the window, left to right: own 8 (weights rising), then the right neighbour's 8 (falling).
+                // Each vote is a read-add-write on the lane's own bin in LDS; the two cells' chains are independent.
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int p = j & 7;
+                    float mv; int bv;
+                    if (j < 8) { mv = m[p]; bv = bo[p]; }
+                    else {
+                        mv = __uint_as_float(from_next_lane<DPP>(__float_as_uint(m[p]), next_addr));
+                        bv = (int)from_next_lane<DPP>((uint32_t)bo[p], next_addr);
+                    }
+                    const float fx = ((float)p + 0.5f) / 8.0f;
+                    const float wx = (j < 8) ? fx : 1.0f - fx;
+                    const float vl = accL[bv], vu = accU[bv];
+                    accL[bv] = vl + ((1.0f - fy) * wx) * mv;
+                    accU[bv] = vu + (fy * wx) * mv;
+                }
+            }
+        }
+        // cell row c = gb - 1 is complete (for c = y0: a half-filled cell that only has to be cleared; its energy is shifted out of
+        // e0..e2 before the first feature row is formed): energy in the oracle's order (straight from LDS: the new bins and the
+        // previous row's never sit in registers together)
+        const int c = gb - 1;
+        float e = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 9; ++o) { const float s2 = accL[64 * o] + accL[64 * (o + 9)]; e = e + s2 * s2; }
+        e2 = e1; e1 = e0; e0 = e;
+        if (c >= y0 + 3) {
+            // features of the centre cell row c - 1 (histograms in hprev), hog row y = c - 3; norms: rows c-2, c-1, c x lanes L-1, L, L+1
+            float n[9];
+            n[1] = e2; n[4] = e1; n[7] = e0;
+            n[0] = __uint_as_float(from_prev_lane<DPP>(__float_as_uint(e2), prev_addr)); n[2] = __uint_as_float(from_next_lane<DPP>(__float_as_uint(e2), next_addr));
+            n[3] = __uint_as_float(from_prev_lane<DPP>(__float_as_uint(e1), prev_addr)); n[5] = __uint_as_float(from_next_lane<DPP>(__float_as_uint(e1), next_addr));
+            n[6] = __uint_as_float(from_prev_lane<DPP>(__float_as_uint(e0), prev_addr)); n[8] = __uint_as_float(from_next_lane<DPP>(__float_as_uint(e0), next_addr));
+            const int x = FUSED_OUT * sx + lane - 1, yh = c - 3;
+            if (lane >= 1 && lane <= FUSED_OUT && x < d.hog_nc) {
+                float o[32];
+                cell_features(hprev, n, o);
+                float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)(yh + oy) * d.fw + (x + ox)) * PVF_FHOG_STRIDE);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+            }
+        }
+        // the finished cell row becomes the centre of the next feature row: its bins move to registers, the LDS words are cleared
+#pragma unroll
+        for (int k = 0; k < 18; ++k) { hprev[k] = accL[64 * k]; accL[64 * k] = 0.0f; }
+    };
+    for (int gb = g_first; gb <= g_last; ++gb) {
+        if (gb & 1) band(gb, accO, accE);                           // upper half -> the odd cell row gb, lower half -> the even row gb - 1
+        else band(gb, accE, accO);
+    }
+#undef BYTE_OF
+}
+
+// writes the zero border of the feature maps (the padding ring around the hog cells: (frows-1)/2 cells above / left, the rest below / right).
+// Needed once per (buffer, plan): the fused kernel only ever writes hog cells, so the ring stays valid across batches.
+__global__ void __launch_bounds__(256) feat_ring_zero_k(MlStarts st, const LvDesc* __restrict__ lv, int B, float* __restrict__ feat_base, int oy, int ox)
+{
+    const int g = ml_block(st);
+    if (g >= st.b0[st.nl]) return;
+    const int l = ml_level(st, g);
+    const LvDesc d = lv[l];
+    const int local = g - st.b0[l];
+    const int xb = local % d.feat_bx;
+    const int py = (local / d.feat_bx) % d.fh;
+    const int b = local / (d.feat_bx * d.fh);
+    const int px = xb * 256 + threadIdx.x;
+    if (px >= d.fw) return;
+    const int x = px - ox, y = py - oy;
+    if (x >= 0 && y >= 0 && x < d.hog_nc && y < d.hog_nr) return;
+    float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)py * d.fw + px) * PVF_FHOG_STRIDE);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3 systolic: the fmaf chain of one output position runs through the 8 waves of a block.
+//
+// The chain of a score is ordered (filter row m, cell n', plane p): 10 x 12 x 32 steps (12 cells per row because three neighbouring
+// output columns share one 16-column MFMA tile, see above).  It is cut into 8 consecutive segments of 15 (m, n') pairs; wave w
+// owns segment w for EVERY output row of the block's column tile and keeps that segment's B fragments (15 x 8 registers) for
+// the whole kernel -- no weight traffic at all in the loop.  Output row r enters wave 0 at step r and leaves wave 7 at step
+// r + 7; between two waves the two accumulator tiles travel through LDS (2 KB per hand-over) and continue as the C operand of
+// the next wave's first MFMA, so every accumulator still receives its terms in (m, n', p) order: bit-identical to the oracle.
+// At step s wave w works on output row s - w and needs feature rows (s - w) + m for its one or two m: rows s .. s + 2 for all
+// waves, so the block keeps a ring of 4 feature rows in LDS (3 live, the next one being written) that ALL waves read: every
+// feature row is fetched from HBM once per 96-column tile (1.11 x with the 11-cell overlap) instead of 3.25 x, and the inner
+// loop is ds_read_b32 (A) + MFMA only.  One barrier per step (240 MFMAs per wave).
+template <bool TWO>
+__device__ __forceinline__ void sys_mfma_pair(f32x4& acc0, f32x4& acc1, const float* a, const float* bq)
+{
+#pragma unroll
+    for (int pq = 0; pq < 8; ++pq) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * pq], bq[pq], acc0, 0, 0, 0);
+        if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * pq + 1], bq[pq], acc1, 0, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+score_sys_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base, const float* __restrict__ Bg,
+               ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
+{
+    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, WCOLS = 96, SEG = WCOLS + 11, NW = 8, NQ = 15;
+    constexpr int ROW_FLOATS = SEG * PITCH;                        // one staged feature row
+    constexpr int RSRC_FLAGS = 0x00020000;
+    extern __shared__ __attribute__((aligned(16))) float s_sys[];  // ring [4][SEG][PITCH] + hand-over [2][NW][2 tiles][64 lanes][4]
+    float* ring = s_sys;
+    float* hand = s_sys + 4 * ROW_FLOATS;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = ml_block(st);
+    if (g >= st.b0[st.nl]) return;
+    const int l = ml_level(st, g);
+    const LvDesc d = lv[l];
+    const int local = g - st.b0[l];
+    const int bx = local % d.score_bx;
+    const int b = local / d.score_bx;
+    const int fh = d.fh, fw = d.fw;
+    const int c_base = bx * WCOLS;
+    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
+    const int out_rows = r1 - FR / 2;                              // output rows 0 .. out_rows-1 (window top row = output row index)
+    const bool two_tiles = (c_base + 48 + FC / 2 < c1);            // block-uniform: a ragged right end runs one 48-column tile
+    const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride + (size_t)c_base * PVF_FHOG_STRIDE;
+    const int seg_cells = (fw - c_base < SEG) ? fw - c_base : SEG;
+
+    // this wave's segment of the chain: pairs q = 15 w .. 15 w + 14, q = m * 12 + n'
+    float bq[NQ][8];
+    {
+        const float* bp = Bg + ((size_t)(NQ * w) * 8) * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int pq = 0; pq < 8; ++pq) bq[q][pq] = bp[(q * 8 + pq) * 64];
+    }
+    const int q0 = NQ * w;
+    const int m_lo = q0 / NK;                                      // first filter row of the segment (the last is m_lo or m_lo + 1)
+    const int dly = (w < 4) ? 0 : 1;                               // rows (s - w) + m_lo = s + dly
+    // staging: thread t moves 16-byte pieces t and t + 512 of a feature row segment (SEG * 8 = 856 pieces)
+    const int t = threadIdx.x;
+    auto stage_load = [&](int frow, u32x4* v) {
+        const int bytes = (frow < fh) ? seg_cells * PVF_FHOG_STRIDE * 4 : 0;
+        const int fr = frow < fh ? frow : fh - 1;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + (size_t)fr * fw * PVF_FHOG_STRIDE), 0, bytes, RSRC_FLAGS);
+        v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 16, 0, 0);
+        v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 16, 512 * 16, 0);
+    };
+    auto stage_store = [&](int frow, const u32x4* v) {
+        float* row = ring + (frow & 3) * ROW_FLOATS;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = t + 512 * u;
+            if (idx < SEG * 8) {
+                uint2* dd = reinterpret_cast<uint2*>(row + (idx >> 3) * PITCH + 4 * (idx & 7));
+                dd[0] = make_uint2(v[u].x, v[u].y);
+                dd[1] = make_uint2(v[u].z, v[u].w);
+            }
+        }
+    };
+    const int r_top = 0;                                           // window top row of output row 0 is feature row 0
+    {
+        u32x4 v[2];
+        for (int fr = 0; fr < 3; ++fr) { stage_load(r_top + fr, v); stage_store(fr, v); }
+    }
+    __syncthreads();
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int a_off = (3 * i16) * PITCH + kq;                      // A fragment: position i16 (3 cells apart), plane 4 pq + kq
+    const int steps = out_rows + NW - 1;
+    for (int s = 0; s < steps; ++s) {
+        u32x4 nv[2];
+        stage_load(s + 3, nv);                                     // lands in the ring at the end of this step
+        const int r = s - w;                                       // output row of this wave at this step
+        if (r >= 0 && r < out_rows) {                              // wave-uniform
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (w > 0) {
+                const float* hp = hand + ((((s - 1) & 1) * NW + (w - 1)) * 2) * 256 + lane * 4;
+                acc0 = *reinterpret_cast<const f32x4*>(hp);
+                if (two_tiles) acc1 = *reinterpret_cast<const f32x4*>(hp + 256);
+            }
+            const float* rowA = ring + ((s + dly) & 3) * ROW_FLOATS + a_off;        // feature row r + m_lo
+            const float* rowB = ring + ((s + dly + 1) & 3) * ROW_FLOATS + a_off;    // feature row r + m_lo + 1
+            // A fragments of pair q: 8 k-steps x 2 tiles; fetched one pair ahead of the MFMAs that use them
+            float an[16];
+            auto fetch = [&](int q, float* dst) {
+                const int qq = q0 + q;                             // compile-time after unrolling: w is uniform, q constant
+                const int m = qq / NK, np = qq - m * NK;
+                const float* base = (m == m_lo ? rowA : rowB) + np * PITCH;
+#pragma unroll
+                for (int pq = 0; pq < 8; ++pq) {
+                    dst[2 * pq] = base[4 * pq];
+                    dst[2 * pq + 1] = base[48 * PITCH + 4 * pq];
+                }
+            };
+            fetch(0, an);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                float ac[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ac[k] = an[k];
+                if (q + 1 < NQ) fetch(q + 1, an);
+                __builtin_amdgcn_sched_barrier(0);
+                if (two_tiles) sys_mfma_pair<true>(acc0, acc1, ac, bq[q]);
+                else sys_mfma_pair<false>(acc0, acc1, ac, bq[q]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (w < NW - 1) {
+                float* hp = hand + (((s & 1) * NW + w) * 2) * 256 + lane * 4;
+                *reinterpret_cast<f32x4*>(hp) = acc0;
+                if (two_tiles) *reinterpret_cast<f32x4*>(hp + 256) = acc1;
+            } else {
+                // C/D layout of the 16x16 MFMA: column j = lane & 15, row = 4 * (lane >> 4) + reg
+                const int jc = lane & 15;
+                if (jc < 15) {
+                    const int sh = jc / 5, f = jc % 5;
+                    const float th = sp.thresh[f];
+                    const int rr = r + FR / 2;
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt) {
+                        if (tt == 1 && !two_tiles) break;
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int pos = 4 * (lane >> 4) + reg;
+                            const int cc = c_base + tt * 48 + 3 * pos + sh + FC / 2;
+                            const float v = tt == 0 ? acc0[reg] : acc1[reg];
+                            if (cc < c1 && v >= th) {
+                                const int idx = atomicAdd(&counts[b], 1);
+                                if (idx < sp.cap) {
+                                    CandRec rec;
+                                    rec.score = v - th; rec.filter = f; rec.level = l; rec.r = rr; rec.c = cc;
+                                    cands[(size_t)b * sp.cap + idx] = rec;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        stage_store(s + 3, nv);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K3 v3: one wave owns R consecutive output rows x 96 columns and walks the R + 9 feature rows it needs ONCE.
 // Staged feature row t feeds output row j through filter row m = t - j, so every A fragment read from the slab is used for
 // up to R MFMAs and the slab is filled (R+9)/R times per output row instead of 10 times.  B fragments (packed four k-steps
@@ -1390,42 +1027,52 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
     }
 }
 
-// output rows per wave of the scoring kernel (PVF_SCORE_ROWS = 2 or 4)
-static int score_rows_per_wave()
-{
-    static int r = -1;
-    if (r < 0) {
-        const char* e = getenv("PVF_SCORE_ROWS");
-        r = e ? atoi(e) : 4;
-        if (r != 2 && r != 4) r = 4;
-    }
-    return r;
-}
-
 struct MlPlan {
     int h = 0, w = 0, upsample = -1, B = 0;
     std::vector<LvDesc> lv;
     std::vector<LevelDims> ups;
-    MlStarts grad, hist, feat, score;
-    int grad_blocks = 0, hist_blocks = 0, feat_blocks = 0, score_blocks = 0;
+    MlStarts grad, hist, feat, score, fused, sys;
+    int grad_blocks = 0, hist_blocks = 0, feat_blocks = 0, score_blocks = 0, fused_blocks = 0, sys_blocks = 0;
     size_t img_bytes = 0, px_elems = 0, hist_floats = 0, norm_floats = 0, feat_floats = 0, up_bytes = 0;
     LvDesc* d_lv = nullptr;
+    const void* ring_valid_for = nullptr;      // feature buffer whose zero border was written for this plan (fused FHOG)
+    ~MlPlan() { if (d_lv) (void)hipFree(d_lv); }
+    MlPlan() = default;
+    MlPlan(const MlPlan&) = delete;
+    MlPlan& operator=(const MlPlan&) = delete;
 };
+
+// plans live in their context (one per frame size / upsampling / batch size) and die with it
+struct MlPlanCache {
+    std::map<std::vector<int>, std::unique_ptr<MlPlan>> plans;
+    int dpp_probe = -1;                        // 1: v_mov_b32_dpp wave_shl/wave_shr move data as the fused kernel expects
+};
+void ml_plans_free(Ctx* c)
+{
+    delete c->ml_plans;
+    c->ml_plans = nullptr;
+}
+
+// dev-time switches (removed once the new kernels are validated on hardware)
+static bool env_is(const char* name, const char* val) { const char* e = getenv(name); return e && strcmp(e, val) == 0; }
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
 {
-    static std::map<std::pair<Ctx*, std::vector<int>>, MlPlan> cache;
-    auto key = std::make_pair(c, std::vector<int>{h, w, upsample, B});
-    auto it = cache.find(key);
-    if (it != cache.end()) return &it->second;
+    if (!c->ml_plans) c->ml_plans = new MlPlanCache();
+    const std::vector<int> key{h, w, upsample, B};
+    auto it = c->ml_plans->plans.find(key);
+    if (it != c->ml_plans->plans.end()) return it->second.get();
     const DetectorModel& m = c->det;
-    MlPlan p;
+    std::unique_ptr<MlPlan> pp(new MlPlan());
+    MlPlan& p = *pp;
     p.h = h; p.w = w; p.upsample = upsample; p.B = B;
     std::vector<LevelDims> dims = level_schedule(h, w, upsample, m, &p.ups);
     PVF_REQUIRE((int)dims.size() <= ML_MAX, "too many pyramid levels");
     auto al = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
     for (size_t u = 0; u + 1 < p.ups.size(); ++u) p.up_bytes = std::max(p.up_bytes, (size_t)p.ups[u].h * al((size_t)p.ups[u].w * 3, 64) * B);
-    p.grad.nl = p.hist.nl = p.feat.nl = p.score.nl = (int)dims.size();
+    p.grad.nl = p.hist.nl = p.feat.nl = p.score.nl = p.fused.nl = p.sys.nl = (int)dims.size();
+    const int chunk_big = env_int("PVF_FHOG_CHUNK", 32);
     for (size_t l = 0; l < dims.size(); ++l) {
         LvDesc d;
         memset(&d, 0, sizeof d);
@@ -1451,20 +1098,29 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         p.feat_floats += (size_t)d.feat_stride * B;
         d.grad_bx = (d.pitch / 4 + 255) / 256; d.hist_bx = (d.hc + 255) / 256; d.feat_bx = std::max((d.fw + 255) / 256, 0);
         const int out_r = d.fh - 9, out_c = d.fw - 9;
-        const int rows_per_block = 4 * score_rows_per_wave();
-        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + rows_per_block - 1) / rows_per_block : 0;
+        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + 15) / 16 : 0;
+        d.sys_bx = d.score_bx;
+        // fused FHOG tasks: strips of 61 feature columns x chunks of feature rows (smaller chunks for the small levels: more tasks)
+        d.strips = feat_ok ? (d.hog_nc + FUSED_OUT - 1) / FUSED_OUT : 0;
+        d.chunk_rows = (d.hog_nr >= 2 * chunk_big) ? chunk_big : std::max((d.hog_nr + 1) / 2, 1);
+        d.chunks = feat_ok ? (d.hog_nr + d.chunk_rows - 1) / d.chunk_rows : 0;
+        d.fused_tasks = d.strips * d.chunks * B;
         p.grad.b0[l] = p.grad_blocks; p.grad_blocks += d.grad_bx * ((d.rows_t + GRAD_ROWS - 1) / GRAD_ROWS) * B;
         p.hist.b0[l] = p.hist_blocks; p.hist_blocks += d.hist_bx * ((d.hr + HIST_CELLS - 1) / HIST_CELLS) * B;
         p.feat.b0[l] = p.feat_blocks; p.feat_blocks += d.feat_bx * d.fh * B;
         p.score.b0[l] = p.score_blocks; p.score_blocks += d.score_bx * d.score_by * B;
+        p.fused.b0[l] = p.fused_blocks; p.fused_blocks += (d.fused_tasks + 3) / 4;
+        p.sys.b0[l] = p.sys_blocks; p.sys_blocks += d.sys_bx * B;
         p.lv.push_back(d);
     }
     const int nl = (int)dims.size();
     p.grad.b0[nl] = p.grad_blocks; p.hist.b0[nl] = p.hist_blocks; p.feat.b0[nl] = p.feat_blocks; p.score.b0[nl] = p.score_blocks;
+    p.fused.b0[nl] = p.fused_blocks; p.sys.b0[nl] = p.sys_blocks;
     HIP_CHECK(hipMalloc((void**)&p.d_lv, sizeof(LvDesc) * nl));
     HIP_CHECK(hipMemcpy(p.d_lv, p.lv.data(), sizeof(LvDesc) * nl, hipMemcpyHostToDevice));
-    auto res = cache.emplace(key, std::move(p));
-    return &res.first->second;
+    MlPlan* raw = pp.get();
+    c->ml_plans->plans[key] = std::move(pp);
+    return raw;
 }
 
 // builds the whole pyramid of the batch into s_pyr (level images at plan->lv[l].img_off); returns the plan
@@ -1503,6 +1159,33 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
     return p;
 }
 
+// does `v_mov_b32_dpp ... wave_shl:1 / wave_shr:1` hand lane i the value of lane i + 1 / i - 1 (lanes without a source keeping 0)?
+__global__ void dpp_probe_k(int* out)
+{
+    const int lane = threadIdx.x;
+    out[lane] = (int)from_next_lane<true>((uint32_t)(lane + 100), 0);
+    out[64 + lane] = (int)from_prev_lane<true>((uint32_t)(lane + 100), 0);
+}
+static bool dpp_moves_as_expected(Ctx* c)
+{
+    MlPlanCache* pc = c->ml_plans;
+    if (pc->dpp_probe < 0) {
+        c->s_misc.ensure(128 * sizeof(int));
+        hipLaunchKernelGGL(dpp_probe_k, dim3(1), dim3(64), 0, c->stream, c->s_misc.as<int>());
+        int h[128];
+        HIP_CHECK(hipMemcpyAsync(h, c->s_misc.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        bool ok = true;
+        for (int i = 0; i < 64; ++i) {
+            ok = ok && h[i] == (i < 63 ? i + 101 : 0);
+            ok = ok && h[64 + i] == (i > 0 ? i + 99 : 0);
+        }
+        pc->dpp_probe = ok ? 1 : 0;
+        if (getenv("PVF_VERBOSE")) fprintf(stderr, "[pvface] DPP wave shift probe: %s\n", ok ? "as expected" : "NOT as expected, using ds_bpermute");
+    }
+    return pc->dpp_probe == 1;
+}
+
 // pyramid + FHOG features of every level of the batch (s_feat at plan->lv[l].feat_off); returns the plan
 static MlPlan* ml_features(Ctx* c, const std::vector<Frame>& frames, int upsample)
 {
@@ -1510,27 +1193,44 @@ static MlPlan* ml_features(Ctx* c, const std::vector<Frame>& frames, int upsampl
     const int B = (int)frames.size();
     MlPlan* p = ml_build_pyramid(c, frames, upsample);
     const uint8_t* lut2 = orientation_lut_tiled(c);
+    const int oy = (m.frows - 1) / 2, ox = (m.fcols - 1) / 2;
+    const void* feat_before = c->s_feat.p;
+    c->s_feat.ensure(p->feat_floats * sizeof(float) + 64);
+    if (!env_is("PVF_FHOG", "old")) {
+        if (p->fused_blocks == 0) return p;
+        // the fused kernel writes hog cells only: the zero padding ring is written when this plan first meets this buffer (other
+        // plans and the stage-access entries share s_feat, so the owner is tracked)
+        if (c->s_feat.p != feat_before || c->feat_ring_owner != (const void*)p) {
+            ProfScope p0(c, "fhog");
+            hipLaunchKernelGGL(feat_ring_zero_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_feat.as<float>(), oy, ox);
+            c->feat_ring_owner = (const void*)p;
+        }
+        ProfScope ps(c, "fhog");
+        const bool dpp = dpp_moves_as_expected(c) && !env_is("PVF_FHOG", "bperm");
+        if (!dpp)
+            hipLaunchKernelGGL((fhog_fused_ml_k<false, 2>), dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
+                               c->s_feat.as<float>(), lut2, oy, ox);
+        else if (env_int("PVF_FHOG_WAVES", 2) == 3)
+            hipLaunchKernelGGL((fhog_fused_ml_k<true, 3>), dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
+                               c->s_feat.as<float>(), lut2, oy, ox);
+        else
+            hipLaunchKernelGGL((fhog_fused_ml_k<true, 2>), dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
+                               c->s_feat.as<float>(), lut2, oy, ox);
+        return p;
+    }
+    c->feat_ring_owner = nullptr;
     c->s_grad.ensure(p->px_elems * 4 + 256);
     c->s_hist.ensure(p->hist_floats * sizeof(float) + 64);
     c->s_norm.ensure(p->norm_floats * sizeof(float) + 64);
-    c->s_feat.ensure(p->feat_floats * sizeof(float) + 64);
     uint32_t* d_px = c->s_grad.as<uint32_t>();
     {
         ProfScope ps(c, "fhog");
-        {
-            ProfScope p1(c, "fhog_grad");
-            hipLaunchKernelGGL(fhog_grad4r_ml_k, dim3(ml_grid(p->grad_blocks)), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_px, lut2);
-        }
-        {
-            ProfScope p2(c, "fhog_hist");
-            hipLaunchKernelGGL(fhog_hist4_ml_k, dim3(ml_grid(p->hist_blocks)), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_px, c->s_hist.as<float>(),
-                               c->s_norm.as<float>());
-        }
-        if (p->feat_blocks > 0) {
-            ProfScope p3(c, "fhog_feat");
+        hipLaunchKernelGGL(fhog_grad4r_ml_k, dim3(ml_grid(p->grad_blocks)), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_px, lut2);
+        hipLaunchKernelGGL(fhog_hist4_ml_k, dim3(ml_grid(p->hist_blocks)), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_px, c->s_hist.as<float>(),
+                           c->s_norm.as<float>());
+        if (p->feat_blocks > 0)
             hipLaunchKernelGGL(fhog_feat_ml_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_hist.as<float>(),
-                               c->s_norm.as<float>(), c->s_feat.as<float>(), (m.frows - 1) / 2, (m.fcols - 1) / 2);
-        }
+                               c->s_norm.as<float>(), c->s_feat.as<float>(), oy, ox);
     }
     return p;
 }
@@ -1540,17 +1240,23 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
     const DetectorModel& m = c->det;
     const int B = (int)frames.size();
     MlPlan* p = ml_features(c, frames, upsample);
-    if (p->score_blocks > 0) {
-        ProfScope ps(c, "score");
-        const size_t lds = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
-        const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
-        if (score_rows_per_wave() == 2)
-            hipLaunchKernelGGL(score_mfma_rows_ml_k<2>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
-                               sp0, d_counts, d_cands);
-        else
-            hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
-                               sp0, d_counts, d_cands);
+    if (p->score_blocks == 0) return;
+    ProfScope ps(c, "score");
+    if (!env_is("PVF_SCORE", "old")) {
+        constexpr size_t lds = (size_t)(4 * (96 + 11) * 34 + 2 * 8 * 2 * 256) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)score_sys_ml_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(score_sys_ml_k, dim3(ml_grid(p->sys_blocks)), dim3(512), lds, c->stream, p->sys, p->d_lv, B, c->s_feat.as<float>(), m.d_bmfma,
+                           sp0, d_counts, d_cands);
+        return;
     }
+    const size_t lds = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
+    const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
+    hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
+                       sp0, d_counts, d_cands);
 }
 
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* oh, int* ow)
@@ -1610,56 +1316,7 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     ScoreParams sp;
     for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
     sp.n_filters = m.n_filters; sp.cap = cap;
-    static const bool per_level = getenv("PVF_PER_LEVEL") != nullptr;
-    if (m.n_filters == 5 && m.d_bmfma && !per_level) {
-        det_run_batch_ml(c, frames, upsample, sp, d_counts, d_cands);
-    } else
-    run_pyramid(c, frames, upsample, -1, [&](int l, const uint8_t* img, int h, int w) {
-        int fh, fw;
-        fhog_dims(h, w, m.cell, m.frows, m.fcols, &fh, &fw);
-        if (fh < m.frows || fw < m.fcols) return;
-        const size_t feat_stride = (size_t)fh * fw * PVF_FHOG_STRIDE;
-        c->s_feat.ensure(feat_stride * B * sizeof(float));
-        {
-            ProfScope ps(c, "fhog");
-            fhog_device(c, img, B, h, w, m.cell, m.frows, m.fcols, c->s_feat.as<float>(), c->s_hist, c->s_norm, (((size_t)h * w * 3 + 15) & ~(size_t)15));
-        }
-        {
-            ProfScope ps(c, "score");
-            sp.level = l;
-            const int out_r = fh - 9, out_c = fw - 9;
-            dim3 grid((out_c + 31) / 32, (out_r + 7) / 8, B);
-            const size_t lds = (size_t)(8 + 9) * (32 + 9) * 36 * sizeof(float);
-#define LAUNCH_SCORE(NF)                                                                                                       \
-    {                                                                                                                          \
-        static bool attr_set = false;                                                                                          \
-        if (!attr_set) {                                                                                                       \
-            HIP_CHECK(hipFuncSetAttribute((const void*)score_k<NF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-            attr_set = true;                                                                                                   \
-        }                                                                                                                      \
-    }                                                                                                                        \
-    hipLaunchKernelGGL((score_k<NF>), grid, dim3(256), lds, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_w, sp, \
-                       d_counts, d_cands)
-            if (false) {
-            } else if (m.n_filters == 5 && m.d_bmfma) {
-                const size_t lds2 = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
-                dim3 g2((out_c + 95) / 96, (out_r + 3) / 4, B);
-                hipLaunchKernelGGL(score_mfma_k, g2, dim3(256), lds2, c->stream, c->s_feat.as<float>(), feat_stride, fh, fw, m.d_bmfma, sp,
-                                   d_counts, d_cands);
-            } else
-            switch (m.n_filters) {
-                case 1: LAUNCH_SCORE(1); break;
-                case 2: LAUNCH_SCORE(2); break;
-                case 3: LAUNCH_SCORE(3); break;
-                case 4: LAUNCH_SCORE(4); break;
-                case 5: LAUNCH_SCORE(5); break;
-                case 6: LAUNCH_SCORE(6); break;
-                case 7: LAUNCH_SCORE(7); break;
-                default: LAUNCH_SCORE(8); break;
-            }
-#undef LAUNCH_SCORE
-        }
-    });
+    det_run_batch_ml(c, frames, upsample, sp, d_counts, d_cands);
     HIP_CHECK(hipGetLastError());
     c->h_cand.ensure((size_t)B * cap * sizeof(CandRec) + (size_t)B * sizeof(int) + 64);
     int* h_counts = c->h_cand.as<int>();
@@ -1709,8 +1366,7 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
     PVF_REQUIRE(!frames.empty() && batch > 0, "no frames");
     const int N = (int)frames.size();
     raw_sorted.assign(N, {});
-    static const bool per_level = getenv("PVF_PER_LEVEL") != nullptr;
-    if (!(m.n_filters == 5 && m.d_bmfma && !per_level) || N <= batch) {
+    if (N <= batch) {
         for (int o = 0; o < N; o += batch) {                   // plain batch-by-batch form
             std::vector<Frame> fr(frames.begin() + o, frames.begin() + std::min(N, o + batch));
             std::vector<std::vector<RawDet>> part;

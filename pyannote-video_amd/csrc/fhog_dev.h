@@ -1,0 +1,87 @@
+// fhog_dev.h -- device helpers shared by the FHOG kernels (detector: detect.hip, tracker chips: fhog.hip).
+// All arithmetic follows the orders stated in oracle/pvo_fhog.c.
+#pragma once
+#include "pvf_internal.h"
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4u __attribute__((aligned(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// orientation-bin tables (fhog.hip): row-major 511 x 511, and the same in 8 x 8 tiles (one 64-byte line each)
+const uint8_t* orientation_lut(Ctx* c);
+const uint8_t* orientation_lut_tiled(Ctx* c);
+
+// correctly rounded sqrt of a non-negative integer-valued float < 2^24: the hardware estimate (<= 1 ulp) stepped to the
+// neighbour the exact residuals ask for.  Same result as sqrtf(); skips its denormal scaling and class checks.
+__device__ __forceinline__ float sqrt_exact_small(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
+    float r = (rm <= 0.0f) ? sm : s;
+    r = (rp > 0.0f) ? sp : r;
+    return r;
+}
+
+// colour channel with the largest |g|^2 (first wins); magnitude by arithmetic, orientation bin from the tiled table
+__device__ __forceinline__ void grad_lookup(const int u[3], const int d[3], const int l[3], const int r[3],
+                                            const uint8_t* __restrict__ lut_t, float* v, int* o)
+{
+    int bx = r[0] - l[0], by = d[0] - u[0];
+    int bv = bx * bx + by * by;
+    int bi = by * 512 + bx;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+        const int cx = r[k] - l[k], cy = d[k] - u[k];
+        const int cv = cx * cx + cy * cy;
+        const int ci = cy * 512 + cx;
+        if (cv > bv) { bv = cv; bi = ci; }
+    }
+    const unsigned P = (unsigned)(bi + 255 * 512 + 255);           // Y << 9 | X
+    const unsigned off = (P & 0x3F007u) | ((P & 0x1F8u) << 3) | ((P >> 6) & 0x38u);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lut_t, 0, 64 * 64 * 64, 0x00020000);
+    *o = (int)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
+    *v = sqrt_exact_small((float)bv);
+}
+
+__device__ __forceinline__ void cell_features(const float* h, const float* n, float* o)
+{
+    const float eps = 0.0001f;
+    const float z1[4] = {n[4], n[1], n[3], n[0]};
+    const float z2[4] = {n[5], n[2], n[4], n[1]};
+    const float z3[4] = {n[7], n[4], n[6], n[3]};
+    const float z4[4] = {n[8], n[5], n[7], n[4]};
+    float nn[4], nv[4], t[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        nn[k] = 0.2f * sqrtf((((z1[k] + z2[k]) + z3[k]) + z4[k]) + eps);
+        nv[k] = 0.1f / nn[k];
+    }
+#pragma unroll
+    for (int g = 0; g < 18; g += 3) {
+        float hh[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) hh[j][k] = fminf(h[g + j], nn[k]) * nv[k];
+            o[g + j] = (hh[j][0] + hh[j][1]) + (hh[j][2] + hh[j][3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = t[k] + ((hh[0][k] + hh[1][k]) + hh[2][k]);
+    }
+    const float tscale = (float)(2 * 0.2357);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] = t[k] * tscale;
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        const float s = h[g] + h[g + 9];
+        float hh[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hh[k] = fminf(s, nn[k]) * nv[k];
+        o[18 + g] = (hh[0] + hh[1]) + (hh[2] + hh[3]);
+    }
+    o[27] = t[0]; o[28] = t[1]; o[29] = t[2]; o[30] = t[3];
+    o[31] = 0.0f;
+}
+

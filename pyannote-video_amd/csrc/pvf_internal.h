@@ -99,7 +99,6 @@ struct DetectorModel {
     double nms_iou = 0, nms_covered = 0;
     std::vector<float> thresh;
     float* d_w = nullptr;    // [nf][frows][fcols][32]
-    float* d_wt = nullptr;   // [frows][fcols][32][8] filter-minor copy (unused by the current kernels)
     float* d_bmfma4 = nullptr; // same fragments, [10][12][2][64][4] (four k-steps per lane) for score_mfma_rows_ml_k
     float* d_bmfma = nullptr; // [10][12][8][64] B fragments of score_mfma_k (3 shifts x 5 filters per 16-column tile)
 };
@@ -193,7 +192,9 @@ struct Ctx {
     hipEvent_t det_ev[2] = {nullptr, nullptr};
     int det_slot = 0;
     int n_cu = 256;
-    uint8_t* d_orient_lut = nullptr; // 511x511 orientation bins (detect.hip)
+    struct MlPlanCache* ml_plans = nullptr;   // detector launch plans of this context (detect.hip); freed by ml_plans_free
+    const void* feat_ring_owner = nullptr;    // plan whose zero padding ring s_feat currently holds
+    uint8_t* d_orient_lut = nullptr; // 511x511 orientation bins (fhog.hip)
     void* d_grad_lut = nullptr;          // orientation bins in 8 x 8 tiles (64^3 bytes): orientation_lut_tiled()
 
     Frame& frame(uint64_t id)
@@ -226,6 +227,7 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
                    std::vector<std::vector<RawDet>>& raw_sorted);
 void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsample, double adjust,
                   std::vector<std::vector<RawDet>>& raw_sorted);
+void ml_plans_free(Ctx* c);
 void det_nms(const DetectorModel& m, const std::vector<RawDet>& sorted, std::vector<RawDet>& out);
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* h, int* w);
 void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::vector<float>* out, int* fh, int* fw);
@@ -252,5 +254,5 @@ void overlap_matrix_host(const double* a, int na, const double* b, int nb, doubl
 void munkres_host(const double* cost, int n, int32_t* row_to_col);
 // clustering (cluster.hip)
 void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* row_start, int T, double* h_D, double** d_D_keep,
-                        int t0 = 0, int t1 = -1);
+                        int t0 = 0, int t1 = -1, int metric = 0);
 int hac_dev(Ctx* c, double* d_D, const int32_t* row_start, int T, double threshold, int32_t* labels, double* merge_log);

@@ -60,6 +60,7 @@ _SIGS = {
     "pvf_embed_chips": (C.c_int32, [H, P, C.c_int32, P]),
     "pvf_face_chips": (C.c_int32, [H, P, P, C.c_int32, P]),
     "pvf_pair_mean_dist": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, P]),
+    "pvf_pair_mean_dist_metric": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P]),
     "pvf_pair_mean_dist_rows": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P]),
     "pvf_cluster_dist": (C.c_int32, [H, P, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_cluster_tracks": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),

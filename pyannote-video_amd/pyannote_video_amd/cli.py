@@ -1,0 +1,193 @@
+"""`pyannote-face` verbs on the HIP path (reference scripts/pyannote-face.py:29-89 usage, :239-314 bodies, :415-455 dispatch).
+
+    python -m pyannote_video_amd track   [options] <video> <shot.json> <tracking>
+    python -m pyannote_video_amd extract [options] <video> <tracking> <landmark_model> <embedding_model> <landmarks> <embeddings>
+    python -m pyannote_video_amd cluster [options] <embeddings> <labels>
+
+`track` and `extract` take the reference's arguments and options and write byte-compatible files (track.txt, landmarks.txt,
+embedding.txt: formats.py).  `cluster` is the verb BASELINE.json's north_star names; the reference offers clustering through the API
+only (face/clustering.py:130-134).  It writes `identifier label` lines, the file `demo --label` reads (pyannote-face.py:87,391-397).
+`demo` (video rendering through moviepy) is out of scope.
+
+<video>: decoding through ffmpeg (reference video.py:345-406) is not part of this path; the verbs read frames that are already
+decoded -- a `.npy` file holding uint8 [N, H, W, 3] RGB frames (memory mapped; frame rate from --fps) -- or render the bench's
+synthetic clip: `synthetic:<width>x<height>x<frames>[:shots[:faces[:seed]]]`.
+<shot.json>: a JSON list of [start, end] seconds (what pyannote.core.json holds for a Timeline reduces to this for our purpose).
+"""
+import argparse
+import json
+import sys
+import numpy as np
+from . import formats
+
+MIN_OVERLAP_RATIO = 0.5      # pyannote-face.py:112-114
+MIN_CONFIDENCE = 10.
+MAX_GAP = 1.
+
+
+class NpyVideo(object):
+    """decoded frames with the iteration contract of the reference's Video (video.py:411-464): yields (t, uint8 HxWx3 RGB)"""
+
+    def __init__(self, path, frame_rate=25.0):
+        self._frames = np.load(path, mmap_mode="r")
+        if self._frames.dtype != np.uint8 or self._frames.ndim != 4 or self._frames.shape[3] != 3:
+            raise IOError("%s: expected uint8 frames of shape [N, H, W, 3]" % path)
+        self.frame_rate = float(frame_rate)
+        self._size = (int(self._frames.shape[2]), int(self._frames.shape[1]))
+        self._frame_size = self._size
+        self.duration = len(self._frames) / self.frame_rate
+
+    @property
+    def size(self):
+        return self._size
+
+    @property
+    def frame_size(self):
+        return self._frame_size
+
+    @frame_size.setter
+    def frame_size(self, value):
+        self._frame_size = tuple(int(v) for v in value)     # applied by the consumer on the device (FaceTracking: detect_min_size)
+
+    def __len__(self):
+        return len(self._frames)
+
+    def __iter__(self):
+        for i in range(len(self._frames)):
+            yield i / self.frame_rate, np.ascontiguousarray(self._frames[i])
+
+
+def open_video(spec, frame_rate):
+    if spec.startswith("synthetic:"):
+        from . import synth
+        parts = spec[len("synthetic:"):].split(":")
+        w, h, n = (int(v) for v in parts[0].lower().split("x"))
+        kw = {}
+        for name, val in zip(("n_shots", "faces", "seed"), parts[1:]):
+            kw[name] = int(val)
+        return synth.SyntheticVideo(width=w, height=h, n_frames=n, frame_rate=frame_rate, **kw)
+    return NpyVideo(spec, frame_rate)
+
+
+class _Shot(object):
+    def __init__(self, start, end):
+        self.start, self.end = float(start), float(end)
+
+
+def load_shots(path):
+    with open(path) as f:
+        data = json.load(f)
+    if isinstance(data, dict):                      # pyannote.core.json Timeline: {"pyannote": "Timeline", "content": [{"start":..,"end":..}]}
+        data = [(s["start"], s["end"]) for s in data.get("content", [])]
+    return [_Shot(a, b) for a, b in data]
+
+
+def track(video, shot, output, detect_min_size=0.0, detect_every=0.0, track_min_overlap_ratio=MIN_OVERLAP_RATIO,
+          track_min_confidence=MIN_CONFIDENCE, track_max_gap=MAX_GAP, ctx=None):
+    """Tracking by detection (pyannote-face.py:239-269): track.txt, one line per (track, frame), flushed per track"""
+    from .face_tracking import FaceTracking
+    tracking = FaceTracking(detect_min_size=detect_min_size, detect_every=detect_every, track_min_overlap_ratio=track_min_overlap_ratio,
+                            track_min_confidence=track_min_confidence, track_max_gap=track_max_gap, ctx=ctx)
+    shots = load_shots(shot) if isinstance(shot, str) else shot
+    with open(output, 'w') as foutput:
+        for identifier, trk in enumerate(tracking(video, shots)):
+            for line in formats.track_lines(identifier, trk):
+                foutput.write(line)
+            foutput.flush()
+
+
+def extract(video, landmark_model, embedding_model, tracking, landmark_output, embedding_output, ctx=None, batch=256):
+    """Facial features (pyannote-face.py:271-314): landmarks.txt and embedding.txt for every face of the track file.  The faces
+    are paired with frames by getFaceGenerator's rules (pipeline.faces_per_frame) and computed `batch` faces per library call."""
+    from . import pipeline, runtime
+    ctx = ctx or runtime.default_context()
+    ctx.load_shape_predictor(landmark_model)
+    ctx.load_embedder(embedding_model)
+    frame_width, frame_height = video.frame_size
+    rows = formats.read_tracks(tracking)
+    frame_times = [t for t, _ in _times(video)]
+    plan = pipeline.faces_per_frame(rows, frame_times, frame_width, frame_height)
+    want = {}
+    for fi, T, g in plan:
+        want[fi] = (T, g)
+    with open(landmark_output, 'w') as flandmark, open(embedding_output, 'w') as fembedding:
+        pend_f, pend_b, pend_k = [], [], []
+
+        def flush():
+            if not pend_b:
+                return
+            pts = ctx.landmarks(pend_f, pend_b)
+            emb = ctx.embed(pend_f, pts)
+            for (T, ident), p, e in zip(pend_k, pts, emb):
+                flandmark.write(formats.landmark_line(T, ident, p, frame_width, frame_height))
+                fembedding.write(formats.embedding_line(T, ident, e))
+            flandmark.flush(); fembedding.flush()
+            del pend_f[:], pend_b[:], pend_k[:]
+        for fi, (t, rgb) in enumerate(video):
+            if fi not in want:
+                continue
+            T, g = want[fi]
+            dev = ctx.upload(rgb)
+            for ident, box in g:
+                pend_f.append(dev); pend_b.append(box); pend_k.append((T, ident))
+            if len(pend_b) >= batch:
+                flush()
+        flush()
+
+
+def _times(video):
+    n = len(video)
+    return [(i / video.frame_rate, None) for i in range(n)]
+
+
+def cluster(embeddings, output, threshold=0.6, force=False, metric="euclidean", ctx=None):
+    """FaceClustering on an embedding file (face/clustering.py:130-134) -> `identifier label` lines for `demo --label`.
+    Tracks that take no part in the clustering (a single timestamp: clustering.py:78-79) keep their own identifier as label."""
+    from .clustering import FaceClustering
+    clustering = FaceClustering(threshold=threshold, force=force, metric=metric, ctx=ctx)
+    starting_point, features = clustering.model.preprocess(embeddings)
+    result = clustering(starting_point, features=features)
+    label = {int(track): int(lab) for _, track, lab in result.itertracks(yield_label=True)}
+    with open(output, 'w') as f:
+        for identifier in sorted(set(int(t) for t in np.unique(features.track))):
+            f.write('{identifier:d} {label:d}\n'.format(identifier=identifier, label=label.get(identifier, identifier)))
+    return label
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="pyannote-face", description="face tracking => feature extraction => face clustering (MI355X)")
+    ap.add_argument("--fps", type=float, default=25.0, help="frame rate of a .npy / synthetic video")
+    ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK or 0)")
+    sub = ap.add_subparsers(dest="verb", required=True)
+    t = sub.add_parser("track")
+    t.add_argument("video"); t.add_argument("shot"); t.add_argument("tracking")
+    t.add_argument("--min-size", type=float, default=0.0)
+    t.add_argument("--every", type=float, default=0.0)
+    t.add_argument("--min-overlap", type=float, default=MIN_OVERLAP_RATIO)
+    t.add_argument("--min-confidence", type=float, default=MIN_CONFIDENCE)
+    t.add_argument("--max-gap", type=float, default=MAX_GAP)
+    e = sub.add_parser("extract")
+    for name in ("video", "tracking", "landmark_model", "embedding_model", "landmarks", "embeddings"):
+        e.add_argument(name)
+    c = sub.add_parser("cluster")
+    c.add_argument("embeddings"); c.add_argument("labels")
+    c.add_argument("--threshold", type=float, default=0.6)
+    c.add_argument("--force", action="store_true")
+    c.add_argument("--metric", choices=("euclidean", "cosine"), default="euclidean")
+    a = ap.parse_args(argv)
+    ctx = None
+    if a.device is not None:
+        from .runtime import Context
+        ctx = Context(device=a.device)
+    if a.verb == "track":
+        track(open_video(a.video, a.fps), a.shot, a.tracking, detect_min_size=a.min_size, detect_every=a.every,
+              track_min_overlap_ratio=a.min_overlap, track_min_confidence=a.min_confidence, track_max_gap=a.max_gap, ctx=ctx)
+    elif a.verb == "extract":
+        extract(open_video(a.video, a.fps), a.landmark_model, a.embedding_model, a.tracking, a.landmarks, a.embeddings, ctx=ctx)
+    else:
+        cluster(a.embeddings, a.labels, threshold=a.threshold, force=a.force, metric=a.metric, ctx=ctx)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -50,12 +50,18 @@ class FaceClustering(object):
     Parameters
     ----------
     threshold : float, optional    stop merging when the closest pair's mean distance exceeds it. Defaults to 0.6.
-    force : bool, optional         (reference: keep the violating merge) -- not supported, must stay False
+    force : bool, optional         passed to the stopping criterion like the reference does (clustering.py:138-141,
+                                   DistanceThreshold(threshold=threshold, force=force)).  [EXT pyannote.algorithms]: with force the
+                                   agglomeration runs on to a single cluster so that `history` holds the complete dendrogram, while
+                                   the result is still the partition at which the threshold was crossed.
+    metric : 'euclidean' (the reference, clustering.py:101) or 'cosine' (named by BASELINE.json's north_star; 1 - cos of the pair)
     """
 
-    def __init__(self, threshold=0.6, force=False, logger=None, ctx=None):
-        if force:
-            raise NotImplementedError("force=True is not on the reference's documented path")
+    def __init__(self, threshold=0.6, force=False, logger=None, ctx=None, metric="euclidean"):
+        if metric not in ("euclidean", "cosine"):
+            raise ValueError("metric must be 'euclidean' or 'cosine'")
+        self.force = bool(force)
+        self.metric = metric
         self.threshold = threshold
         self.model = _Model()
         self.ctx = ctx
@@ -73,16 +79,28 @@ class FaceClustering(object):
         Xs = np.ascontiguousarray(X[rows], np.float64)
         counts = np.array([(rt == t).sum() for t in track_ids], np.int64)
         row_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-        if self.shard is None:
-            labels, log = ctx.cluster_tracks(Xs, row_start, self.threshold)
+        cut = float("inf") if self.force else self.threshold
+        if self.metric == "cosine":
+            D = ctx.pair_mean_dist(Xs, row_start, metric=1)
+            labels, log = ctx.cluster_dist(D, row_start, cut)
+        elif self.shard is None:
+            labels, log = ctx.cluster_tracks(Xs, row_start, cut)
         else:
             # several GPUs, every one holding all rows: each computes the distance-matrix rows of its share of the tracks
             # (balanced by row count), the rows are exchanged, and every rank agglomerates the same complete matrix
             T = len(track_ids)
             t0, t1 = self.shard.track_range(row_start)
             D = self.shard.assemble(ctx.pair_mean_dist_rows(Xs, row_start, t0, t1), row_start)
-            labels, log = ctx.cluster_dist(D, row_start, self.threshold)
+            labels, log = ctx.cluster_dist(D, row_start, cut)
         self.history = [(int(track_ids[int(a)]), int(track_ids[int(b)]), float(d)) for a, b, d, _ in log]
+        if self.force:
+            # complete dendrogram in `history`; the partition returned is the one before the first merge above the threshold
+            # (average linkage never merges at a smaller distance later on, so that is a prefix of the merge list)
+            labels = np.arange(len(track_ids))
+            for a, b, d, _ in log:
+                if not (d <= self.threshold):
+                    break
+                labels[labels == int(b)] = int(a)
         return [int(track_ids[int(l)]) for l in labels]
 
     def __call__(self, starting_point, features=None):

@@ -1,4 +1,5 @@
 """`Context`: one GPU, one HIP stream, the loaded models and the frames staged in HBM.  Thin Python over the C ABI."""
+import contextlib
 import ctypes as C
 import numpy as np
 from . import _lib
@@ -42,6 +43,7 @@ class Context(object):
         self._staged = {}      # (id, data ptr) -> DeviceFrame for numpy frames passed through the dlib-like API
         self._staged_order = []
         self.stage_capacity = 1024
+        self._hold = 0         # > 0 while a call is collecting frame handles: nothing staged may be evicted until it has run
         self._tables = False
         if detector:
             self.load_detector(detector)
@@ -125,12 +127,32 @@ class Context(object):
             f.keep = rgb   # keeps the id stable while cached
             self._staged[key] = f
             self._staged_order.append(key)
-            while len(self._staged_order) > self.stage_capacity:
-                old = self._staged_order.pop(0)
-                g = self._staged.pop(old, None)
-                if g is not None:
-                    g.release()
+            if not self._hold:
+                self._trim()
         return f
+
+    def _trim(self):
+        while len(self._staged_order) > self.stage_capacity:
+            old = self._staged_order.pop(0)
+            g = self._staged.pop(old, None)
+            if g is not None:
+                g.release()
+
+    @contextlib.contextmanager
+    def _staging(self):
+        """Frames staged inside the block stay resident until the block ends: one call may reference more distinct numpy
+        frames than the cache holds (a 4096-tracker batch of a long shot), and a handle released before the C call runs is
+        an 'unknown frame handle'.  The cache is trimmed back to its capacity afterwards."""
+        self._hold += 1
+        try:
+            yield
+        finally:
+            self._hold -= 1
+            if not self._hold:
+                self._trim()
+
+    def _handles(self, frames):
+        return handles([self.stage(f).handle for f in frames])
 
     def unstage_all(self):
         for f in self._staged.values():
@@ -140,24 +162,26 @@ class Context(object):
 
     # ---- S1
     def detect_batch(self, frames, upsample=1, adjust_threshold=0.0, cap=256):
-        fr = [self.stage(f) for f in frames]
-        hs = handles([f.handle for f in fr])
-        n = len(fr)
+        n = len(frames)
         out = np.zeros((n, cap, 4), np.int32)
         scores = np.zeros((n, cap), np.float32)
         counts = np.zeros(n, np.int32)
-        check(self._l.pvf_detect_batch(self._h, ptr(hs), n, int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
+        with self._staging():
+            hs = self._handles(frames)
+            check(self._l.pvf_detect_batch(self._h, ptr(hs), n, int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
+        if int(counts.max(initial=0)) >= cap:     # a frame filled its slots: repeat with room for every detection (like detect_many)
+            return self.detect_batch(frames, upsample, adjust_threshold, cap * 8)
         return [([tuple(int(v) for v in out[i, k]) for k in range(counts[i])], scores[i, :counts[i]].copy()) for i in range(n)]
 
     def detect_many(self, frames, batch, upsample=1, adjust_threshold=0.0, cap=64):
         """any number of frames of one size, `batch` at a time, host post-processing overlapped with the next batch's kernels"""
-        fr = [self.stage(f) for f in frames]
-        hs = handles([f.handle for f in fr])
-        n = len(fr)
+        n = len(frames)
         out = np.zeros((n, cap, 4), np.int32)
         scores = np.zeros((n, cap), np.float32)
         counts = np.zeros(n, np.int32)
-        check(self._l.pvf_detect_many(self._h, ptr(hs), n, int(batch), int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
+        with self._staging():
+            hs = self._handles(frames)
+            check(self._l.pvf_detect_many(self._h, ptr(hs), n, int(batch), int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
         if int(counts.max(initial=0)) >= cap:     # a frame filled its slots: repeat with room for every detection
             return self.detect_many(frames, batch, upsample, adjust_threshold, cap * 8)
         return [([tuple(int(v) for v in out[i, k]) for k in range(counts[i])], scores[i, :counts[i]].copy()) for i in range(n)]
@@ -232,27 +256,27 @@ class Context(object):
     def tracker_start_many(self, trks, frames, boxes):
         if not len(trks):
             return
-        fr = [self.stage(f) for f in frames]
         b = np.ascontiguousarray(boxes, np.float64).reshape(-1, 4)
-        check(self._l.pvf_tracker_start_many(self._h, ptr(handles(trks)), ptr(handles([f.handle for f in fr])), ptr(b), len(trks)))
+        with self._staging():
+            check(self._l.pvf_tracker_start_many(self._h, ptr(handles(trks)), ptr(self._handles(frames)), ptr(b), len(trks)))
 
     def tracker_update_many(self, trks, frames, defer=False):
         """defer=True: confidence and position only, the filter update is left to tracker_commit_many (same frames)"""
         n = len(trks)
         if not n:
             return np.zeros(0), np.zeros((0, 4))
-        fr = [self.stage(f) for f in frames]
         psr = np.zeros(n, np.float64)
         boxes = np.zeros((n, 4), np.float64)
         fn = self._l.pvf_tracker_update_many_deferred if defer else self._l.pvf_tracker_update_many
-        check(fn(self._h, ptr(handles(trks)), ptr(handles([f.handle for f in fr])), n, ptr(psr), ptr(boxes)))
+        with self._staging():
+            check(fn(self._h, ptr(handles(trks)), ptr(self._handles(frames)), n, ptr(psr), ptr(boxes)))
         return psr, boxes
 
     def tracker_commit_many(self, trks, frames):
         n = len(trks)
         if n:
-            fr = [self.stage(f) for f in frames]
-            check(self._l.pvf_tracker_commit_many(self._h, ptr(handles(trks)), ptr(handles([f.handle for f in fr])), n))
+            with self._staging():
+                check(self._l.pvf_tracker_commit_many(self._h, ptr(handles(trks)), ptr(self._handles(frames)), n))
 
     def tracker_position(self, trk):
         b = np.zeros(4, np.float64)
@@ -272,11 +296,11 @@ class Context(object):
         pts = np.zeros((n, 68, 2), np.int32)
         if n == 0:
             return pts
-        fr = [self.stage(f) for f in frames]
         r = (Rect * n)()
         for i, b in enumerate(boxes):
             r[i] = Rect(int(b[0]), int(b[1]), int(b[2]), int(b[3]))
-        check(self._l.pvf_landmarks(self._h, ptr(handles([f.handle for f in fr])), r, n, ptr(pts)))
+        with self._staging():
+            check(self._l.pvf_landmarks(self._h, ptr(self._handles(frames)), r, n, ptr(pts)))
         return pts
 
     def embed(self, frames, pts):
@@ -285,16 +309,16 @@ class Context(object):
         out = np.zeros((n, 128), np.float32)
         if n == 0:
             return out
-        fr = [self.stage(f) for f in frames]
-        check(self._l.pvf_embed(self._h, ptr(handles([f.handle for f in fr])), ptr(pts), n, ptr(out)))
+        with self._staging():
+            check(self._l.pvf_embed(self._h, ptr(self._handles(frames)), ptr(pts), n, ptr(out)))
         return out
 
     def face_chips(self, frames, pts):
         pts = np.ascontiguousarray(pts, np.int32).reshape(-1, 68, 2)
         n = len(pts)
         out = np.zeros((n, 150, 150, 3), np.uint8)
-        fr = [self.stage(f) for f in frames]
-        check(self._l.pvf_face_chips(self._h, ptr(handles([f.handle for f in fr])), ptr(pts), n, ptr(out)))
+        with self._staging():
+            check(self._l.pvf_face_chips(self._h, ptr(self._handles(frames)), ptr(pts), n, ptr(out)))
         return out
 
     def embed_chips(self, chips):
@@ -311,12 +335,13 @@ class Context(object):
         return out
 
     # ---- S5
-    def pair_mean_dist(self, X, row_start):
+    def pair_mean_dist(self, X, row_start, metric=0):
+        """T x T matrix of mean pair distances between the rows of two tracks; metric 0 = Euclidean (reference), 1 = cosine"""
         X = np.ascontiguousarray(X, np.float64)
         rs = np.ascontiguousarray(row_start, np.int32)
         T = len(rs) - 1
         D = np.zeros((T, T), np.float64)
-        check(self._l.pvf_pair_mean_dist(self._h, ptr(X), X.shape[0], X.shape[1], ptr(rs), T, ptr(D)))
+        check(self._l.pvf_pair_mean_dist_metric(self._h, ptr(X), X.shape[0], X.shape[1], ptr(rs), T, int(metric), ptr(D)))
         return D
 
     def cluster_tracks(self, X, row_start, threshold):

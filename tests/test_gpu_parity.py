@@ -278,3 +278,56 @@ def test_pair_mean_dist_and_hac(ctx, oracle):
         assert np.array_equal(Dsum, D)
         l2, log2 = ctx.cluster_dist(Dsum, rs, 0.6)
         assert np.array_equal(l2, labels) and np.array_equal(log2, log)
+
+
+def _tracks(rng, sizes, K=40, noise=0.05):
+    centres = rng.normal(0, 1, (K, 128)); centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    ident = rng.integers(0, K, len(sizes))
+    rows = []
+    for t, n in enumerate(sizes):
+        x = centres[ident[t]] + noise * rng.normal(0, 1, (n, 128))
+        rows.append(np.round(0.55 * x / np.linalg.norm(x, axis=1, keepdims=True), 5))
+    return np.concatenate(rows), np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), ident
+
+
+def test_pair_mean_dist_matrix_core_kernel_all_block_shapes(ctx, oracle):
+    """K10 on the f64 matrix cores: tracks shorter than / equal to / longer than a 16-row block, packed and chunked, identical and
+    near-identical rows (the Gram form's cancellation zone), against the oracle's direct double loop"""
+    rng = np.random.default_rng(11)
+    sizes = np.array([1, 1, 1, 15, 16, 17, 2, 3, 31, 32, 33, 1, 5, 5, 5, 1, 64, 7, 9, 250, 1, 1], np.int64)
+    X, rs, _ = _tracks(rng, sizes)
+    X[rs[3] + 1] = X[rs[3]]                                  # identical rows inside a track and across tracks
+    X[rs[5]] = X[rs[4]]
+    X[rs[8] + 2] = X[rs[8] + 1] + 1e-5
+    D = ctx.pair_mean_dist(X, rs)
+    Dr = oracle.pair_mean_dist(X, rs)
+    assert np.allclose(D, Dr, rtol=1e-12, atol=1e-13), np.abs(D - Dr).max()
+    assert not D.diagonal().any()
+    # row ranges stitched == whole, bit for bit, wherever the cuts fall
+    for cuts in ([0, 4, 9, 22], [0, 1, 20, 22], [0, 10, 22]):
+        Ds = np.zeros_like(D)
+        for t0, t1 in zip(cuts, cuts[1:]):
+            Ds[t0:t1] = ctx.pair_mean_dist_rows(X, rs, t0, t1)[t0:t1]
+        assert np.array_equal(Ds, D)
+    # cosine distance (north_star's metric): mean of 1 - cos over the block
+    Dc = ctx.pair_mean_dist(X, rs, metric=1)
+    Xn = X / np.linalg.norm(X, axis=1, keepdims=True)
+    full = 1.0 - Xn @ Xn.T
+    want = np.array([[full[rs[i]:rs[i + 1], rs[j]:rs[j + 1]].mean() if i != j else 0.0 for j in range(len(sizes))] for i in range(len(sizes))])
+    assert np.allclose(Dc, want, rtol=1e-10, atol=1e-12)
+
+
+def test_hac_persistent_kernel_3000_tracks_equals_oracle(ctx, oracle):
+    """K11 as one persistent workgroup: T = 3000 tracks (1-6 rows), labels and merge order == the CPU oracle"""
+    rng = np.random.default_rng(12)
+    T = 3000
+    sizes = rng.integers(1, 7, T)
+    X, rs, ident = _tracks(rng, sizes, K=150)
+    labels, log = ctx.cluster_tracks(X, rs, 0.6)
+    Dr = oracle.pair_mean_dist(X, rs)
+    lr, logr = oracle.hac(Dr, sizes, 0.6)
+    assert np.array_equal(labels, lr)
+    assert len(log) == len(logr) and np.array_equal(log[:, :2], logr[:, :2])
+    assert np.allclose(log[:, 2], logr[:, 2], rtol=1e-11)
+    for t in range(T):
+        assert ident[labels[t]] == ident[t]

@@ -1,0 +1,121 @@
+"""GPU parity at the configuration bench.py times (BASELINE.json configs[1]): 1920 x 1080, upsample 1 (20 pyramid levels), batches of
+32 frames, the FULL landmark model (15 cascades x 500 trees x 500 pixels), 4096-tracker bulk calls -- plus the detector alone at
+configs[3] (1280 x 720) and configs[4] (3840 x 2160).  Everything is compared with the CPU oracle on the same bytes:
+raw candidates, NMS boxes and scores, landmarks, chips (bit-exact), embeddings (L2 <= 1e-4), tracker PSR and positions (bit-exact)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_models(tmp_path_factory):
+    from pyannote_video_amd import models
+    return models.ensure_synthetic_models(str(tmp_path_factory.mktemp("models_full")), small=False)
+
+
+@pytest.fixture(scope="module")
+def ctx_full(full_models):
+    from pyannote_video_amd.runtime import Context
+    c = Context(device=0, landmarks=full_models[0], embedding=full_models[1])
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def clip1080():
+    from pyannote_video_amd import synth
+    # the bench generator at its own size; 4 frames that straddle the first shot cut (frames 248..251 of the 1000-frame clip layout)
+    v = synth.SyntheticVideo(width=1920, height=1080, n_frames=8, n_shots=2, faces=8, seed=20260925)
+    return v, [v.frame(i) for i in (2, 3, 4, 5)]
+
+
+def _oracle_detector(oracle):
+    from pyannote_video_amd import models
+    oracle.lib().pvo_set_threads(64)
+    return oracle.Detector(models.load_container(models.DEFAULT_DETECTOR))
+
+
+def test_detector_1080p_batch32_bit_exact(ctx_full, oracle, clip1080):
+    _, frames = clip1080
+    det = _oracle_detector(oracle)
+    want = [det.detect(f, 1) for f in frames]
+    assert all(len(w) >= 6 for w in want)                       # ~8 faces per frame fire
+    dev = [ctx_full.upload(f) for f in frames]
+    # raw candidates of one frame (single-frame plan) == oracle, record for record
+    raw = ctx_full.detect_raw(dev[0], 1)
+    ref = det.detect_raw(frames[0], 1)
+    assert len(raw) == len(ref) > 0
+    assert raw == [(r[0], r[1], r[2], r[3], r[4], tuple(r[5])) for r in ref]
+    # a batch of 32 (the four frames eight times, as the bench's batches) through the pipelined entry: every copy equals the oracle
+    res = ctx_full.detect_many([dev[i % 4] for i in range(64)], 32, 1)
+    for i, (boxes, scores) in enumerate(res):
+        w = want[i % 4]
+        assert boxes == [tuple(d[5]) for d in w]
+        assert np.array_equal(scores, np.array([d[0] for d in w], np.float32))
+
+
+def test_full_landmark_model_chips_and_embeddings_1080p(ctx_full, oracle, clip1080, full_models):
+    from pyannote_video_amd import models
+    _, frames = clip1080
+    det = _oracle_detector(oracle)
+    sp = oracle.ShapePredictor(models.load_container(full_models[0]))
+    emb = oracle.Embedder(models.load_container(full_models[1]))
+    fr, boxes = [], []
+    for f in frames[:2]:
+        for d in det.detect(f, 1):
+            fr.append(f); boxes.append(tuple(d[5]))
+    assert len(boxes) >= 12
+    pts = ctx_full.landmarks(fr, boxes)
+    want = np.stack([sp(f, b) for f, b in zip(fr, boxes)])
+    assert np.array_equal(pts, want)                           # 15 x 500 trees, 500 feature pixels: bit-exact integer points
+    chips = ctx_full.face_chips(fr, pts)
+    assert np.array_equal(chips, np.stack([emb.chip(f, p) for f, p in zip(fr, want)]))
+    e = ctx_full.embed(fr, pts)
+    ref = np.stack([emb(f, p) for f, p in zip(fr, want)])
+    assert np.linalg.norm(e.astype(np.float64) - ref.astype(np.float64), axis=1).max() <= 1e-4
+
+
+def test_trackers_1080p_bulk_bit_exact(ctx_full, oracle, clip1080):
+    from pyannote_video_amd import models
+    _, frames = clip1080
+    det = _oracle_detector(oracle)
+    boxes = [tuple(float(v) for v in d[5]) for d in det.detect(frames[0], 1)]
+    n = len(boxes)
+    tabs = models.dsst_tables()
+    ref = []
+    for b in boxes:
+        t = oracle.Tracker(tabs)
+        t.start_track(frames[0], b)
+        ref.append(t)
+    want = [(t.update(frames[1]), t.get_position()) for t in ref]
+    want2 = [(t.update(frames[2]), t.get_position()) for t in ref]
+    hs = ctx_full.tracker_create_many(n)
+    dev = [ctx_full.upload(f) for f in frames[:3]]
+    ctx_full.tracker_start_many(hs, [dev[0]] * n, boxes)
+    psr, pos = ctx_full.tracker_update_many(hs, [dev[1]] * n, defer=True)       # the bulk path: deferred, then committed
+    assert psr.tolist() == [w[0] for w in want]
+    assert [tuple(p) for p in pos] == [w[1] for w in want]
+    ctx_full.tracker_commit_many(hs, [dev[1]] * n)
+    psr, pos = ctx_full.tracker_update_many(hs, [dev[2]] * n)
+    assert psr.tolist() == [w[0] for w in want2]
+    assert [tuple(p) for p in pos] == [w[1] for w in want2]
+    ctx_full.tracker_destroy_many(hs)
+
+
+@pytest.mark.parametrize("size", [(1280, 720), (3840, 2160)])
+def test_detector_other_configs_single_frame(ctx_full, oracle, size):
+    """configs[3] (720p clips) and configs[4] (4K crowd): raw candidates and boxes of one frame == oracle"""
+    from pyannote_video_amd import synth
+    w, h = size
+    v = synth.SyntheticVideo(width=w, height=h, n_frames=2, n_shots=1, faces=8 if w < 3000 else 40, seed=20260925 + w)
+    f = v.frame(1)
+    det = _oracle_detector(oracle)
+    ref = det.detect_raw(f, 1)
+    raw = ctx_full.detect_raw(f, 1, cap=1 << 17)
+    assert len(raw) == len(ref) > 0
+    assert raw == [(r[0], r[1], r[2], r[3], r[4], tuple(r[5])) for r in ref]
+    boxes, scores = ctx_full.detect(f, 1)
+    want = det.detect(f, 1)
+    assert boxes == [tuple(d[5]) for d in want] and len(boxes) >= (6 if w < 3000 else 25)
+    assert np.array_equal(scores, np.array([d[0] for d in want], np.float32))

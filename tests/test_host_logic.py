@@ -306,3 +306,31 @@ def test_inline_overlap_gate_equals_rectangle_form():
                 a[2:] = np.maximum(a[2:], a[:2]); b[2:] = np.maximum(b[2:], b[:2])
             want = tbd._match(drectangle(*a), drectangle(*b)) == 0
             assert tbd._no_match(tuple(a), tuple(b)) == want, (ratio, a, b)
+
+
+def test_frames_staged_for_one_call_are_not_evicted_before_it_runs():
+    """one batched call may reference more distinct numpy frames than the staging cache holds (a 4096-tracker batch of
+    a long shot): nothing is released until the call has run, then the cache shrinks back to its capacity"""
+    from pyannote_video_amd.runtime import Context
+
+    class FakeFrame(object):
+        def __init__(self, k): self.handle, self.keep, self.released = k, None, False
+        def release(self): self.released = True
+
+    c = object.__new__(Context)
+    c._h, c._staged, c._staged_order, c.stage_capacity, c._hold = None, {}, [], 4, 0
+    made = []
+
+    def upload(rgb):
+        made.append(FakeFrame(len(made) + 1))
+        return made[-1]
+    c.upload = upload
+    frames = [np.zeros((2, 2, 3), np.uint8) for _ in range(10)]
+    with c._staging():
+        hs = c._handles(frames)
+        assert list(hs) == list(range(1, 11))
+        assert not any(f.released for f in made)          # all ten are still resident while the C call would run
+    assert [f.released for f in made] == [True] * 6 + [False] * 4
+    assert len(c._staged) == 4
+    c._handles(frames[6:])                                # cached ones are reused, not uploaded again
+    assert len(made) == 10

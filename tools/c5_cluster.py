@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[4], clustering-only stressor: X f64 [N, 128] drawn around K = 500 identity centres so
+that within-identity distances sit at 0.3-0.5 and between-identity ones near 0.8 (they bracket the reference's 0.6 threshold,
+clustering.py:138), T = 10 000 tracks with 1 (N = 1e4) or 10 (N = 1e5) rows each.  Times K10 (pair_tiles_k on the f64 matrix cores)
+and K11 (hac_persist_k) with the library's HIP events and checks the result against the generator's ground truth.
+    python tools/c5_cluster.py [out.json]
+"""
+import json
+import os
+import sys
+import time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "pyannote-video_amd"))
+from pyannote_video_amd.runtime import Context  # noqa: E402
+
+F64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix = fp64 vector peak
+
+
+def make(T, rows, K=500, seed=20260925):
+    rng = np.random.default_rng(seed)
+    cent = rng.normal(size=(K, 128)); cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    ident = rng.integers(0, K, T)
+    x = cent[np.repeat(ident, rows)] + 0.05 * rng.normal(size=(T * rows, 128))
+    x = np.round(0.55 * x / np.linalg.norm(x, axis=1, keepdims=True), 5)
+    return x, (np.arange(T + 1) * rows).astype(np.int32), ident
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else None
+    ctx = Context(device=0, detector=None)
+    res = []
+    for T, rows in ((10000, 1), (10000, 10), (2000, 50)):
+        X, rs, ident = make(T, rows)
+        N = len(X)
+        ctx.cluster_tracks(X[:rs[64]], rs[:65], 0.6)                  # warm-up (module load, buffers)
+        ctx.prof_reset(); ctx.prof_enable(True)
+        t0 = time.perf_counter()
+        labels, log = ctx.cluster_tracks(X, rs, 0.6)
+        wall = time.perf_counter() - t0
+        ctx.prof_enable(False)
+        pd_ms, _ = ctx.prof_get("pdist")
+        hac_ms, _ = ctx.prof_get("hac")
+        pure = all(ident[labels[t]] == ident[t] for t in range(T))
+        one = len(set(labels.tolist())) == len(set(ident.tolist()))
+        flop = 2.0 * 128 * N * N                                       # Gram form: N^2 dot products of 128 dims
+        res.append({"T": T, "rows_per_track": rows, "N": N, "pdist_ms": round(pd_ms, 3), "hac_ms": round(hac_ms, 3), "wall_s": round(wall, 3),
+                    "pdist_fp64_tflops": round(flop / (pd_ms * 1e-3) / 1e12, 2), "pdist_frac_of_fp64_mfma_peak": round(flop / (pd_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 3),
+                    "merges": int(len(log)), "merges_per_s": round(len(log) / max(hac_ms * 1e-3, 1e-9)),
+                    "hac_D_bytes": int(T) * int(T) * 8, "clusters": int(len(set(labels.tolist()))), "identities": int(len(set(ident.tolist()))),
+                    "clusters_pure": bool(pure), "one_cluster_per_identity": bool(one)})
+        print(json.dumps(res[-1]))
+        sys.stdout.flush()
+    if out:
+        with open(out, "w") as f:
+            json.dump({"what": "configs[4] clustering stressor on one MI355X: pair_tiles_k (v_mfma_f64_16x16x4_f64) + hac_persist_k", "results": res}, f, indent=1)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
