@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--detect-batch", type=int, default=32)
     ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the all-core CPU-oracle sample, centred on the first shot cut (0 = skip)")
     ap.add_argument("--cpu-frames-1t", type=int, default=4, help="frames of the single-thread CPU-oracle sample (same centre)")
+    ap.add_argument("--no-host-ingest", action="store_true", help="skip the extra pass whose frames start in pinned host memory")
     ap.add_argument("--no-overlap", action="store_true", help="no GPU-feeding thread: every stage runs in the caller's thread, shot after shot")
     ap.add_argument("--small-models", action="store_true", help="debug only: reduced landmark model")
     args = ap.parse_args()
@@ -168,6 +169,9 @@ def main():
     cpu, parity = None, None
     if world == 1 and args.cpu_frames > 0:
         cpu, parity = cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args)
+    host = None
+    if world == 1 and not args.no_host_ingest:
+        host = host_ingest_pass(ctx, pipe, frames_t, times, video, shots, args)
 
     n_clusters = len(set(labels.values()))
     out = {
@@ -184,6 +188,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity": parity,
+        "host_ingest": host,
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
         "kernel_families_ms": fam,
         "results": {"tracks": len(res["tracks"]), "faces_embedded": int(len(res["face_T"])), "clusters": n_clusters,
@@ -191,6 +196,47 @@ def main():
         "setup_seconds": {"generate_frames_in_hbm": round(t_gen, 1)},
     }
     print(json.dumps(out))
+
+
+def host_ingest_pass(ctx, pipe, frames_t, times, video, shots, args):
+    """Outside the timed region (`value` is quoted with the frames resident in HBM): the same step with the frames starting in pinned
+    host memory -- where a decoder would leave them -- and reaching HBM through the ingest ring: one asynchronous copy per frame on the
+    copy stream, kernels waiting per frame on the device, so the uploads of later shots run beside the detector of the first ones."""
+    import numpy as np
+    n = len(times)
+    h, w = int(frames_t.shape[1]), int(frames_t.shape[2])
+    ring = ctx.ingest_ring(h, w, depth=n)                  # the whole clip "decoded" into pinned slots, once
+    for i in range(n):
+        np.copyto(ring.slot(), frames_t[i].cpu().numpy())
+    bytes_total = float(n) * h * w * 3
+
+    def submit_all():
+        out = []
+        for i in range(n):
+            ring.slot()                                    # slot i again (its bytes are still there); waits for its previous upload
+            out.append(ring.submit())
+        return out
+    ctx.sync()
+    t0 = time.perf_counter()
+    dev = submit_all()
+    ring.wait()
+    t_copy = time.perf_counter() - t0                      # uploads alone: what PCIe delivers
+    for f in dev:
+        f.release()
+    best = None
+    for _ in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        dev = submit_all()
+        res = pipe.run(dev, times, video.frame_rate, shots, cluster=True)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        for f in dev:
+            f.release()
+    ring.close()
+    return {"value": round(n / best, 2), "unit": "frames/s", "frames_start_in": "pinned host memory (ingest ring, async H2D on a copy stream, per-frame waits on the device)",
+            "pcie_GBps_uploads_alone": round(bytes_total / t_copy / 1e9, 2), "ms_per_step": round(1000 * best, 2), "tracks": len(res["tracks"])}
 
 
 def cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args):

@@ -62,6 +62,21 @@ int32_t pvf_frame_release(pvf_handle ctx, pvf_handle frame);
 /* device address of a staged frame (to share it with a second context on the same GPU, e.g. a detector stream) */
 int32_t pvf_frame_device_ptr(pvf_handle ctx, pvf_handle frame, const void** dev_rgb);
 
+/* ---- frame ingest ------------------------------------------------------------ */
+/* ref: video.py:368-406 (one pipe read + numpy array per frame), :402-403 (cv2.resize), pyannote-face.py:261,287 (two decodes).
+ * A ring of `depth` pinned host slots of one frame size; the decoder writes a frame into the slot pvf_ingest_acquire hands out
+ * (it returns when that slot's previous upload has left the buffer), pvf_ingest_submit queues ONE asynchronous host-to-HBM copy
+ * on the ring's own copy stream and returns a frame handle at once: kernels that read the frame wait for its copy on the device,
+ * so uploads overlap the detector.  Release the frame with pvf_frame_release (its buffer is recycled). */
+int32_t pvf_ingest_create(pvf_handle ctx, int32_t h, int32_t w, int32_t depth, pvf_handle* ring);
+int32_t pvf_ingest_destroy(pvf_handle ctx, pvf_handle ring);
+int32_t pvf_ingest_acquire(pvf_handle ctx, pvf_handle ring, int32_t* slot, uint8_t** host_rgb);
+int32_t pvf_ingest_submit(pvf_handle ctx, pvf_handle ring, int32_t slot, pvf_handle* frame);
+int32_t pvf_ingest_wait(pvf_handle ctx, pvf_handle ring);       /* all queued uploads done (measurement, shutdown) */
+/* ref: video.py:180-187,402-403 + tracking.py:389-400  cv2.resize(frame, (w, h)) for detection on down-scaled frames (--min-size):
+ * OpenCV's 8-bit INTER_LINEAR on the device; the source frame stays resident for `extract` */
+int32_t pvf_frame_resize(pvf_handle ctx, pvf_handle frame, int32_t out_w, int32_t out_h, pvf_handle* out);
+
 /* ---- S1 detector ---------------------------------------------------------------------------------- */
 /* ref: face.py:64-67  for face in self.face_detector_(rgb, 1)  -> dlib.rectangle list, NMS order.
  * scores (optional) receive dlib's detection_confidence (score - threshold). */

@@ -60,6 +60,14 @@ def resize_bilinear(img, oh, ow):
     return out
 
 
+def cv_resize(img, ow, oh):
+    """cv2.resize(img, (ow, oh)) (INTER_LINEAR, uint8) restated -- the reference's down-scaled detection frames (video.py:402-403)"""
+    img = _u8(img)
+    out = np.empty((oh, ow, 3), np.uint8)
+    lib().pvo_cv_resize_linear_rgb(_p(img), img.shape[0], img.shape[1], _p(out), oh, ow)
+    return out
+
+
 def pyr_down2(img):
     img = _u8(img)
     oh, ow = C.c_int(), C.c_int()

@@ -32,6 +32,8 @@ extern "C" {
 
 /* ---------------------------------------------------------------- image ops (pvo_image.c) */
 void pvo_resize_bilinear_rgb(const uint8_t* in, int ih, int iw, uint8_t* out, int oh, int ow);
+/* cv2.resize(img, (ow, oh)), INTER_LINEAR, uint8 RGB (reference video.py:402-403) */
+void pvo_cv_resize_linear_rgb(const uint8_t* in, int ih, int iw, uint8_t* out, int oh, int ow);
 void pvo_pyramid_up_dims(int ih, int iw, int* oh, int* ow);
 void pvo_pyramid_down6_dims(int ih, int iw, int* oh, int* ow);
 void pvo_pyr_down2_dims(int ih, int iw, int* oh, int* ow);

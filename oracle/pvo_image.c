@@ -46,6 +46,42 @@ void pvo_resize_bilinear_rgb(const uint8_t* in, int ih, int iw, uint8_t* out, in
     }
 }
 
+/* [EXT OpenCV resize.cpp, INTER_LINEAR, 8-bit, 3 channels] -- cv2.resize(frame, (ow, oh)) as the reference's Video applies it to
+ * down-scaled detection frames (video.py:402-403, tracking.py:389-400).  PARITY UNPINNED (OpenCV is not installed here).
+ * Pixel-centre mapping, clamped source index, 11-bit coefficients cvRound(f * 2048) (round half to even), horizontal pass in int,
+ * vertical pass (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2. */
+static void cv_linear_coeffs(int in, int out, int d, int* idx, int* c0, int* c1)
+{
+    const double scale = (double)in / out;
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0; s = 0; }
+    if (s >= in - 1) { f = 0; s = in - 1; }
+    *idx = s;
+    *c0 = (int)(short)nearbyintf((1.f - f) * 2048.f);
+    *c1 = (int)(short)nearbyintf(f * 2048.f);
+}
+
+void pvo_cv_resize_linear_rgb(const uint8_t* in, int ih, int iw, uint8_t* out, int oh, int ow)
+{
+    for (int y = 0; y < oh; ++y) {
+        int sy, b0, b1;
+        cv_linear_coeffs(ih, oh, y, &sy, &b0, &b1);
+        const int sy1 = imin(sy + 1, ih - 1);
+        for (int x = 0; x < ow; ++x) {
+            int sx, a0, a1;
+            cv_linear_coeffs(iw, ow, x, &sx, &a0, &a1);
+            const int sx1 = imin(sx + 1, iw - 1);
+            for (int k = 0; k < 3; ++k) {
+                const int S0 = in[((size_t)sy * iw + sx) * 3 + k] * a0 + in[((size_t)sy * iw + sx1) * 3 + k] * a1;
+                const int S1 = in[((size_t)sy1 * iw + sx) * 3 + k] * a0 + in[((size_t)sy1 * iw + sx1) * 3 + k] * a1;
+                out[((size_t)y * ow + x) * 3 + k] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+}
+
 /* [EXT dlib pyramid_up(in,out,pyramid_down<2>)]: out size = rect_up(get_rect(in)) bottom/right + 1 with
  * pyramid_down<2>::point_up(p) = (p + (1.25,0.75))*2 and point rounding floor(v+0.5). */
 void pvo_pyramid_up_dims(int ih, int iw, int* oh, int* ow)

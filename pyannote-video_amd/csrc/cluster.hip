@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
     __shared__ double tileD[4][16][17];
     __shared__ double colS[4][16][17];
     __shared__ int colInfo[2][16][2];                 // per staged column: track (or -1 for padding), last-row flag
+    __shared__ double colNrm[2][16];                  // ... and |b|^2
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ab = blockIdx.x * 4 + wave;             // row block of this wave
     const bool have = ab < a.n_blocks;
@@ -139,8 +140,21 @@ __global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
         if (tid < 16) {
             colInfo[buf][tid][0] = tid < nr ? a.row_track[r0 + tid] : -1;
             colInfo[buf][tid][1] = tid < nr ? a.row_last[r0 + tid] : 0;
+            colNrm[buf][tid] = tid < nr ? a.nrm[r0 + tid] : 0.0;
         }
     };
+    // row side of the reduction, fixed for the whole sweep: lane + 64 q <-> (row r, column c); a row that starts a row track carries
+    // the number of rows of that track inside this block
+    int seg_len[4], seg_track[4];
+    double seg_cnt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = (lane + 64 * q) >> 4;
+        seg_len[q] = (have && r < anr) ? a.row_seg_len[ar0 + r] : 0;
+        seg_track[q] = seg_len[q] > 0 ? a.row_track[ar0 + r] : -1;
+        if (seg_track[q] >= 0 && !(seg_track[q] >= a.t0 && seg_track[q] < a.t1)) seg_len[q] = 0;    // rows of another rank's share
+        seg_cnt[q] = seg_track[q] >= 0 ? (double)(a.row_start[seg_track[q] + 1] - a.row_start[seg_track[q]]) : 1.0;
+    }
     if (cb0 < cb1) stage(cb0, 0);
     __syncthreads();
     for (int cb = cb0; cb < cb1; ++cb) {
@@ -154,7 +168,7 @@ __global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
             for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bp[4 * s], acc, 0, 0, 0);
             // C/D of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
             const int ct = colInfo[buf][i16][0];
-            const double nb = ct >= 0 ? a.nrm[br0 + i16] : 0.0;
+            const double nb = colNrm[buf][i16];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = k4 + 4 * r;
@@ -164,7 +178,9 @@ __global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
                     if (a.metric == 1) d = 1.0 - g / sqrt(na4[r] * nb);
                     else {
                         double d2 = sum - 2.0 * g;
-                        if (d2 < 1e-2 * sum) {         // the Gram form cancels for close rows: take the differences instead
+                        // the Gram form cancels for close rows: its absolute error in d is ~1e-16 (|a|^2 + |b|^2) / d, i.e. below 1e-13 down
+                        // to d ~ 3e-3 |x|; closer pairs (identical or near-identical rows) take the differences instead
+                        if (d2 < 1e-5 * sum) {
                             const double* xa = a.X + (size_t)(ar0 + row) * DIM;
                             const double* xb = a.X + (size_t)(br0 + i16) * DIM;
                             d2 = 0.0;
@@ -191,17 +207,14 @@ __global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int idx = lane + 64 * q, r = idx >> 4, c = idx & 15;
-                const int len = (r < anr) ? a.row_seg_len[ar0 + r] : 0;
-                if (len > 0 && colInfo[buf][c][1]) {
-                    const int i = a.row_track[ar0 + r], j = colInfo[buf][c][0];
-                    if (i >= a.t0 && i < a.t1) {
-                        double s = 0.0;
-                        for (int rr = r; rr < r + len; ++rr) s += colS[wave][rr][c];
-                        if (achunk >= 0) a.P[(size_t)achunk * a.T + j] = s;
-                        else {
-                            const double cnt = (double)(a.row_start[i + 1] - a.row_start[i]) * (double)(a.row_start[j + 1] - a.row_start[j]);
-                            a.D[(size_t)i * a.T + j] = (i == j) ? 0.0 : s / cnt;
-                        }
+                if (seg_len[q] > 0 && colInfo[buf][c][1]) {
+                    const int i = seg_track[q], j = colInfo[buf][c][0];
+                    double s = 0.0;
+                    for (int rr = r; rr < r + seg_len[q]; ++rr) s += colS[wave][rr][c];
+                    if (achunk >= 0) a.P[(size_t)achunk * a.T + j] = s;
+                    else {
+                        const double cnt = seg_cnt[q] * (double)(a.row_start[j + 1] - a.row_start[j]);
+                        a.D[(size_t)i * a.T + j] = (i == j) ? 0.0 : s / cnt;
                     }
                 }
             }

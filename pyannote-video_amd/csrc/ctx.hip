@@ -88,7 +88,6 @@ static void load_detector(Ctx* c, const char* path)
     d.thresh.assign(th.f32(), th.f32() + d.n_filters);
     if (d.d_w) (void)hipFree(d.d_w);
     d.d_w = upload<float>(w.f32(), w.numel());
-    if (d.d_bmfma) { (void)hipFree(d.d_bmfma); d.d_bmfma = nullptr; }
     {
         // B fragments of score_mfma_k: index ((m*12 + n')*8 + pq)*64 + lane ; lane -> k = lane>>4 (plane 4pq+k), column j = lane&15 = 5*s + f
         std::vector<float> bm((size_t)10 * 12 * 8 * 64, 0.0f);
@@ -102,7 +101,6 @@ static void load_detector(Ctx* c, const char* path)
                         if (n < 0 || n >= 10) continue;
                         bm[(((size_t)mm * 12 + np) * 8 + pq) * 64 + l] = w.f32()[(((size_t)f * 10 + mm) * 10 + n) * 32 + p];
                     }
-        d.d_bmfma = upload<float>(bm.data(), bm.size());
         // the same fragments packed four k-steps per lane for score_mfma_rows_ml_k: [m][n'][half][lane][4]
         std::vector<float> b4(bm.size());
         for (int mn = 0; mn < 10 * 12; ++mn)
@@ -156,15 +154,17 @@ static void load_embedder(Ctx* c, const char* path)
         ConvLayer L{cin, cout, k, stride, pad, nullptr, nullptr, nullptr, nullptr};
         const size_t nw = (size_t)cout * cin * k * k;
         PVF_REQUIRE(p + nw + 3 * (size_t)cout <= end, "emb.blob too short");
-        // [cout][cin][r][s] -> [(r*k+s)*cp + c][cout]; the 3-channel input layer is stored with a fourth, all-zero channel
-        // (cp = 4) so that the kernel stages one pixel tap with one 16-byte load: x + 0 * w is exact, the chain is unchanged
+        // [cout][cin][r][s] -> [cout][(r*k+s)*cp + c], rows zero-padded to a multiple of 32 (the conv kernel's K chunk); the 3-channel
+        // input layer is stored with a fourth, all-zero channel (cp = 4) so that the kernel stages one pixel tap with one 16-byte load:
+        // x + 0 * w is exact, the chain is unchanged
         const int cp = (cin == 3) ? 4 : cin;
-        std::vector<float> wt((size_t)k * k * cp * cout, 0.0f);
+        const int K = k * k * cp, Kpad = (K + 31) / 32 * 32;
+        std::vector<float> wt((size_t)cout * Kpad, 0.0f);
         for (int o = 0; o < cout; ++o)
             for (int ci = 0; ci < cin; ++ci)
                 for (int r = 0; r < k; ++r)
                     for (int s = 0; s < k; ++s)
-                        wt[((size_t)(r * k + s) * cp + ci) * cout + o] = p[(((size_t)o * cin + ci) * k + r) * k + s];
+                        wt[(size_t)o * Kpad + (size_t)(r * k + s) * cp + ci] = p[(((size_t)o * cin + ci) * k + r) * k + s];
         L.d_w = upload<float>(wt.data(), wt.size());
         p += nw;
         L.d_bias = upload<float>(p, cout); p += cout;
@@ -279,6 +279,8 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
     for (auto p : c->tracker_pool) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) if (c->det_ev[k]) (void)hipEventDestroy(c->det_ev[k]);
     ml_plans_free(c);
+    ingest_free_all(c);
+    for (auto& kv : c->frame_pool) for (auto q : kv.second) (void)hipFree(q);
     if (c->d_orient_lut) (void)hipFree(c->d_orient_lut);
     if (c->d_grad_lut) (void)hipFree(c->d_grad_lut);
     (void)hipStreamDestroy(c->stream);
@@ -405,10 +407,12 @@ extern "C" int32_t pvf_frame_release(pvf_handle h, pvf_handle frame)
     Ctx* c = pvf_ctx(h);
     auto it = c->frames.find(frame);
     PVF_REQUIRE(it != c->frames.end(), "unknown frame handle");
+    if (it->second.ready) { (void)hipEventSynchronize(it->second.ready); (void)hipEventDestroy(it->second.ready); }
     if (it->second.owned) {
         HIP_CHECK(hipSetDevice(c->device));
         HIP_CHECK(hipStreamSynchronize(c->stream));
-        HIP_CHECK(hipFree((void*)it->second.d));
+        if (it->second.pooled) c->frame_pool[(size_t)it->second.h * it->second.w * 3].push_back((uint8_t*)it->second.d);
+        else HIP_CHECK(hipFree((void*)it->second.d));
     }
     c->frames.erase(it);
     API_END

@@ -198,24 +198,21 @@ static void upload_frame_ptrs(Ctx* c, const std::vector<Frame>& frames, const ui
 
 // =====================================================================================================
 // All pyramid levels in one launch per stage.  HBM is large (288 GB): the whole pyramid of a batch stays resident
-// (81 MB of images + 136 MB of gradient planes + 33 MB of histograms + 58 MB of features per 1080p frame), so after the
-// (sequentially dependent) resize chain, FHOG pass 1, pass 2, the feature pass and the scoring each run as ONE grid that
-// covers every level -- 4 launches instead of 80 per batch, and the small levels fill the CUs the big ones leave idle.
+// (83 MB of images + 58 MB of features per 1080p frame), so after the (sequentially dependent) resize chain the fused FHOG pass
+// and the scoring each run as ONE grid that covers every level -- 2 launches instead of 60 per batch, and the small levels
+// fill the CUs the big ones leave idle.
 // A block finds its level with a short scan of block-start offsets passed by value (kernarg / scalar cache).
 // =====================================================================================================
 #define ML_MAX 32
 struct LvDesc {
     int h, w, rb;                               // level image, row pitch in bytes (multiple of 64)
-    int cells_nr, cells_nc, hr, hc, visible_nr, visible_nc;
-    int rows_t, pitch;                          // gradient planes
-    int fh, fw, hog_nr, hog_nc;                 // features
-    int grad_bx, hist_bx, feat_bx, score_bx, score_by;
+    int cells_nr, cells_nc, visible_nr, visible_nc;
+    int fh, fw, hog_nr, hog_nc;                 // feature map (with its zero border) and the cells that carry features
+    int feat_bx, score_bx, score_by;
     int valid_score;
     int strips, chunks, chunk_rows, fused_tasks;  // fused FHOG: 64-lane strips of 61 feature columns x chunks of chunk_rows feature rows
-    int sys_bx;                                 // systolic scoring: 96-column tiles
     long long img_off, img_stride;              // bytes
-    long long px_off, px_stride;                // elements
-    long long hist_off, hist_stride, norm_off, norm_stride, feat_off, feat_stride;   // floats
+    long long feat_off, feat_stride;            // floats
 };
 struct MlStarts { int nl; int b0[ML_MAX + 1]; };
 
@@ -230,254 +227,6 @@ __device__ __forceinline__ int ml_level(const MlStarts& st, int g)
     int l = 0;
     while (l + 1 < st.nl && g >= st.b0[l + 1]) ++l;
     return l;
-}
-
-// v3 of the gradient pass: one lane owns 4 pixel columns x GR rows.  The 20-byte neighbourhood of a row is loaded once
-// (5 unaligned dwords) and serves as the "down" row of the row above, the centre row, and the "up" row of the row below,
-// so an interior row costs 5 loads instead of 11 and the level lookup / index arithmetic is paid once per GR rows.
-#define GRAD_ROWS 8
-// (magnitude, bin) of a pixel in ONE dword.  A magnitude is 0 or sqrt of an integer in [1, 130050], i.e. in [1, 361): scaled by
-// 2^-126 (exact, still a normal number) its exponent field is 1..9, so the sign bit and the top four exponent bits are zero and
-// hold the 5-bit orientation bin.  The histogram pass undoes it with one AND and one exact multiply.  4 bytes per pixel instead
-// of 5 and one store / one load stream instead of two.
-__device__ __forceinline__ uint32_t pack_mag_bin(float mag, int bin) { return __float_as_uint(mag * 0x1p-126f) | ((uint32_t)bin << 27); }
-__device__ __forceinline__ float packed_mag(uint32_t w) { return __uint_as_float(w & 0x07FFFFFFu) * 0x1p+126f; }
-__device__ __forceinline__ int packed_bin(uint32_t w) { return (int)(w >> 27); }
-
-__global__ void __launch_bounds__(256) fhog_grad4r_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
-                                                        uint32_t* __restrict__ px_base,
-                                                        const uint8_t* __restrict__ lut2)
-{
-    constexpr int C = 8, GR = GRAD_ROWS;
-    const int g = ml_block(st);
-    if (g >= st.b0[st.nl]) return;
-    const int l = ml_level(st, g);
-    const LvDesc d = lv[l];
-    const int local = g - st.b0[l];
-    const int nyb = (d.rows_t + GR - 1) / GR;
-    const int qb = local % d.grad_bx;
-    const int yb = (local / d.grad_bx) % nyb;
-    const int b = local / (d.grad_bx * nyb);
-    const int xx = 4 * (qb * 256 + threadIdx.x);
-    if (xx >= d.pitch) return;
-    const int x0 = xx - 3 * C / 2;
-    const int yy0 = yb * GR;
-    const int rb = d.rb;
-    const uint8_t* im = img_base + d.img_off + (size_t)b * d.img_stride;
-    uint32_t* pxo = px_base + d.px_off + (size_t)b * d.px_stride + xx;
-    const bool col_any = (x0 + 3 >= 1 && x0 < d.visible_nc);
-    const bool col_fast = (x0 >= 1 && x0 + 4 <= d.visible_nc && x0 + 6 <= d.w);
-    if (col_fast) {
-        // all GR + 2 image rows of this lane are requested up front (one latency per block, not one per row); a row outside
-        // the image is never used.  The bin look-ups of row r are in flight while row r + 1 is computed; row r is stored then.
-        uint32_t w[GR + 2][5];
-        const uint8_t* pc = im + 3 * x0 - 3;
-        const int yfirst = yy0 - 3 * C / 2;
-#pragma unroll
-        for (int k = 0; k < GR + 2; ++k) {
-            const int y = yfirst - 1 + k;
-            if (y >= 0 && y < d.h) {
-                const uint8_t* p = pc + (size_t)y * rb;
-                // aligned dwords + a byte funnel shift (the misalignment is the same for every lane of a row): unaligned
-                // 16-byte loads measured 20 % slower for the whole kernel
-                const unsigned sh = (unsigned)(uintptr_t)p & 3u;
-                const uint8_t* pa = p - sh;
-                const u32x4 q = *reinterpret_cast<const u32x4u*>(pa);
-                const uint32_t a0 = q.x, a1 = q.y, a2 = q.z, a3 = q.w;
-                const uint32_t a4 = *reinterpret_cast<const uint32_t*>(pa + 16), a5 = *reinterpret_cast<const uint32_t*>(pa + 20);
-                w[k][0] = __builtin_amdgcn_alignbyte(a1, a0, sh); w[k][1] = __builtin_amdgcn_alignbyte(a2, a1, sh);
-                w[k][2] = __builtin_amdgcn_alignbyte(a3, a2, sh); w[k][3] = __builtin_amdgcn_alignbyte(a4, a3, sh);
-                w[k][4] = __builtin_amdgcn_alignbyte(a5, a4, sh);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 5; ++j) w[k][j] = 0;
-            }
-        }
-#define BYTE_OF(w, i) (int)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
-        float pv[4] = {0.f, 0.f, 0.f, 0.f};
-        int po[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int r = 0; r <= GR; ++r) {
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            int o[4] = {0, 0, 0, 0};
-            if (r < GR) {
-                const int y = yfirst + r;
-                if (yy0 + r < d.rows_t && y >= 1 && y < d.visible_nr) {            // block-uniform
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        int u[3], dd[3], ll[3], rr[3];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            u[k] = BYTE_OF(w[r], 3 * p + 3 + k); dd[k] = BYTE_OF(w[r + 2], 3 * p + 3 + k);
-                            ll[k] = BYTE_OF(w[r + 1], 3 * p + k); rr[k] = BYTE_OF(w[r + 1], 3 * p + 6 + k);
-                        }
-                        grad_lookup(u, dd, ll, rr, lut2, &v[p], &o[p]);
-                    }
-                }
-            }
-            if (r >= 1 && yy0 + r - 1 < d.rows_t) {
-                const size_t idx = (size_t)(yy0 + r - 1) * d.pitch;
-                *reinterpret_cast<uint4*>(pxo + idx) = make_uint4(pack_mag_bin(pv[0], po[0]), pack_mag_bin(pv[1], po[1]), pack_mag_bin(pv[2], po[2]),
-                                                                  pack_mag_bin(pv[3], po[3]));
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) { pv[p] = v[p]; po[p] = o[p]; }
-        }
-#undef BYTE_OF
-        return;
-    }
-    for (int r = 0; r < GR; ++r) {
-        const int yy = yy0 + r, y = yy - 3 * C / 2;
-        if (yy >= d.rows_t) break;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        int o[4] = {0, 0, 0, 0};
-        if (col_any && y >= 1 && y < d.visible_nr) {
-            const uint8_t* rc = im + (size_t)y * rb;
-            const uint8_t* ru = rc - rb;
-            const uint8_t* rd = rc + rb;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int x = x0 + p;
-                if (x >= 1 && x < d.visible_nc) {
-                    int u[3], dd[3], ll[3], rr[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { u[k] = ru[3 * x + k]; dd[k] = rd[3 * x + k]; ll[k] = rc[3 * x - 3 + k]; rr[k] = rc[3 * x + 3 + k]; }
-                    grad_lookup(u, dd, ll, rr, lut2, &v[p], &o[p]);
-                }
-            }
-        }
-        const size_t idx = (size_t)yy * d.pitch;
-        *reinterpret_cast<uint4*>(pxo + idx) = make_uint4(pack_mag_bin(v[0], o[0]), pack_mag_bin(v[1], o[1]), pack_mag_bin(v[2], o[2]), pack_mag_bin(v[3], o[3]));
-    }
-}
-
-// v3 of the histogram pass: one lane owns HK vertically consecutive cells of one cell column and walks the 8 (HK + 1) pixel rows
-// they cover ONCE, top to bottom.  A row in band g feeds the lower half of cell g - 1 and the upper half of cell g, so every cell
-// still receives its votes in row-major order of its own 16 x 16 window (the order dlib's scatter loop produces), while the
-// (magnitude, bin) planes are read (HK + 1) / HK times instead of twice.  Two accumulator sets in LDS alternate between cells.
-#define HIST_CELLS 4
-__global__ void __launch_bounds__(256) fhog_hist4_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint32_t* __restrict__ px_base,
-                                                       float* __restrict__ hist_base,
-                                                       float* __restrict__ norm_base)
-{
-    constexpr int C = 8, HK = HIST_CELLS, NV = 2 * C / 4;
-    __shared__ float acc[2][18][256];
-    const int g0 = ml_block(st);
-    if (g0 >= st.b0[st.nl]) return;
-    const int l = ml_level(st, g0);
-    const LvDesc d = lv[l];
-    const int local = g0 - st.b0[l];
-    const int nyb = (d.hr + HK - 1) / HK;
-    const int xb = local % d.hist_bx;
-    const int yb = (local / d.hist_bx) % nyb;
-    const int b = local / (d.hist_bx * nyb);
-    const int hx = xb * 256 + threadIdx.x;
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int o = 0; o < 18; ++o) { acc[0][o][tid] = 0.0f; acc[1][o][tid] = 0.0f; }
-    if (hx >= d.hc) return;
-    const int hy0 = yb * HK;
-    const int ncell = (d.hr - hy0 < HK) ? d.hr - hy0 : HK;       // cells of this lane that exist (block-uniform)
-    const uint32_t* pxi = px_base + d.px_off + (size_t)b * d.px_stride + (size_t)C * hx + (size_t)(C * hy0) * d.pitch;
-    uint4 pw[2][NV];
-    auto load_row = [&](int r, uint4* dw) {
-        const size_t row = (size_t)r * d.pitch;
-#pragma unroll
-        for (int q = 0; q < NV; ++q) dw[q] = *reinterpret_cast<const uint4*>(pxi + row + 4 * q);
-    };
-    auto finish = [&](int j) {                                     // cell j of this lane is complete: write it out, clear its set
-        const int hy = hy0 + j, set = j & 1;
-        float* h = hist_base + d.hist_off + (size_t)b * d.hist_stride + ((size_t)hy * d.hc + hx) * 18;
-        float e = 0.0f;
-#pragma unroll
-        for (int o = 0; o < 9; ++o) {
-            const float a0 = acc[set][o][tid], a1 = acc[set][o + 9][tid];
-            h[o] = a0; h[o + 9] = a1;
-            const float s2 = a0 + a1;
-            e = e + s2 * s2;
-            acc[set][o][tid] = 0.0f; acc[set][o + 9][tid] = 0.0f;
-        }
-        if (hy >= 1 && hy <= d.cells_nr && hx >= 1 && hx <= d.cells_nc)
-            norm_base[d.norm_off + (size_t)b * d.norm_stride + (size_t)(hy - 1) * d.cells_nc + (hx - 1)] = e;
-    };
-    const int nrows = C * (ncell + 1);
-    load_row(0, pw[0]);
-    for (int g = 0; g <= ncell; ++g) {
-        const bool lower = (g >= 1);            // rows of this band are the lower half of cell g - 1
-        const bool upper = (g < ncell);         // ... and the upper half of cell g
-        float* accl = &acc[(g + 1) & 1][0][tid];
-        float* accu = &acc[g & 1][0][tid];
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-            const int cur = i & 1;
-            const int r = C * g + i;
-            if (r + 1 < nrows) load_row(r + 1, pw[cur ^ 1]);
-            const float fy = ((float)i + 0.5f) / (float)C;
-            float v[2 * C];
-            int ob[2 * C];
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                const uint32_t w4[4] = {pw[cur][q].x, pw[cur][q].y, pw[cur][q].z, pw[cur][q].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[4 * q + e] = packed_mag(w4[e]); ob[4 * q + e] = packed_bin(w4[e]); }
-            }
-            if (lower) {
-#pragma unroll
-                for (int wx = 0; wx < 2 * C; ++wx) {
-                    const int j = wx % C;
-                    const float fx = ((float)j + 0.5f) / (float)C;
-                    const float wxv = (wx < C) ? fx : 1.0f - fx;
-                    const int o = ob[wx];
-                    accl[o * 256] = accl[o * 256] + ((1.0f - fy) * wxv) * v[wx];
-                }
-            }
-            if (upper) {
-#pragma unroll
-                for (int wx = 0; wx < 2 * C; ++wx) {
-                    const int j = wx % C;
-                    const float fx = ((float)j + 0.5f) / (float)C;
-                    const float wxv = (wx < C) ? fx : 1.0f - fx;
-                    const int o = ob[wx];
-                    accu[o * 256] = accu[o * 256] + (fy * wxv) * v[wx];
-                }
-            }
-        }
-        if (lower) finish(g - 1);
-    }
-}
-
-__global__ void __launch_bounds__(256) fhog_feat_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ hist_base,
-                                                      const float* __restrict__ norm_base, float* __restrict__ feat_base, int oy, int ox)
-{
-    const int g = ml_block(st);
-    if (g >= st.b0[st.nl]) return;
-    const int l = ml_level(st, g);
-    const LvDesc d = lv[l];
-    const int local = g - st.b0[l];
-    const int xb = local % d.feat_bx;
-    const int py = (local / d.feat_bx) % d.fh;
-    const int b = local / (d.feat_bx * d.fh);
-    const int px = xb * 256 + threadIdx.x;
-    if (px >= d.fw) return;
-    float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)py * d.fw + px) * PVF_FHOG_STRIDE);
-    const int x = px - ox, y = py - oy;
-    if (x < 0 || y < 0 || x >= d.hog_nc || y >= d.hog_nr) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dst[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    float n[9], h[18], o[32];
-    const float* nb = norm_base + d.norm_off + (size_t)b * d.norm_stride;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) n[i * 3 + j] = nb[(size_t)(y + i) * d.cells_nc + (x + j)];
-    const float* hp = hist_base + d.hist_off + (size_t)b * d.hist_stride + ((size_t)(y + 2) * d.hc + (x + 2)) * 18;
-#pragma unroll
-    for (int k = 0; k < 18; ++k) h[k] = hp[k];
-    cell_features(h, n, o);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -504,23 +253,13 @@ __global__ void __launch_bounds__(256) fhog_feat_ml_k(MlStarts st, const LvDesc*
 // (lane 63 only supplies gradients to lane 62; lanes 0 and 62 only supply cell energies).  Row chunks of `chunk_rows` feature
 // rows re-walk 24 + 2 pixel rows of their upper neighbour (3 cell rows of histogram context).
 #define FUSED_OUT 61
-template <bool DPP>
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t v, int next_addr)
-{
-    if (DPP) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-    return (uint32_t)__builtin_amdgcn_ds_bpermute(next_addr, (int)v);
-}
-template <bool DPP>
-__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v, int prev_addr)
-{
-    if (DPP) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    return (uint32_t)__builtin_amdgcn_ds_bpermute(prev_addr, (int)v);
-}
+// value of the lane to the right / left (v_mov_b32_dpp wave_shl:1 / wave_shr:1; the last / first lane, which has no source, gets 0).
+// The direction is checked once per context on the device (dpp_probe_k): a mismatch is an error, not a fallback.
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 
-typedef __attribute__((address_space(3))) float lds_float;
 
-template <bool DPP, int WAVES>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) fhog_fused_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
+__global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
                                                        float* __restrict__ feat_base, const uint8_t* __restrict__ lut2, int oy, int ox)
 {
     constexpr int RSRC_FLAGS = 0x00020000;
@@ -553,7 +292,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     // give negative offsets, which are huge as unsigned: out of range for the row's buffer descriptor => zeros.  Both offsets go
     // through the VGPR: the range check does not see an SGPR offset, so -16 + an SGPR 16 would be rejected although it is byte 0.
     const int voff = 3 * x_first - 4, voff2 = voff + 16;
-    const int next_addr = ((lane + 1) & 63) * 4, prev_addr = ((lane + 63) & 63) * 4;
     float* accE = &s_even[wave][0][lane];                          // bin k of this lane: accE[64 * k]
     float* accO = &s_odd[wave][0][lane];
 #pragma unroll
@@ -575,6 +313,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     load_row(y_begin - 1, rw[0]);
     load_row(y_begin, rw[1]);
     load_row(y_begin + 1, rw[2]);
+    load_row(y_begin + 2, rw[3]);
 
     float hprev[18];
     float e0 = 0.f, e1 = 0.f, e2 = 0.f;
@@ -582,54 +321,67 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
     for (int k = 0; k < 18; ++k) hprev[k] = 0.f;
 
 #define BYTE_OF(w, i) (int)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
+    // (magnitude, bin offset) of pixel p of image row y from the three row buffers; rows / columns without a gradient give magnitude 0
+    auto grad_px = [&](const uint32_t* up, const uint32_t* ce, const uint32_t* dn, int p, bool row_ok, float* mo, int* bof) {
+        int u3[3], d3[3], l3[3], r3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u3[k] = BYTE_OF(up, 4 + 3 * p + k); d3[k] = BYTE_OF(dn, 4 + 3 * p + k);
+            l3[k] = BYTE_OF(ce, 1 + 3 * p + k); r3[k] = BYTE_OF(ce, 7 + 3 * p + k);
+        }
+        float v; int o;
+        grad_lookup(u3, d3, l3, r3, lut2, &v, &o);
+        *mo = (row_ok && ((xmask >> p) & 1u)) ? v : 0.0f;
+        *bof = o << 6;                                             // float offset of the bin's row of 64 lanes
+    };
+    // the votes of a row are a chain of LDS read-add-writes (latency bound); the gradients of the NEXT row are pure VALU work plus a table
+    // look-up: they are computed in between, one pixel per two votes, so that a wave fills its own LDS waits and the look-ups of a row are
+    // back long before its votes start
+    float mc[8];
+    int bc[8];
+    {
+        const bool ok0 = (y_begin >= 1 && y_begin < d.visible_nr);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) grad_px(rw[0], rw[1], rw[2], p, ok0, &mc[p], &bc[p]);
+    }
     // One band = 8 pixel rows: the upper half of cell row gb (bins in accU) and the lower half of cell row gb - 1 (bins in accL).
     // The first band's lower half (cell row y0) and the last band's upper half (cell row y0 + R + 3) belong to cells this chunk
     // does not need; they are accumulated all the same (no branches in the vote loop): the first is read and dropped, the last
-    // is never read.
+    // is never read.  Rows without gradients vote with magnitude 0 (x + 0 = x: nothing changes).
     auto band = [&](int gb, float* accU, float* accL) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int y = 8 * gb + i - 12;
-            uint32_t* up = rw[i & 3];
-            uint32_t* ce = rw[(i + 1) & 3];
-            uint32_t* dn = rw[(i + 2) & 3];
-            load_row(y + 2, rw[(i + 3) & 3]);                      // next step's lower row, in flight during this step
-            if (y >= 1 && y < d.visible_nr) {                      // wave-uniform; other rows hold no gradients (nothing to add)
-                float m[8];
-                int bo[8];
+            const int y = 8 * gb + i - 12;                         // the row whose votes are cast in this step (gradients in mc / bc)
+            // buffers: rows y, y + 1, y + 2 in rw[(i+1)&3], rw[(i+2)&3], rw[(i+3)&3]; rw[i & 3] held row y - 1 (done with) and takes
+            // row y + 3, which is needed one step from now: a full step to arrive
+            load_row(y + 3, rw[i & 3]);
+            const uint32_t* nu = rw[(i + 1) & 3];                  // rows around y + 1, whose gradients are formed meanwhile
+            const uint32_t* nc = rw[(i + 2) & 3];
+            const uint32_t* nd = rw[(i + 3) & 3];
+            const bool nok = (y + 1 >= 1 && y + 1 < d.visible_nr);
+            float mn[8];
+            int bn[8];
+            const float fy = ((float)i + 0.5f) / 8.0f;
+            // the 16 columns of the window, left to right: own 8 (weights rising), then the right neighbour's 8 (falling).
+            // Each vote is a read-add-write on the lane's own bin in LDS; the two cells' chains are independent.
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    int u3[3], d3[3], l3[3], r3[3];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        u3[k] = BYTE_OF(up, 4 + 3 * p + k); d3[k] = BYTE_OF(dn, 4 + 3 * p + k);
-                        l3[k] = BYTE_OF(ce, 1 + 3 * p + k); r3[k] = BYTE_OF(ce, 7 + 3 * p + k);
-                    }
-                    float v; int o;
-                    grad_lookup(u3, d3, l3, r3, lut2, &v, &o);
-                    const bool ok = (xmask >> p) & 1u;
-                    m[p] = ok ? v : 0.0f;
-                    bo[p] = o << 6;                                // float offset of the bin's row of 64 lanes
+            for (int j = 0; j < 16; ++j) {
+                const int p = j & 7;
+                float mv; int bv;
+                if (j < 8) { mv = mc[p]; bv = bc[p]; }
+                else {
+                    mv = __uint_as_float(from_next_lane(__float_as_uint(mc[p])));
+                    bv = (int)from_next_lane((uint32_t)bc[p]);
                 }
-                const float fy = ((float)i + 0.5f) / 8.0f;
-                // the 16 columns of the window, left to right: own 8 (weights rising), then the right neighbour's 8 (falling).
-                // Each vote is a read-add-write on the lane's own bin in LDS; the two cells' chains are independent.
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int p = j & 7;
-                    float mv; int bv;
-                    if (j < 8) { mv = m[p]; bv = bo[p]; }
-                    else {
-                        mv = __uint_as_float(from_next_lane<DPP>(__float_as_uint(m[p]), next_addr));
-                        bv = (int)from_next_lane<DPP>((uint32_t)bo[p], next_addr);
-                    }
-                    const float fx = ((float)p + 0.5f) / 8.0f;
-                    const float wx = (j < 8) ? fx : 1.0f - fx;
-                    const float vl = accL[bv], vu = accU[bv];
-                    accL[bv] = vl + ((1.0f - fy) * wx) * mv;
-                    accU[bv] = vu + (fy * wx) * mv;
-                }
+                const float fx = ((float)p + 0.5f) / 8.0f;
+                const float wx = (j < 8) ? fx : 1.0f - fx;
+                const float vl = accL[bv], vu = accU[bv];
+                if ((j & 1) == 0) grad_px(nu, nc, nd, j >> 1, nok, &mn[j >> 1], &bn[j >> 1]);
+                accL[bv] = vl + ((1.0f - fy) * wx) * mv;
+                accU[bv] = vu + (fy * wx) * mv;
             }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) { mc[p] = mn[p]; bc[p] = bn[p]; }
         }
         // cell row c = gb - 1 is complete (for c = y0: a half-filled cell that only has to be cleared; its energy is shifted out of
         // e0..e2 before the first feature row is formed): energy in the oracle's order (straight from LDS: the new bins and the
@@ -643,9 +395,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES,
             // features of the centre cell row c - 1 (histograms in hprev), hog row y = c - 3; norms: rows c-2, c-1, c x lanes L-1, L, L+1
             float n[9];
             n[1] = e2; n[4] = e1; n[7] = e0;
-            n[0] = __uint_as_float(from_prev_lane<DPP>(__float_as_uint(e2), prev_addr)); n[2] = __uint_as_float(from_next_lane<DPP>(__float_as_uint(e2), next_addr));
-            n[3] = __uint_as_float(from_prev_lane<DPP>(__float_as_uint(e1), prev_addr)); n[5] = __uint_as_float(from_next_lane<DPP>(__float_as_uint(e1), next_addr));
-            n[6] = __uint_as_float(from_prev_lane<DPP>(__float_as_uint(e0), prev_addr)); n[8] = __uint_as_float(from_next_lane<DPP>(__float_as_uint(e0), next_addr));
+            n[0] = __uint_as_float(from_prev_lane(__float_as_uint(e2))); n[2] = __uint_as_float(from_next_lane(__float_as_uint(e2)));
+            n[3] = __uint_as_float(from_prev_lane(__float_as_uint(e1))); n[5] = __uint_as_float(from_next_lane(__float_as_uint(e1)));
+            n[6] = __uint_as_float(from_prev_lane(__float_as_uint(e0))); n[8] = __uint_as_float(from_next_lane(__float_as_uint(e0)));
             const int x = FUSED_OUT * sx + lane - 1, yh = c - 3;
             if (lane >= 1 && lane <= FUSED_OUT && x < d.hog_nc) {
                 float o[32];
@@ -685,172 +437,6 @@ __global__ void __launch_bounds__(256) feat_ring_zero_k(MlStarts st, const LvDes
     float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)py * d.fw + px) * PVF_FHOG_STRIDE);
 #pragma unroll
     for (int k = 0; k < 8; ++k) dst[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K3 systolic: the fmaf chain of one output position runs through the 8 waves of a block.
-//
-// The chain of a score is ordered (filter row m, cell n', plane p): 10 x 12 x 32 steps (12 cells per row because three neighbouring
-// output columns share one 16-column MFMA tile, see above).  It is cut into 8 consecutive segments of 15 (m, n') pairs; wave w
-// owns segment w for EVERY output row of the block's column tile and keeps that segment's B fragments (15 x 8 registers) for
-// the whole kernel -- no weight traffic at all in the loop.  Output row r enters wave 0 at step r and leaves wave 7 at step
-// r + 7; between two waves the two accumulator tiles travel through LDS (2 KB per hand-over) and continue as the C operand of
-// the next wave's first MFMA, so every accumulator still receives its terms in (m, n', p) order: bit-identical to the oracle.
-// At step s wave w works on output row s - w and needs feature rows (s - w) + m for its one or two m: rows s .. s + 2 for all
-// waves, so the block keeps a ring of 4 feature rows in LDS (3 live, the next one being written) that ALL waves read: every
-// feature row is fetched from HBM once per 96-column tile (1.11 x with the 11-cell overlap) instead of 3.25 x, and the inner
-// loop is ds_read_b32 (A) + MFMA only.  One barrier per step (240 MFMAs per wave).
-template <bool TWO>
-__device__ __forceinline__ void sys_mfma_pair(f32x4& acc0, f32x4& acc1, const float* a, const float* bq)
-{
-#pragma unroll
-    for (int pq = 0; pq < 8; ++pq) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * pq], bq[pq], acc0, 0, 0, 0);
-        if (TWO) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * pq + 1], bq[pq], acc1, 0, 0, 0);
-    }
-}
-
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-score_sys_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base, const float* __restrict__ Bg,
-               ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
-{
-    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, WCOLS = 96, SEG = WCOLS + 11, NW = 8, NQ = 15;
-    constexpr int ROW_FLOATS = SEG * PITCH;                        // one staged feature row
-    constexpr int RSRC_FLAGS = 0x00020000;
-    extern __shared__ __attribute__((aligned(16))) float s_sys[];  // ring [4][SEG][PITCH] + hand-over [2][NW][2 tiles][64 lanes][4]
-    float* ring = s_sys;
-    float* hand = s_sys + 4 * ROW_FLOATS;
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = ml_block(st);
-    if (g >= st.b0[st.nl]) return;
-    const int l = ml_level(st, g);
-    const LvDesc d = lv[l];
-    const int local = g - st.b0[l];
-    const int bx = local % d.score_bx;
-    const int b = local / d.score_bx;
-    const int fh = d.fh, fw = d.fw;
-    const int c_base = bx * WCOLS;
-    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
-    const int out_rows = r1 - FR / 2;                              // output rows 0 .. out_rows-1 (window top row = output row index)
-    const bool two_tiles = (c_base + 48 + FC / 2 < c1);            // block-uniform: a ragged right end runs one 48-column tile
-    const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride + (size_t)c_base * PVF_FHOG_STRIDE;
-    const int seg_cells = (fw - c_base < SEG) ? fw - c_base : SEG;
-
-    // this wave's segment of the chain: pairs q = 15 w .. 15 w + 14, q = m * 12 + n'
-    float bq[NQ][8];
-    {
-        const float* bp = Bg + ((size_t)(NQ * w) * 8) * 64 + lane;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int pq = 0; pq < 8; ++pq) bq[q][pq] = bp[(q * 8 + pq) * 64];
-    }
-    const int q0 = NQ * w;
-    const int m_lo = q0 / NK;                                      // first filter row of the segment (the last is m_lo or m_lo + 1)
-    const int dly = (w < 4) ? 0 : 1;                               // rows (s - w) + m_lo = s + dly
-    // staging: thread t moves 16-byte pieces t and t + 512 of a feature row segment (SEG * 8 = 856 pieces)
-    const int t = threadIdx.x;
-    auto stage_load = [&](int frow, u32x4* v) {
-        const int bytes = (frow < fh) ? seg_cells * PVF_FHOG_STRIDE * 4 : 0;
-        const int fr = frow < fh ? frow : fh - 1;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + (size_t)fr * fw * PVF_FHOG_STRIDE), 0, bytes, RSRC_FLAGS);
-        v[0] = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 16, 0, 0);
-        v[1] = __builtin_amdgcn_raw_buffer_load_b128(rs, t * 16, 512 * 16, 0);
-    };
-    auto stage_store = [&](int frow, const u32x4* v) {
-        float* row = ring + (frow & 3) * ROW_FLOATS;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int idx = t + 512 * u;
-            if (idx < SEG * 8) {
-                uint2* dd = reinterpret_cast<uint2*>(row + (idx >> 3) * PITCH + 4 * (idx & 7));
-                dd[0] = make_uint2(v[u].x, v[u].y);
-                dd[1] = make_uint2(v[u].z, v[u].w);
-            }
-        }
-    };
-    const int r_top = 0;                                           // window top row of output row 0 is feature row 0
-    {
-        u32x4 v[2];
-        for (int fr = 0; fr < 3; ++fr) { stage_load(r_top + fr, v); stage_store(fr, v); }
-    }
-    __syncthreads();
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int a_off = (3 * i16) * PITCH + kq;                      // A fragment: position i16 (3 cells apart), plane 4 pq + kq
-    const int steps = out_rows + NW - 1;
-    for (int s = 0; s < steps; ++s) {
-        u32x4 nv[2];
-        stage_load(s + 3, nv);                                     // lands in the ring at the end of this step
-        const int r = s - w;                                       // output row of this wave at this step
-        if (r >= 0 && r < out_rows) {                              // wave-uniform
-            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (w > 0) {
-                const float* hp = hand + ((((s - 1) & 1) * NW + (w - 1)) * 2) * 256 + lane * 4;
-                acc0 = *reinterpret_cast<const f32x4*>(hp);
-                if (two_tiles) acc1 = *reinterpret_cast<const f32x4*>(hp + 256);
-            }
-            const float* rowA = ring + ((s + dly) & 3) * ROW_FLOATS + a_off;        // feature row r + m_lo
-            const float* rowB = ring + ((s + dly + 1) & 3) * ROW_FLOATS + a_off;    // feature row r + m_lo + 1
-            // A fragments of pair q: 8 k-steps x 2 tiles; fetched one pair ahead of the MFMAs that use them
-            float an[16];
-            auto fetch = [&](int q, float* dst) {
-                const int qq = q0 + q;                             // compile-time after unrolling: w is uniform, q constant
-                const int m = qq / NK, np = qq - m * NK;
-                const float* base = (m == m_lo ? rowA : rowB) + np * PITCH;
-#pragma unroll
-                for (int pq = 0; pq < 8; ++pq) {
-                    dst[2 * pq] = base[4 * pq];
-                    dst[2 * pq + 1] = base[48 * PITCH + 4 * pq];
-                }
-            };
-            fetch(0, an);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                float ac[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) ac[k] = an[k];
-                if (q + 1 < NQ) fetch(q + 1, an);
-                __builtin_amdgcn_sched_barrier(0);
-                if (two_tiles) sys_mfma_pair<true>(acc0, acc1, ac, bq[q]);
-                else sys_mfma_pair<false>(acc0, acc1, ac, bq[q]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (w < NW - 1) {
-                float* hp = hand + (((s & 1) * NW + w) * 2) * 256 + lane * 4;
-                *reinterpret_cast<f32x4*>(hp) = acc0;
-                if (two_tiles) *reinterpret_cast<f32x4*>(hp + 256) = acc1;
-            } else {
-                // C/D layout of the 16x16 MFMA: column j = lane & 15, row = 4 * (lane >> 4) + reg
-                const int jc = lane & 15;
-                if (jc < 15) {
-                    const int sh = jc / 5, f = jc % 5;
-                    const float th = sp.thresh[f];
-                    const int rr = r + FR / 2;
-#pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
-                        if (tt == 1 && !two_tiles) break;
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const int pos = 4 * (lane >> 4) + reg;
-                            const int cc = c_base + tt * 48 + 3 * pos + sh + FC / 2;
-                            const float v = tt == 0 ? acc0[reg] : acc1[reg];
-                            if (cc < c1 && v >= th) {
-                                const int idx = atomicAdd(&counts[b], 1);
-                                if (idx < sp.cap) {
-                                    CandRec rec;
-                                    rec.score = v - th; rec.filter = f; rec.level = l; rec.r = rr; rec.c = cc;
-                                    cands[(size_t)b * sp.cap + idx] = rec;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        stage_store(s + 3, nv);
-        __syncthreads();
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1031,9 +617,9 @@ struct MlPlan {
     int h = 0, w = 0, upsample = -1, B = 0;
     std::vector<LvDesc> lv;
     std::vector<LevelDims> ups;
-    MlStarts grad, hist, feat, score, fused, sys;
-    int grad_blocks = 0, hist_blocks = 0, feat_blocks = 0, score_blocks = 0, fused_blocks = 0, sys_blocks = 0;
-    size_t img_bytes = 0, px_elems = 0, hist_floats = 0, norm_floats = 0, feat_floats = 0, up_bytes = 0;
+    MlStarts feat, score, fused;
+    int feat_blocks = 0, score_blocks = 0, fused_blocks = 0;
+    size_t img_bytes = 0, feat_floats = 0, up_bytes = 0;
     LvDesc* d_lv = nullptr;
     const void* ring_valid_for = nullptr;      // feature buffer whose zero border was written for this plan (fused FHOG)
     ~MlPlan() { if (d_lv) (void)hipFree(d_lv); }
@@ -1053,10 +639,6 @@ void ml_plans_free(Ctx* c)
     c->ml_plans = nullptr;
 }
 
-// dev-time switches (removed once the new kernels are validated on hardware)
-static bool env_is(const char* name, const char* val) { const char* e = getenv(name); return e && strcmp(e, val) == 0; }
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-
 static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
 {
     if (!c->ml_plans) c->ml_plans = new MlPlanCache();
@@ -1071,16 +653,14 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
     PVF_REQUIRE((int)dims.size() <= ML_MAX, "too many pyramid levels");
     auto al = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
     for (size_t u = 0; u + 1 < p.ups.size(); ++u) p.up_bytes = std::max(p.up_bytes, (size_t)p.ups[u].h * al((size_t)p.ups[u].w * 3, 64) * B);
-    p.grad.nl = p.hist.nl = p.feat.nl = p.score.nl = p.fused.nl = p.sys.nl = (int)dims.size();
-    const int chunk_big = env_int("PVF_FHOG_CHUNK", 32);
+    p.feat.nl = p.score.nl = p.fused.nl = (int)dims.size();
+    const int chunk_big = 32;                  // feature rows per fused-FHOG task on the large levels
     for (size_t l = 0; l < dims.size(); ++l) {
         LvDesc d;
         memset(&d, 0, sizeof d);
         d.h = dims[l].h; d.w = dims[l].w;
         d.cells_nr = (int)((double)d.h / 8.0 + 0.5); d.cells_nc = (int)((double)d.w / 8.0 + 0.5);
-        d.hr = d.cells_nr + 2; d.hc = d.cells_nc + 2;
         d.visible_nr = std::min(d.cells_nr * 8, d.h) - 1; d.visible_nc = std::min(d.cells_nc * 8, d.w) - 1;
-        d.rows_t = 8 * (d.hr + 1); d.pitch = (8 * (d.hc + 1) + 15) / 16 * 16;
         d.hog_nr = d.cells_nr - 2; d.hog_nc = d.cells_nc - 2;
         const bool feat_ok = d.hog_nr > 0 && d.hog_nc > 0;
         d.fh = feat_ok ? d.hog_nr + m.frows - 1 : 0; d.fw = feat_ok ? d.hog_nc + m.fcols - 1 : 0;
@@ -1088,34 +668,24 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         d.rb = (int)al((size_t)d.w * 3, 64);
         d.img_off = (long long)p.img_bytes; d.img_stride = (long long)d.h * d.rb;
         p.img_bytes += (size_t)d.img_stride * B;
-        d.px_off = (long long)p.px_elems; d.px_stride = (long long)d.rows_t * d.pitch;
-        p.px_elems += (size_t)d.px_stride * B;
-        d.hist_off = (long long)p.hist_floats; d.hist_stride = (long long)d.hr * d.hc * 18;
-        p.hist_floats += al((size_t)d.hist_stride * B, 4);
-        d.norm_off = (long long)p.norm_floats; d.norm_stride = (long long)d.cells_nr * d.cells_nc;
-        p.norm_floats += al((size_t)d.norm_stride * B, 4);
         d.feat_off = (long long)p.feat_floats; d.feat_stride = (long long)d.fh * d.fw * PVF_FHOG_STRIDE;
         p.feat_floats += (size_t)d.feat_stride * B;
-        d.grad_bx = (d.pitch / 4 + 255) / 256; d.hist_bx = (d.hc + 255) / 256; d.feat_bx = std::max((d.fw + 255) / 256, 0);
+        d.feat_bx = std::max((d.fw + 255) / 256, 0);
         const int out_r = d.fh - 9, out_c = d.fw - 9;
         d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + 15) / 16 : 0;
-        d.sys_bx = d.score_bx;
         // fused FHOG tasks: strips of 61 feature columns x chunks of feature rows (smaller chunks for the small levels: more tasks)
         d.strips = feat_ok ? (d.hog_nc + FUSED_OUT - 1) / FUSED_OUT : 0;
         d.chunk_rows = (d.hog_nr >= 2 * chunk_big) ? chunk_big : std::max((d.hog_nr + 1) / 2, 1);
         d.chunks = feat_ok ? (d.hog_nr + d.chunk_rows - 1) / d.chunk_rows : 0;
         d.fused_tasks = d.strips * d.chunks * B;
-        p.grad.b0[l] = p.grad_blocks; p.grad_blocks += d.grad_bx * ((d.rows_t + GRAD_ROWS - 1) / GRAD_ROWS) * B;
-        p.hist.b0[l] = p.hist_blocks; p.hist_blocks += d.hist_bx * ((d.hr + HIST_CELLS - 1) / HIST_CELLS) * B;
         p.feat.b0[l] = p.feat_blocks; p.feat_blocks += d.feat_bx * d.fh * B;
         p.score.b0[l] = p.score_blocks; p.score_blocks += d.score_bx * d.score_by * B;
         p.fused.b0[l] = p.fused_blocks; p.fused_blocks += (d.fused_tasks + 3) / 4;
-        p.sys.b0[l] = p.sys_blocks; p.sys_blocks += d.sys_bx * B;
         p.lv.push_back(d);
     }
     const int nl = (int)dims.size();
-    p.grad.b0[nl] = p.grad_blocks; p.hist.b0[nl] = p.hist_blocks; p.feat.b0[nl] = p.feat_blocks; p.score.b0[nl] = p.score_blocks;
-    p.fused.b0[nl] = p.fused_blocks; p.sys.b0[nl] = p.sys_blocks;
+    p.feat.b0[nl] = p.feat_blocks; p.score.b0[nl] = p.score_blocks;
+    p.fused.b0[nl] = p.fused_blocks;
     HIP_CHECK(hipMalloc((void**)&p.d_lv, sizeof(LvDesc) * nl));
     HIP_CHECK(hipMemcpy(p.d_lv, p.lv.data(), sizeof(LvDesc) * nl, hipMemcpyHostToDevice));
     MlPlan* raw = pp.get();
@@ -1163,10 +733,10 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
 __global__ void dpp_probe_k(int* out)
 {
     const int lane = threadIdx.x;
-    out[lane] = (int)from_next_lane<true>((uint32_t)(lane + 100), 0);
-    out[64 + lane] = (int)from_prev_lane<true>((uint32_t)(lane + 100), 0);
+    out[lane] = (int)from_next_lane((uint32_t)(lane + 100));
+    out[64 + lane] = (int)from_prev_lane((uint32_t)(lane + 100));
 }
-static bool dpp_moves_as_expected(Ctx* c)
+static void check_dpp_direction(Ctx* c)
 {
     MlPlanCache* pc = c->ml_plans;
     if (pc->dpp_probe < 0) {
@@ -1181,9 +751,8 @@ static bool dpp_moves_as_expected(Ctx* c)
             ok = ok && h[64 + i] == (i > 0 ? i + 99 : 0);
         }
         pc->dpp_probe = ok ? 1 : 0;
-        if (getenv("PVF_VERBOSE")) fprintf(stderr, "[pvface] DPP wave shift probe: %s\n", ok ? "as expected" : "NOT as expected, using ds_bpermute");
     }
-    return pc->dpp_probe == 1;
+    PVF_REQUIRE(pc->dpp_probe == 1, "v_mov_b32_dpp wave_shl / wave_shr do not move data as the FHOG kernel expects on this device");
 }
 
 // pyramid + FHOG features of every level of the batch (s_feat at plan->lv[l].feat_off); returns the plan
@@ -1196,42 +765,17 @@ static MlPlan* ml_features(Ctx* c, const std::vector<Frame>& frames, int upsampl
     const int oy = (m.frows - 1) / 2, ox = (m.fcols - 1) / 2;
     const void* feat_before = c->s_feat.p;
     c->s_feat.ensure(p->feat_floats * sizeof(float) + 64);
-    if (!env_is("PVF_FHOG", "old")) {
-        if (p->fused_blocks == 0) return p;
-        // the fused kernel writes hog cells only: the zero padding ring is written when this plan first meets this buffer (other
-        // plans and the stage-access entries share s_feat, so the owner is tracked)
-        if (c->s_feat.p != feat_before || c->feat_ring_owner != (const void*)p) {
-            ProfScope p0(c, "fhog");
-            hipLaunchKernelGGL(feat_ring_zero_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_feat.as<float>(), oy, ox);
-            c->feat_ring_owner = (const void*)p;
-        }
-        ProfScope ps(c, "fhog");
-        const bool dpp = dpp_moves_as_expected(c) && !env_is("PVF_FHOG", "bperm");
-        if (!dpp)
-            hipLaunchKernelGGL((fhog_fused_ml_k<false, 2>), dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
-                               c->s_feat.as<float>(), lut2, oy, ox);
-        else if (env_int("PVF_FHOG_WAVES", 2) == 3)
-            hipLaunchKernelGGL((fhog_fused_ml_k<true, 3>), dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
-                               c->s_feat.as<float>(), lut2, oy, ox);
-        else
-            hipLaunchKernelGGL((fhog_fused_ml_k<true, 2>), dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
-                               c->s_feat.as<float>(), lut2, oy, ox);
-        return p;
+    if (p->fused_blocks == 0) return p;
+    check_dpp_direction(c);
+    ProfScope ps(c, "fhog");
+    // the fused kernel writes hog cells only: the zero padding ring is written when this plan first meets this buffer (other plans
+    // and the stage-access entries share s_feat, so the owner is tracked)
+    if (c->s_feat.p != feat_before || c->feat_ring_owner != (const void*)p) {
+        hipLaunchKernelGGL(feat_ring_zero_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_feat.as<float>(), oy, ox);
+        c->feat_ring_owner = (const void*)p;
     }
-    c->feat_ring_owner = nullptr;
-    c->s_grad.ensure(p->px_elems * 4 + 256);
-    c->s_hist.ensure(p->hist_floats * sizeof(float) + 64);
-    c->s_norm.ensure(p->norm_floats * sizeof(float) + 64);
-    uint32_t* d_px = c->s_grad.as<uint32_t>();
-    {
-        ProfScope ps(c, "fhog");
-        hipLaunchKernelGGL(fhog_grad4r_ml_k, dim3(ml_grid(p->grad_blocks)), dim3(256), 0, c->stream, p->grad, p->d_lv, B, c->s_pyr.as<uint8_t>(), d_px, lut2);
-        hipLaunchKernelGGL(fhog_hist4_ml_k, dim3(ml_grid(p->hist_blocks)), dim3(256), 0, c->stream, p->hist, p->d_lv, B, d_px, c->s_hist.as<float>(),
-                           c->s_norm.as<float>());
-        if (p->feat_blocks > 0)
-            hipLaunchKernelGGL(fhog_feat_ml_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_hist.as<float>(),
-                               c->s_norm.as<float>(), c->s_feat.as<float>(), oy, ox);
-    }
+    hipLaunchKernelGGL(fhog_fused_ml_k, dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
+                       c->s_feat.as<float>(), lut2, oy, ox);
     return p;
 }
 
@@ -1242,17 +786,6 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
     MlPlan* p = ml_features(c, frames, upsample);
     if (p->score_blocks == 0) return;
     ProfScope ps(c, "score");
-    if (!env_is("PVF_SCORE", "old")) {
-        constexpr size_t lds = (size_t)(4 * (96 + 11) * 34 + 2 * 8 * 2 * 256) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)score_sys_ml_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(score_sys_ml_k, dim3(ml_grid(p->sys_blocks)), dim3(512), lds, c->stream, p->sys, p->d_lv, B, c->s_feat.as<float>(), m.d_bmfma,
-                           sp0, d_counts, d_cands);
-        return;
-    }
     const size_t lds = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
     const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
     hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,

@@ -374,6 +374,7 @@ void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, 
     HIP_CHECK(hipMemcpyAsync(c->s_pyr.p, himg, (size_t)h * w * 3, hipMemcpyHostToDevice, c->stream));
     const size_t nf = (size_t)(*fh) * (*fw) * PVF_FHOG_STRIDE;
     c->s_feat.ensure(nf * sizeof(float));
+    c->feat_ring_owner = nullptr;            // s_feat is shared with the detector's feature maps: their zero border is gone after this
     fhog_device(c, c->s_pyr.as<uint8_t>(), 1, h, w, cell, pad_r, pad_c, c->s_feat.as<float>(), c->s_hist, c->s_norm, 0);
     out.resize(nf);
     HIP_CHECK(hipMemcpyAsync(out.data(), c->s_feat.p, nf * sizeof(float), hipMemcpyDeviceToHost, c->stream));

@@ -85,6 +85,8 @@ struct Frame {
     const uint8_t* d = nullptr; // device, HWC RGB contiguous
     int h = 0, w = 0;
     bool owned = false;
+    bool pooled = false;        // owned memory that goes back to Ctx::frame_pool on release (ingest ring, device resize)
+    hipEvent_t ready = nullptr; // asynchronous upload still in flight: the compute stream waits for it on first use (Ctx::frame)
 };
 
 struct ProfFamily {
@@ -99,8 +101,7 @@ struct DetectorModel {
     double nms_iou = 0, nms_covered = 0;
     std::vector<float> thresh;
     float* d_w = nullptr;    // [nf][frows][fcols][32]
-    float* d_bmfma4 = nullptr; // same fragments, [10][12][2][64][4] (four k-steps per lane) for score_mfma_rows_ml_k
-    float* d_bmfma = nullptr; // [10][12][8][64] B fragments of score_mfma_k (3 shifts x 5 filters per 16-column tile)
+    float* d_bmfma4 = nullptr; // B fragments of score_mfma_rows_ml_k: [10][12][2][64 lanes][4 k-steps] (3 shifts x 5 filters per 16-column MFMA tile)
 };
 
 struct ShapeModel {
@@ -117,7 +118,7 @@ struct ShapeModel {
 
 struct ConvLayer {
     int cin, cout, k, stride, pad;
-    float* d_w;     // [k*k*cin][cout]  (k index = (r*k+s)*cin + c)
+    float* d_w;     // [cout][K padded to 32], K index = (r*k+s)*cin + c
     float* d_bias;  // [cout]
     float* d_gamma; // [cout]
     float* d_beta;  // [cout]
@@ -192,6 +193,8 @@ struct Ctx {
     hipEvent_t det_ev[2] = {nullptr, nullptr};
     int det_slot = 0;
     int n_cu = 256;
+    std::map<size_t, std::vector<uint8_t*>> frame_pool;   // released pooled frame buffers by size (ingest.hip)
+    void* ingest_rings = nullptr;                          // pinned staging rings of this context (ingest.hip)
     struct MlPlanCache* ml_plans = nullptr;   // detector launch plans of this context (detect.hip); freed by ml_plans_free
     const void* feat_ring_owner = nullptr;    // plan whose zero padding ring s_feat currently holds
     uint8_t* d_orient_lut = nullptr; // 511x511 orientation bins (fhog.hip)
@@ -201,7 +204,13 @@ struct Ctx {
     {
         auto it = frames.find(id);
         if (it == frames.end()) throw PvfError("unknown frame handle");
-        return it->second;
+        Frame& f = it->second;
+        if (f.ready) {          // queued by pvf_ingest_submit on the copy stream: order this context's kernels behind the copy
+            HIP_CHECK(hipStreamWaitEvent(stream, f.ready, 0));
+            (void)hipEventDestroy(f.ready);
+            f.ready = nullptr;
+        }
+        return f;
     }
     Tracker& tracker(uint64_t id)
     {
@@ -228,6 +237,7 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
 void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsample, double adjust,
                   std::vector<std::vector<RawDet>>& raw_sorted);
 void ml_plans_free(Ctx* c);
+void ingest_free_all(Ctx* c);
 void det_nms(const DetectorModel& m, const std::vector<RawDet>& sorted, std::vector<RawDet>& out);
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* h, int* w);
 void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::vector<float>* out, int* fh, int* fw);

@@ -5,6 +5,7 @@
 #include "pvf_internal.h"
 #include <cmath>
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256) prep_input_k(const uint8_t* __restrict__ 
 
 struct ConvArgs {
     const float* in; int B, H, W, Cin;
-    const float* w; int K;             // K = ksz*ksz*Cin (logical), weights [K][Cout]
+    const float* w; int K;             // K = ksz*ksz*Cin (k = (r*ksz + s)*Cin + c), weights transposed: [Cout][K padded to 32]
     const float* bias; const float* gamma; const float* beta;
     float* out; int OH, OW, Cout;      // output tensor dims
     int AH, AW;                        // conv-valid dims (<= OH, OW)
@@ -65,34 +66,37 @@ struct ConvArgs {
     const float* skip; int XH, XW, XC, SH, SW;
 };
 
-// BM = 32*WM output pixels, BN = 32*WN output channels, KC = 32 per stage
+// Implicit-GEMM convolution on v_mfma_f32_32x32x2_f32.  Block tile BM x BN = (64 WM) x (32 WN) output pixels x channels, 4 waves; a wave owns
+// a 64 x 32 tile = two 32 x 32 accumulators that share every B fragment.  K (= taps x input channels, the order of the oracle's chain)
+// advances in chunks of 32 through LDS; the next chunk's global loads are in flight during the MFMAs of the current one.
+// LDS layout: one row of 32 k-values per output pixel (A) / output channel (B), padded to 36 floats, with the even k first and the odd k
+// behind them (position (k >> 1) + 16 (k & 1)): lane (i, h) of a 32 x 32 x 2 MFMA needs k = 2 s + h for s = 0..15, i.e. 16 CONTIGUOUS floats
+// = 4 ds_read_b128 per 16 MFMAs (the 36-float pitch makes them conflict-free), instead of one ds_read_b32 per operand and MFMA.
+// Weights are stored transposed ([cout][K padded to 32], ctx.hip) so that both tiles are staged with the same 16-byte loads along k.
 template <int WM, int WN>
 __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
 {
-    constexpr int BM = 32 * WM, BN = 32 * WN, KC = 32;
-    constexpr int PA = BM + 2, PB = BN + 4;     // PB: 16-byte aligned rows -> one ds_write_b128 per staged float4
-    __shared__ float As[KC * PA];
-    __shared__ __attribute__((aligned(16))) float Bs[KC * PB];
+    constexpr int BM = 64 * WM, BN = 32 * WN, KC = 32, PITCH = 36;
+    static_assert(WM * WN == 4, "four waves per block");
+    __shared__ __attribute__((aligned(16))) float As[BM * PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const long M = (long)a.B * a.OH * a.OW;
     const long m0 = (long)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
-    f32x16 acc;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 
-    // staging roles. fast path: thread loads float4s of A: (pixel i, 4 channels); BM*KC/4 float4 per stage
-    constexpr int A_F4 = BM * KC / 4 / 256; // float4 per thread (2 for BM=64, 4 for BM=128)
-    constexpr int B_F4 = KC * BN / 4 / 256;
-    int pa_b[A_F4], pa_y[A_F4], pa_x[A_F4], pa_i[A_F4], pa_j[A_F4];
+    // staging roles: A tile = BM rows x 8 float4 (4 consecutive k = 4 input channels of one tap), B tile = BN rows x 8 float4
+    constexpr int A_F4 = BM * 8 / 256, B_F4 = BN * 8 / 256;
+    int pa_b[A_F4], pa_y[A_F4], pa_x[A_F4];
     bool pa_ok[A_F4];
 #pragma unroll
     for (int q = 0; q < A_F4; ++q) {
-        const int idx = tid + q * 256;     // over BM * 8
-        const int i = idx >> 3, j = idx & 7;
+        const int i = (tid + q * 256) >> 3;
         const long m = m0 + i;
-        pa_i[q] = i; pa_j[q] = j;
         pa_ok[q] = false; pa_b[q] = 0; pa_y[q] = 0; pa_x[q] = 0;
         if (m < M) {
             const int ox = (int)(m % a.OW);
@@ -104,88 +108,92 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
         }
     }
     const int Kpad = (a.K + KC - 1) / KC * KC;
-    // fast path: the global loads of K-chunk k0 + KC are issued before the MFMAs of chunk k0 and land in LDS after them, so
-    // a block no longer waits for memory between its two barriers
+    const int j4 = tid & 7;                             // which float4 of a row this thread moves
     float4 va[A_F4], vb[B_F4];
     auto fetch = [&](int k0) {
-        // one float4 = 4 consecutive input channels of one filter tap.  Cin >= 32: the whole chunk lies in one tap;
-        // Cin == 4 (the padded RGB input): every float4 is a tap of its own
+        // Cin >= 32: the whole chunk lies in one tap; Cin == 4 (the padded RGB input): every float4 is a tap of its own
         const bool one_tap = (a.Cin >= KC);
         const int tap0 = k0 / a.Cin, c00 = k0 - tap0 * a.Cin;
+        const int kq = k0 + 4 * j4;
+        int tap = tap0, c0 = c00 + 4 * j4;
+        if (!one_tap) { tap = kq / a.Cin; c0 = kq - tap * a.Cin; }
+        const int r = tap / a.ksz, sft = tap - r * a.ksz;
 #pragma unroll
         for (int q = 0; q < A_F4; ++q) {
             va[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int kq = k0 + 4 * pa_j[q];
-            int tap = tap0, c0 = c00 + 4 * pa_j[q];
-            if (!one_tap) { tap = kq / a.Cin; c0 = kq - tap * a.Cin; }
-            const int r = tap / a.ksz, s = tap - r * a.ksz;
-            const int iy = pa_y[q] + r, ix = pa_x[q] + s;
+            const int iy = pa_y[q] + r, ix = pa_x[q] + sft;
             if (kq < a.K && pa_ok[q] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
                 va[q] = *reinterpret_cast<const float4*>(a.in + (((size_t)pa_b[q] * a.H + iy) * a.W + ix) * a.Cin + c0);
         }
 #pragma unroll
         for (int q = 0; q < B_F4; ++q) {
-            const int idx = tid + q * 256;          // over KC * BN/4
-            const int kk = idx / (BN / 4), j4 = idx % (BN / 4);
-            const int k = k0 + kk;
-            vb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < a.K) vb[q] = *reinterpret_cast<const float4*>(a.w + (size_t)k * a.Cout + n0 + 4 * j4);
+            const int j = (tid + q * 256) >> 3;
+            vb[q] = *reinterpret_cast<const float4*>(a.w + (size_t)(n0 + j) * Kpad + kq);     // zero-padded beyond K
         }
     };
     auto park = [&]() {
 #pragma unroll
         for (int q = 0; q < A_F4; ++q) {
-            const int kk = 4 * pa_j[q];
-            As[(kk + 0) * PA + pa_i[q]] = va[q].x;
-            As[(kk + 1) * PA + pa_i[q]] = va[q].y;
-            As[(kk + 2) * PA + pa_i[q]] = va[q].z;
-            As[(kk + 3) * PA + pa_i[q]] = va[q].w;
+            float* row = &As[((tid + q * 256) >> 3) * PITCH + 2 * j4];
+            *reinterpret_cast<float2*>(row) = make_float2(va[q].x, va[q].z);          // k = 4 j4, 4 j4 + 2   (even half)
+            *reinterpret_cast<float2*>(row + 16) = make_float2(va[q].y, va[q].w);     // k = 4 j4 + 1, + 3    (odd half)
         }
 #pragma unroll
         for (int q = 0; q < B_F4; ++q) {
-            const int idx = tid + q * 256;
-            const int kk = idx / (BN / 4), j4 = idx % (BN / 4);
-            *reinterpret_cast<float4*>(&Bs[kk * PB + 4 * j4]) = vb[q];
+            float* row = &Bs[((tid + q * 256) >> 3) * PITCH + 2 * j4];
+            *reinterpret_cast<float2*>(row) = make_float2(vb[q].x, vb[q].z);
+            *reinterpret_cast<float2*>(row + 16) = make_float2(vb[q].y, vb[q].w);
         }
     };
+    const int li = lane & 31, kh = lane >> 5;
+    const float* pa0 = &As[(wm * 64 + li) * PITCH + 16 * kh];
+    const float* pa1 = pa0 + 32 * PITCH;
+    const float* pb = &Bs[(wn * 32 + li) * PITCH + 16 * kh];
     fetch(0);
     for (int k0 = 0; k0 < Kpad; k0 += KC) {
         park();
         __syncthreads();
         if (k0 + KC < Kpad) fetch(k0 + KC);
-        const int ai = wm * 32 + (lane & 31), bj = wn * 32 + (lane & 31), kh = lane >> 5;
+        f32x4 fa0[4], fa1[4], fb[4];
 #pragma unroll
-        for (int kk = 0; kk < KC; kk += 2) {
-            const float av = As[(kk + kh) * PA + ai];
-            const float bv = Bs[(kk + kh) * PB + bj];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+            fa0[q] = *reinterpret_cast<const f32x4*>(pa0 + 4 * q);
+            fa1[q] = *reinterpret_cast<const f32x4*>(pa1 + 4 * q);
+            fb[q] = *reinterpret_cast<const f32x4*>(pb + 4 * q);
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s >> 2][s & 3], fb[s >> 2][s & 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s >> 2][s & 3], fb[s >> 2][s & 3], acc1, 0, 0, 0);
         }
         __syncthreads();
     }
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    const int col = n0 + wn * 32 + (lane & 31);
+    const int col = n0 + wn * 32 + li;
     const float bias = a.bias[col], g = a.gamma[col], bt = a.beta[col];
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        const long m = m0 + wm * 32 + row;
-        if (m >= M) continue;
-        const int ox = (int)(m % a.OW);
-        const long t = m / a.OW;
-        const int oy = (int)(t % a.OH);
-        const int b = (int)(t / a.OH);
-        float v = 0.0f;
-        if (oy < a.AH && ox < a.AW) v = (acc[reg] + bias) * g + bt;
-        if (a.skip_mode == 1) v += a.skip[(size_t)m * a.Cout + col];
-        else if (a.skip_mode == 2) {
-            if (col < a.XC && oy < a.SH && ox < a.SW) {
-                const float* q = a.skip + (((size_t)b * a.XH + 2 * oy) * a.XW + 2 * ox) * a.XC + col;
-                v += (((q[0] + q[a.XC]) + q[(size_t)a.XW * a.XC]) + q[(size_t)a.XW * a.XC + a.XC]) * 0.25f;
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            const long m = m0 + wm * 64 + t * 32 + row;
+            if (m >= M) continue;
+            const int ox = (int)(m % a.OW);
+            const long tq = m / a.OW;
+            const int oy = (int)(tq % a.OH);
+            const int b = (int)(tq / a.OH);
+            float v = 0.0f;
+            if (oy < a.AH && ox < a.AW) v = ((t == 0 ? acc0[reg] : acc1[reg]) + bias) * g + bt;
+            if (a.skip_mode == 1) v += a.skip[(size_t)m * a.Cout + col];
+            else if (a.skip_mode == 2) {
+                if (col < a.XC && oy < a.SH && ox < a.SW) {
+                    const float* q = a.skip + (((size_t)b * a.XH + 2 * oy) * a.XW + 2 * ox) * a.XC + col;
+                    v += (((q[0] + q[a.XC]) + q[(size_t)a.XW * a.XC]) + q[(size_t)a.XW * a.XC + a.XC]) * 0.25f;
+                }
             }
+            if (a.relu && v < 0.0f) v = 0.0f;
+            a.out[(size_t)m * a.Cout + col] = v;
         }
-        if (a.relu && v < 0.0f) v = 0.0f;
-        a.out[(size_t)m * a.Cout + col] = v;
-    }
 }
 
 __global__ void __launch_bounds__(256) maxpool3s2_k(const float* __restrict__ in, int B, int H, int W, int C, float* __restrict__ out, int OH, int OW)
@@ -228,10 +236,10 @@ static void launch_conv(Ctx* c, const ConvArgs& a)
     const long M = (long)a.B * a.OH * a.OW;
     PVF_REQUIRE(a.Cin % 32 == 0 || a.Cin == 4, "conv: input channels must be 4 (padded RGB) or a multiple of 32");
     if (a.Cout == 32) {
-        hipLaunchKernelGGL((conv_mfma_k<4, 1>), dim3((unsigned)((M + 127) / 128), 1), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((conv_mfma_k<4, 1>), dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, c->stream, a);
     } else {
         PVF_REQUIRE(a.Cout % 64 == 0, "conv: Cout must be 32 or a multiple of 64");
-        hipLaunchKernelGGL((conv_mfma_k<2, 2>), dim3((unsigned)((M + 63) / 64), a.Cout / 64), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((conv_mfma_k<2, 2>), dim3((unsigned)((M + 127) / 128), a.Cout / 64), dim3(256), 0, c->stream, a);
     }
 }
 

@@ -37,6 +37,12 @@ _SIGS = {
     "pvf_frame_wrap_device": (C.c_int32, [H, P, C.c_int32, C.c_int32, P]),
     "pvf_frame_release": (C.c_int32, [H, H]),
     "pvf_frame_device_ptr": (C.c_int32, [H, H, P]),
+    "pvf_ingest_create": (C.c_int32, [H, C.c_int32, C.c_int32, C.c_int32, P]),
+    "pvf_ingest_destroy": (C.c_int32, [H, H]),
+    "pvf_ingest_acquire": (C.c_int32, [H, H, P, P]),
+    "pvf_ingest_submit": (C.c_int32, [H, H, C.c_int32, P]),
+    "pvf_ingest_wait": (C.c_int32, [H, H]),
+    "pvf_frame_resize": (C.c_int32, [H, H, C.c_int32, C.c_int32, P]),
     "pvf_detect": (C.c_int32, [H, H, C.c_int32, C.c_double, P, P, C.c_int32, P]),
     "pvf_detect_batch": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_double, P, P, P, C.c_int32]),
     "pvf_detect_many": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int32, C.c_double, P, P, P, C.c_int32]),

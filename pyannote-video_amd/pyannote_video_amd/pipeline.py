@@ -200,6 +200,7 @@ class FacePipeline(object):
                                      track_max_gap=track_max_gap, ctx=ctx, detect_batch_size=detect_batch_size)
         self.clustering = FaceClustering(threshold=threshold, ctx=ctx)
         self.detect_every = detect_every
+        self.detect_min_size = detect_min_size
 
     def _run_pipelined(self, shot_inputs, backend, ex, normalize, mark):
         """GPU thread: detect(k), speculate(k), extract(k-1) ...; this thread: lanes + merging of shot k as soon as its detections
@@ -328,9 +329,17 @@ class FacePipeline(object):
         every = int(self.detect_every * frame_rate) if self.detect_every > 0.0 else 1
         every = max(every, 1)
         ranges = split_into_shots(times, shots)
+        # --min-size: detection and tracking run on frames scaled down so that the smallest face wanted is ~36 px tall; boxes are
+        # normalised by that size (tracking.py:389-400,414) and `extract` works on the native frames (pyannote-face.py:275-277)
+        tw, th, track_frames = w, h, frames
+        if self.detect_min_size > 0.0:
+            ratio = min(1.0, self.tracking.detect_smallest / (self.detect_min_size * h))
+            tw, th = int(w * ratio), int(h * ratio)
+            if (tw, th) != (w, h):
+                track_frames = [self.ctx.resize(f, tw, th) for f in frames]
         shot_inputs = []
         for i0, i1 in ranges:
-            cache = [(times[i], frames[i]) for i in range(i0, i1)]
+            cache = [(times[i], track_frames[i]) for i in range(i0, i1)]
             flags = [(i % every == 0) for i in range(i0, i1)]
             shot_inputs.append((cache, flags))
         backend = HipTrackers(self.ctx)
@@ -338,7 +347,7 @@ class FacePipeline(object):
         mark = {}
 
         def normalize(shot_tracks):
-            return [self.tracking._normalize_track(tr, w, h) for tr in shot_tracks]
+            return [self.tracking._normalize_track(tr, tw, th) for tr in shot_tracks]
 
         if not self.overlap:
             for k, shot_tracks in enumerate(self.tracking.process_shots(shot_inputs, backend)):

@@ -31,6 +31,50 @@ class DeviceFrame(object):
             pass
 
 
+class IngestRing(object):
+    """Pinned host slots of one frame size + a copy stream (pvf_ingest_*).  `slot()` hands out the next slot as a numpy view for the
+    decoder to write into; `submit()` queues its upload and returns a DeviceFrame at once -- kernels that read the frame wait for
+    the copy on the device, so uploads run beside the compute stream."""
+
+    def __init__(self, ctx, height, width, depth=8):
+        self.ctx, self.h, self.w, self.depth = ctx, int(height), int(width), int(depth)
+        r = C.c_uint64(0)
+        check(ctx._l.pvf_ingest_create(ctx._h, self.h, self.w, self.depth, C.byref(r)))
+        self._r = r.value
+        self._cur = None
+
+    def slot(self):
+        s, p = C.c_int32(0), C.c_void_p(0)
+        check(self.ctx._l.pvf_ingest_acquire(self.ctx._h, self._r, C.byref(s), C.byref(p)))
+        self._cur = s.value
+        buf = (C.c_uint8 * (self.h * self.w * 3)).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(self.h, self.w, 3)
+
+    def submit(self):
+        h = C.c_uint64(0)
+        check(self.ctx._l.pvf_ingest_submit(self.ctx._h, self._r, self._cur, C.byref(h)))
+        return DeviceFrame(self.ctx, h.value, self.h, self.w)
+
+    def wait(self):
+        check(self.ctx._l.pvf_ingest_wait(self.ctx._h, self._r))
+
+    def push(self, rgb):
+        """copy a decoded frame into the next slot and queue its upload (a decoder would write into slot() directly)"""
+        np.copyto(self.slot(), rgb)
+        return self.submit()
+
+    def close(self):
+        if self._r is not None and self.ctx._h is not None:
+            self.ctx._l.pvf_ingest_destroy(self.ctx._h, self._r)
+        self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context(object):
     def __init__(self, device=0, detector=_models.DEFAULT_DETECTOR, landmarks=None, embedding=None, priority=0):
         self._h = None
@@ -115,6 +159,16 @@ class Context(object):
         """t: torch.uint8 CUDA tensor [H, W, 3], contiguous"""
         assert t.is_cuda and t.is_contiguous() and t.dim() == 3 and t.shape[2] == 3 and t.element_size() == 1
         return self.wrap_device(t.data_ptr(), t.shape[0], t.shape[1], keep=t)
+
+    def resize(self, frame, width, height):
+        """cv2.resize(frame, (width, height)) on the device (reference video.py:402-403): a new DeviceFrame; the source stays resident"""
+        f = self.stage(frame)
+        h = C.c_uint64(0)
+        check(self._l.pvf_frame_resize(self._h, f.handle, int(width), int(height), C.byref(h)))
+        return DeviceFrame(self, h.value, int(height), int(width))
+
+    def ingest_ring(self, height, width, depth=8):
+        return IngestRing(self, height, width, depth)
 
     def stage(self, rgb):
         """DeviceFrame for whatever the caller holds: DeviceFrame (as is) or numpy array (uploaded once, cached by identity)."""

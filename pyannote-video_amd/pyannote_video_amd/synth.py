@@ -181,9 +181,9 @@ class SyntheticVideo(object):
 
     @frame_size.setter
     def frame_size(self, value):
-        if tuple(value) != self._size:
-            raise NotImplementedError("SyntheticVideo renders at native size only")
-        self._frame_size = tuple(value)
+        # the reference's Video resizes every frame it hands out to this size (video.py:180-187,402-403); this source keeps rendering
+        # at native size and leaves the resize to the consumer (TrackingByDetection does it on the device)
+        self._frame_size = tuple(int(v) for v in value)
 
     def __len__(self):
         return self.n_frames

@@ -486,6 +486,13 @@ class TrackingByDetection(object):
         self._run_lanes([l for j in jobs for l in j["lanes"]], backend)
         return [self.finish_shot(j) for j in jobs]
 
+    @staticmethod
+    def _detection_frame(frame, width, height, backend):
+        ctx = getattr(backend, "ctx", None)
+        if ctx is None:
+            raise NotImplementedError("detect_min_size needs frames of the detection size, or a GPU tracker backend that resizes them")
+        return ctx.resize(frame, width, height)
+
     def _backend(self):
         if self._trackers_backend is None:
             from . import runtime
@@ -509,6 +516,10 @@ class TrackingByDetection(object):
         backend = self._backend()
         cache, flags = [], []
         for i, (t, frame) in enumerate(video):
+            # the reference's Video hands out frames already resized to frame_size (video.py:402-403: cv2.resize per frame on the host);
+            # a source that yields native frames gets them resized on the device, where they are staged anyway
+            if (frame.shape[1], frame.shape[0]) != (frame_width, frame_height):
+                frame = self._detection_frame(frame, frame_width, frame_height, backend)
             segment = segment_generator.send(t)
             if segment:
                 for track in self.process_shots([(cache, flags)], backend)[0]:
