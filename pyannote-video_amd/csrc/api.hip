@@ -172,6 +172,16 @@ extern "C" int32_t pvf_tracker_clone_many(pvf_handle h, const pvf_handle* src, i
     API_END
 }
 
+// released tracker states are kept for reuse up to this many (2.39 MB each); beyond it they go back to the allocator, so a long shot's
+// burst of trackers does not stay resident for the rest of the video
+static const size_t TRACKER_POOL_KEEP = 4096;
+static void pool_tracker_state(Ctx* c, double* d_state)
+{
+    if (c->tracker_pool.size() < TRACKER_POOL_KEEP) { c->tracker_pool.push_back(d_state); return; }
+    HIP_CHECK(hipStreamSynchronize(c->stream));      // kernels that still read the state have finished
+    HIP_CHECK(hipFree(d_state));
+}
+
 extern "C" int32_t pvf_tracker_destroy_many(pvf_handle h, const pvf_handle* trks, int32_t n)
 {
     API_BEGIN
@@ -179,7 +189,7 @@ extern "C" int32_t pvf_tracker_destroy_many(pvf_handle h, const pvf_handle* trks
     for (int i = 0; i < n; ++i) {
         auto it = c->trackers.find(trks[i]);
         PVF_REQUIRE(it != c->trackers.end(), "unknown tracker handle");
-        c->tracker_pool.push_back(it->second->d_state);
+        pool_tracker_state(c, it->second->d_state);
         c->trackers.erase(it);
     }
     API_END
@@ -191,7 +201,7 @@ extern "C" int32_t pvf_tracker_destroy(pvf_handle h, pvf_handle trk)
     Ctx* c = enter(h);
     auto it = c->trackers.find(trk);
     PVF_REQUIRE(it != c->trackers.end(), "unknown tracker handle");
-    c->tracker_pool.push_back(it->second->d_state);
+    pool_tracker_state(c, it->second->d_state);
     c->trackers.erase(it);
     API_END
 }

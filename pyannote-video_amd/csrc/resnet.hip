@@ -171,6 +171,23 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int col = n0 + wn * 32 + li;
     const float bias = a.bias[col], g = a.gamma[col], bt = a.beta[col];
+    if (a.AH == a.OH && a.AW == a.OW && a.skip_mode != 2) {
+        // every output pixel is a convolution result and the skip tensor (if any) has the output's shape: 24 of the 29 layers.
+        // No pixel coordinates are needed -- the 64 integer divisions per lane of the general form below cost as much as the K loop of
+        // a 3 x 3 x 32 layer
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const long m = m0 + wm * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                if (m >= M) continue;
+                float v = ((t == 0 ? acc0[reg] : acc1[reg]) + bias) * g + bt;
+                if (a.skip_mode == 1) v += a.skip[(size_t)m * a.Cout + col];
+                if (a.relu && v < 0.0f) v = 0.0f;
+                a.out[(size_t)m * a.Cout + col] = v;
+            }
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll

@@ -4,7 +4,116 @@ per-rank (time, track id, 128-D embedding) rows over RCCL/xGMI, followed by a si
 
 Track ids: the reference numbers tracks in yield order over the whole video (pyannote-face.py:261) and tracks never span
 shots (tracking.py:359-362,410-417), so global id = local id + exclusive prefix sum of the per-rank track counts."""
+import ctypes as C
+import os
 import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DIST_LIB_PATH = os.path.join(_HERE, "libpvface_dist.so")
+_DIST_SIGS = {
+    "pvfd_last_error": (C.c_char_p, []),
+    "pvfd_unique_id": (C.c_int32, [C.c_void_p]),
+    "pvfd_comm_create": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pvfd_comm_destroy": (C.c_int32, [C.c_uint64]),
+    "pvfd_allgather_rows": (C.c_int32, [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pvfd_max_rows": (C.c_int32, [C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
+}
+DIST_EXPORTS = sorted(_DIST_SIGS)
+_dist_lib = None
+
+
+def dist_lib():
+    """libpvface_dist.so (include/pvface_dist.h): the RCCL all-gather behind a C ABI"""
+    global _dist_lib
+    if _dist_lib is None:
+        l = C.CDLL(DIST_LIB_PATH)
+        for name, (res, args) in _DIST_SIGS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _dist_lib = l
+    return _dist_lib
+
+
+class RcclRows(object):
+    """one communicator of libpvface_dist.so per process: all-gather of float64 rows with a different count per rank"""
+
+    def __init__(self, device, rank, world, unique_id):
+        self.l = dist_lib()
+        self.rank, self.world = rank, world
+        h = C.c_uint64(0)
+        idb = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self.l.pvfd_comm_create(int(device), int(rank), int(world), idb, C.byref(h)))
+        self.h = h.value
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("libpvface_dist: " + self.l.pvfd_last_error().decode("utf-8", "replace"))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        l = dist_lib()
+        if l.pvfd_unique_id(buf) != 0:
+            raise RuntimeError("libpvface_dist: " + l.pvfd_last_error().decode("utf-8", "replace"))
+        return bytes(buf)
+
+    def allgather_rows(self, rows):
+        """rows float64 [n, k] (n may differ per rank, k must not) -> (all rows in rank order [N, k], counts per rank)"""
+        rows = np.ascontiguousarray(rows, np.float64)
+        n, k = rows.shape
+        counts = np.zeros(self.world, np.int64)
+        total = C.c_int64(0)
+        self._check(self.l.pvfd_max_rows(self.h, n, counts.ctypes.data_as(C.c_void_p), C.byref(total)))
+        out = np.zeros((max(total.value, 1), k), np.float64)
+        self._check(self.l.pvfd_allgather_rows(self.h, rows.ctypes.data_as(C.c_void_p), n, k, counts.ctypes.data_as(C.c_void_p),
+                                               out.ctypes.data_as(C.c_void_p), len(out), C.byref(total)))
+        return out[:total.value], [int(c) for c in counts]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.l.pvfd_comm_destroy(self.h)
+            self.h = None
+
+
+_rccl = {"tried": False, "comm": None}
+
+
+def rccl_rows():
+    """The process's RCCL communicator of libpvface_dist.so, or None when the job does not run on GPUs over nccl (CPU tests over gloo),
+    when PVF_DIST_COLLECTIVE=torch asks for the torch.distributed collectives, or when any rank failed to set it up (all ranks then
+    agree to use torch.distributed instead -- decided with one all-reduce, so no rank is left waiting in a collective)."""
+    import torch
+    import torch.distributed as dist
+    if _rccl["tried"]:
+        return _rccl["comm"]
+    _rccl["tried"] = True
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    if dist.get_backend() != "nccl" or os.environ.get("PVF_DIST_COLLECTIVE", "rccl") == "torch":
+        return None
+    rank, world = dist.get_rank(), dist.get_world_size()
+    comm, ok = None, 1
+    try:
+        box = [RcclRows.unique_id() if rank == 0 else None]
+    except Exception:
+        box, ok = [None], 0
+    dist.broadcast_object_list(box, src=0)
+    try:
+        if box[0] is None:
+            raise RuntimeError("no communicator id")
+        comm = RcclRows(torch.cuda.current_device(), rank, world, box[0])
+    except Exception as e:                      # noqa: BLE001 -- any failure means: use the torch path, together
+        import sys
+        sys.stderr.write("[pvface] libpvface_dist unavailable on rank %d (%s); using torch.distributed collectives\n" % (rank, e))
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if comm is not None:
+            comm.close()
+        comm = None
+    _rccl["comm"] = comm
+    return comm
 
 
 def shard_shots(shot_ranges, world_size):
@@ -62,6 +171,43 @@ def gather_rows(face_T, face_id, X, n_tracks, device=None, file_T=None, file_id=
             T, ids, Xa = T[perm], ids[perm], Xa[perm]
         return T, ids, Xa, [0]
     world = dist.get_world_size()
+    rc = rccl_rows()
+    if rc is not None:
+        # the C-ABI collective (libpvface_dist.so): one row of (T, local id, 128 values, this rank's track count) per face; a rank
+        # without faces still announces its track count with a marker row
+        nT = len(face_T)
+        loc = np.zeros((max(nT, 1), 131), np.float64)
+        loc[:, 130] = float(n_tracks)
+        if nT:
+            loc[:, 0] = np.asarray(face_T, np.float64); loc[:, 1] = np.asarray(face_id, np.float64); loc[:, 2:130] = np.asarray(X, np.float64)
+        else:
+            loc[0, 1] = -1.0
+        allrows, counts = rc.allgather_rows(loc)
+        tracks, o = [], 0
+        for cnt in counts:
+            tracks.append(int(allrows[o, 130])); o += cnt
+        offsets = [0]
+        for k in tracks[:-1]:
+            offsets.append(offsets[-1] + k)
+        Ts, ids, Xs, o = [], [], [], 0
+        for r, cnt in enumerate(counts):
+            a = allrows[o:o + cnt]; o += cnt
+            a = a[a[:, 1] >= 0]
+            Ts.append(a[:, 0]); ids.append(a[:, 1].astype(np.int64) + offsets[r]); Xs.append(a[:, 2:130])
+        T, gid, Xa = np.concatenate(Ts), np.concatenate(ids), np.ascontiguousarray(np.concatenate(Xs))
+        if file_T is not None:
+            ft = np.stack([np.asarray(file_T, np.float64), np.asarray(file_id, np.float64)], 1).reshape(-1, 2)
+            marker = len(ft) == 0
+            fall, fcounts = rc.allgather_rows(ft if not marker else np.array([[0.0, -1.0]]))
+            fT, fid, o = [], [], 0
+            for r, cnt in enumerate(fcounts):
+                a = fall[o:o + cnt]; o += cnt
+                a = a[a[:, 1] >= 0]
+                fT.append(a[:, 0]); fid.append(a[:, 1].astype(np.int64) + offsets[r])
+            if len(T):
+                perm = formats.file_order(T, gid, np.concatenate(fT), np.concatenate(fid))
+                T, gid, Xa = T[perm], gid[perm], np.ascontiguousarray(Xa[perm])
+        return T, gid, Xa, offsets
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
     counts = torch.tensor([len(face_T), int(n_tracks)], dtype=torch.int64, device=dev)
     allc = [torch.zeros_like(counts) for _ in range(world)]
@@ -126,6 +272,12 @@ class DistanceShard(object):
         import torch.distributed as dist
         T = D_mine.shape[0]
         cuts = self.bounds(row_start)
+        rc = rccl_rows()
+        if rc is not None:
+            a, b = cuts[self.rank], cuts[self.rank + 1]
+            allrows, counts = rc.allgather_rows(np.ascontiguousarray(D_mine[a:b]).reshape(b - a, T))
+            assert counts == [cuts[r + 1] - cuts[r] for r in range(self.world)] and len(allrows) == T
+            return np.ascontiguousarray(allrows)
         dev = self.device if self.device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
         t = torch.from_numpy(np.ascontiguousarray(D_mine)).to(dev)
         parts = [torch.zeros_like(t) for _ in range(self.world)]

@@ -143,6 +143,14 @@ class ExtractStream(object):
         """reorder: put the faces of one timestamp into the order the reference's `extract` writes them (formats.file_order).
         A shard of a longer video leaves that to the step that sees the whole track table (dist.gather_rows)."""
         self.compute(self._emit(len(self.groups) - (1 if drop_last else 0)))
+        if not drop_last and self.gi < len(self.groups):
+            # a shard that is not the end of the video must hand on ALL its groups.  A group is left over when '%.3f' rounded a frame time
+            # UP (e.g. 30 fps: t = 0.066667 -> T = 0.067 > t): the reference then serves that group one frame late and carries the lag
+            # across the shot boundary, i.e. into the next shard -- a shard cannot reproduce that on its own.  All BASELINE.json
+            # configurations run at 25 / 50 fps, whose frame times survive the rounding.
+            raise ValueError("frame-range shard ends with %d face group(s) whose rounded time lies behind the shard's last frame; cut the "
+                             "video at shots whose frame times survive 3-decimal rounding (25 / 50 fps do) or run it unsharded"
+                             % (len(self.groups) - self.gi))
         pts = np.concatenate(self.pts) if self.pts else np.zeros((0, 68, 2), np.int32)
         emb = np.concatenate(self.emb) if self.emb else np.zeros((0, 128), np.float32)
         if reorder and len(self.face_T):

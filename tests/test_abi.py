@@ -20,6 +20,18 @@ def test_library_exports_every_declared_symbol():
     assert l.pvf_version() >= 100
 
 
+def test_dist_library_exports_every_declared_symbol():
+    """libpvface_dist.so (the RCCL all-gather behind a C ABI, include/pvface_dist.h) loads and exports what its header declares"""
+    from pyannote_video_amd import dist
+    hdr = open(os.path.join(ROOT, "include", "pvface_dist.h")).read()
+    declared = sorted(set(re.findall(r"\b(pvfd_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) == 6
+    l = dist.dist_lib()
+    for name in declared:
+        assert hasattr(l, name), name
+    assert set(declared) == set(dist.DIST_EXPORTS)
+
+
 def test_host_entry_points_without_gpu():
     from pyannote_video_amd import _lib
     assert _lib.munkres(np.array([[4., 1.], [2., 3.]])) == [(0, 1), (1, 0)]

@@ -15,6 +15,13 @@ import torch.distributed as dist
 from pyannote_video_amd import dist as pd
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
+if os.environ.get("PVF_TEST_ROWS_OVER_GLOO"):
+    # drive the code path of the C-ABI collective (libpvface_dist.so: RcclRows.allgather_rows) with a gloo stand-in of the same interface
+    class GlooRows(object):
+        def allgather_rows(self, rows):
+            parts = pd._gather_padded(np.ascontiguousarray(rows, np.float64), "cpu")
+            return np.concatenate(parts), [len(p) for p in parts]
+    pd._rccl["tried"] = True; pd._rccl["comm"] = GlooRows()
 rng = np.random.default_rng(100 + rank)
 n_tracks = 3 + rank
 rows = 5 + 2 * rank
@@ -28,11 +35,18 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_gather_rows_world2(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("rows_lib_path", [False, True])
+def test_gather_rows_world2(tmp_path, rows_lib_path):
+    """rows_lib_path: the branch of gather_rows that goes through the C-ABI collective's interface (driven over gloo here)"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "out")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if rows_lib_path:
+        env["PVF_TEST_ROWS_OVER_GLOO"] = "1"
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                            "--master-port", "29613", str(script), ROOT, out], env=env, timeout=240)
     import json
@@ -55,6 +69,13 @@ import torch.distributed as dist
 from pyannote_video_amd import dist as pd
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
+if os.environ.get("PVF_TEST_ROWS_OVER_GLOO"):
+    # drive the code path of the C-ABI collective (libpvface_dist.so: RcclRows.allgather_rows) with a gloo stand-in of the same interface
+    class GlooRows(object):
+        def allgather_rows(self, rows):
+            parts = pd._gather_padded(np.ascontiguousarray(rows, np.float64), "cpu")
+            return np.concatenate(parts), [len(p) for p in parts]
+    pd._rccl["tried"] = True; pd._rccl["comm"] = GlooRows()
 table = json.loads(open(sys.argv[3]).read())[rank]                     # this rank's share of the track table, file order
 fT, fid = np.array(table["T"]), np.array(table["id"])
 order = np.random.default_rng(rank).permutation(len(fT))               # faces arrive in any order within the shard
@@ -65,7 +86,8 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_gather_rows_restores_reference_row_order_world2(tmp_path):
+@pytest.mark.parametrize("rows_lib_path", [False, True])
+def test_gather_rows_restores_reference_row_order_world2(tmp_path, rows_lib_path):
     """faces of one timestamp come out in the order pandas' (unstable) sort of the WHOLE track table gives (formats.file_order),
     however the table was split over the ranks"""
     import json
@@ -85,8 +107,8 @@ def test_gather_rows_restores_reference_row_order_world2(tmp_path):
     script.write_text(ORDER_WORKER)
     out = str(tmp_path / "out")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                           "--master-port", "29617", str(script), ROOT, out, str(tmp_path / "table.json")], env=dict(os.environ, MASTER_ADDR="127.0.0.1"),
-                          timeout=240)
+                           "--master-port", "29617", str(script), ROOT, out, str(tmp_path / "table.json")],
+                          env=dict(os.environ, MASTER_ADDR="127.0.0.1", **({"PVF_TEST_ROWS_OVER_GLOO": "1"} if rows_lib_path else {})), timeout=240)
     r0, r1 = (json.loads(open(out + ".%d" % r).read()) for r in (0, 1))
     want = formats.pandas_sort_order(fT)
     assert r0 == r1

@@ -69,6 +69,22 @@ def test_two_shards_equal_single_process(tmp_path, model_dir):
     ctx.close()
 
 
+def test_rccl_allgather_rows_single_rank():
+    """libpvface_dist.so on the one GPU of this box: communicator of size 1 -- id, ncclCommInitRank, both collectives of a gather, teardown
+    (a box with one GPU cannot host two ranks of one RCCL communicator; the N > 1 exchange logic is covered over gloo on CPU)"""
+    from pyannote_video_amd import dist
+    rng = np.random.default_rng(3)
+    comm = dist.RcclRows(0, 0, 1, dist.RcclRows.unique_id())
+    for n in (0, 1, 37, 5000):
+        rows = rng.normal(size=(n, 131))
+        out, counts = comm.allgather_rows(rows)
+        assert counts == [n] and out.shape == (n, 131) and np.array_equal(out, rows)
+    D = rng.normal(size=(40, 40))
+    out, counts = comm.allgather_rows(D)
+    assert np.array_equal(out, D)
+    comm.close()
+
+
 def test_cluster_stress_reduced_config5(ctx, oracle):
     """config 5 at reduced scale: T = 1500 tracks x 4 rows around 120 centres, distances bracket the 0.6 threshold"""
     rng = np.random.default_rng(17)
