@@ -50,11 +50,10 @@ extern "C" int32_t pvf_detect_many(pvf_handle h, const pvf_handle* frames, int32
     PVF_REQUIRE(upsample >= 0 && upsample <= 2, "pvf_detect_many: upsample must be 0..2");
     std::vector<Frame> fr(n_frames);
     for (int i = 0; i < n_frames; ++i) fr[i] = c->frame(frames[i]);
-    std::vector<std::vector<RawDet>> raw;
-    det_run_many(c, fr, batch, upsample, adjust, raw);
-    std::vector<RawDet> kept;
+    std::vector<std::vector<RawDet>> kept_all;
+    det_run_many(c, fr, batch, upsample, adjust, kept_all, true);
     for (int i = 0; i < n_frames; ++i) {
-        det_nms(c->det, raw[i], kept);
+        const std::vector<RawDet>& kept = kept_all[i];
         const int n = std::min<int>((int)kept.size(), cap);
         counts[i] = n;
         for (int k = 0; k < n; ++k) {

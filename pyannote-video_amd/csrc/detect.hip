@@ -892,7 +892,7 @@ static void decode_candidates(const DetectorModel& m, int upsample, const CandRe
 }
 
 void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsample, double adjust,
-                  std::vector<std::vector<RawDet>>& raw_sorted)
+                  std::vector<std::vector<RawDet>>& raw_sorted, bool nms)
 {
     const DetectorModel& m = c->det;
     PVF_REQUIRE(m.loaded, "detector not loaded");
@@ -904,7 +904,10 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
             std::vector<Frame> fr(frames.begin() + o, frames.begin() + std::min(N, o + batch));
             std::vector<std::vector<RawDet>> part;
             det_run_batch(c, fr, upsample, adjust, part);
-            for (size_t i = 0; i < part.size(); ++i) raw_sorted[o + i] = std::move(part[i]);
+            for (size_t i = 0; i < part.size(); ++i) {
+                if (nms) det_nms(m, part[i], raw_sorted[o + i]);
+                else raw_sorted[o + i] = std::move(part[i]);
+            }
         }
         return;
     }
@@ -944,11 +947,16 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
         for (int b = 0; b < B; ++b) {
             const int n = h_counts[b];
             if (n > cap) throw PvfError("detector: candidate buffer overflow (threshold far too low for this input)");
-            if (n <= PF) { decode_candidates(m, upsample, h_cands + (size_t)b * PF, n, raw_sorted[o + b]); continue; }
-            big.resize(n);                                      // rare: more candidates than were copied back ahead
-            HIP_CHECK(hipMemcpyAsync(big.data(), d_cands + (size_t)b * cap, (size_t)n * sizeof(CandRec), hipMemcpyDeviceToHost, c->stream));
-            HIP_CHECK(hipStreamSynchronize(c->stream));
-            decode_candidates(m, upsample, big.data(), n, raw_sorted[o + b]);
+            std::vector<RawDet> sorted_raw;
+            std::vector<RawDet>& dst = nms ? sorted_raw : raw_sorted[o + b];
+            if (n <= PF) decode_candidates(m, upsample, h_cands + (size_t)b * PF, n, dst);
+            else {
+                big.resize(n);                                  // rare: more candidates than were copied back ahead
+                HIP_CHECK(hipMemcpyAsync(big.data(), d_cands + (size_t)b * cap, (size_t)n * sizeof(CandRec), hipMemcpyDeviceToHost, c->stream));
+                HIP_CHECK(hipStreamSynchronize(c->stream));
+                decode_candidates(m, upsample, big.data(), n, dst);
+            }
+            if (nms) det_nms(m, sorted_raw, raw_sorted[o + b]);  // the suppression too runs while the next batch's kernels are queued
         }
     };
     submit(0, 0);

@@ -234,8 +234,9 @@ void pvf_set_error(const char* msg);
 struct RawDet { float score; int32_t filter, level, r, c, l, t, rr, b; };
 void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, double adjust,
                    std::vector<std::vector<RawDet>>& raw_sorted);
+// raw_sorted[i]: the candidates of frame i in canonical order, or -- with nms -- what survives det_nms (done batch by batch, overlapped)
 void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsample, double adjust,
-                  std::vector<std::vector<RawDet>>& raw_sorted);
+                  std::vector<std::vector<RawDet>>& raw_sorted, bool nms = false);
 void ml_plans_free(Ctx* c);
 void ingest_free_all(Ctx* c);
 void det_nms(const DetectorModel& m, const std::vector<RawDet>& sorted, std::vector<RawDet>& out);

@@ -136,13 +136,28 @@ def overlap_matrix(a, b, ratio):
     return out
 
 
+_assoc_buf = {}
+
+
 def associate(trackers, detections, ratio):
-    """[(tracker row, detection index)] of the reference's _associate, tracker rows ascending"""
-    a = np.ascontiguousarray(trackers, np.float64).reshape(-1, 4)
-    b = np.ascontiguousarray(detections, np.float64).reshape(-1, 4)
-    out = np.empty(len(a), np.int32)
-    check(lib().pvf_associate(ptr(a), len(a), ptr(b), len(b), float(ratio), ptr(out)))
-    return [(t, int(d)) for t, d in enumerate(out) if d >= 0]
+    """[(tracker row, detection index)] of the reference's _associate, tracker rows ascending.
+    Called once per frame and pass by the tracking state machine (thousands of times per shot): plain ctypes arrays, reused per size."""
+    na, nb = len(trackers), len(detections)
+    key = (na, nb)
+    buf = _assoc_buf.get(key)
+    if buf is None:
+        buf = _assoc_buf[key] = ((C.c_double * (4 * na))(), (C.c_double * (4 * nb))(), (C.c_int32 * max(na, 1))())
+    a, b, out = buf
+    k = 0
+    for box in trackers:
+        a[k], a[k + 1], a[k + 2], a[k + 3] = box
+        k += 4
+    k = 0
+    for box in detections:
+        b[k], b[k + 1], b[k + 2], b[k + 3] = box
+        k += 4
+    check(lib().pvf_associate(a, na, b, nb, float(ratio), out))
+    return [(t, d) for t, d in enumerate(out[:na]) if d >= 0]
 
 
 def munkres(cost):

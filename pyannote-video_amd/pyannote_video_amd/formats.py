@@ -42,7 +42,7 @@ def quantise_track_box(box, frame_width, frame_height):
 
 
 def quantise_time(t):
-    return float("%.3f" % t)
+    return round(t, 3)       # == float("%.3f" % t): both are the correctly rounded 3-decimal value (tests/test_host_logic.py)
 
 
 def pandas_sort_order(times):

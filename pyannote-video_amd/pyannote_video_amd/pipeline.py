@@ -113,10 +113,15 @@ class ExtractStream(object):
         """host part for the normalised tracks of the next shot (in shot order): the track-file rows, their timestamp groups,
         and the faces that can be extracted now"""
         base = len(self.tracks)
-        rows = []
+        # the track file's rows: time and box with 3 decimals ('%.3f'), the box then parsed as float32 (pyannote-face.py:125-127).
+        # round(v, 3) is the correctly rounded 3-decimal value, i.e. float('%.3f' % v); the float32 parse is one array cast.
+        flat = [round(v, 3) for track in tracks for _, box, _ in track for v in box]
+        q32 = np.asarray(flat, np.float64).astype(np.float32).astype(np.float64).reshape(-1, 4).tolist() if flat else []
+        rows, i = [], 0
         for k, track in enumerate(tracks):
-            for t, box, status in track:
-                rows.append((formats.quantise_time(t), base + k, tuple(np.float32("%.3f" % v) for v in box), status))
+            for t, _, status in track:
+                rows.append((round(t, 3), base + k, tuple(q32[i]), status))
+                i += 1
         self.file_T.extend(r[0] for r in rows)
         self.file_id.extend(r[1] for r in rows)
         rows.sort(key=lambda r: r[0])

@@ -385,6 +385,12 @@ class TrackingByDetection(object):
         fixed_track = []
         for t, group in itertools.groupby(sorted(track), key=lambda x: x[0]):
             group = list(group)
+            if len(group) == 1:
+                # the usual case with detection on every frame: one node at this time.  No pair to check, mean of one box = the box
+                # (float64 / 1 is exact), int(round()) of its coordinates
+                _, pos, status = group[0]
+                fixed_track.append((t, (int(round(pos[0])), int(round(pos[1])), int(round(pos[2])), int(round(pos[3]))), status))
+                continue
             error = False
             for (_, pos1, _), (_, pos2, _) in itertools.combinations(group, 2):
                 if self._no_match(pos1, pos2):
@@ -393,14 +399,15 @@ class TrackingByDetection(object):
             status = "+".join(sorted((status for _, _, status in group), key=lambda s: _STATUS_ORDER[s]))
             if error:
                 status = "error({0})".format(status)
-            # == np.mean(np.vstack(boxes), axis=0): float64 row-by-row sum, then one division (same IEEE operations)
+            # == np.mean(np.vstack(boxes), axis=0): float64 row-by-row sum, then one division -- the same IEEE operations on Python
+            # floats; round() of a Python float and of a numpy float64 are both round-half-to-even
             n = len(group)
             pos = []
             for k in range(4):
                 s = float(group[0][1][k])
                 for g in group[1:]:
                     s = s + float(g[1][k])
-                pos.append(int(round(np.float64(s) / n)))
+                pos.append(int(round(s / n)))
             pos = tuple(pos)
             fixed_track.append((t, pos, status))
         return fixed_track

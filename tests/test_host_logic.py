@@ -334,3 +334,14 @@ def test_frames_staged_for_one_call_are_not_evicted_before_it_runs():
     assert len(c._staged) == 4
     c._handles(frames[6:])                                # cached ones are reused, not uploaded again
     assert len(made) == 10
+
+
+def test_round3_equals_text_round_trip():
+    """formats.quantise_time / ExtractStream.prepare use round(v, 3) for the '%.3f' round trip of the track file"""
+    rng = np.random.default_rng(9)
+    vals = np.concatenate([rng.random(200000), rng.random(50000) * 40, (np.arange(100000) + 0.5) / 1000.0, (np.arange(100000) + 0.5) / 1000.0 + 1e-17])
+    for v in vals.tolist():
+        assert round(v, 3) == float("%.3f" % v)
+    box = (0.123456, 0.5, 0.987654, 0.75)
+    q = np.asarray([round(v, 3) for v in box], np.float64).astype(np.float32).astype(np.float64).tolist()
+    assert q == [float(np.float32("%.3f" % v)) for v in box]
