@@ -134,9 +134,7 @@ extern "C" int32_t pvf_debug_fhog(pvf_handle h, const uint8_t* img, int32_t ih, 
 // ---- S2 -------------------------------------------------------------------------------------------
 static pvf_handle tracker_new(Ctx* c)
 {
-    std::unique_ptr<Tracker> t(new Tracker());
-    if (!c->tracker_pool.empty()) { t->d_state = c->tracker_pool.back(); c->tracker_pool.pop_back(); }
-    else HIP_CHECK(hipMalloc((void**)&t->d_state, TRK_DOUBLES * sizeof(double)));
+    std::unique_ptr<Tracker> t(new Tracker());          // device state: taken by the first start_track (dsst_start_many) or shared by a clone
     const uint64_t id = c->next_id++;
     c->trackers[id] = std::move(t);
     return id;
@@ -174,8 +172,17 @@ extern "C" int32_t pvf_tracker_clone_many(pvf_handle h, const pvf_handle* src, i
 // released tracker states are kept for reuse up to this many (2.39 MB each); beyond it they go back to the allocator, so a long shot's
 // burst of trackers does not stay resident for the rest of the video
 static const size_t TRACKER_POOL_KEEP = 4096;
-static void pool_tracker_state(Ctx* c, double* d_state)
+static void pool_tracker_state(Ctx* c, Tracker& t)
 {
+    double* d_state = t.d_state;
+    t.d_state = nullptr;
+    if (t.share) {                                   // clones: the last owner returns the buffer
+        int* sh = t.share;
+        t.share = nullptr;
+        if (--*sh > 0) return;
+        delete sh;
+    }
+    if (!d_state) return;
     if (c->tracker_pool.size() < TRACKER_POOL_KEEP) { c->tracker_pool.push_back(d_state); return; }
     HIP_CHECK(hipStreamSynchronize(c->stream));      // kernels that still read the state have finished
     HIP_CHECK(hipFree(d_state));
@@ -188,7 +195,7 @@ extern "C" int32_t pvf_tracker_destroy_many(pvf_handle h, const pvf_handle* trks
     for (int i = 0; i < n; ++i) {
         auto it = c->trackers.find(trks[i]);
         PVF_REQUIRE(it != c->trackers.end(), "unknown tracker handle");
-        pool_tracker_state(c, it->second->d_state);
+        pool_tracker_state(c, *it->second);
         c->trackers.erase(it);
     }
     API_END
@@ -200,7 +207,7 @@ extern "C" int32_t pvf_tracker_destroy(pvf_handle h, pvf_handle trk)
     Ctx* c = enter(h);
     auto it = c->trackers.find(trk);
     PVF_REQUIRE(it != c->trackers.end(), "unknown tracker handle");
-    pool_tracker_state(c, it->second->d_state);
+    pool_tracker_state(c, *it->second);
     c->trackers.erase(it);
     API_END
 }
@@ -268,6 +275,7 @@ extern "C" int32_t pvf_debug_tracker_state(pvf_handle h, pvf_handle trk, double*
     API_BEGIN
     Ctx* c = enter(h);
     Tracker& t = c->tracker(trk);
+    PVF_REQUIRE(t.d_state, "tracker has no state yet (start_track first)");
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (F && c->s_trk1.p) HIP_CHECK(hipMemcpy(F, c->s_trk1.p, (size_t)32 * 64 * 64 * 2 * sizeof(double), hipMemcpyDeviceToHost));
     if (A) HIP_CHECK(hipMemcpy(A, t.d_state + TRK_A, (size_t)32 * 64 * 64 * 2 * sizeof(double), hipMemcpyDeviceToHost));

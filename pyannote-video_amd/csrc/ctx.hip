@@ -275,7 +275,11 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
     HIP_CHECK(hipSetDevice(c->device));
     (void)hipStreamSynchronize(c->stream);
     for (auto& kv : c->frames) if (kv.second.owned) (void)hipFree((void*)kv.second.d);
-    for (auto& kv : c->trackers) if (kv.second->d_state) (void)hipFree(kv.second->d_state);
+    for (auto& kv : c->trackers) {
+        Tracker& t = *kv.second;
+        if (t.share) { if (--*t.share > 0) continue; delete t.share; t.share = nullptr; }      // clones: the last owner frees
+        if (t.d_state) (void)hipFree(t.d_state);
+    }
     for (auto p : c->tracker_pool) (void)hipFree(p);
     for (int k = 0; k < 2; ++k) if (c->det_ev[k]) (void)hipEventDestroy(c->det_ev[k]);
     ml_plans_free(c);

@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) feat_ring_zero_k(MlStarts st, const LvDes
 // next feature row is loaded into registers while the current one is multiplied.  Each accumulator still receives its
 // terms in (m, n, p) order  =>  bit-identical to the oracle's chain.
 template <int R>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base,
                      const float4* __restrict__ Bg4, ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
 {
@@ -455,8 +455,7 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
     constexpr int NST = (SEG * 8 + 63) / 64;
     constexpr int RSRC_FLAGS = 0x00020000;          // raw buffer, 32-bit data format (out-of-range lanes read 0)
     extern __shared__ __attribute__((aligned(16))) float s_seg[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x;
     const int g = ml_block(st);
     if (g >= st.b0[st.nl]) return;
     const int l = ml_level(st, g);
@@ -466,10 +465,9 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
     const int by = (local / d.score_bx) % d.score_by;
     const int b = __builtin_amdgcn_readfirstlane(local / (d.score_bx * d.score_by));
     const int fh = d.fh, fw = d.fw;
-    const int r_top = (by * 4 + wave) * R, c_base = bx * WCOLS;
+    const int r_top = by * R, c_base = bx * WCOLS;
     const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
-    if (r_top + FR / 2 >= r1) return;               // wave-uniform
-    float* seg = s_seg + (size_t)wave * SEG * PITCH;
+    float* seg = s_seg;
     const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride + (size_t)c_base * PVF_FHOG_STRIDE;
     const int seg_cells = (fw - c_base < SEG) ? fw - c_base : SEG;
     const int i = lane & 15, kq = lane >> 4;
@@ -503,32 +501,38 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
     };
     load_row(r_top);
     fill_slab();
+    load_row(r_top + 1);
     const float* a0 = seg + (3 * i) * PITCH + kq;
+    // B fragments of output row j at step t: filter row m = t - j.  A row that is not active at that step (m outside the filter, or
+    // an output row past the level's last one) gets a lane offset beyond the table: a raw buffer load that is out of range returns
+    // zeros without touching memory, so the ramp steps at both ends of the walk do not pay for fragments they never use.
+    auto row_on = [&](int t, int j) { const int m = t - j; return (m >= 0 && m < FR) && (r_top + j + FR / 2 < r1); };
+    auto b_off = [&](int t, int j) { const int m = t - j; return (m < 0 ? 0 : (m >= FR ? FR - 1 : m)) * NK * 2048; };
+    auto b_lane = [&](int t, int j) { return row_on(t, j) ? lane16 : lane16 + 0x40000000; };
+    u32x4 bn[R][2];
+    float an[8 * MT];
+    // the (t, n) walk is ONE software pipeline: fragments of (t, n + 1) -- or of (t + 1, 0), after the slab has been refilled -- are
+    // requested before the MFMAs of (t, n) are issued, so a wave never reaches a step boundary with nothing in flight
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, b_lane(0, j), b_off(0, j), 0);
+        bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, b_lane(0, j), b_off(0, j) + 1024, 0);
+    }
+#pragma unroll
+    for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+        for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 4 * pq];
     for (int t = 0; t < NT; ++t) {
-        if (t + 1 < NT) load_row(r_top + t + 1);
-        // filter row of output row j at this step (clamped: the fragments of an inactive row are loaded but never used)
-        int bo[R];
+        int bo[R], bl[R];
         bool on[R];
         bool all_on = two_tiles;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            const int m = t - j;
-            on[j] = (m >= 0 && m < FR);
+            on[j] = row_on(t, j);
             all_on = all_on && on[j];
-            const int mc = m < 0 ? 0 : (m >= FR ? FR - 1 : m);
-            bo[j] = mc * NK * 2048;
+            bo[j] = b_off(t, j);
+            bl[j] = b_lane(t, j);
         }
-        u32x4 bn[R][2];
-        float an[8 * MT];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j], 0);
-            bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + 1024, 0);
-        }
-#pragma unroll
-        for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-            for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 4 * pq];
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
             float ac[8 * MT];
@@ -546,13 +550,28 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
             if (n + 1 < NK) {
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + (n + 1) * 2048, 0);
-                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + (n + 1) * 2048 + 1024, 0);
+                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, bl[j], bo[j] + (n + 1) * 2048, 0);
+                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, bl[j], bo[j] + (n + 1) * 2048 + 1024, 0);
                 }
 #pragma unroll
                 for (int pq = 0; pq < 8; ++pq)
 #pragma unroll
                     for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48 + n + 1) * PITCH + 4 * pq];
+            } else {
+                // last cell column of this feature row: its A fragments are in registers, so the slab takes the next row now
+                // (LDS serves a wave's requests in order), and the first fragments of step t + 1 follow it
+                fill_slab();
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int o = b_off(t + 1, j), v = b_lane(t + 1, j);
+                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, v, o, 0);
+                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, v, o + 1024, 0);
+                }
+#pragma unroll
+                for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                    for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 4 * pq];
+                load_row(r_top + t + 2);                    // (past the last step: fetched, never used)
             }
             __builtin_amdgcn_sched_barrier(0);
             if (all_on) {
@@ -583,7 +602,6 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (t + 1 < NT) fill_slab();
     }
     const int jc = lane & 15;
     if (jc < 15) {
@@ -672,7 +690,7 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         p.feat_floats += (size_t)d.feat_stride * B;
         d.feat_bx = std::max((d.fw + 255) / 256, 0);
         const int out_r = d.fh - 9, out_c = d.fw - 9;
-        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + 15) / 16 : 0;
+        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + 3) / 4 : 0;      // one wave (= one workgroup) per 4 rows x 96 columns
         // fused FHOG tasks: strips of 61 feature columns x chunks of feature rows (smaller chunks for the small levels: more tasks)
         d.strips = feat_ok ? (d.hog_nc + FUSED_OUT - 1) / FUSED_OUT : 0;
         d.chunk_rows = (d.hog_nr >= 2 * chunk_big) ? chunk_big : std::max((d.hog_nr + 1) / 2, 1);
@@ -786,9 +804,9 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
     MlPlan* p = ml_features(c, frames, upsample);
     if (p->score_blocks == 0) return;
     ProfScope ps(c, "score");
-    const size_t lds = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
+    const size_t lds = (size_t)(2 * 48 + 11) * 34 * sizeof(float);
     const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
-    hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
+    hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(64), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
                        sp0, d_counts, d_cands);
 }
 

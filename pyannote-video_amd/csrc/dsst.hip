@@ -15,11 +15,12 @@
 static constexpr double REG_SPACE = 0.001, NU_SPACE = 0.025, REG_SCALE = 0.001, NU_SCALE = 0.025, ALPHA = 1.020;
 
 struct TrkJob {
-    double* state;
+    double* state;   // A, B, As, Bs (may be shared by clones: only the full update / start write it)
+    double* pos;     // this call's working position (4 doubles of scratch; starts as `box`)
     const uint8_t* img; int h, w;
     double map[4];   // chip (x,y) -> image (map0 + x*map2, map1 + y*map3)
     double cx, cy;   // start: object centre in chip coordinates
-    double box[4];   // start: initial position (written to the tracker state by target_fft_k)
+    double box[4];   // position the call starts from
 };
 
 __device__ __forceinline__ double det_exp(double x)
@@ -69,7 +70,8 @@ __device__ __forceinline__ void bfly(double2& a, double2& b, double wr, double w
 // element x_br[k] never moves from position brev6(k), hence the OUTPUT IS LEFT IN BIT-REVERSED POSITIONS along both axes:
 //   X[kr][kc]  is found at  s[brev6(kr) * LP + brev6(kc)]            (use FFT_AT below).
 #define FFT_AT(s, r, c) (s)[brev6(r) * LP + brev6(c)]
-__device__ void fft2d_lds(double2* s, const double* __restrict__ tw, bool inverse)
+template <int NT = 256>     // threads of the block: 256 (two line tasks per thread and phase) or 512 (one)
+__device__ __forceinline__ void fft2d_lds(double2* s, const double* __restrict__ tw, bool inverse)
 {
     const int tid = threadIdx.x;
     const double sg = inverse ? 1.0 : -1.0;      // wi = +sin (inverse) / -sin (forward)
@@ -77,8 +79,8 @@ __device__ void fft2d_lds(double2* s, const double* __restrict__ tw, bool invers
     for (int pass = 0; pass < 2; ++pass) {
         // ---- phase 1: task (line, q): positions brev6(8q + i) = 8 * brev3(i) + brev3(q)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int tt = tid + 256 * u, line = tt >> 3, q = tt & 7;
+        for (int u = 0; u < 512 / NT; ++u) {
+            const int tt = tid + NT * u, line = tt >> 3, q = tt & 7;
             const int rq = (int)(__brev((unsigned)q) >> 29);
             double2 e[8];
 #pragma unroll
@@ -106,8 +108,8 @@ __device__ void fft2d_lds(double2* s, const double* __restrict__ tw, bool invers
         __syncthreads();
         // ---- phase 2: task (line, b): x[8a + b] lives at brev6(8a + b) = 8 * brev3(b) + brev3(a)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int tt = tid + 256 * u, line = tt >> 3, b = tt & 7;
+        for (int u = 0; u < 512 / NT; ++u) {
+            const int tt = tid + NT * u, line = tt >> 3, b = tt & 7;
             const int rb = (int)(__brev((unsigned)b) >> 29);
             double2 f[8];
 #pragma unroll
@@ -143,7 +145,7 @@ __device__ void fft2d_lds(double2* s, const double* __restrict__ tw, bool invers
 }
 
 // sequential 32-point FFT on x[32] (double2), one thread
-__device__ void fft32_seq(double2* x, const double* __restrict__ tw, bool inverse)
+__device__ __forceinline__ void fft32_seq(double2* x, const double* __restrict__ tw, bool inverse)
 {
     for (int i = 0; i < NSC; ++i) {
         const int j = (int)(__brev((unsigned)i) >> 27);
@@ -167,24 +169,33 @@ __device__ void fft32_seq(double2* x, const double* __restrict__ tw, bool invers
     }
 }
 
-// ---- translation features: plane i of tracker b -> mask * value -> 2-D FFT -> F[b][i]
-__global__ void __launch_bounds__(256) trans_planes_fft_k(const uint8_t* __restrict__ chips, const float* __restrict__ feat,
-                                                          const double* __restrict__ mask64, const double* __restrict__ tw64,
-                                                          double2* __restrict__ F)
+// ---- translation features: plane i of tracker b -> mask * value -> s (natural positions).  Features are plane-major
+// ([b][31][64*64] floats, fhog_device(..., planes = true)): a plane is 16 KB of consecutive floats; plane 31 is the grey chip.
+template <int NT = 256>
+__device__ __forceinline__ void load_plane_lds(double2* s, const uint8_t* __restrict__ chip, const float* __restrict__ fb, int i,
+                                               const double* __restrict__ mask64)
 {
-    extern __shared__ __attribute__((aligned(16))) double2 s[];
-    const int i = blockIdx.x, b = blockIdx.y;
-    const uint8_t* chip = chips + (size_t)b * FS * FS * 3;
-    const float* fb = feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE;
-    for (int q = threadIdx.x; q < FS * FS; q += 256) {
+#pragma unroll
+    for (int k = 0; k < FS * FS / NT; ++k) {
+        const int q = threadIdx.x + NT * k;
         float v;
-        if (i < 31) v = fb[(size_t)q * PVF_FHOG_STRIDE + i];
+        if (i < 31) v = fb[(size_t)i * FS * FS + q];
         else {
             const uint8_t* p = chip + (size_t)q * 3;
             v = (float)(((unsigned)p[0] + p[1] + p[2]) / 3) / 255.0f;
         }
         s[(q >> 6) * LP + (q & 63)] = make_double2((double)v * mask64[q], 0.0);
     }
+}
+
+// plane spectra to HBM: only the full (filter-updating) update needs them twice, see dsst_update_many
+__global__ void __launch_bounds__(256) trans_planes_fft_k(const uint8_t* __restrict__ chips, const float* __restrict__ feat,
+                                                          const double* __restrict__ mask64, const double* __restrict__ tw64,
+                                                          double2* __restrict__ F)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s[];
+    const int i = blockIdx.x, b = blockIdx.y;
+    load_plane_lds(s, chips + (size_t)b * FS * FS * 3, feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE, i, mask64);
     __syncthreads();
     fft2d_lds(s, tw64, false);
     double2* out = F + ((size_t)b * NPL + i) * FS * FS;
@@ -192,12 +203,13 @@ __global__ void __launch_bounds__(256) trans_planes_fft_k(const uint8_t* __restr
 }
 
 // target image exp(-dist/3) in a 21x21 window around (px,py), FFT, conj; spectrum left in s in bit-reversed positions (FFT_AT)
-__device__ void make_target_lds(double2* s, double px, double py, const double* __restrict__ tw64)
+template <int NT = 256>
+__device__ __forceinline__ void make_target_lds(double2* s, double px, double py, const double* __restrict__ tw64)
 {
-    for (int q = threadIdx.x; q < FS * FS; q += 256) s[(q >> 6) * LP + (q & 63)] = make_double2(0.0, 0.0);
+    for (int q = threadIdx.x; q < FS * FS; q += NT) s[(q >> 6) * LP + (q & 63)] = make_double2(0.0, 0.0);
     __syncthreads();
     const long cx = (long)floor(px + 0.5), cy = (long)floor(py + 0.5);
-    for (int q = threadIdx.x; q < 21 * 21; q += 256) {
+    for (int q = threadIdx.x; q < 21 * 21; q += NT) {
         const long r = cy - 10 + q / 21, c = cx - 10 + q % 21;
         if (r < 0 || c < 0 || r > FS - 1 || c > FS - 1) continue;
         const double dx = (double)c - px, dy = (double)r - py;
@@ -205,8 +217,8 @@ __device__ void make_target_lds(double2* s, double px, double py, const double* 
         s[r * LP + c] = make_double2(det_exp(-dist / 3.0), 0.0);
     }
     __syncthreads();
-    fft2d_lds(s, tw64, false);
-    for (int q = threadIdx.x; q < FS * FS; q += 256) { const int p = (q >> 6) * LP + (q & 63); s[p].y = -s[p].y; }
+    fft2d_lds<NT>(s, tw64, false);
+    for (int q = threadIdx.x; q < FS * FS; q += NT) { const int p = (q >> 6) * LP + (q & 63); s[p].y = -s[p].y; }
     __syncthreads();
 }
 
@@ -214,7 +226,6 @@ __global__ void __launch_bounds__(256) target_fft_k(const TrkJob* __restrict__ j
 {
     extern __shared__ __attribute__((aligned(16))) double2 s[];
     const TrkJob j = jobs[blockIdx.x];
-    if (threadIdx.x < 4) j.state[TRK_POS + threadIdx.x] = j.box[threadIdx.x];
     make_target_lds(s, j.cx, j.cy, tw64);
     double2* out = Ghat + (size_t)blockIdx.x * FS * FS;
     for (int q = threadIdx.x; q < FS * FS; q += 256) out[q] = FFT_AT(s, q >> 6, q & 63);
@@ -251,29 +262,26 @@ __global__ void __launch_bounds__(256) corr_k(const TrkJob* __restrict__ jobs, c
     Gfreq[(size_t)b * FS * FS + q] = make_double2(gr * rec, gi * rec);
 }
 
-// response -> peak, PSR, new position; then the new target's spectrum
-__global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ Gfreq, const double* __restrict__ tw64,
-                                              double* __restrict__ results /* [n][8] */, double2* __restrict__ Ghat)
+// response spectrum in s (natural positions) -> response -> peak, PSR, new position; then (Ghat != nullptr) the new target's spectrum
+template <int NT = 256>
+__device__ __forceinline__ void peak_body(double2* s, const TrkJob& j, int b, const double* __restrict__ tw64, double* __restrict__ results /* [n][8] */,
+                          double2* __restrict__ Ghat)
 {
-    extern __shared__ __attribute__((aligned(16))) double2 s[];
-    __shared__ double red_v[256];
-    __shared__ int red_i[256];
+    __shared__ double red_v[NT];
+    __shared__ int red_i[NT];
     __shared__ double row_s[FS], row_q[FS], row_c[FS];
     __shared__ double pk[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const TrkJob j = jobs[b];
-    for (int q = tid; q < FS * FS; q += 256) s[(q >> 6) * LP + (q & 63)] = Gfreq[(size_t)b * FS * FS + q];
-    __syncthreads();
-    fft2d_lds(s, tw64, true);
+    const int tid = threadIdx.x;
+    fft2d_lds<NT>(s, tw64, true);
     // arg-max of the real part, first occurrence in row-major order
     double bv = -INFINITY; int bi = 0x7fffffff;
-    for (int q = tid; q < FS * FS; q += 256) {
+    for (int q = tid; q < FS * FS; q += NT) {
         const double v = FFT_AT(s, q >> 6, q & 63).x;
         if (v > bv) { bv = v; bi = q; }
     }
     red_v[tid] = bv; red_i[tid] = bi;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
+    for (int off = NT / 2; off > 0; off >>= 1) {
         if (tid < off) {
             const double ov = red_v[tid + off]; const int oi = red_i[tid + off];
             if (ov > red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) { red_v[tid] = ov; red_i[tid] = oi; }
@@ -338,18 +346,121 @@ __global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, c
         if (qx > FS - 1) qx = FS - 1;
         if (qy > FS - 1) qy = FS - 1;
         const double psr = (FFT_AT(s, (int)qy, (int)qx).x - mean) / sqrt(var);
-        double* st = j.state;
-        const double g0 = st[TRK_POS], g1 = st[TRK_POS + 1], g2 = st[TRK_POS + 2], g3 = st[TRK_POS + 3];
+        double* ps = j.pos;
+        const double g0 = ps[0], g1 = ps[1], g2 = ps[2], g3 = ps[3];
         const double ix = j.map[0] + ppx * j.map[2], iy = j.map[1] + ppy * j.map[3];
         const double vx = ix - (g0 + g2) / 2, vy = iy - (g1 + g3) / 2;
-        st[TRK_POS] = g0 + vx; st[TRK_POS + 1] = g1 + vy; st[TRK_POS + 2] = g2 + vx; st[TRK_POS + 3] = g3 + vy;
+        ps[0] = g0 + vx; ps[1] = g1 + vy; ps[2] = g2 + vx; ps[3] = g3 + vy;
         results[(size_t)b * 8] = psr;
         results[(size_t)b * 8 + 5] = ppx; results[(size_t)b * 8 + 6] = ppy;
     }
+    if (!Ghat) return;                          // block-uniform
     __syncthreads();
-    make_target_lds(s, ppx, ppy, tw64);
+    make_target_lds<NT>(s, ppx, ppy, tw64);
     double2* out = Ghat + (size_t)b * FS * FS;
-    for (int q = tid; q < FS * FS; q += 256) out[q] = FFT_AT(s, q >> 6, q & 63);
+    for (int q = tid; q < FS * FS; q += NT) out[q] = FFT_AT(s, q >> 6, q & 63);
+}
+
+__global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ Gfreq, const double* __restrict__ tw64,
+                                              double* __restrict__ results, double2* __restrict__ Ghat)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s[];
+    const int b = blockIdx.x;
+    const TrkJob j = jobs[b];
+    for (int q = threadIdx.x; q < FS * FS; q += 256) s[(q >> 6) * LP + (q & 63)] = Gfreq[(size_t)b * FS * FS + q];
+    __syncthreads();
+    peak_body(s, j, b, tw64, results, Ghat);
+}
+
+// ---- start_track in one pass per tracker: the block walks the 32 planes; a plane's spectrum goes straight from LDS into
+// A_i = G * F_i and into the running |F|^2 sum (plane order, like start_filters_k) and is never written out.
+// HBM per tracker: 0.5 MB of features in, 2.06 MB of filters out (three-kernel form: + 2 MB F written and read, + G).
+// 512 threads: one line task per thread and FFT phase, 8 spectrum points per thread -- four waves per SIMD hide the LDS and
+// fp64 latencies of the butterfly chains (a 256-thread form needed > 256 registers and ran one wave per SIMD).
+#define FUSED_NT 512
+#define FUSED_PT (FS * FS / FUSED_NT)
+__global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) start_fused_k(const TrkJob* __restrict__ jobs, const uint8_t* __restrict__ chips, const float* __restrict__ feat,
+                                                          const double* __restrict__ mask64, const double* __restrict__ tw64)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s[];
+    __shared__ double tw_lds[2 * FS];           // twiddles next to the data: re-read after every barrier instead of pinned in registers
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const TrkJob j = jobs[b];
+    if (tid < 2 * FS) tw_lds[tid] = tw64[tid];
+    __syncthreads();
+    tw64 = tw_lds;
+    make_target_lds<FUSED_NT>(s, j.cx, j.cy, tw64);
+    double2 g[FUSED_PT];
+#pragma unroll
+    for (int k = 0; k < FUSED_PT; ++k) { const int q = tid + FUSED_NT * k; g[k] = FFT_AT(s, q >> 6, q & 63); }
+    __syncthreads();
+    double bsum[FUSED_PT];
+#pragma unroll
+    for (int k = 0; k < FUSED_PT; ++k) bsum[k] = 0;
+    double2* A = reinterpret_cast<double2*>(j.state + TRK_A);
+    const uint8_t* chip = chips + (size_t)b * FS * FS * 3;
+    const float* fb = feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE;
+    for (int i = 0; i < NPL; ++i) {
+        const double* mk = mask64;
+        asm volatile("" : "+s"(mk));               // the window is re-read per plane (L1/L2 hits), not kept in 16 registers across the loop
+        load_plane_lds<FUSED_NT>(s, chip, fb, i, mk);
+        __syncthreads();
+        fft2d_lds<FUSED_NT>(s, tw64, false);
+#pragma unroll
+        for (int k = 0; k < FUSED_PT; ++k) {
+            const int q = tid + FUSED_NT * k;
+            const double2 f = FFT_AT(s, q >> 6, q & 63);
+            A[(size_t)i * FS * FS + q] = make_double2(g[k].x * f.x - g[k].y * f.y, g[k].x * f.y + g[k].y * f.x);
+            bsum[k] = bsum[k] + (f.x * f.x + f.y * f.y);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < FUSED_PT; ++k) j.state[TRK_B + tid + FUSED_NT * k] = bsum[k];
+}
+
+// ---- deferred update in one pass per tracker: plane spectra are multiplied into the response sum as they appear (plane order,
+// like corr_k), then normalised, inverted and searched in the same block.  Filters are only read (2.06 MB per tracker).
+__global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) update_fused_k(const TrkJob* __restrict__ jobs, const uint8_t* __restrict__ chips, const float* __restrict__ feat,
+                                                           const double* __restrict__ mask64, const double* __restrict__ tw64, double* __restrict__ results)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s[];
+    __shared__ double tw_lds[2 * FS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const TrkJob j = jobs[b];
+    if (tid < 2 * FS) tw_lds[tid] = tw64[tid];
+    __syncthreads();
+    tw64 = tw_lds;
+    const double2* A = reinterpret_cast<const double2*>(j.state + TRK_A);
+    const uint8_t* chip = chips + (size_t)b * FS * FS * 3;
+    const float* fb = feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE;
+    double gr[FUSED_PT], gi[FUSED_PT];
+#pragma unroll
+    for (int k = 0; k < FUSED_PT; ++k) { gr[k] = 0; gi[k] = 0; }
+    for (int i = 0; i < NPL; ++i) {
+        const double* mk = mask64;
+        asm volatile("" : "+s"(mk));
+        load_plane_lds<FUSED_NT>(s, chip, fb, i, mk);
+        __syncthreads();
+        fft2d_lds<FUSED_NT>(s, tw64, false);
+#pragma unroll
+        for (int k = 0; k < FUSED_PT; ++k) {
+            const int q = tid + FUSED_NT * k;
+            const double2 f = FFT_AT(s, q >> 6, q & 63);
+            const double2 a = A[(size_t)i * FS * FS + q];          // four waves per SIMD cover this latency
+            gr[k] = gr[k] + (f.x * a.x + f.y * a.y);
+            gi[k] = gi[k] + (f.y * a.x - f.x * a.y);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < FUSED_PT; ++k) {
+        const int q = tid + FUSED_NT * k;
+        const double rec = 1.0 / (j.state[TRK_B + q] + REG_SPACE);
+        s[(q >> 6) * LP + (q & 63)] = make_double2(gr[k] * rec, gi[k] * rec);
+    }
+    __syncthreads();
+    peak_body<FUSED_NT>(s, j, b, tw64, results, nullptr);
 }
 
 __global__ void __launch_bounds__(256) filter_update_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ F, const double2* __restrict__ Ghat)
@@ -382,7 +493,7 @@ __global__ void __launch_bounds__(256) scale_chips_k(const TrkJob* __restrict__ 
 {
     const int k = blockIdx.x, b = blockIdx.y;
     const TrkJob j = jobs[b];
-    double ppp[4] = {j.state[TRK_POS], j.state[TRK_POS + 1], j.state[TRK_POS + 2], j.state[TRK_POS + 3]};
+    double ppp[4] = {j.pos[0], j.pos[1], j.pos[2], j.pos[3]};
     scale_rect_d(ppp, alpha_pow_m16);
     for (int i = 0; i < k; ++i) scale_rect_d(ppp, ALPHA);
     const double m0 = (ppp[2] - ppp[0]) / (double)(SWIN - 1), m3 = (ppp[3] - ppp[1]) / (double)(SWIN - 1);
@@ -429,7 +540,7 @@ __global__ void __launch_bounds__(128) scale_fft_k(const uint8_t* __restrict__ c
     for (int k = 0; k < NSC; ++k) out[k] = x[k];
 }
 
-__device__ void scale_target_seq(double2* g, double pos, const double* __restrict__ tw32)
+__device__ __forceinline__ void scale_target_seq(double2* g, double pos, const double* __restrict__ tw32)
 {
     for (int i = 0; i < NSC; ++i) {
         const double dist = fabs((double)i - pos);
@@ -498,9 +609,10 @@ __global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__
                 if (pos > p3) pos = p3;
             }
         }
-        double r[4] = {st[TRK_POS], st[TRK_POS + 1], st[TRK_POS + 2], st[TRK_POS + 3]};
+        double* ps = jobs[b].pos;
+        double r[4] = {ps[0], ps[1], ps[2], ps[3]};
         scale_rect_d(r, det_exp((pos - (double)NSC / 2) * ln_alpha));
-        st[TRK_POS] = r[0]; st[TRK_POS + 1] = r[1]; st[TRK_POS + 2] = r[2]; st[TRK_POS + 3] = r[3];
+        ps[0] = r[0]; ps[1] = r[1]; ps[2] = r[2]; ps[3] = r[3];
         results[(size_t)b * 8 + 1] = r[0]; results[(size_t)b * 8 + 2] = r[1]; results[(size_t)b * 8 + 3] = r[2]; results[(size_t)b * 8 + 4] = r[3];
         results[(size_t)b * 8 + 7] = pos;
         if (update_model) scale_target_seq(Gs, pos, tw32);
@@ -525,42 +637,64 @@ __global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__
     }
 }
 
-// copies of freshly started trackers (both passes of a shot start one tracker per detection from the same frame and box, so the
-// second pass clones the first pass's trackers instead of computing the same filters again)
-__global__ void __launch_bounds__(256) clone_state_k(const double* const* __restrict__ src, double* const* __restrict__ dst)
+// Clones share the filters of their source until one of them is about to write them (start_track or a full update): both passes of a
+// shot start one tracker per detection from the same frame and box, the first (deferred) updates only read the filters, and nearly
+// every such tracker is dropped right after -- so the usual clone costs no device work at all.
+__global__ void __launch_bounds__(256) copy_state_k(const double* __restrict__ src, double* __restrict__ dst)
 {
-    const double2* s = reinterpret_cast<const double2*>(src[blockIdx.y]);
-    double2* d = reinterpret_cast<double2*>(dst[blockIdx.y]);
+    const double2* s = reinterpret_cast<const double2*>(src);
+    double2* d = reinterpret_cast<double2*>(dst);
     constexpr int N2 = (int)(TRK_DOUBLES / 2);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < N2; i += gridDim.x * 256) d[i] = s[i];
+}
+
+double* tracker_state_alloc(Ctx* c)
+{
+    double* d = nullptr;
+    if (!c->tracker_pool.empty()) { d = c->tracker_pool.back(); c->tracker_pool.pop_back(); }
+    else HIP_CHECK(hipMalloc((void**)&d, TRK_DOUBLES * sizeof(double)));
+    return d;
+}
+
+// make t the only owner of its filters (copy = keep their contents)
+static void own_state(Ctx* c, Tracker* t, bool copy)
+{
+    if (!t->share) return;
+    if (*t->share > 1) {
+        static_assert(TRK_DOUBLES % 2 == 0, "tracker state is copied as double2");
+        double* fresh = tracker_state_alloc(c);
+        if (copy) {
+            ProfScope ps(c, "dsst");
+            hipLaunchKernelGGL(copy_state_k, dim3(64), dim3(256), 0, c->stream, t->d_state, fresh);
+        }
+        --*t->share;
+        t->d_state = fresh;
+    } else {
+        delete t->share;
+    }
+    t->share = nullptr;
 }
 
 void dsst_clone_many(Ctx* c, const std::vector<Tracker*>& src, const std::vector<Tracker*>& dst)
 {
     const int n = (int)src.size();
-    if (n == 0) return;
-    static_assert(TRK_DOUBLES % 2 == 0, "tracker state is copied as double2");
-    c->s_misc.ensure((size_t)2 * n * sizeof(void*));
-    c->h_misc.ensure((size_t)2 * n * sizeof(void*));
-    double** hp = c->h_misc.as<double*>();
     for (int i = 0; i < n; ++i) {
         PVF_REQUIRE(src[i]->started && !src[i]->pending, "clone: source tracker must be started and have no deferred update");
-        hp[i] = src[i]->d_state; hp[n + i] = dst[i]->d_state;
+        PVF_REQUIRE(dst[i]->d_state == nullptr && dst[i]->share == nullptr, "clone: destination already owns a state");
+        if (!src[i]->share) src[i]->share = new int(1);
+        ++*src[i]->share;
+        dst[i]->share = src[i]->share;
+        dst[i]->d_state = src[i]->d_state;
         memcpy(dst[i]->pos, src[i]->pos, sizeof src[i]->pos);
         dst[i]->started = true; dst[i]->pending = false;
     }
-    HIP_CHECK(hipMemcpyAsync(c->s_misc.p, hp, (size_t)2 * n * sizeof(void*), hipMemcpyHostToDevice, c->stream));
-    ProfScope ps(c, "dsst");
-    hipLaunchKernelGGL(clone_state_k, dim3(64, n), dim3(256), 0, c->stream, c->s_misc.as<const double*>(), c->s_misc.as<double*>() + n);
-    HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(c->stream));
 }
 
-// commit of a deferred update: put the position the update started from back into the tracker state
-__global__ void restore_pos_k(const TrkJob* __restrict__ jobs, int n)
+// every call works on its own copy of the position (the tracker's position lives on the host, Tracker::pos)
+__global__ void init_pos_k(const TrkJob* __restrict__ jobs, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n * 4) jobs[i >> 2].state[TRK_POS + (i & 3)] = jobs[i >> 2].box[i & 3];
+    if (i < n * 4) jobs[i >> 2].pos[i & 3] = jobs[i >> 2].box[i & 3];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -571,10 +705,10 @@ static void scale_rect_h(double r[4], double s)
     r[0] = cx - w / 2; r[1] = cy - h / 2; r[2] = cx + w / 2; r[3] = cy + h / 2;
 }
 
-struct DsstBuffers { uint8_t* chips64; uint8_t* chips_sc; float* feat; double2* F; double2* G0; double2* G1; double2* Fs; double* results; TrkJob* jobs; };
+struct DsstBuffers { uint8_t* chips64; uint8_t* chips_sc; float* feat; double2* F; double2* G0; double2* G1; double2* Fs; double* results; double* pos; TrkJob* jobs; };
 
 static DsstBuffers prepare(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes,
-                           std::vector<TrkJob>& jobs, std::vector<ChipJob>& cj)
+                           std::vector<TrkJob>& jobs, std::vector<ChipJob>& cj, bool need_F)
 {
     const int n = (int)t.size();
     PVF_REQUIRE(c->ttab.set, "tracker tables not set (pvf_set_tracker_tables)");
@@ -601,18 +735,24 @@ static DsstBuffers prepare(Ctx* c, const std::vector<Tracker*>& t, const std::ve
     b.chips_sc = b.chips64 + (chips64 + 63) / 64 * 64;
     c->s_feat.ensure((size_t)n * FS * FS * PVF_FHOG_STRIDE * sizeof(float));
     b.feat = c->s_feat.as<float>();
-    c->s_trk1.ensure((size_t)n * NPL * FS * FS * sizeof(double2));
-    b.F = c->s_trk1.as<double2>();
-    const size_t g = (size_t)n * FS * FS * sizeof(double2), fs = (size_t)n * SDIM * NSC * sizeof(double2);
-    c->s_trk2.ensure(2 * g + fs + (size_t)n * 8 * sizeof(double) + (size_t)n * sizeof(TrkJob) + 256);
+    b.F = nullptr;
+    if (need_F) {                                  // plane spectra in HBM: the full update only (2 MB per tracker)
+        c->s_trk1.ensure((size_t)n * NPL * FS * FS * sizeof(double2));
+        b.F = c->s_trk1.as<double2>();
+    }
+    const size_t g = need_F ? (size_t)n * FS * FS * sizeof(double2) : 0, fs = (size_t)n * SDIM * NSC * sizeof(double2);
+    c->s_trk2.ensure(2 * g + fs + (size_t)n * 12 * sizeof(double) + (size_t)n * sizeof(TrkJob) + 256);
     uint8_t* q = c->s_trk2.as<uint8_t>();
     b.G0 = reinterpret_cast<double2*>(q); q += g;
     b.G1 = reinterpret_cast<double2*>(q); q += g;
     b.Fs = reinterpret_cast<double2*>(q); q += fs;
     b.results = reinterpret_cast<double*>(q); q += (size_t)n * 8 * sizeof(double);
+    b.pos = reinterpret_cast<double*>(q); q += (size_t)n * 4 * sizeof(double);
     b.jobs = reinterpret_cast<TrkJob*>(q);
+    for (int i = 0; i < n; ++i) jobs[i].pos = b.pos + 4 * (size_t)i;
     HIP_CHECK(hipMemcpyAsync(b.jobs, jobs.data(), (size_t)n * sizeof(TrkJob), hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(init_pos_k, dim3((4 * n + 255) / 256), dim3(256), 0, c->stream, b.jobs, n);
     return b;
 }
 
@@ -622,8 +762,8 @@ static void translation_features(Ctx* c, const DsstBuffers& b, const std::vector
 {
     chip_extract_batch(c, cj, b.chips64);
     ProfScope ps(c, "dsst");
-    fhog_device(c, b.chips64, n, FS, FS, 1, 3, 3, b.feat, c->s_hist, c->s_norm);
-    hipLaunchKernelGGL(trans_planes_fft_k, dim3(NPL, n), dim3(256), LDS_FFT, c->stream, b.chips64, b.feat, c->ttab.d_mask64, c->ttab.d_tw64, b.F);
+    fhog_device(c, b.chips64, n, FS, FS, 1, 3, 3, b.feat, c->s_hist, c->s_norm, 0, true);
+    if (b.F) hipLaunchKernelGGL(trans_planes_fft_k, dim3(NPL, n), dim3(256), LDS_FFT, c->stream, b.chips64, b.feat, c->ttab.d_mask64, c->ttab.d_tw64, b.F);
 }
 
 static void scale_features(Ctx* c, const DsstBuffers& b, int n)
@@ -643,6 +783,8 @@ static void ensure_fft_lds()
     HIP_CHECK(hipFuncSetAttribute((const void*)trans_planes_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)target_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)peak_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
+    HIP_CHECK(hipFuncSetAttribute((const void*)start_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
+    HIP_CHECK(hipFuncSetAttribute((const void*)update_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)scale_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 33 * sizeof(double2))));
     done = true;
 }
@@ -653,17 +795,18 @@ void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<F
     if (n == 0) return;
     ensure_fft_lds();
     for (int i = 0; i < n; ++i) {
+        own_state(c, t[i], false);
+        if (!t[i]->d_state) t[i]->d_state = tracker_state_alloc(c);
         memcpy(t[i]->pos, boxes + 4 * i, 4 * sizeof(double));
         t[i]->started = true;
         t[i]->pending = false;
     }
     std::vector<TrkJob> jobs; std::vector<ChipJob> cj;
-    DsstBuffers b = prepare(c, t, f, boxes, jobs, cj);
+    DsstBuffers b = prepare(c, t, f, boxes, jobs, cj, false);
     translation_features(c, b, cj, n);
     {
         ProfScope ps(c, "dsst");
-        hipLaunchKernelGGL(target_fft_k, dim3(n), dim3(256), LDS_FFT, c->stream, b.jobs, c->ttab.d_tw64, b.G0);
-        hipLaunchKernelGGL(start_filters_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G0);
+        hipLaunchKernelGGL(start_fused_k, dim3(n), dim3(FUSED_NT), LDS_FFT, c->stream, b.jobs, b.chips64, b.feat, c->ttab.d_mask64, c->ttab.d_tw64);
     }
     scale_features(c, b, n);
     {
@@ -694,16 +837,20 @@ void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<
             PVF_REQUIRE(!t[i]->pending, "tracker has a deferred update: commit it (with the frame it was computed on) first");
         }
         if (mode == 1) memcpy(t[i]->prev_pos, t[i]->pos, sizeof t[i]->pos);
+        else own_state(c, t[i], true);             // the filters are about to be written
     }
     std::vector<TrkJob> jobs; std::vector<ChipJob> cj;
-    DsstBuffers b = prepare(c, t, f, nullptr, jobs, cj);
-    if (mode == 2) hipLaunchKernelGGL(restore_pos_k, dim3((4 * n + 255) / 256), dim3(256), 0, c->stream, b.jobs, n);
+    DsstBuffers b = prepare(c, t, f, nullptr, jobs, cj, mode != 1);
     translation_features(c, b, cj, n);
-    {
+    if (mode == 1) {
+        ProfScope ps(c, "dsst");
+        hipLaunchKernelGGL(update_fused_k, dim3(n), dim3(FUSED_NT), LDS_FFT, c->stream, b.jobs, b.chips64, b.feat, c->ttab.d_mask64, c->ttab.d_tw64, b.results);
+    } else {
+        // the full update reads every plane spectrum twice (response, then filter update with the NEW target): spectra go through HBM
         ProfScope ps(c, "dsst");
         hipLaunchKernelGGL(corr_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G0);
         hipLaunchKernelGGL(peak_k, dim3(n), dim3(256), LDS_FFT, c->stream, b.jobs, b.G0, c->ttab.d_tw64, b.results, b.G1);
-        if (mode != 1) hipLaunchKernelGGL(filter_update_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G1);
+        hipLaunchKernelGGL(filter_update_k, dim3(FS * FS / 256, n), dim3(256), 0, c->stream, b.jobs, b.F, b.G1);
     }
     scale_features(c, b, n);
     {

@@ -277,12 +277,20 @@ __global__ void __launch_bounds__(256) fhog1_grad_k(const uint8_t* __restrict__ 
 
 __global__ void __launch_bounds__(256) fhog1_feat_k(const float* __restrict__ norm, const uint8_t* __restrict__ angle, size_t px_stride,
                                                     int iw, float* __restrict__ feat, size_t feat_stride, int fw, int hog_nr, int hog_nc,
-                                                    int oy, int ox, int fh, int n_img)
+                                                    int oy, int ox, int fh, int n_img, int planes)
 {
     int px, py, b;
     if (!flat_index(fw, fh, n_img, &px, &py, &b)) return;
     const int x = px - ox, y = py - oy;
+    // planes: [image][31][fh * fw] (a plane is contiguous: the correlation tracker transforms plane by plane) instead of [image][cell][32]
+    float* pl = feat + (size_t)b * feat_stride + (size_t)py * fw + px;
+    const size_t plane = (size_t)fh * fw;
     if (x < 0 || y < 0 || x >= hog_nc || y >= hog_nr) {
+        if (planes) {
+#pragma unroll
+            for (int k = 0; k < 31; ++k) pl[k * plane] = 0.f;
+            return;
+        }
         float4* z = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)py * fw + px) * PVF_FHOG_STRIDE);
 #pragma unroll
         for (int k = 0; k < 8; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -299,6 +307,11 @@ __global__ void __launch_bounds__(256) fhog1_feat_k(const float* __restrict__ no
 #pragma unroll
     for (int k = 0; k < 18; ++k) h[k] = (k == a) ? mag : 0.0f;
     cell_features(h, n, o);
+    if (planes) {
+#pragma unroll
+        for (int k = 0; k < 31; ++k) pl[k * plane] = o[k];
+        return;
+    }
     float4* dst = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)(y + oy) * fw + (x + ox)) * PVF_FHOG_STRIDE);
 #pragma unroll
     for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
@@ -319,8 +332,9 @@ void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw)
 }
 
 void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat, DevBuf& hist, DevBuf& norm,
-                 size_t img_stride_in)
+                 size_t img_stride_in, bool planes)
 {
+    PVF_REQUIRE(!planes || cell == 1, "fhog: plane-major output exists for cell size 1 only");
     DevBuf& grad = c->s_grad;
     const uint8_t* lut = orientation_lut(c);
     int fh, fw;
@@ -335,7 +349,7 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
         hist.ensure(px * n);
         hipLaunchKernelGGL(fhog1_grad_k, flat_grid(w, h, n), dim3(256), 0, c->stream, d_img, img_stride, h, w, norm.as<float>(), hist.as<uint8_t>(), px, lut, n);
         hipLaunchKernelGGL(fhog1_feat_k, flat_grid(fw, fh, n), dim3(256), 0, c->stream, norm.as<float>(), hist.as<uint8_t>(), px, w, d_feat, feat_stride, fw,
-                           h - 2, w - 2, oy, ox, fh, n);
+                           h - 2, w - 2, oy, ox, fh, n, planes ? 1 : 0);
         return;
     }
     PVF_REQUIRE(cell == 8 || cell == 4, "fhog: cell size 1, 4 or 8");

@@ -144,7 +144,8 @@ struct TrackerTables {
 };
 
 struct Tracker {
-    double* d_state = nullptr; // A[32*64*64*2] B[64*64] As[512*32*2] Bs[32] pos[4]
+    double* d_state = nullptr; // A[32*64*64*2] B[64*64] As[512*32*2] Bs[32] (+4 unused doubles); allocated by the first start_track
+    int* share = nullptr;      // clones: owners of d_state (copy-on-write, dsst.hip own_state); nullptr = sole owner
     double pos[4] = {0, 0, 0, 0};
     double prev_pos[4] = {0, 0, 0, 0};   // position before a deferred update (dsst_update_many mode 1)
     bool started = false;
@@ -245,7 +246,7 @@ void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::ve
 void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, int pad_c, std::vector<float>& out, int* fh, int* fw);
 // device fhog used by dsst.hip too: img u8 [n][h][w][3] -> feat [n][fh][fw][32]
 void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat,
-                 DevBuf& hist, DevBuf& norm, size_t img_stride_in = 0);
+                 DevBuf& hist, DevBuf& norm, size_t img_stride_in = 0, bool planes = false);
 void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw);
 // chips (chip.hip)
 ChipJob chip_plan(const Frame& f, const ChipDetails& d);
@@ -259,6 +260,7 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out);
 // tracker (dsst.hip)
 void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes);
 void dsst_clone_many(Ctx* c, const std::vector<Tracker*>& src, const std::vector<Tracker*>& dst);
+double* tracker_state_alloc(Ctx* c);
 void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, double* psr, double* boxes_out, int mode = 0);
 // association (assoc.cpp part of api)
 void overlap_matrix_host(const double* a, int na, const double* b, int nb, double ratio, double* out);
