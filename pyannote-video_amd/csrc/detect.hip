@@ -503,27 +503,27 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
     fill_slab();
     load_row(r_top + 1);
     const float* a0 = seg + (3 * i) * PITCH + kq;
-    // B fragments of output row j at step t: filter row m = t - j.  A row that is not active at that step (m outside the filter, or
-    // an output row past the level's last one) gets a lane offset beyond the table: a raw buffer load that is out of range returns
-    // zeros without touching memory, so the ramp steps at both ends of the walk do not pay for fragments they never use.
+    // B fragments of output row j at step t: filter row m = t - j, clamped: the fragments of a row that is not active at that step (m
+    // outside the filter, or an output row past the level's last one) are loaded but never used.  (Sending those loads out of range
+    // instead -- a per-row lane offset beyond the table, so that they return zeros without touching memory -- was measured 5 % slower:
+    // the extra offset registers push spills into the loop.)
     auto row_on = [&](int t, int j) { const int m = t - j; return (m >= 0 && m < FR) && (r_top + j + FR / 2 < r1); };
     auto b_off = [&](int t, int j) { const int m = t - j; return (m < 0 ? 0 : (m >= FR ? FR - 1 : m)) * NK * 2048; };
-    auto b_lane = [&](int t, int j) { return row_on(t, j) ? lane16 : lane16 + 0x40000000; };
     u32x4 bn[R][2];
     float an[8 * MT];
     // the (t, n) walk is ONE software pipeline: fragments of (t, n + 1) -- or of (t + 1, 0), after the slab has been refilled -- are
     // requested before the MFMAs of (t, n) are issued, so a wave never reaches a step boundary with nothing in flight
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, b_lane(0, j), b_off(0, j), 0);
-        bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, b_lane(0, j), b_off(0, j) + 1024, 0);
+        bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, b_off(0, j), 0);
+        bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, b_off(0, j) + 1024, 0);
     }
 #pragma unroll
     for (int pq = 0; pq < 8; ++pq)
 #pragma unroll
         for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 4 * pq];
     for (int t = 0; t < NT; ++t) {
-        int bo[R], bl[R];
+        int bo[R];
         bool on[R];
         bool all_on = two_tiles;
 #pragma unroll
@@ -531,7 +531,6 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
             on[j] = row_on(t, j);
             all_on = all_on && on[j];
             bo[j] = b_off(t, j);
-            bl[j] = b_lane(t, j);
         }
 #pragma unroll
         for (int n = 0; n < NK; ++n) {
@@ -550,8 +549,8 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
             if (n + 1 < NK) {
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, bl[j], bo[j] + (n + 1) * 2048, 0);
-                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, bl[j], bo[j] + (n + 1) * 2048 + 1024, 0);
+                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + (n + 1) * 2048, 0);
+                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + (n + 1) * 2048 + 1024, 0);
                 }
 #pragma unroll
                 for (int pq = 0; pq < 8; ++pq)
@@ -563,9 +562,9 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
                 fill_slab();
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    const int o = b_off(t + 1, j), v = b_lane(t + 1, j);
-                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, v, o, 0);
-                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, v, o + 1024, 0);
+                    const int o = b_off(t + 1, j);
+                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, o, 0);
+                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, o + 1024, 0);
                 }
 #pragma unroll
                 for (int pq = 0; pq < 8; ++pq)

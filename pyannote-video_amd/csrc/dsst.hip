@@ -66,7 +66,11 @@ __device__ __forceinline__ void bfly(double2& a, double2& b, double wr, double w
 //   phase 1: lane owns x[8q .. 8q+7] of the bit-reversed line        -> stages 1-3 (pairs at distance 1, 2, 4)
 //   phase 2: lane owns x[8a + b], a = 0..7                            -> stages 4-6 (pairs at distance 8, 16, 32)
 // Butterflies, operand order and twiddles are those of the stage-by-stage form (oracle/pvo_dsst.c fft1d), so values are
-// bit-identical.  Everything is done IN PLACE on the positions a lane reads (no intra-phase barrier, 8 live values per lane):
+// bit-identical.  Lane <-> task: phase 1 gives consecutive lanes consecutive q (their 16-byte elements are neighbours along a row,
+// 65 elements = 4 banks apart along a column); phase 2 gives them consecutive LINES of one b -- with consecutive b the elements of
+// the lanes that LDS serves together lie 8 (rows) or 8 * 65 (columns) elements = a multiple of 32 banks apart, an 8-way conflict on
+// every ds_read/write_b128 that made the transform LDS-bound (measured: 2.9 -> ... ms per 2000 trackers).
+// Everything is done IN PLACE on the positions a lane reads (no intra-phase barrier, 8 live values per lane):
 // element x_br[k] never moves from position brev6(k), hence the OUTPUT IS LEFT IN BIT-REVERSED POSITIONS along both axes:
 //   X[kr][kc]  is found at  s[brev6(kr) * LP + brev6(kc)]            (use FFT_AT below).
 #define FFT_AT(s, r, c) (s)[brev6(r) * LP + brev6(c)]
@@ -109,7 +113,7 @@ __device__ __forceinline__ void fft2d_lds(double2* s, const double* __restrict__
         // ---- phase 2: task (line, b): x[8a + b] lives at brev6(8a + b) = 8 * brev3(b) + brev3(a)
 #pragma unroll
         for (int u = 0; u < 512 / NT; ++u) {
-            const int tt = tid + NT * u, line = tt >> 3, b = tt & 7;
+            const int tt = tid + NT * u, line = tt & 63, b = tt >> 6;     // a wave = the 64 lines of one b (see the bank note above)
             const int rb = (int)(__brev((unsigned)b) >> 29);
             double2 f[8];
 #pragma unroll
@@ -390,9 +394,11 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
     __syncthreads();
     tw64 = tw_lds;
     make_target_lds<FUSED_NT>(s, j.cx, j.cy, tw64);
+    // a thread owns the spectrum points at the LDS positions ph = tid + 512 k (consecutive lanes = neighbouring elements: no bank
+    // conflict); position (pr, pc) holds the point X[brev6(pr)][brev6(pc)], and a wave's 64 points are one row of A (1 KB, permuted)
     double2 g[FUSED_PT];
 #pragma unroll
-    for (int k = 0; k < FUSED_PT; ++k) { const int q = tid + FUSED_NT * k; g[k] = FFT_AT(s, q >> 6, q & 63); }
+    for (int k = 0; k < FUSED_PT; ++k) { const int ph = tid + FUSED_NT * k; g[k] = s[(ph >> 6) * LP + (ph & 63)]; }
     __syncthreads();
     double bsum[FUSED_PT];
 #pragma unroll
@@ -408,15 +414,18 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
         fft2d_lds<FUSED_NT>(s, tw64, false);
 #pragma unroll
         for (int k = 0; k < FUSED_PT; ++k) {
-            const int q = tid + FUSED_NT * k;
-            const double2 f = FFT_AT(s, q >> 6, q & 63);
+            const int ph = tid + FUSED_NT * k, q = brev6(ph >> 6) * FS + brev6(ph & 63);
+            const double2 f = s[(ph >> 6) * LP + (ph & 63)];
             A[(size_t)i * FS * FS + q] = make_double2(g[k].x * f.x - g[k].y * f.y, g[k].x * f.y + g[k].y * f.x);
             bsum[k] = bsum[k] + (f.x * f.x + f.y * f.y);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int k = 0; k < FUSED_PT; ++k) j.state[TRK_B + tid + FUSED_NT * k] = bsum[k];
+    for (int k = 0; k < FUSED_PT; ++k) {
+        const int ph = tid + FUSED_NT * k, q = brev6(ph >> 6) * FS + brev6(ph & 63);
+        j.state[TRK_B + q] = bsum[k];
+    }
 }
 
 // ---- deferred update in one pass per tracker: plane spectra are multiplied into the response sum as they appear (plane order,
@@ -445,8 +454,8 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
         fft2d_lds<FUSED_NT>(s, tw64, false);
 #pragma unroll
         for (int k = 0; k < FUSED_PT; ++k) {
-            const int q = tid + FUSED_NT * k;
-            const double2 f = FFT_AT(s, q >> 6, q & 63);
+            const int ph = tid + FUSED_NT * k, q = brev6(ph >> 6) * FS + brev6(ph & 63);     // as in start_fused_k
+            const double2 f = s[(ph >> 6) * LP + (ph & 63)];
             const double2 a = A[(size_t)i * FS * FS + q];          // four waves per SIMD cover this latency
             gr[k] = gr[k] + (f.x * a.x + f.y * a.y);
             gi[k] = gi[k] + (f.y * a.x - f.x * a.y);
@@ -455,9 +464,9 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
     }
 #pragma unroll
     for (int k = 0; k < FUSED_PT; ++k) {
-        const int q = tid + FUSED_NT * k;
+        const int ph = tid + FUSED_NT * k, q = brev6(ph >> 6) * FS + brev6(ph & 63);
         const double rec = 1.0 / (j.state[TRK_B + q] + REG_SPACE);
-        s[(q >> 6) * LP + (q & 63)] = make_double2(gr[k] * rec, gi[k] * rec);
+        s[(q >> 6) * LP + (q & 63)] = make_double2(gr[k] * rec, gi[k] * rec);       // natural positions for the inverse transform
     }
     __syncthreads();
     peak_body<FUSED_NT>(s, j, b, tw64, results, nullptr);
