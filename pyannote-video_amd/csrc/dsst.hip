@@ -383,6 +383,45 @@ __global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, c
 // fp64 latencies of the butterfly chains (a 256-thread form needed > 256 registers and ran one wave per SIMD).
 #define FUSED_NT 512
 #define FUSED_PT (FS * FS / FUSED_NT)
+// A thread owns the spectrum points at the LDS positions ph = tid + 512 k, k = 0..7: row (tid >> 6) + 8 k, column tid & 63 (consecutive
+// lanes = neighbouring elements, no bank conflict).  Position (pr, pc) holds X[brev6(pr)][brev6(pc)]; with w = tid >> 6 that is
+// logical row 8 brev3(w) + brev3(k), column brev6(tid & 63): the 8 points of a thread are q0 + 64 brev3(k) -- constant offsets from
+// one address, and a wave's 64 points of one k are one 1 KB row of A (permuted).
+struct FusedOwn { int lds0; int q0; };
+__device__ __forceinline__ FusedOwn fused_own()
+{
+    const int tid = threadIdx.x, w = tid >> 6;
+    const int b3 = ((w & 1) << 2) | (w & 2) | ((w >> 2) & 1);
+    return FusedOwn{w * LP + (tid & 63), b3 * 8 * FS + brev6(tid & 63)};
+}
+#define FUSED_LDS(k) (8 * LP * (k))                                                        // k-th owned LDS position, from lds0
+#define FUSED_Q(k) (FS * ((((k) & 1) << 2) | ((k) & 2) | (((k) >> 2) & 1)))                // k-th owned logical index, from q0
+
+// plane i of the tracker's features -> mask * value -> s.  All eight loads of a thread are issued before the first is used
+// (the plane test is block-uniform: no branch inside the element loop).
+__device__ __forceinline__ void fused_load_plane(double2* s, const uint8_t* __restrict__ chip, const float* __restrict__ fb, int i,
+                                                 const double* __restrict__ mask64)
+{
+    const int tid = threadIdx.x;
+    float v[FUSED_PT];
+    double m[FUSED_PT];
+    if (i < 31) {
+        const float* pl = fb + (size_t)i * FS * FS + tid;
+#pragma unroll
+        for (int k = 0; k < FUSED_PT; ++k) v[k] = pl[FUSED_NT * k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < FUSED_PT; ++k) {
+            const uint8_t* p = chip + (size_t)(tid + FUSED_NT * k) * 3;
+            v[k] = (float)(((unsigned)p[0] + p[1] + p[2]) / 3) / 255.0f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < FUSED_PT; ++k) m[k] = mask64[tid + FUSED_NT * k];
+#pragma unroll
+    for (int k = 0; k < FUSED_PT; ++k) s[(tid >> 6) * LP + (tid & 63) + FUSED_LDS(k)] = make_double2((double)v[k] * m[k], 0.0);
+}
+
 __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) start_fused_k(const TrkJob* __restrict__ jobs, const uint8_t* __restrict__ chips, const float* __restrict__ feat,
                                                           const double* __restrict__ mask64, const double* __restrict__ tw64)
 {
@@ -394,38 +433,35 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
     __syncthreads();
     tw64 = tw_lds;
     make_target_lds<FUSED_NT>(s, j.cx, j.cy, tw64);
-    // a thread owns the spectrum points at the LDS positions ph = tid + 512 k (consecutive lanes = neighbouring elements: no bank
-    // conflict); position (pr, pc) holds the point X[brev6(pr)][brev6(pc)], and a wave's 64 points are one row of A (1 KB, permuted)
+    const FusedOwn own = fused_own();
     double2 g[FUSED_PT];
 #pragma unroll
-    for (int k = 0; k < FUSED_PT; ++k) { const int ph = tid + FUSED_NT * k; g[k] = s[(ph >> 6) * LP + (ph & 63)]; }
+    for (int k = 0; k < FUSED_PT; ++k) g[k] = s[own.lds0 + FUSED_LDS(k)];
     __syncthreads();
     double bsum[FUSED_PT];
 #pragma unroll
     for (int k = 0; k < FUSED_PT; ++k) bsum[k] = 0;
-    double2* A = reinterpret_cast<double2*>(j.state + TRK_A);
+    double2* A = reinterpret_cast<double2*>(j.state + TRK_A) + own.q0;
     const uint8_t* chip = chips + (size_t)b * FS * FS * 3;
     const float* fb = feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE;
     for (int i = 0; i < NPL; ++i) {
         const double* mk = mask64;
         asm volatile("" : "+s"(mk));               // the window is re-read per plane (L1/L2 hits), not kept in 16 registers across the loop
-        load_plane_lds<FUSED_NT>(s, chip, fb, i, mk);
+        fused_load_plane(s, chip, fb, i, mk);
         __syncthreads();
         fft2d_lds<FUSED_NT>(s, tw64, false);
+        double2* Ai = A + (size_t)i * FS * FS;
 #pragma unroll
         for (int k = 0; k < FUSED_PT; ++k) {
-            const int ph = tid + FUSED_NT * k, q = brev6(ph >> 6) * FS + brev6(ph & 63);
-            const double2 f = s[(ph >> 6) * LP + (ph & 63)];
-            A[(size_t)i * FS * FS + q] = make_double2(g[k].x * f.x - g[k].y * f.y, g[k].x * f.y + g[k].y * f.x);
+            const double2 f = s[own.lds0 + FUSED_LDS(k)];
+            Ai[FUSED_Q(k)] = make_double2(g[k].x * f.x - g[k].y * f.y, g[k].x * f.y + g[k].y * f.x);
             bsum[k] = bsum[k] + (f.x * f.x + f.y * f.y);
         }
         __syncthreads();
     }
+    double* Bq = j.state + TRK_B + own.q0;
 #pragma unroll
-    for (int k = 0; k < FUSED_PT; ++k) {
-        const int ph = tid + FUSED_NT * k, q = brev6(ph >> 6) * FS + brev6(ph & 63);
-        j.state[TRK_B + q] = bsum[k];
-    }
+    for (int k = 0; k < FUSED_PT; ++k) Bq[FUSED_Q(k)] = bsum[k];
 }
 
 // ---- deferred update in one pass per tracker: plane spectra are multiplied into the response sum as they appear (plane order,
@@ -440,7 +476,8 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
     if (tid < 2 * FS) tw_lds[tid] = tw64[tid];
     __syncthreads();
     tw64 = tw_lds;
-    const double2* A = reinterpret_cast<const double2*>(j.state + TRK_A);
+    const FusedOwn own = fused_own();
+    const double2* A = reinterpret_cast<const double2*>(j.state + TRK_A) + own.q0;
     const uint8_t* chip = chips + (size_t)b * FS * FS * 3;
     const float* fb = feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE;
     double gr[FUSED_PT], gi[FUSED_PT];
@@ -449,23 +486,26 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
     for (int i = 0; i < NPL; ++i) {
         const double* mk = mask64;
         asm volatile("" : "+s"(mk));
-        load_plane_lds<FUSED_NT>(s, chip, fb, i, mk);
+        fused_load_plane(s, chip, fb, i, mk);
         __syncthreads();
         fft2d_lds<FUSED_NT>(s, tw64, false);
+        const double2* Ai = A + (size_t)i * FS * FS;
+        double2 a[FUSED_PT];
+#pragma unroll
+        for (int k = 0; k < FUSED_PT; ++k) a[k] = Ai[FUSED_Q(k)];         // all eight in flight together
 #pragma unroll
         for (int k = 0; k < FUSED_PT; ++k) {
-            const int ph = tid + FUSED_NT * k, q = brev6(ph >> 6) * FS + brev6(ph & 63);     // as in start_fused_k
-            const double2 f = s[(ph >> 6) * LP + (ph & 63)];
-            const double2 a = A[(size_t)i * FS * FS + q];          // four waves per SIMD cover this latency
-            gr[k] = gr[k] + (f.x * a.x + f.y * a.y);
-            gi[k] = gi[k] + (f.y * a.x - f.x * a.y);
+            const double2 f = s[own.lds0 + FUSED_LDS(k)];
+            gr[k] = gr[k] + (f.x * a[k].x + f.y * a[k].y);
+            gi[k] = gi[k] + (f.y * a[k].x - f.x * a[k].y);
         }
         __syncthreads();
     }
+    const double* Bq = j.state + TRK_B + own.q0;
 #pragma unroll
     for (int k = 0; k < FUSED_PT; ++k) {
-        const int ph = tid + FUSED_NT * k, q = brev6(ph >> 6) * FS + brev6(ph & 63);
-        const double rec = 1.0 / (j.state[TRK_B + q] + REG_SPACE);
+        const int q = own.q0 + FUSED_Q(k);
+        const double rec = 1.0 / (Bq[FUSED_Q(k)] + REG_SPACE);
         s[(q >> 6) * LP + (q & 63)] = make_double2(gr[k] * rec, gi[k] * rec);       // natural positions for the inverse transform
     }
     __syncthreads();

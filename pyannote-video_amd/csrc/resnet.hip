@@ -6,6 +6,7 @@
 #include <cmath>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------
@@ -89,54 +90,72 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
 
-    // staging roles: A tile = BM rows x 8 float4 (4 consecutive k = 4 input channels of one tap), B tile = BN rows x 8 float4
+    // staging roles: A tile = BM rows x 8 float4 (4 consecutive k = 4 input channels of one tap), B tile = BN rows x 8 float4.
+    // Input pixels are fetched with raw buffer loads: a tap that falls outside the image (or a row past M, or k past K) gets an offset
+    // beyond the buffer and comes back as zeros -- no branch around any load, so the address arithmetic of the next chunk is one
+    // straight-line block the scheduler spreads between the MFMAs of the current one.
     constexpr int A_F4 = BM * 8 / 256, B_F4 = BN * 8 / 256;
-    int pa_b[A_F4], pa_y[A_F4], pa_x[A_F4];
-    bool pa_ok[A_F4];
+    constexpr int RSRC_FLAGS = 0x00020000;
+    constexpr int OOB = (int)0x80000000;
+    const int hw = a.OH * a.OW;
+    const int b_first = (int)(m0 / hw);                                    // the tile's first face: offsets below stay small
+    const size_t face = (size_t)a.H * a.W * a.Cin;
+    const size_t in_bytes = (size_t)(a.B - b_first) * face * sizeof(float);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b_first * face), 0,
+                                                                           in_bytes > 0x7ffffff0u ? 0x7ffffff0 : (int)in_bytes, RSRC_FLAGS);
+    int pa_off[A_F4], pa_y[A_F4], pa_x[A_F4];       // float index of the input pixel under tap (0, 0); its coordinates (y = -2^20: no pixel)
 #pragma unroll
     for (int q = 0; q < A_F4; ++q) {
         const int i = (tid + q * 256) >> 3;
         const long m = m0 + i;
-        pa_ok[q] = false; pa_b[q] = 0; pa_y[q] = 0; pa_x[q] = 0;
+        pa_off[q] = 0; pa_y[q] = -(1 << 20); pa_x[q] = 0;
         if (m < M) {
             const int ox = (int)(m % a.OW);
             const long t = m / a.OW;
             const int oy = (int)(t % a.OH);
-            pa_b[q] = (int)(t / a.OH);
-            pa_ok[q] = (oy < a.AH && ox < a.AW);
-            pa_y[q] = oy * a.stride - a.pad; pa_x[q] = ox * a.stride - a.pad;
+            const int bb = (int)(t / a.OH) - b_first;
+            if (oy < a.AH && ox < a.AW) {
+                pa_y[q] = oy * a.stride - a.pad; pa_x[q] = ox * a.stride - a.pad;
+                pa_off[q] = ((bb * a.H + pa_y[q]) * a.W + pa_x[q]) * a.Cin;
+            }
         }
     }
     const int Kpad = (a.K + KC - 1) / KC * KC;
     const int j4 = tid & 7;                             // which float4 of a row this thread moves
-    float4 va[A_F4], vb[B_F4];
+    const float* wrow[B_F4];
+#pragma unroll
+    for (int q = 0; q < B_F4; ++q) wrow[q] = a.w + (size_t)(n0 + ((tid + q * 256) >> 3)) * Kpad + 4 * j4;
+    u32x4 va[A_F4];
+    float4 vb[B_F4];
     auto fetch = [&](int k0) {
-        // Cin >= 32: the whole chunk lies in one tap; Cin == 4 (the padded RGB input): every float4 is a tap of its own
-        const bool one_tap = (a.Cin >= KC);
-        const int tap0 = k0 / a.Cin, c00 = k0 - tap0 * a.Cin;
+        // Cin >= 32: the whole chunk lies in one tap (r, sft are wave-uniform); Cin == 4 (the padded RGB input): every float4 is a tap of its own
         const int kq = k0 + 4 * j4;
-        int tap = tap0, c0 = c00 + 4 * j4;
-        if (!one_tap) { tap = kq / a.Cin; c0 = kq - tap * a.Cin; }
-        const int r = tap / a.ksz, sft = tap - r * a.ksz;
+        int r, sft, delta;
+        if (a.Cin >= KC) {
+            const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
+            r = tap / a.ksz; sft = tap - r * a.ksz;
+            delta = (r * a.W + sft) * a.Cin + c0 + 4 * j4;
+        } else {
+            const int tap = kq / a.Cin, c0 = kq - tap * a.Cin;
+            r = tap / a.ksz; sft = tap - r * a.ksz;
+            delta = (r * a.W + sft) * a.Cin + c0;
+        }
+        const bool k_ok = kq < a.K;
 #pragma unroll
         for (int q = 0; q < A_F4; ++q) {
-            va[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int iy = pa_y[q] + r, ix = pa_x[q] + sft;
-            if (kq < a.K && pa_ok[q] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                va[q] = *reinterpret_cast<const float4*>(a.in + (((size_t)pa_b[q] * a.H + iy) * a.W + ix) * a.Cin + c0);
+            const bool ok = k_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            va[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? (pa_off[q] + delta) * 4 : OOB, 0, 0);
         }
 #pragma unroll
-        for (int q = 0; q < B_F4; ++q) {
-            const int j = (tid + q * 256) >> 3;
-            vb[q] = *reinterpret_cast<const float4*>(a.w + (size_t)(n0 + j) * Kpad + kq);     // zero-padded beyond K
-        }
+        for (int q = 0; q < B_F4; ++q) vb[q] = *reinterpret_cast<const float4*>(wrow[q] + k0);     // zero-padded beyond K
     };
     auto park = [&]() {
 #pragma unroll
         for (int q = 0; q < A_F4; ++q) {
-            float* row = &As[((tid + q * 256) >> 3) * PITCH + 2 * j4];
-            *reinterpret_cast<float2*>(row) = make_float2(va[q].x, va[q].z);          // k = 4 j4, 4 j4 + 2   (even half)
-            *reinterpret_cast<float2*>(row + 16) = make_float2(va[q].y, va[q].w);     // k = 4 j4 + 1, + 3    (odd half)
+            uint32_t* row = reinterpret_cast<uint32_t*>(&As[((tid + q * 256) >> 3) * PITCH + 2 * j4]);
+            *reinterpret_cast<uint2*>(row) = make_uint2(va[q].x, va[q].z);          // k = 4 j4, 4 j4 + 2   (even half)
+            *reinterpret_cast<uint2*>(row + 16) = make_uint2(va[q].y, va[q].w);     // k = 4 j4 + 1, + 3    (odd half)
         }
 #pragma unroll
         for (int q = 0; q < B_F4; ++q) {
@@ -153,7 +172,7 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     for (int k0 = 0; k0 < Kpad; k0 += KC) {
         park();
         __syncthreads();
-        if (k0 + KC < Kpad) fetch(k0 + KC);
+        fetch(k0 + KC < Kpad ? k0 + KC : k0);         // (the last chunk fetches itself again: no branch, the values are dropped)
         f32x4 fa0[4], fa1[4], fb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
