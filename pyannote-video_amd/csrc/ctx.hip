@@ -154,17 +154,19 @@ static void load_embedder(Ctx* c, const char* path)
         ConvLayer L{cin, cout, k, stride, pad, nullptr, nullptr, nullptr, nullptr};
         const size_t nw = (size_t)cout * cin * k * k;
         PVF_REQUIRE(p + nw + 3 * (size_t)cout <= end, "emb.blob too short");
-        // [cout][cin][r][s] -> [cout][(r*k+s)*cp + c], rows zero-padded to a multiple of 32 (the conv kernel's K chunk); the 3-channel
-        // input layer is stored with a fourth, all-zero channel (cp = 4) so that the kernel stages one pixel tap with one 16-byte load:
-        // x + 0 * w is exact, the chain is unchanged
+        // [cout][cin][r][s] -> [cout][kk], kk = (r*k+s)*cp + c, rows zero-padded to a multiple of 32 (the conv kernel's K chunk); the
+        // 3-channel input layer is stored with a fourth, all-zero channel (cp = 4) so that the kernel stages one pixel tap with one 16-byte
+        // load: x + 0 * w is exact, the chain is unchanged
         const int cp = (cin == 3) ? 4 : cin;
         const int K = k * k * cp, Kpad = (K + 31) / 32 * 32;
         std::vector<float> wt((size_t)cout * Kpad, 0.0f);
         for (int o = 0; o < cout; ++o)
             for (int ci = 0; ci < cin; ++ci)
                 for (int r = 0; r < k; ++r)
-                    for (int s = 0; s < k; ++s)
-                        wt[(size_t)o * Kpad + (size_t)(r * k + s) * cp + ci] = p[(((size_t)o * cin + ci) * k + r) * k + s];
+                    for (int s = 0; s < k; ++s) {
+                        const int kk = (r * k + s) * cp + ci;
+                        wt[(size_t)o * Kpad + kk] = p[(((size_t)o * cin + ci) * k + r) * k + s];
+                    }
         L.d_w = upload<float>(wt.data(), wt.size());
         p += nw;
         L.d_bias = upload<float>(p, cout); p += cout;

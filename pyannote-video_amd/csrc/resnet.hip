@@ -74,7 +74,23 @@ struct ConvArgs {
 // behind them (position (k >> 1) + 16 (k & 1)): lane (i, h) of a 32 x 32 x 2 MFMA needs k = 2 s + h for s = 0..15, i.e. 16 CONTIGUOUS floats
 // = 4 ds_read_b128 per 16 MFMAs (the 36-float pitch makes them conflict-free), instead of one ds_read_b32 per operand and MFMA.
 // Weights are stored transposed ([cout][K padded to 32], ctx.hip) so that both tiles are staged with the same 16-byte loads along k.
-template <int WM, int WN>
+// (Keeping the activations in that even / odd order in HBM as well -- so that a chunk could be staged with plain 16-byte copies -- was
+// measured 10 % SLOWER: the epilogue's stores and skip loads then scatter within each 128-byte line, and four scattered dwords per lane
+// quad cost the memory pipeline more than the 36 register moves per chunk that the split on the way into LDS costs.)
+
+// exact x / d for 0 <= x < 2^22, 1 <= d < 2^22 (rd = 1.0f / d): float estimate, one correction step.  Output pixel -> (face, row, column)
+// needs two divisions per tile row; 64-bit integer division is emulated with ~100 instructions, and 16 of them per thread took about as
+// long as the K loop of a 3 x 3 x 32 layer.
+__device__ __forceinline__ int small_div(int x, int d, float rd)
+{
+    int q = (int)((float)x * rd);
+    const int r = x - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+
+template <int WM, int WN, bool RGB4>        // RGB4: the first layer (4 stored input channels, every float4 of a chunk is a tap of its own)
 __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
 {
     constexpr int BM = 64 * WM, BN = 32 * WN, KC = 32, PITCH = 36;
@@ -98,7 +114,9 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     constexpr int RSRC_FLAGS = 0x00020000;
     constexpr int OOB = (int)0x80000000;
     const int hw = a.OH * a.OW;
-    const int b_first = (int)(m0 / hw);                                    // the tile's first face: offsets below stay small
+    const int b_first = (int)(m0 / hw);                                    // the tile's first face: offsets below stay small (scalar)
+    const int rel0 = (int)(m0 - (long)b_first * hw);                       // tile rows are rel0 + i within [first face ...): < hw + BM
+    const float r_hw = 1.0f / (float)hw, r_ow = 1.0f / (float)a.OW;
     const size_t face = (size_t)a.H * a.W * a.Cin;
     const size_t in_bytes = (size_t)(a.B - b_first) * face * sizeof(float);
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b_first * face), 0,
@@ -110,10 +128,11 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
         const long m = m0 + i;
         pa_off[q] = 0; pa_y[q] = -(1 << 20); pa_x[q] = 0;
         if (m < M) {
-            const int ox = (int)(m % a.OW);
-            const long t = m / a.OW;
-            const int oy = (int)(t % a.OH);
-            const int bb = (int)(t / a.OH) - b_first;
+            const int rel = rel0 + i;
+            const int bb = small_div(rel, hw, r_hw);
+            const int rem = rel - bb * hw;
+            const int oy = small_div(rem, a.OW, r_ow);
+            const int ox = rem - oy * a.OW;
             if (oy < a.AH && ox < a.AW) {
                 pa_y[q] = oy * a.stride - a.pad; pa_x[q] = ox * a.stride - a.pad;
                 pa_off[q] = ((bb * a.H + pa_y[q]) * a.W + pa_x[q]) * a.Cin;
@@ -127,28 +146,44 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     for (int q = 0; q < B_F4; ++q) wrow[q] = a.w + (size_t)(n0 + ((tid + q * 256) >> 3)) * Kpad + 4 * j4;
     u32x4 va[A_F4];
     float4 vb[B_F4];
-    auto fetch = [&](int k0) {
-        // Cin >= 32: the whole chunk lies in one tap (r, sft are wave-uniform); Cin == 4 (the padded RGB input): every float4 is a tap of its own
-        const int kq = k0 + 4 * j4;
+    // Three stages per chunk, one chunk apart: its byte offsets are worked out (plain VALU work, spread between the MFMAs of an earlier
+    // chunk), its loads are issued right after the barrier of the chunk before it, and it is parked in LDS one barrier later.
+    // Chunk walk of the 32-or-more-channel layers: (tap row, tap column, first channel) advance with scalar adds, no division in the loop.
+    int f_r = 0, f_s = 0, f_c = 0, f_k = 0;             // the chunk whose offsets are computed next
+    int voff[A_F4], woff = 0;
+    auto offsets = [&]() {
+        const int kq = f_k + 4 * j4;
         int r, sft, delta;
-        if (a.Cin >= KC) {
-            const int tap = k0 / a.Cin, c0 = k0 - tap * a.Cin;
-            r = tap / a.ksz; sft = tap - r * a.ksz;
-            delta = (r * a.W + sft) * a.Cin + c0 + 4 * j4;
+        if (RGB4) {
+            const int tap = kq >> 2;                    // 4 stored channels per tap
+            r = small_div(tap, a.ksz, 1.0f / (float)a.ksz); sft = tap - r * a.ksz;
+            delta = (r * a.W + sft) * 4;
         } else {
-            const int tap = kq / a.Cin, c0 = kq - tap * a.Cin;
-            r = tap / a.ksz; sft = tap - r * a.ksz;
-            delta = (r * a.W + sft) * a.Cin + c0;
+            r = f_r; sft = f_s;                         // wave-uniform
+            delta = (r * a.W + sft) * a.Cin + f_c + 4 * j4;
         }
-        const bool k_ok = kq < a.K;
+        const int k_ok = (kq < a.K) ? -1 : 0;
 #pragma unroll
         for (int q = 0; q < A_F4; ++q) {
             const int iy = pa_y[q] + r, ix = pa_x[q] + sft;
-            const bool ok = k_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            va[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? (pa_off[q] + delta) * 4 : OOB, 0, 0);
+            // all-ones when the tap lies inside the image: plain integer logic (no short-circuit branches around the loads)
+            const int ok = k_ok & -(int)((unsigned)iy < (unsigned)a.H) & -(int)((unsigned)ix < (unsigned)a.W);
+            voff[q] = (((pa_off[q] + delta) * 4) & ok) | (OOB & ~ok);
         }
+        woff = f_k;
+        if (f_k + KC < Kpad) {                          // (past the last chunk: stay on it; those loads are issued but never parked)
+            f_k += KC;
+            if (!RGB4) {
+                f_c += KC;
+                if (f_c >= a.Cin) { f_c = 0; if (++f_s == a.ksz) { f_s = 0; ++f_r; } }
+            }
+        }
+    };
+    auto issue = [&]() {
 #pragma unroll
-        for (int q = 0; q < B_F4; ++q) vb[q] = *reinterpret_cast<const float4*>(wrow[q] + k0);     // zero-padded beyond K
+        for (int q = 0; q < A_F4; ++q) va[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[q], 0, 0);
+#pragma unroll
+        for (int q = 0; q < B_F4; ++q) vb[q] = *reinterpret_cast<const float4*>(wrow[q] + woff);     // zero-padded beyond K
     };
     auto park = [&]() {
 #pragma unroll
@@ -168,11 +203,15 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     const float* pa0 = &As[(wm * 64 + li) * PITCH + 16 * kh];
     const float* pa1 = pa0 + 32 * PITCH;
     const float* pb = &Bs[(wn * 32 + li) * PITCH + 16 * kh];
-    fetch(0);
+    offsets();
+    issue();
+    offsets();
     for (int k0 = 0; k0 < Kpad; k0 += KC) {
         park();
         __syncthreads();
-        fetch(k0 + KC < Kpad ? k0 + KC : k0);         // (the last chunk fetches itself again: no branch, the values are dropped)
+        issue();                                      // chunk k0 + KC: in flight during all of this chunk's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        offsets();                                    // chunk k0 + 2 KC
         f32x4 fa0[4], fa1[4], fb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -214,10 +253,12 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
             const int row = (reg & 3) + 8 * (reg >> 2) + 4 * kh;
             const long m = m0 + wm * 64 + t * 32 + row;
             if (m >= M) continue;
-            const int ox = (int)(m % a.OW);
-            const long tq = m / a.OW;
-            const int oy = (int)(tq % a.OH);
-            const int b = (int)(tq / a.OH);
+            const int rel = rel0 + wm * 64 + t * 32 + row;
+            const int bb = small_div(rel, hw, r_hw);
+            const int rem = rel - bb * hw;
+            const int oy = small_div(rem, a.OW, r_ow);
+            const int ox = rem - oy * a.OW;
+            const int b = b_first + bb;
             float v = 0.0f;
             if (oy < a.AH && ox < a.AW) v = ((t == 0 ? acc0[reg] : acc1[reg]) + bias) * g + bt;
             if (a.skip_mode == 1) v += a.skip[(size_t)m * a.Cout + col];
@@ -271,11 +312,15 @@ static void launch_conv(Ctx* c, const ConvArgs& a)
 {
     const long M = (long)a.B * a.OH * a.OW;
     PVF_REQUIRE(a.Cin % 32 == 0 || a.Cin == 4, "conv: input channels must be 4 (padded RGB) or a multiple of 32");
-    if (a.Cout == 32) {
-        hipLaunchKernelGGL((conv_mfma_k<4, 1>), dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, c->stream, a);
+    PVF_REQUIRE(a.OH * a.OW < (1 << 21) && a.Cout % 32 == 0, "conv: output map too large for the kernel's index arithmetic / Cout not a multiple of 32");
+    if (a.Cin == 4) {
+        PVF_REQUIRE(a.Cout == 32, "conv: the RGB layer has 32 output channels");
+        hipLaunchKernelGGL((conv_mfma_k<4, 1, true>), dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, c->stream, a);
+    } else if (a.Cout == 32) {
+        hipLaunchKernelGGL((conv_mfma_k<4, 1, false>), dim3((unsigned)((M + 255) / 256), 1), dim3(256), 0, c->stream, a);
     } else {
         PVF_REQUIRE(a.Cout % 64 == 0, "conv: Cout must be 32 or a multiple of 64");
-        hipLaunchKernelGGL((conv_mfma_k<2, 2>), dim3((unsigned)((M + 127) / 128), a.Cout / 64), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((conv_mfma_k<2, 2, false>), dim3((unsigned)((M + 127) / 128), a.Cout / 64), dim3(256), 0, c->stream, a);
     }
 }
 
@@ -285,13 +330,15 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
     const EmbedModel& e = c->emb;
     PVF_REQUIRE(e.loaded, "embedder not loaded");
     const int S = e.chip_size;
-    const int MAXB = 1024;   // faces per forward: deep layers (4x4, 2x2 maps) need the batch to fill 256 CUs
+    const int MAXB = 4096;   // faces per forward: the deep layers (9x9 ... 2x2 maps) have few output rows per face, and a grid of one to two rounds of
+                             // blocks leaves half the chip idle in its tail (measured at 1024: 1.2 rounds, matrix pipe 50 % busy); 6 GB of activations
     const int h1 = 1 + (S - 7) / 2;       // 72
     const int hp = 1 + (h1 - 3) / 2;      // 35
-    const size_t big = (size_t)MAXB * h1 * h1 * 32;
-    c->s_act0.ensure(std::max(big, (size_t)MAXB * S * S * 4) * sizeof(float));
+    const int cap = std::min(n, MAXB);                   // the arenas grow with the largest batch seen, not to the limit
+    const size_t big = (size_t)cap * h1 * h1 * 32;
+    c->s_act0.ensure(std::max(big, (size_t)cap * S * S * 4) * sizeof(float));
     c->s_act1.ensure(big * sizeof(float));
-    c->s_act2.ensure((size_t)MAXB * hp * hp * 32 * sizeof(float) + (size_t)MAXB * 128 * sizeof(float));
+    c->s_act2.ensure((size_t)cap * hp * hp * 32 * sizeof(float) + (size_t)cap * 128 * sizeof(float));
     for (int b0 = 0; b0 < n; b0 += MAXB) {
         const int B = std::min(MAXB, n - b0);
         ProfScope ps(c, "conv");
@@ -336,7 +383,7 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
             float* old = cur; cur = t2; t2 = old;
             H = oh; W = ow;
         }
-        float* d_out = reinterpret_cast<float*>(c->s_act2.as<uint8_t>() + (size_t)MAXB * hp * hp * 32 * sizeof(float));
+        float* d_out = reinterpret_cast<float*>(c->s_act2.as<uint8_t>() + (size_t)cap * hp * hp * 32 * sizeof(float));
         // cur may alias s_act2's front part; the embedding slot sits behind it
         hipLaunchKernelGGL(head_k, dim3(B), dim3(256), 0, c->stream, cur, H * W, e.d_fc, d_out);
         HIP_CHECK(hipGetLastError());
