@@ -95,8 +95,11 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
 {
     constexpr int BM = 64 * WM, BN = 32 * WN, KC = 32, PITCH = 36;
     static_assert(WM * WN == 4, "four waves per block");
-    __shared__ __attribute__((aligned(16))) float As[BM * PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * PITCH];
+    // A tile, B tile; after the K loop the same space takes each wave's 64 x 32 results for the transposing epilogue
+    constexpr int SM_ROWS = (BM + BN > 256) ? BM + BN : 256;
+    __shared__ __attribute__((aligned(16))) float smem[SM_ROWS * PITCH];
+    float* As = smem;
+    float* Bs = smem + BM * PITCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const long M = (long)a.B * a.OH * a.OW;
@@ -231,19 +234,34 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     const float bias = a.bias[col], g = a.gamma[col], bt = a.beta[col];
     if (a.AH == a.OH && a.AW == a.OW && a.skip_mode != 2) {
         // every output pixel is a convolution result and the skip tensor (if any) has the output's shape: 24 of the 29 layers.
-        // No pixel coordinates are needed -- the 64 integer divisions per lane of the general form below cost as much as the K loop of
-        // a 3 x 3 x 32 layer
+        // The accumulators hold one channel per lane (32 four-byte stores and skip loads per lane, two 128-byte rows per instruction);
+        // the wave's tile is turned through LDS so that a lane owns four neighbouring channels of a pixel: 8 sixteen-byte stores (and
+        // skip loads), each instruction covering eight full 128-byte rows.  Per-element arithmetic and its order are unchanged.
+        float* T = smem + wave * 64 * PITCH;            // (all waves are past the K loop's last barrier)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const long m = m0 + wm * 64 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                if (m >= M) continue;
-                float v = ((t == 0 ? acc0[reg] : acc1[reg]) + bias) * g + bt;
-                if (a.skip_mode == 1) v += a.skip[(size_t)m * a.Cout + col];
-                if (a.relu && v < 0.0f) v = 0.0f;
-                a.out[(size_t)m * a.Cout + col] = v;
+            for (int reg = 0; reg < 16; ++reg)
+                T[(t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh) * PITCH + li] = (t == 0 ? acc0[reg] : acc1[reg]);
+        __builtin_amdgcn_wave_barrier();                // LDS serves a wave's requests in order; this only pins the compiler's order
+        const int c4 = lane & 7, cb = n0 + wn * 32 + 4 * c4;
+        const float4 bias4 = *reinterpret_cast<const float4*>(a.bias + cb), g4 = *reinterpret_cast<const float4*>(a.gamma + cb),
+                     bt4 = *reinterpret_cast<const float4*>(a.beta + cb);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3);
+            const long m = m0 + wm * 64 + row;
+            if (m >= M) continue;
+            const float4 x = *reinterpret_cast<const float4*>(&T[row * PITCH + 4 * c4]);
+            float4 v = make_float4((x.x + bias4.x) * g4.x + bt4.x, (x.y + bias4.y) * g4.y + bt4.y, (x.z + bias4.z) * g4.z + bt4.z,
+                                   (x.w + bias4.w) * g4.w + bt4.w);
+            if (a.skip_mode == 1) {
+                const float4 sk = *reinterpret_cast<const float4*>(a.skip + (size_t)m * a.Cout + cb);
+                v.x += sk.x; v.y += sk.y; v.z += sk.z; v.w += sk.w;
             }
+            if (a.relu) { v.x = v.x < 0.0f ? 0.0f : v.x; v.y = v.y < 0.0f ? 0.0f : v.y; v.z = v.z < 0.0f ? 0.0f : v.z; v.w = v.w < 0.0f ? 0.0f : v.w; }
+            *reinterpret_cast<float4*>(a.out + (size_t)m * a.Cout + cb) = v;
+        }
         return;
     }
 #pragma unroll
