@@ -98,12 +98,14 @@ def main():
 
     def step():
         tm = {}
+        t_step = time.perf_counter()
         res = pipe.run(frames, times, video.frame_rate, shots, timings=tm, cluster=False, last_shard=(rank == world - 1), reorder=(world == 1))
         T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["X"], len(res["tracks"]), device=device,
                                                file_T=res["file_T"] if world > 1 else None, file_id=res["file_id"] if world > 1 else None)
         t0 = time.perf_counter()
         labels = pdist.global_cluster(pipe.clustering, T, ids, X)
         tm["cluster_s"] = time.perf_counter() - t0
+        tm["step_wall_s"] = time.perf_counter() - t_step
         return res, labels, tm
 
     ctxs = [ctx]

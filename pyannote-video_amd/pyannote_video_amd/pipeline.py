@@ -144,10 +144,10 @@ class ExtractStream(object):
     def feed(self, tracks):
         self.compute(self.prepare(tracks))
 
-    def finish(self, drop_last=True, reorder=True):
-        """reorder: put the faces of one timestamp into the order the reference's `extract` writes them (formats.file_order).
-        A shard of a longer video leaves that to the step that sees the whole track table (dist.gather_rows)."""
-        self.compute(self._emit(len(self.groups) - (1 if drop_last else 0)))
+    def plan_finish(self, drop_last=True, reorder=True):
+        """Host part of finish() that does not need the embeddings: the last faces to extract, the file order of all faces and the
+        sorted track rows.  The pipelined run calls it while the GPU still embeds the last shot's faces."""
+        self._final_work = self._emit(len(self.groups) - (1 if drop_last else 0))
         if not drop_last and self.gi < len(self.groups):
             # a shard that is not the end of the video must hand on ALL its groups.  A group is left over when '%.3f' rounded a frame time
             # UP (e.g. 30 fps: t = 0.066667 -> T = 0.067 > t): the reference then serves that group one frame late and carries the lag
@@ -156,17 +156,28 @@ class ExtractStream(object):
             raise ValueError("frame-range shard ends with %d face group(s) whose rounded time lies behind the shard's last frame; cut the "
                              "video at shots whose frame times survive 3-decimal rounding (25 / 50 fps do) or run it unsharded"
                              % (len(self.groups) - self.gi))
-        pts = np.concatenate(self.pts) if self.pts else np.zeros((0, 68, 2), np.int32)
-        emb = np.concatenate(self.emb) if self.emb else np.zeros((0, 128), np.float32)
+        self._perm = None
         if reorder and len(self.face_T):
             perm = formats.file_order(self.face_T, self.face_id, self.file_T, self.file_id)
+            self._perm = perm
             self.face_T = [self.face_T[i] for i in perm]
             self.face_id = [self.face_id[i] for i in perm]
             self.face_boxes = [self.face_boxes[i] for i in perm]
-            pts, emb = pts[perm], emb[perm]
         order = formats.pandas_sort_order(self.file_T)
         by_key = {(r[0], r[1]): r for r in self.rows}
         self.rows = [by_key[(self.file_T[i], self.file_id[i])] for i in order]
+        self._planned = True
+
+    def finish(self, drop_last=True, reorder=True):
+        """reorder: put the faces of one timestamp into the order the reference's `extract` writes them (formats.file_order).
+        A shard of a longer video leaves that to the step that sees the whole track table (dist.gather_rows)."""
+        if not getattr(self, "_planned", False):
+            self.plan_finish(drop_last, reorder)
+        self.compute(self._final_work)
+        pts = np.concatenate(self.pts) if self.pts else np.zeros((0, 68, 2), np.int32)
+        emb = np.concatenate(self.emb) if self.emb else np.zeros((0, 128), np.float32)
+        if self._perm is not None:
+            pts, emb = pts[self._perm], emb[self._perm]
         return pts, emb
 
 
@@ -215,7 +226,7 @@ class FacePipeline(object):
         self.detect_every = detect_every
         self.detect_min_size = detect_min_size
 
-    def _run_pipelined(self, shot_inputs, backend, ex, normalize, mark):
+    def _run_pipelined(self, shot_inputs, backend, ex, normalize, mark, before_join=None):
         """GPU thread: detect(k), speculate(k), extract(k-1) ...; this thread: lanes + merging of shot k as soon as its detections
         and bulk tracker results exist.  ctypes releases the GIL inside every library call."""
         import threading
@@ -245,6 +256,7 @@ class FacePipeline(object):
                 for k, (cache, flags) in enumerate(shot_inputs):
                     dets = [[] for _ in cache]
                     idx = [i for i, f in enumerate(flags) if f]
+                    note("detect begin", k)
                     if idx:
                         with lock:
                             res = ctx.detect_many([cache[i][1] for i in idx], bs, 1)
@@ -259,6 +271,7 @@ class FacePipeline(object):
                                 work = done.get_nowait()
                             except queue.Empty:
                                 break
+                            note("extract begin", extracted)
                             with lock:
                                 ex.compute(work)
                             extracted += 1
@@ -271,6 +284,7 @@ class FacePipeline(object):
                     if k < n - 1:
                         drain()
                     det_at = {t: d for (t, _), d in zip(cache, dets)}
+                    note("speculate begin", k)
                     with lock:
                         release_dead()
                         if hasattr(backend, "speculate_pair"):
@@ -286,6 +300,7 @@ class FacePipeline(object):
                     work = done.get()
                     if work is None:
                         return
+                    note("extract begin", extracted)
                     with lock:
                         ex.compute(work)
                     extracted += 1
@@ -310,13 +325,19 @@ class FacePipeline(object):
                 if isinstance(item, BaseException):
                     raise item
                 _, dets, plans = item
+                note("host begin", k)
                 job = self.tracking.begin_shot(cache, flags, dets, lane_backend, plans)
                 self.tracking._run_lanes(job["lanes"], lane_backend)
+                note("lanes done", k)
                 tracks = self.tracking.finish_shot(job)
                 note("tracked", k)
                 if k == n - 1:
                     mark["tracked"] = _time.perf_counter()
                 done.put(ex.prepare(normalize(tracks)))
+                note("prepared", k)
+            if before_join is not None:
+                before_join()                 # host work that only needs the tracks: runs while the GPU thread embeds the last faces
+                note("planned")
             ok = True
         finally:
             if not ok:
@@ -372,7 +393,8 @@ class FacePipeline(object):
             was_enabled = gc.isenabled()
             gc.disable()      # a full collection in the middle of a shot stalls both threads for tens of milliseconds
             try:
-                self._run_pipelined(shot_inputs, backend, ex, normalize, mark)
+                self._run_pipelined(shot_inputs, backend, ex, normalize, mark,
+                                    before_join=lambda: ex.plan_finish(drop_last=last_shard, reorder=reorder))
             finally:
                 if was_enabled:
                     gc.enable()

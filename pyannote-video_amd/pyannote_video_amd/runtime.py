@@ -206,7 +206,13 @@ class Context(object):
                 self._trim()
 
     def _handles(self, frames):
+        if isinstance(frames, np.ndarray) and frames.dtype == np.uint64:     # handles the caller looked up before (frame_handles)
+            return np.ascontiguousarray(frames)
         return handles([self.stage(f).handle for f in frames])
+
+    def frame_handles(self, frames):
+        """uint64 array of the staged frames' handles: look them up once, index the array for every batched call"""
+        return self._handles(frames)
 
     def unstage_all(self):
         for f in self._staged.values():
@@ -286,18 +292,18 @@ class Context(object):
         check(self._l.pvf_tracker_create(self._h, C.byref(h)))
         return h.value
 
-    def tracker_create_many(self, n):
+    def tracker_create_many(self, n, as_array=False):
         self.ensure_tracker_tables()
         out = np.zeros(int(n), np.uint64)
         if n:
             check(self._l.pvf_tracker_create_many(self._h, int(n), ptr(out)))
-        return [int(v) for v in out]
+        return out if as_array else out.tolist()
 
-    def tracker_clone_many(self, trks):
+    def tracker_clone_many(self, trks, as_array=False):
         out = np.zeros(len(trks), np.uint64)
         if len(trks):
             check(self._l.pvf_tracker_clone_many(self._h, ptr(handles(trks)), len(trks), ptr(out)))
-        return [int(v) for v in out]
+        return out if as_array else out.tolist()
 
     def tracker_destroy_many(self, trks):
         if self._h is not None and len(trks):
@@ -350,11 +356,9 @@ class Context(object):
         pts = np.zeros((n, 68, 2), np.int32)
         if n == 0:
             return pts
-        r = (Rect * n)()
-        for i, b in enumerate(boxes):
-            r[i] = Rect(int(b[0]), int(b[1]), int(b[2]), int(b[3]))
+        r = np.ascontiguousarray(np.asarray(boxes).astype(np.int64).astype(np.int32)).reshape(n, 4)    # int() of each coordinate; = pvf_rect_i32[n]
         with self._staging():
-            check(self._l.pvf_landmarks(self._h, ptr(self._handles(frames)), r, n, ptr(pts)))
+            check(self._l.pvf_landmarks(self._h, ptr(self._handles(frames)), ptr(r), n, ptr(pts)))
         return pts
 
     def embed(self, frames, pts):

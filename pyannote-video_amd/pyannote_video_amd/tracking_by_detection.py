@@ -119,37 +119,38 @@ class HipTrackers(object):
         """speculate() for the forward AND the backward pass of a shot: (plan_forward, plan_backward).
 
         Both passes start one tracker per detection from the same frame and box, i.e. with bit-identical filters, so the
-        trackers are started once and cloned for the second pass (a 2.4 MB device copy instead of features + 33 FFTs); only
-        the first updates differ (frame i+1 for the forward pass, frame i-1 for the backward one)."""
-        flat_f, flat_b, owner = [], [], []
-        for i, (t, frame) in enumerate(cache):
-            for d in detections_at.get(t, []):
-                flat_f.append(frame)
-                flat_b.append(tuple(float(v) for v in d))
-                owner.append(i)
-        n = len(flat_b)
-        hs_f, hs_b = [], []
+        trackers are started once and cloned for the second pass (clones share the filters until one side writes them: no device
+        work); only the first updates differ (frame i+1 for the forward pass, frame i-1 for the backward one).
+        Frame handles, owners and boxes are arrays built once per shot; every batched call indexes them."""
+        ctx = self.ctx
+        counts = [len(detections_at.get(t, ())) for t, _ in cache]
+        n = sum(counts)
+        fh = ctx.frame_handles([f for _, f in cache])
+        owner = np.repeat(np.arange(len(cache)), counts)
+        boxes = np.array([d for t, _ in cache for d in detections_at.get(t, ())], np.float64).reshape(-1, 4)
+        hs_f = ctx.tracker_create_many(n, as_array=True)
         for o in range(0, n, chunk):
-            part = self.start_many(flat_f[o:o + chunk], flat_b[o:o + chunk])
-            hs_f.extend(part)
-            hs_b.extend(self.ctx.tracker_clone_many(part))      # before any update touches the originals
+            ctx.tracker_start_many(hs_f[o:o + chunk], fh[owner[o:o + chunk]], boxes[o:o + chunk])
+        hs_b = ctx.tracker_clone_many(hs_f, as_array=True)          # before any update touches the originals
         last = len(cache) - 1
+        starts = np.concatenate([[0], np.cumsum(counts)])
         plans = []
         for hs, step, edge in ((hs_f, 1, last), (hs_b, -1, 0)):
-            upd = [k for k in range(n) if owner[k] != edge]
+            upd = np.nonzero(owner != edge)[0]
             psr = np.zeros(n, np.float64)
             pos = np.zeros((n, 4), np.float64)
             for o in range(0, len(upd), chunk):
                 ks = upd[o:o + chunk]
-                p, b = self.update_many([hs[k] for k in ks], [cache[owner[k] + step][1] for k in ks], True)
+                p, b = ctx.tracker_update_many(hs[ks], fh[owner[ks] + step], True)
                 psr[ks] = p
                 pos[ks] = b
-            plan, k = {}, 0
+            hl = hs.tolist()
+            plan = {}
             for i, (t, _) in enumerate(cache):
-                m = len(detections_at.get(t, []))
+                m = counts[i]
                 if m:
-                    plan[t] = (hs[k:k + m], psr[k:k + m] if i != edge else None, pos[k:k + m] if i != edge else None)
-                    k += m
+                    k = int(starts[i])
+                    plan[t] = (hl[k:k + m], psr[k:k + m] if i != edge else None, pos[k:k + m] if i != edge else None)
             plans.append(plan)
         return plans[0], plans[1]
 
@@ -476,14 +477,57 @@ class TrackingByDetection(object):
         lanes = [self._lane(cache, det_at, FORWARD, ef, backend, pf), self._lane(list(reversed(cache)), det_at, BACKWARD, eb, backend, pb)]
         return {"graph": g, "ef": ef, "eb": eb, "lanes": lanes}
 
-    def finish_shot(self, job):
-        """replay the lanes' graph mutations in the reference's order (forward pass, then backward) and extract the tracks"""
+    def finish_shot_graph(self, job):
+        """the reference's own data structure: replay the lanes' graph mutations in its order (forward pass, then backward) into the
+        networkx graph and take the tracks from it (tracking.py:359-362)"""
         g = job["graph"]
         for u, v, conf in job["ef"]:
             g.add_edge(u, v, confidence=conf)
         for u, v, conf in job["eb"]:
             g.add_edge(u, v, confidence=conf)
         return self._tracks_from_graph(g)
+
+    def finish_shot(self, job):
+        """Same tracks as finish_shot_graph without building the graph: the tracks are the connected components of the non-timestamp
+        nodes, listed in the order of each component's first node in the graph's node order (networkx yields them that way) -- and a
+        node enters the graph with the first add_edge that names it: detections frame by frame (begin_shot), then the forward edges,
+        then the backward ones.  A union-find over that same node order gives the same components in the same order; what happens to
+        them afterwards (_fix, _fill_gaps, the final sort) is shared."""
+        index = {}
+        parent = []
+        for n in job["graph"]:                      # node order so far: timestamps and their detections
+            if isinstance(n, tuple):
+                index[n] = len(parent)
+                parent.append(len(parent))
+        for edges in (job["ef"], job["eb"]):
+            for u, v, _ in edges:
+                iu = index.get(u)
+                if iu is None:
+                    iu = index[u] = len(parent)
+                    parent.append(iu)
+                iv = index.get(v)
+                if iv is None:
+                    iv = index[v] = len(parent)
+                    parent.append(iv)
+                while parent[iu] != iu:
+                    parent[iu] = parent[parent[iu]]
+                    iu = parent[iu]
+                while parent[iv] != iv:
+                    parent[iv] = parent[parent[iv]]
+                    iv = parent[iv]
+                if iu != iv:
+                    if iu < iv:
+                        parent[iv] = iu
+                    else:
+                        parent[iu] = iv
+        comps = {}
+        for n, i in index.items():                  # dict order == node order
+            while parent[i] != i:
+                i = parent[i]
+            comps.setdefault(i, []).append(n)
+        tracks = [self._fix(track) for track in comps.values()]     # roots are each component's first node: dict order == component order
+        tracks = self._fill_gaps(tracks)
+        return sorted(tracks, key=get_min_max_t)
 
     def process_shots(self, shots, backend):
         """shots: list of (cache, flags[, detections]) -- [(t, frame)], [run detection on frame i], optional precomputed

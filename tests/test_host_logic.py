@@ -345,3 +345,19 @@ def test_round3_equals_text_round_trip():
     box = (0.123456, 0.5, 0.987654, 0.75)
     q = np.asarray([round(v, 3) for v in box], np.float64).astype(np.float32).astype(np.float64).tolist()
     assert q == [float(np.float32("%.3f" % v)) for v in box]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tracks_without_the_graph_equal_tracks_from_the_graph(seed):
+    """finish_shot (union-find over the recorded edges, in the graph's node order) == finish_shot_graph (networkx, the reference's
+    own structure): same tracks, same order"""
+    frames, dets = scenario(100 + seed, n=60, faces=4, p_miss=0.4, p_false=0.15)
+    times = [i / 25.0 for i in range(len(frames))]
+    cache = list(zip(times, frames))
+    tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0, trackers=ObjectTrackers(ScriptTracker))
+    backend = tbd._backend()
+    job = tbd.begin_shot(cache, [True] * len(cache), dets, backend)
+    tbd._run_lanes(job["lanes"], backend)
+    fast = tbd.finish_shot(job)
+    slow = tbd.finish_shot_graph(job)
+    assert fast == slow and len(fast) >= 2
