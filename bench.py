@@ -271,7 +271,7 @@ def cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args):
     import numpy as np
     from pyannote_video_amd import models, pipeline
     from oracle import oracle, ref_flow
-    nproc = os.cpu_count() or 1
+    nproc = oracle.usable_cpus(cap=1024)          # CPUs this process owns (affinity mask and cgroup quota), not the host's processor count
     cut = video.shot_bounds[1] if video.n_shots > 1 else video.n_frames // 2
     det = oracle.Detector(models.load_container(models.DEFAULT_DETECTOR))
     sp = oracle.ShapePredictor(models.load_model_file(lp, "shape_predictor"))

@@ -1,14 +1,24 @@
-mkdir -p gpurun_out
-R=$GRAFT_REPO_ROOT
-python -m pytest tests -q -m gpu -x --no-header -p no:cacheprovider 2>&1 | tail -4 > gpurun_out/t44.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" >> gpurun_out/t44.log 2>&1
-python bench.py > gpurun_out/b44.json 2> gpurun_out/b44.err
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof44 /tmp/pmc44a /tmp/pmc44b
-rocprofv3 --kernel-trace --stats -d /tmp/prof44 -- python $R/bench.py --cpu-frames 0 > /tmp/p44.log 2>&1
-DB=$(find /tmp/prof44 -name "*_results.db" | head -1); python $R/tools/rocprof_top.py $DB > $R/gpurun_out/prof44_stats.txt
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc44a -- python $R/bench.py --cpu-frames 0 --steps 1 --warmup 0 > /tmp/p44a.log 2>&1
-DB=$(find /tmp/pmc44a -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/gpurun_out/pmc44_fetch.txt
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmc44b -- python $R/bench.py --cpu-frames 0 --steps 1 --warmup 0 > /tmp/p44b.log 2>&1
-DB=$(find /tmp/pmc44b -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/gpurun_out/pmc44_write.txt
-cd $R; cat gpurun_out/t44.log; head -c 300 gpurun_out/b44.json; echo; head -12 gpurun_out/prof44_stats.txt; head -5 gpurun_out/pmc44_fetch.txt
+#!/bin/bash
+# One GPU session that produces everything profiles/ holds for a round: usage  bash tools/measure_round.sh r02
+#   tests (-m gpu) + smoke, the default bench line (with cpu_baseline / parity / host_ingest), a rocprofv3 kernel-trace summary of the
+#   same workload, three separate PMC passes (FETCH_SIZE, WRITE_SIZE, matrix-pipe counters) and the C5 clustering stressor.
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+O=gpurun_out/$TAG; mkdir -p $O
+t() { name=$1; lim=$2; shift; shift; echo "=== $name" >> $O/summary.log; s=$(date +%s); ( timeout $lim "$@" ) > $O/$name.log 2>&1; echo "rc=$? $(( $(date +%s) - s ))s" >> $O/summary.log; tail -3 $O/$name.log | cut -c1-600 >> $O/summary.log; }
+t tests 600 python -m pytest tests -q -m gpu --durations=5
+t smoke 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
+timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "=== bench rc=$?" >> $O/summary.log
+t bench_b64 200 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-host-ingest --detect-batch 64
+t c5 400 python tools/c5_cluster.py $O/c5_cluster.json
+cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/prof /tmp/pmca /tmp/pmcb /tmp/pmcc
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --cpu-frames 0 --no-host-ingest > $R/$O/prof_bench.log 2>&1
+DB=$(find /tmp/prof -name "*_results.db" | head -1); python $R/tools/rocprof_top.py $DB > $R/$O/rocprof_kernel_stats.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmca -- python $R/bench.py --cpu-frames 0 --no-host-ingest --steps 1 --warmup 0 > /tmp/pa.log 2>&1
+DB=$(find /tmp/pmca -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_fetch.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcb -- python $R/bench.py --cpu-frames 0 --no-host-ingest --steps 1 --warmup 0 > /tmp/pb.log 2>&1
+DB=$(find /tmp/pmcb -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_write.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmcc -- python $R/bench.py --cpu-frames 0 --no-host-ingest --steps 1 --warmup 0 > /tmp/pc.log 2>&1
+DB=$(find /tmp/pmcc -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_mfma_busy.txt 2>&1
+cd $R; cat $O/summary.log | cut -c1-400; head -c 600 $O/bench.json; echo; head -14 $O/rocprof_kernel_stats.txt; head -4 $O/pmc_fetch.txt; head -3 $O/pmc_mfma_busy.txt
