@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) feat_ring_zero_k(MlStarts st, const LvDes
 // next feature row is loaded into registers while the current one is multiplied.  Each accumulator still receives its
 // terms in (m, n, p) order  =>  bit-identical to the oracle's chain.
 template <int R>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base,
                      const float4* __restrict__ Bg4, ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
 {
@@ -455,7 +455,8 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
     constexpr int NST = (SEG * 8 + 63) / 64;
     constexpr int RSRC_FLAGS = 0x00020000;          // raw buffer, 32-bit data format (out-of-range lanes read 0)
     extern __shared__ __attribute__((aligned(16))) float s_seg[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = ml_block(st);
     if (g >= st.b0[st.nl]) return;
     const int l = ml_level(st, g);
@@ -465,9 +466,13 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
     const int by = (local / d.score_bx) % d.score_by;
     const int b = __builtin_amdgcn_readfirstlane(local / (d.score_bx * d.score_by));
     const int fh = d.fh, fw = d.fw;
-    const int r_top = by * R, c_base = bx * WCOLS;
+    // A block = four waves on four vertically adjacent row groups of one column strip.  They share no data on chip, but they start
+    // together and walk in step, and their re-reads of each other's feature rows partly hit in L2: measured 6.0 GB per launch from
+    // beyond L2 against 7.4 GB when every wave is a workgroup of its own (same kernel time either way).
+    const int r_top = (by * 4 + wave) * R, c_base = bx * WCOLS;
     const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
-    float* seg = s_seg;
+    if (r_top + FR / 2 >= r1) return;               // wave-uniform: row group past the level's last output row
+    float* seg = s_seg + (size_t)wave * SEG * PITCH;
     const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride + (size_t)c_base * PVF_FHOG_STRIDE;
     const int seg_cells = (fw - c_base < SEG) ? fw - c_base : SEG;
     const int i = lane & 15, kq = lane >> 4;
@@ -689,7 +694,7 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         p.feat_floats += (size_t)d.feat_stride * B;
         d.feat_bx = std::max((d.fw + 255) / 256, 0);
         const int out_r = d.fh - 9, out_c = d.fw - 9;
-        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + 3) / 4 : 0;      // one wave (= one workgroup) per 4 rows x 96 columns
+        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + 15) / 16 : 0;    // a block = 4 waves x 4 rows x 96 columns
         // fused FHOG tasks: strips of 61 feature columns x chunks of feature rows (smaller chunks for the small levels: more tasks)
         d.strips = feat_ok ? (d.hog_nc + FUSED_OUT - 1) / FUSED_OUT : 0;
         d.chunk_rows = (d.hog_nr >= 2 * chunk_big) ? chunk_big : std::max((d.hog_nr + 1) / 2, 1);
@@ -803,9 +808,9 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
     MlPlan* p = ml_features(c, frames, upsample);
     if (p->score_blocks == 0) return;
     ProfScope ps(c, "score");
-    const size_t lds = (size_t)(2 * 48 + 11) * 34 * sizeof(float);
+    const size_t lds = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
     const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
-    hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(64), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
+    hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
                        sp0, d_counts, d_cands);
 }
 

@@ -36,7 +36,7 @@ def _oracle_detector(oracle):
     return oracle.Detector(models.load_container(models.DEFAULT_DETECTOR))
 
 
-def test_detector_1080p_batch32_bit_exact(ctx_full, oracle, clip1080):
+def test_detector_1080p_batches_bit_exact(ctx_full, oracle, clip1080):
     _, frames = clip1080
     det = _oracle_detector(oracle)
     want = [det.detect(f, 1) for f in frames]
@@ -47,12 +47,13 @@ def test_detector_1080p_batch32_bit_exact(ctx_full, oracle, clip1080):
     ref = det.detect_raw(frames[0], 1)
     assert len(raw) == len(ref) > 0
     assert raw == [(r[0], r[1], r[2], r[3], r[4], tuple(r[5])) for r in ref]
-    # a batch of 32 (the four frames eight times, as the bench's batches) through the pipelined entry: every copy equals the oracle
-    res = ctx_full.detect_many([dev[i % 4] for i in range(64)], 32, 1)
-    for i, (boxes, scores) in enumerate(res):
-        w = want[i % 4]
-        assert boxes == [tuple(d[5]) for d in w]
-        assert np.array_equal(scores, np.array([d[0] for d in w], np.float32))
+    # batches of 32 and of 64 (the four frames repeated; 64 is the bench's batch) through the pipelined entry: every copy equals the oracle
+    for batch in (32, 64):
+        res = ctx_full.detect_many([dev[i % 4] for i in range(64)], batch, 1)
+        for i, (boxes, scores) in enumerate(res):
+            w = want[i % 4]
+            assert boxes == [tuple(d[5]) for d in w]
+            assert np.array_equal(scores, np.array([d[0] for d in w], np.float32))
 
 
 def test_full_landmark_model_chips_and_embeddings_1080p(ctx_full, oracle, clip1080, full_models):

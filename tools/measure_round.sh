@@ -1,24 +1,42 @@
 #!/bin/bash
 # One GPU session that produces everything profiles/ holds for a round: usage  bash tools/measure_round.sh r02
-#   tests (-m gpu) + smoke, the default bench line (with cpu_baseline / parity / host_ingest), a rocprofv3 kernel-trace summary of the
-#   same workload, three separate PMC passes (FETCH_SIZE, WRITE_SIZE, matrix-pipe counters) and the C5 clustering stressor.
+#   tests (-m gpu) + smoke; a FETCH_SIZE pass over the bench workload, turned into profiles/<tag>_pmc_score.json (bench.py attaches it
+#   as roofline.traffic); the default bench line (cpu_baseline / parity / host_ingest); a rocprofv3 kernel-trace summary of the same
+#   workload; WRITE_SIZE and matrix-pipe counter passes (every --pmc pass on its own, with --kernel-trace only); the C5 clustering stressor.
 TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=gpurun_out/$TAG; mkdir -p $O
 t() { name=$1; lim=$2; shift; shift; echo "=== $name" >> $O/summary.log; s=$(date +%s); ( timeout $lim "$@" ) > $O/$name.log 2>&1; echo "rc=$? $(( $(date +%s) - s ))s" >> $O/summary.log; tail -3 $O/$name.log | cut -c1-600 >> $O/summary.log; }
 t tests 600 python -m pytest tests -q -m gpu --durations=5
 t smoke 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
-timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "=== bench rc=$?" >> $O/summary.log
-t bench_b64 200 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-host-ingest --detect-batch 64
-t c5 400 python tools/c5_cluster.py $O/c5_cluster.json
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof /tmp/pmca /tmp/pmcb /tmp/pmcc
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmca -- python $R/bench.py --cpu-frames 0 --no-host-ingest --steps 1 --warmup 0 > /tmp/pa.log 2>&1
+DB=$(find /tmp/pmca -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_fetch_size.txt 2>&1
+cd $R
+python - $O/pmc_fetch_size.txt $TAG <<'PY'
+import json, re, sys
+kb = None
+for line in open(sys.argv[1]):
+    if "score_mfma_rows_ml_k" in line:
+        kb = float(re.search(r"FETCH_SIZE=([0-9.e+]+)", line).group(1)); n = int(re.search(r"n=(\d+)", line).group(1))
+if kb is not None:
+    d = {"kernel": "score_mfma_rows_ml_k<4>", "detect_batch": 64, "frame": "1920x1080", "launches_in_pass": n, "fetch_size_kb_per_launch": kb,
+         "traffic_bytes_per_launch": kb * 1024 * 2,
+         "source": "profiles/%s_pmc_fetch_size.txt (rocprofv3 --kernel-trace --pmc FETCH_SIZE over `bench.py --steps 1`, a pass of its own; average over the "
+                   "launches of the step; x2 gfx950 correction of MI355X_MICROARCH.md section HBM)" % sys.argv[2]}
+    for path in ("profiles/%s_pmc_score.json" % sys.argv[2], "gpurun_out/%s/pmc_score.json" % sys.argv[2]):
+        json.dump(d, open(path, "w"), indent=1)
+PY
+timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "=== bench rc=$?" >> $O/summary.log
+t bench_b32 200 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-host-ingest --detect-batch 32
+t bench_b128 200 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-host-ingest --detect-batch 128
+t c5 400 python tools/c5_cluster.py $O/c5_cluster.json
+cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --cpu-frames 0 --no-host-ingest > $R/$O/prof_bench.log 2>&1
 DB=$(find /tmp/prof -name "*_results.db" | head -1); python $R/tools/rocprof_top.py $DB > $R/$O/rocprof_kernel_stats.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmca -- python $R/bench.py --cpu-frames 0 --no-host-ingest --steps 1 --warmup 0 > /tmp/pa.log 2>&1
-DB=$(find /tmp/pmca -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_fetch.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcb -- python $R/bench.py --cpu-frames 0 --no-host-ingest --steps 1 --warmup 0 > /tmp/pb.log 2>&1
-DB=$(find /tmp/pmcb -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_write.txt 2>&1
+DB=$(find /tmp/pmcb -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_write_size.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmcc -- python $R/bench.py --cpu-frames 0 --no-host-ingest --steps 1 --warmup 0 > /tmp/pc.log 2>&1
 DB=$(find /tmp/pmcc -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_mfma_busy.txt 2>&1
-cd $R; cat $O/summary.log | cut -c1-400; head -c 600 $O/bench.json; echo; head -14 $O/rocprof_kernel_stats.txt; head -4 $O/pmc_fetch.txt; head -3 $O/pmc_mfma_busy.txt
+cd $R; cat $O/summary.log | cut -c1-400; head -c 700 $O/bench.json; echo; head -14 $O/rocprof_kernel_stats.txt; head -4 $O/pmc_fetch_size.txt; head -3 $O/pmc_mfma_busy.txt
