@@ -100,7 +100,8 @@ int32_t pvf_tracker_create_many(pvf_handle ctx, int32_t n, pvf_handle* trks);
 int32_t pvf_tracker_destroy_many(pvf_handle ctx, const pvf_handle* trks, int32_t n);
 /* n new trackers that are exact copies (filters, position) of started trackers without a pending deferred update.  The two
  * passes over a shot (tracking.py:184-259 forward, then backward) start one tracker per detection from the same frame and box:
- * the second pass clones instead of recomputing the same filters. */
+ * the second pass clones instead of recomputing the same filters.  A clone SHARES its source's filters on the device until either
+ * side writes them (start_track, a full update, the commit of a deferred update): only then is the 2.4 MB state copied. */
 int32_t pvf_tracker_clone_many(pvf_handle ctx, const pvf_handle* src, int32_t n, pvf_handle* dst);
 int32_t pvf_tracker_destroy(pvf_handle ctx, pvf_handle trk);
 /* ref: tracking.py:251  tracker.start_track(frame, dlib.drectangle(*detection)) ; box = (l,t,r,b) doubles */
