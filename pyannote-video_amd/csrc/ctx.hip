@@ -89,23 +89,22 @@ static void load_detector(Ctx* c, const char* path)
     if (d.d_w) (void)hipFree(d.d_w);
     d.d_w = upload<float>(w.f32(), w.numel());
     {
-        // B fragments of score_mfma_k: index ((m*12 + n')*8 + pq)*64 + lane ; lane -> k = lane>>4 (plane 4pq+k), column j = lane&15 = 5*s + f
-        std::vector<float> bm((size_t)10 * 12 * 8 * 64, 0.0f);
+        // B fragments of score_mfma_rows_ml_k.  K of one filter row = the 12 cells x 31 planes a tile of three column shifts spans, taken
+        // as ONE run of 372 values (index kk = 31 * cell + plane; no pad plane) = 93 k-steps of 4: lane (column j = lane & 15 = 5 * shift +
+        // filter, kq = lane >> 4) holds kk = 4 * step + kq.  Packed four steps per lane: [m][group of 8 steps: 12][half: 2][lane: 64][4];
+        // steps 93..95 stay zero and are never issued.
+        std::vector<float> b4((size_t)10 * 12 * 2 * 64 * 4, 0.0f);
         for (int mm = 0; mm < 10; ++mm)
-            for (int np = 0; np < 12; ++np)
-                for (int pq = 0; pq < 8; ++pq)
-                    for (int l = 0; l < 64; ++l) {
-                        const int kq = l >> 4, j = l & 15, p = 4 * pq + kq;
-                        if (j >= 15 || p >= 31) continue;
-                        const int s = j / 5, f = j % 5, n = np - s;
-                        if (n < 0 || n >= 10) continue;
-                        bm[(((size_t)mm * 12 + np) * 8 + pq) * 64 + l] = w.f32()[(((size_t)f * 10 + mm) * 10 + n) * 32 + p];
-                    }
-        // the same fragments packed four k-steps per lane for score_mfma_rows_ml_k: [m][n'][half][lane][4]
-        std::vector<float> b4(bm.size());
-        for (int mn = 0; mn < 10 * 12; ++mn)
-            for (int pq = 0; pq < 8; ++pq)
-                for (int l = 0; l < 64; ++l) b4[(((size_t)mn * 2 + (pq >> 2)) * 64 + l) * 4 + (pq & 3)] = bm[((size_t)mn * 8 + pq) * 64 + l];
+            for (int step = 0; step < 93; ++step)
+                for (int l = 0; l < 64; ++l) {
+                    const int kq = l >> 4, j = l & 15, kk = 4 * step + kq;
+                    if (j >= 15) continue;
+                    const int np = kk / 31, p = kk % 31;
+                    const int sh = j / 5, f = j % 5, n = np - sh;
+                    if (n < 0 || n >= 10) continue;
+                    const int grp = step >> 3, pq = step & 7;
+                    b4[((((size_t)mm * 12 + grp) * 2 + (pq >> 2)) * 64 + l) * 4 + (pq & 3)] = w.f32()[(((size_t)f * 10 + mm) * 10 + n) * 32 + p];
+                }
         if (d.d_bmfma4) (void)hipFree(d.d_bmfma4);
         d.d_bmfma4 = upload<float>(b4.data(), b4.size());
     }

@@ -442,8 +442,9 @@ __global__ void __launch_bounds__(256) feat_ring_zero_k(MlStarts st, const LvDes
 // ---------------------------------------------------------------------------------------------------
 // K3 v3: one wave owns R consecutive output rows x 96 columns and walks the R + 9 feature rows it needs ONCE.
 // Staged feature row t feeds output row j through filter row m = t - j, so every A fragment read from the slab is used for
-// up to R MFMAs and the slab is filled (R+9)/R times per output row instead of 10 times.  B fragments (packed four k-steps
-// per lane: [m][n][2][64 lanes][4]) and A fragments are fetched one cell column ahead of the MFMAs that consume them; the
+// up to R MFMAs and the slab is filled (R+9)/R times per output row instead of 10 times.  K of a filter row is the run of 12 cells x 31
+// planes (cells packed in the slab, no pad plane) = 93 k-steps, walked in 12 groups of 8 (the last of 5).  B fragments (packed four
+// k-steps per lane: [m][group][2][64 lanes][4]) and A fragments are fetched one group ahead of the MFMAs that consume them; the
 // next feature row is loaded into registers while the current one is multiplied.  Each accumulator still receives its
 // terms in (m, n, p) order  =>  bit-identical to the oracle's chain.
 template <int R>
@@ -451,7 +452,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base,
                      const float4* __restrict__ Bg4, ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
 {
-    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 34, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11, NT = FR + R - 1;
+    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 31, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11, NT = FR + R - 1;
+    constexpr int LAST_STEPS = 93 - 8 * (NK - 1);   // k-steps of the last group of a filter row (5): 12 cells x 31 planes = 93 steps of 4
     constexpr int NST = (SEG * 8 + 63) / 64;
     constexpr int RSRC_FLAGS = 0x00020000;          // raw buffer, 32-bit data format (out-of-range lanes read 0)
     extern __shared__ __attribute__((aligned(16))) float s_seg[];
@@ -493,14 +495,16 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
         for (int u = 0; u < NST; ++u) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, u * 1024, 0);
     };
     auto fill_slab = [&]() {
+        // cells are packed (31 floats each, the feature map's pad plane is dropped): the 12 x 31 values a tile row spans form ONE run,
+        // 93 k-steps of 4 instead of 12 x 8
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
             const int idx = lane + 64 * u;
             if (idx < SEG * 8) {
                 const int cell = idx >> 3, q = idx & 7;
-                uint2* dd = reinterpret_cast<uint2*>(seg + cell * PITCH + 4 * q);
-                dd[0] = make_uint2(sv[u].x, sv[u].y);
-                dd[1] = make_uint2(sv[u].z, sv[u].w);
+                uint32_t* dd = reinterpret_cast<uint32_t*>(seg + cell * PITCH + 4 * q);
+                dd[0] = sv[u].x; dd[1] = sv[u].y; dd[2] = sv[u].z;
+                if (q != 7) dd[3] = sv[u].w;            // (plane 31 is padding; its slot belongs to the next cell)
             }
         }
     };
@@ -560,7 +564,7 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
 #pragma unroll
                 for (int pq = 0; pq < 8; ++pq)
 #pragma unroll
-                    for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48 + n + 1) * PITCH + 4 * pq];
+                    for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 32 * (n + 1) + 4 * pq];
             } else {
                 // last cell column of this feature row: its A fragments are in registers, so the slab takes the next row now
                 // (LDS serves a wave's requests in order), and the first fragments of step t + 1 follow it
@@ -578,10 +582,11 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
                 load_row(r_top + t + 2);                    // (past the last step: fetched, never used)
             }
             __builtin_amdgcn_sched_barrier(0);
+            const int steps = (n == NK - 1) ? LAST_STEPS : 8;      // (n is an unrolled constant)
             if (all_on) {
                 // steady state: 2R independent accumulator chains interleaved
 #pragma unroll
-                for (int pq = 0; pq < 8; ++pq)
+                for (int pq = 0; pq < steps; ++pq)
 #pragma unroll
                     for (int j = 0; j < R; ++j)
 #pragma unroll
@@ -593,13 +598,13 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
                     if (!on[j]) continue;
                     if (two_tiles) {
 #pragma unroll
-                        for (int pq = 0; pq < 8; ++pq)
+                        for (int pq = 0; pq < steps; ++pq)
 #pragma unroll
                             for (int tt = 0; tt < MT; ++tt)
                                 acc[j][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + tt], bc[j][pq], acc[j][tt], 0, 0, 0);
                     } else {
 #pragma unroll
-                        for (int pq = 0; pq < 8; ++pq)
+                        for (int pq = 0; pq < steps; ++pq)
                             acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT], bc[j][pq], acc[j][0], 0, 0, 0);
                     }
                 }
@@ -808,7 +813,7 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
     MlPlan* p = ml_features(c, frames, upsample);
     if (p->score_blocks == 0) return;
     ProfScope ps(c, "score");
-    const size_t lds = (size_t)4 * (2 * 48 + 11) * 34 * sizeof(float);
+    const size_t lds = (size_t)4 * (2 * 48 + 11) * 31 * sizeof(float);          // four waves x 107 packed cells of 31 planes
     const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
     hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
                        sp0, d_counts, d_cands);

@@ -1,0 +1,10 @@
+#!/bin/bash
+# quick GPU check after a detector change: bench-config parity + detector micro-bench (+ optional end-to-end line)
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
+timeout 300 python -m pytest tests/test_gpu_parity_bench_config.py tests/test_golden.py -q -m gpu -x 2>&1 | tail -2
+timeout 100 python tools/bench_detect.py 64 3 2>&1 | tail -1
+timeout 200 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-host-ingest 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['kernel_families_ms']['score'])"
