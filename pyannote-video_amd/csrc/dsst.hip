@@ -226,30 +226,6 @@ __device__ __forceinline__ void make_target_lds(double2* s, double px, double py
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) target_fft_k(const TrkJob* __restrict__ jobs, const double* __restrict__ tw64, double2* __restrict__ Ghat)
-{
-    extern __shared__ __attribute__((aligned(16))) double2 s[];
-    const TrkJob j = jobs[blockIdx.x];
-    make_target_lds(s, j.cx, j.cy, tw64);
-    double2* out = Ghat + (size_t)blockIdx.x * FS * FS;
-    for (int q = threadIdx.x; q < FS * FS; q += 256) out[q] = FFT_AT(s, q >> 6, q & 63);
-}
-
-__global__ void __launch_bounds__(256) start_filters_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ F, const double2* __restrict__ Ghat)
-{
-    const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
-    double* st = jobs[b].state;
-    double2* A = reinterpret_cast<double2*>(st + TRK_A);
-    const double2 g = Ghat[(size_t)b * FS * FS + q];
-    double bsum = 0;
-    for (int i = 0; i < NPL; ++i) {
-        const double2 f = F[((size_t)b * NPL + i) * FS * FS + q];
-        A[(size_t)i * FS * FS + q] = make_double2(g.x * f.x - g.y * f.y, g.x * f.y + g.y * f.x);
-        bsum = bsum + (f.x * f.x + f.y * f.y);
-    }
-    st[TRK_B + q] = bsum;
-}
-
 __global__ void __launch_bounds__(256) corr_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ F, double2* __restrict__ Gfreq)
 {
     const int b = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
@@ -377,7 +353,7 @@ __global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, c
 }
 
 // ---- start_track in one pass per tracker: the block walks the 32 planes; a plane's spectrum goes straight from LDS into
-// A_i = G * F_i and into the running |F|^2 sum (plane order, like start_filters_k) and is never written out.
+// A_i = G * F_i and into the running |F|^2 sum (plane order) and is never written out.
 // HBM per tracker: 0.5 MB of features in, 2.06 MB of filters out (three-kernel form: + 2 MB F written and read, + G).
 // 512 threads: one line task per thread and FFT phase, 8 spectrum points per thread -- four waves per SIMD hide the LDS and
 // fp64 latencies of the butterfly chains (a 256-thread form needed > 256 registers and ran one wave per SIMD).
@@ -830,7 +806,6 @@ static void ensure_fft_lds()
     static bool done = false;
     if (done) return;
     HIP_CHECK(hipFuncSetAttribute((const void*)trans_planes_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
-    HIP_CHECK(hipFuncSetAttribute((const void*)target_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)peak_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)start_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)update_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));

@@ -75,6 +75,14 @@ class IngestRing(object):
             pass
 
 
+def _boxes_and_scores(out, scores, counts):
+    """[( [(l, t, r, b) Python ints], float32 scores )] per frame.  One tolist() for the whole batch: indexing numpy rows element by
+    element cost 3 ms per 250-frame shot, during which the GPU had nothing queued."""
+    cnt = counts.tolist()
+    rows = out[:, :max(cnt, default=0)].tolist()           # only the filled slots
+    return [([tuple(b) for b in rows[i][:cnt[i]]], scores[i, :cnt[i]].copy()) for i in range(len(cnt))]
+
+
 class Context(object):
     def __init__(self, device=0, detector=_models.DEFAULT_DETECTOR, landmarks=None, embedding=None, priority=0):
         self._h = None
@@ -231,7 +239,7 @@ class Context(object):
             check(self._l.pvf_detect_batch(self._h, ptr(hs), n, int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
         if int(counts.max(initial=0)) >= cap:     # a frame filled its slots: repeat with room for every detection (like detect_many)
             return self.detect_batch(frames, upsample, adjust_threshold, cap * 8)
-        return [([tuple(int(v) for v in out[i, k]) for k in range(counts[i])], scores[i, :counts[i]].copy()) for i in range(n)]
+        return _boxes_and_scores(out, scores, counts)
 
     def detect_many(self, frames, batch, upsample=1, adjust_threshold=0.0, cap=64):
         """any number of frames of one size, `batch` at a time, host post-processing overlapped with the next batch's kernels"""
@@ -244,7 +252,7 @@ class Context(object):
             check(self._l.pvf_detect_many(self._h, ptr(hs), n, int(batch), int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
         if int(counts.max(initial=0)) >= cap:     # a frame filled its slots: repeat with room for every detection
             return self.detect_many(frames, batch, upsample, adjust_threshold, cap * 8)
-        return [([tuple(int(v) for v in out[i, k]) for k in range(counts[i])], scores[i, :counts[i]].copy()) for i in range(n)]
+        return _boxes_and_scores(out, scores, counts)
 
     def detect(self, frame, upsample=1, adjust_threshold=0.0):
         return self.detect_batch([frame], upsample, adjust_threshold)[0]

@@ -361,3 +361,92 @@ def test_tracks_without_the_graph_equal_tracks_from_the_graph(seed):
     fast = tbd.finish_shot(job)
     slow = tbd.finish_shot_graph(job)
     assert fast == slow and len(fast) >= 2
+
+
+class FakeTrackerContext(object):
+    """the slice of runtime.Context that HipTrackers uses, on scripted CPU trackers: handles are integers, frames are looked up through
+    uint64 handle arrays, clones are deep copies, deferred updates leave the tracker's model untouched until commit"""
+    def __init__(self, factory):
+        self.factory, self.frames, self.trk, self.pending, self.next = factory, {}, {}, {}, 1
+        self.clones = self.commits = 0
+
+    def frame_handles(self, frames):
+        out = np.zeros(len(frames), np.uint64)
+        for i, f in enumerate(frames):
+            self.frames[1000 + id(f) % 10**9] = f
+            out[i] = 1000 + id(f) % 10**9
+        return out
+
+    def _frames(self, fh):
+        return [self.frames[int(h)] for h in fh] if isinstance(fh, np.ndarray) else list(fh)
+
+    def tracker_create_many(self, n, as_array=False):
+        ids = np.arange(self.next, self.next + n, dtype=np.uint64)
+        self.next += n
+        for i in ids.tolist():
+            self.trk[i] = None
+        return ids if as_array else ids.tolist()
+
+    def tracker_start_many(self, trks, frames, boxes):
+        for h, f, b in zip(np.asarray(trks).tolist(), self._frames(frames), np.asarray(boxes, np.float64).reshape(-1, 4).tolist()):
+            t = self.factory()
+            t.start_track(f, tuple(b))
+            self.trk[h] = t
+
+    def tracker_clone_many(self, trks, as_array=False):
+        import copy
+        ids = self.tracker_create_many(len(trks), as_array=True)
+        for s, d in zip(np.asarray(trks).tolist(), ids.tolist()):
+            self.trk[d] = copy.deepcopy(self.trk[s])
+            self.clones += 1
+        return ids if as_array else ids.tolist()
+
+    def tracker_update_many(self, trks, frames, defer=False):
+        import copy
+        psr, pos = [], []
+        for h, f in zip(np.asarray(trks).tolist(), self._frames(frames)):
+            assert h not in self.pending, "update of a tracker with an uncommitted deferred update"
+            t = copy.deepcopy(self.trk[h]) if defer else self.trk[h]
+            psr.append(t.update(f))
+            p = t.get_position()
+            pos.append((p.left(), p.top(), p.right(), p.bottom()))
+            if defer:
+                self.pending[h] = f
+        return np.array(psr, np.float64), np.array(pos, np.float64).reshape(-1, 4)
+
+    def tracker_commit_many(self, trks, frames):
+        for h, f in zip(np.asarray(trks).tolist(), self._frames(frames)):
+            assert self.pending.pop(h) is f, "commit with a different frame than the deferred update ran on"
+            self.trk[h].update(f)
+            self.commits += 1
+
+    def tracker_destroy(self, h):
+        self.pending.pop(int(h), None)
+        del self.trk[int(h)]
+
+    def tracker_destroy_many(self, hs):
+        for h in hs:
+            self.tracker_destroy(h)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bulk_pair_path_on_handle_arrays_equals_sequential_reference(seed):
+    """HipTrackers.speculate_pair (starts once, clones for the backward pass, deferred first updates addressed through handle / owner /
+    box arrays) feeding the two lanes of a shot == the frame-by-frame reference flow"""
+    from oracle import ref_flow
+    from pyannote_video_amd.tracking_by_detection import HipTrackers
+    frames, dets = scenario(700 + seed, n=60, faces=4, p_miss=0.4, p_false=0.1)
+    times = [i / 25.0 for i in range(len(frames))]
+    cache = list(zip(times, frames))
+    ctx = FakeTrackerContext(ModelScriptTracker)
+    backend = HipTrackers(ctx)
+    tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0, trackers=backend)
+    det_at = {t: d for (t, _), d in zip(cache, dets)}
+    plans = backend.speculate_pair(cache, det_at)
+    job = tbd.begin_shot(cache, [True] * len(cache), dets, backend, plans)
+    tbd._run_lanes(job["lanes"], backend)
+    got = tbd.finish_shot(job)
+    ref = ref_flow.track_shot(cache, dets, ModelRefTracker, 10., 0.5, 1.0)
+    assert got == ref
+    assert ctx.clones == sum(len(d) for d in dets) and ctx.commits > 0
+    assert not ctx.trk                      # every tracker was released
