@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--faces", type=int, default=8)
     ap.add_argument("--shots", type=int, default=4)
-    ap.add_argument("--detect-batch", type=int, default=64, help="frames whose pyramids, features and scores are resident together (one scoring launch per batch)")
+    ap.add_argument("--detect-batch", type=int, default=128, help="frames whose pyramids, features and scores are resident together (one scoring launch per batch)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): every rank owns --frames frames of an N x --frames video; strong: ONE video of --frames frames "
                          "(BASELINE.json configs[2]'s shape: a fixed video cut into N frame ranges at shot boundaries)")

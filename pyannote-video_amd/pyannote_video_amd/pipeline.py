@@ -181,6 +181,17 @@ class ExtractStream(object):
         return pts, emb
 
 
+def detections_as_lists(n_frames, raw):
+    """[[(l, t, r, b) Python ints]] per frame from the arrays of Context.detect_many(arrays=True): raw = (boxes, counts, frame indices)"""
+    dets = [[] for _ in range(n_frames)]
+    if raw is not None:
+        out, cnt, idx = raw
+        rows, cnt = out.tolist(), cnt.tolist()
+        for j, i in enumerate(idx):
+            dets[i] = [tuple(b) for b in rows[j][:cnt[j]]]
+    return dets
+
+
 class _LaneBackend(object):
     """what the lanes of the tracking thread see of the tracker context while the GPU thread owns it: on-demand updates
     take the context lock, killed trackers are only queued (the GPU thread destroys them between its batches)"""
@@ -254,14 +265,19 @@ class FacePipeline(object):
             extracted = 0
             try:
                 for k, (cache, flags) in enumerate(shot_inputs):
-                    dets = [[] for _ in cache]
                     idx = [i for i, f in enumerate(flags) if f]
+                    counts = np.zeros(len(cache), np.int64)
+                    boxes = np.zeros((0, 4), np.float64)
+                    raw = None
                     note("detect begin", k)
                     if idx:
                         with lock:
-                            res = ctx.detect_many([cache[i][1] for i in idx], bs, 1)
-                        for i, (boxes, _) in zip(idx, res):
-                            dets[i] = [tuple(b) for b in boxes]
+                            out, _, cnt = ctx.detect_many([cache[i][1] for i in idx], bs, 1, arrays=True)
+                        # the boxes go back to the GPU (tracker starts) as an array; the tracking thread turns them into the Python
+                        # tuples its state machine works on while the GPU is busy with those starts
+                        counts[idx] = cnt
+                        boxes = out[np.arange(out.shape[1])[None, :] < cnt[:, None]].astype(np.float64)
+                        raw = (out, cnt, idx)
                     note("detected", k)
 
                     def drain():
@@ -279,21 +295,22 @@ class FacePipeline(object):
 
                     # faces of the shots the tracking thread has finished meanwhile (it is idle now, so the host side of these
                     # calls does not compete with its state machine for the interpreter; measured better than after speculate).
-                    # For the last shot the order is swapped: its state machine then runs while these faces are embedded
-                    # instead of leaving the GPU idle at the very end.
-                    if k < n - 1:
+                    # Towards the end the order changes: the faces of the last TWO finished shots are held back until the last
+                    # shot's bulk tracker work is queued, so that its state machine (17-21 ms on the host, plus its on-demand
+                    # tracker calls) runs beside ~34 ms of embedding instead of leaving the GPU idle at the very end.
+                    if k < n - 2:
                         drain()
-                    det_at = {t: d for (t, _), d in zip(cache, dets)}
                     note("speculate begin", k)
                     with lock:
                         release_dead()
                         if hasattr(backend, "speculate_pair"):
-                            plan_f, plan_b = backend.speculate_pair(cache, det_at)
+                            plan_f, plan_b = backend.speculate_pair(cache, None, counts=counts, boxes=boxes)
                         else:
+                            det_at = {t: d for (t, _), d in zip(cache, detections_as_lists(len(cache), raw))}
                             plan_f = backend.speculate(cache, det_at)
                             plan_b = backend.speculate(list(reversed(cache)), det_at)
                     note("speculated", k)
-                    ready.put((k, dets, (plan_f, plan_b)))
+                    ready.put((k, raw, (plan_f, plan_b)))
                     if k == n - 1:
                         drain()
                 while extracted < n:
@@ -324,8 +341,9 @@ class FacePipeline(object):
                 item = ready.get()
                 if isinstance(item, BaseException):
                     raise item
-                _, dets, plans = item
+                _, raw, plans = item
                 note("host begin", k)
+                dets = detections_as_lists(len(cache), raw)
                 job = self.tracking.begin_shot(cache, flags, dets, lane_backend, plans)
                 self.tracking._run_lanes(job["lanes"], lane_backend)
                 note("lanes done", k)

@@ -241,8 +241,10 @@ class Context(object):
             return self.detect_batch(frames, upsample, adjust_threshold, cap * 8)
         return _boxes_and_scores(out, scores, counts)
 
-    def detect_many(self, frames, batch, upsample=1, adjust_threshold=0.0, cap=64):
-        """any number of frames of one size, `batch` at a time, host post-processing overlapped with the next batch's kernels"""
+    def detect_many(self, frames, batch, upsample=1, adjust_threshold=0.0, cap=64, arrays=False):
+        """any number of frames of one size, `batch` at a time, host post-processing overlapped with the next batch's kernels.
+        arrays=True: (boxes int32 [n, slots, 4], scores float32 [n, slots], counts int32 [n]) instead of Python lists -- a caller that
+        feeds the boxes straight back to the GPU converts them to Python objects when (and where) it has the time"""
         n = len(frames)
         out = np.zeros((n, cap, 4), np.int32)
         scores = np.zeros((n, cap), np.float32)
@@ -251,7 +253,10 @@ class Context(object):
             hs = self._handles(frames)
             check(self._l.pvf_detect_many(self._h, ptr(hs), n, int(batch), int(upsample), float(adjust_threshold), ptr(out), ptr(scores), ptr(counts), cap))
         if int(counts.max(initial=0)) >= cap:     # a frame filled its slots: repeat with room for every detection
-            return self.detect_many(frames, batch, upsample, adjust_threshold, cap * 8)
+            return self.detect_many(frames, batch, upsample, adjust_threshold, cap * 8, arrays)
+        if arrays:
+            m = int(counts.max(initial=0))
+            return out[:, :m], scores[:, :m], counts
         return _boxes_and_scores(out, scores, counts)
 
     def detect(self, frame, upsample=1, adjust_threshold=0.0):

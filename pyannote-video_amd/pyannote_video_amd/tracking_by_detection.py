@@ -115,19 +115,24 @@ class HipTrackers(object):
         return plan
 
 
-    def speculate_pair(self, cache, detections_at, chunk=4096):
+    def speculate_pair(self, cache, detections_at, chunk=4096, counts=None, boxes=None):
         """speculate() for the forward AND the backward pass of a shot: (plan_forward, plan_backward).
 
         Both passes start one tracker per detection from the same frame and box, i.e. with bit-identical filters, so the
         trackers are started once and cloned for the second pass (clones share the filters until one side writes them: no device
         work); only the first updates differ (frame i+1 for the forward pass, frame i-1 for the backward one).
-        Frame handles, owners and boxes are arrays built once per shot; every batched call indexes them."""
+        Frame handles, owners and boxes are arrays built once per shot; every batched call indexes them.  A caller that already holds
+        the detections as arrays passes `counts` (per frame of the cache) and `boxes` ([sum(counts), 4], frame by frame) instead of the dict."""
         ctx = self.ctx
-        counts = [len(detections_at.get(t, ())) for t, _ in cache]
+        if counts is None:
+            counts = [len(detections_at.get(t, ())) for t, _ in cache]
+            boxes = np.array([d for t, _ in cache for d in detections_at.get(t, ())], np.float64).reshape(-1, 4)
+        else:
+            counts = [int(v) for v in counts]
+            boxes = np.ascontiguousarray(boxes, np.float64).reshape(-1, 4)
         n = sum(counts)
         fh = ctx.frame_handles([f for _, f in cache])
         owner = np.repeat(np.arange(len(cache)), counts)
-        boxes = np.array([d for t, _ in cache for d in detections_at.get(t, ())], np.float64).reshape(-1, 4)
         hs_f = ctx.tracker_create_many(n, as_array=True)
         for o in range(0, n, chunk):
             ctx.tracker_start_many(hs_f[o:o + chunk], fh[owner[o:o + chunk]], boxes[o:o + chunk])

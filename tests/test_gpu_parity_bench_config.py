@@ -47,9 +47,9 @@ def test_detector_1080p_batches_bit_exact(ctx_full, oracle, clip1080):
     ref = det.detect_raw(frames[0], 1)
     assert len(raw) == len(ref) > 0
     assert raw == [(r[0], r[1], r[2], r[3], r[4], tuple(r[5])) for r in ref]
-    # batches of 32 and of 64 (the four frames repeated; 64 is the bench's batch) through the pipelined entry: every copy equals the oracle
-    for batch in (32, 64):
-        res = ctx_full.detect_many([dev[i % 4] for i in range(64)], batch, 1)
+    # batches of 32, 64 and 128 (the four frames repeated; 128 is the bench's batch) through the pipelined entry: every copy equals the oracle
+    for batch in (32, 64, 128):
+        res = ctx_full.detect_many([dev[i % 4] for i in range(2 * batch)], batch, 1)
         for i, (boxes, scores) in enumerate(res):
             w = want[i % 4]
             assert boxes == [tuple(d[5]) for d in w]

@@ -7,7 +7,7 @@ TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=gpurun_out/$TAG; mkdir -p $O
 t() { name=$1; lim=$2; shift; shift; echo "=== $name" >> $O/summary.log; s=$(date +%s); ( timeout $lim "$@" ) > $O/$name.log 2>&1; echo "rc=$? $(( $(date +%s) - s ))s" >> $O/summary.log; tail -3 $O/$name.log | cut -c1-600 >> $O/summary.log; }
-t tests 600 python -m pytest tests -q -m gpu --durations=5
+t tests 600 python -m pytest tests -q -m gpu --durations=5 -p no:cacheprovider
 t smoke 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof /tmp/pmca /tmp/pmcb /tmp/pmcc
@@ -21,7 +21,7 @@ for line in open(sys.argv[1]):
     if "score_mfma_rows_ml_k" in line:
         kb = float(re.search(r"FETCH_SIZE=([0-9.e+]+)", line).group(1)); n = int(re.search(r"n=(\d+)", line).group(1))
 if kb is not None:
-    d = {"kernel": "score_mfma_rows_ml_k<4>", "detect_batch": 64, "frame": "1920x1080", "launches_in_pass": n, "fetch_size_kb_per_launch": kb,
+    d = {"kernel": "score_mfma_rows_ml_k<4>", "detect_batch": 128, "frame": "1920x1080", "launches_in_pass": n, "fetch_size_kb_per_launch": kb,
          "traffic_bytes_per_launch": kb * 1024 * 2,
          "source": "profiles/%s_pmc_fetch_size.txt (rocprofv3 --kernel-trace --pmc FETCH_SIZE over `bench.py --steps 1`, a pass of its own; average over the "
                    "launches of the step; x2 gfx950 correction of MI355X_MICROARCH.md section HBM)" % sys.argv[2]}
@@ -30,7 +30,7 @@ if kb is not None:
 PY
 timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "=== bench rc=$?" >> $O/summary.log
 t bench_b32 200 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-host-ingest --detect-batch 32
-t bench_b128 200 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-host-ingest --detect-batch 128
+t bench_b64 200 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-host-ingest --detect-batch 64
 t c5 400 python tools/c5_cluster.py $O/c5_cluster.json
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --cpu-frames 0 --no-host-ingest > $R/$O/prof_bench.log 2>&1
@@ -39,4 +39,4 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcb -- python $R/
 DB=$(find /tmp/pmcb -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_write_size.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmcc -- python $R/bench.py --cpu-frames 0 --no-host-ingest --steps 1 --warmup 0 > /tmp/pc.log 2>&1
 DB=$(find /tmp/pmcc -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_mfma_busy.txt 2>&1
-cd $R; cat $O/summary.log | cut -c1-400; head -c 700 $O/bench.json; echo; head -14 $O/rocprof_kernel_stats.txt; head -4 $O/pmc_fetch_size.txt; head -3 $O/pmc_mfma_busy.txt
+cd $R; grep -h "passed\|failed" $O/tests.log; cat $O/summary.log | cut -c1-400; head -c 700 $O/bench.json; echo; head -14 $O/rocprof_kernel_stats.txt; head -4 $O/pmc_fetch_size.txt; head -3 $O/pmc_mfma_busy.txt
