@@ -55,6 +55,8 @@ def lib():
         _LIB.pvo_det_exp.restype = C.c_double
         _LIB.pvo_det_exp.argtypes = [C.c_double]
         _LIB.pvo_resnet_param_count.restype = C.c_size_t
+        _LIB.pvo_shot_dfd.restype = C.c_double
+        _LIB.pvo_shot_dfd_from_flow.restype = C.c_double
     return _LIB
 
 
@@ -333,3 +335,36 @@ def hac(D, sizes, threshold):
     log = np.zeros((max(T - 1, 1), 4), np.float64)
     n = lib().pvo_hac(_p(D), _p(sz), T, C.c_double(threshold), _p(labels), _p(log))
     return labels, log[:n]
+
+
+# ---- shot boundary detection (structure/shot.py:71-99); PARITY UNPINNED (cv2 absent: cvtColor / resize / Farneback restated)
+def shot_tables():
+    t = np.zeros(22, np.float32)
+    lib().pvo_shot_tables(_p(t))
+    return t
+
+
+def shot_convert(rgb, ow, oh):
+    """cv2.resize(cv2.cvtColor(rgb, COLOR_RGB2GRAY), (ow, oh))"""
+    rgb = _u8(rgb)
+    out = np.zeros((oh, ow), np.uint8)
+    lib().pvo_shot_convert(_p(rgb), rgb.shape[0], rgb.shape[1], _p(out), oh, ow)
+    return out
+
+
+def farneback_small(prev, cur, tables=None):
+    """cv2.calcOpticalFlowFarneback(prev, cur, None, 0.5, 3, 15, 3, 5, 1.1, 0) for single-level sizes (a side < 64 px) -> float32 [h, w, 2]"""
+    prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+    assert prev.ndim == 2 and prev.shape == cur.shape
+    t = shot_tables() if tables is None else tables
+    flow = np.zeros(prev.shape + (2,), np.float32)
+    rc = lib().pvo_farneback_small(_p(prev), _p(cur), prev.shape[0], prev.shape[1], _p(t), _p(flow))
+    if rc != 0:
+        raise NotImplementedError("Farneback restatement covers the single-level case only (an image side below 64 px)")
+    return flow
+
+
+def shot_dfd(prev, cur, tables=None):
+    prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
+    t = shot_tables() if tables is None else tables
+    return float(lib().pvo_shot_dfd(_p(prev), _p(cur), prev.shape[0], prev.shape[1], _p(t)))

@@ -283,6 +283,18 @@ extern "C" int32_t pvf_debug_tracker_state(pvf_handle h, pvf_handle trk, double*
     API_END
 }
 
+extern "C" int32_t pvf_shot_dfd(pvf_handle h, const pvf_handle* frames, int32_t n, int32_t width, int32_t height, const float* tables,
+                                double* dfd, uint8_t* gray_out, float* flow_out)
+{
+    API_BEGIN
+    Ctx* c = enter(h);
+    PVF_REQUIRE(n >= 1 && frames && tables && (n == 1 || dfd), "shot: frames, tables and an output array");
+    std::vector<Frame> f(n);
+    for (int i = 0; i < n; ++i) f[i] = c->frame(frames[i]);
+    shot_dfd(c, f, width, height, tables, dfd, gray_out, flow_out);
+    API_END
+}
+
 // ---- S3 (host) --------------------------------------------------------------------------------------
 static double darea(double l, double t, double r, double b) { return (l > r || t > b) ? 0.0 : (r - l) * (b - t); }
 

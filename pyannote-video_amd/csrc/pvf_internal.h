@@ -261,6 +261,8 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out);
 void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes);
 void dsst_clone_many(Ctx* c, const std::vector<Tracker*>& src, const std::vector<Tracker*>& dst);
 double* tracker_state_alloc(Ctx* c);
+// shot boundary detection (shot.hip)
+void shot_dfd(Ctx* c, const std::vector<Frame>& frames, int ow, int oh, const float* tables22, double* dfd, uint8_t* gray_out, float* flow_out);
 void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, double* psr, double* boxes_out, int mode = 0);
 // association (assoc.cpp part of api)
 void overlap_matrix_host(const double* a, int na, const double* b, int nb, double ratio, double* out);

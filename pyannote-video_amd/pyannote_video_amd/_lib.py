@@ -79,6 +79,7 @@ _SIGS = {
     "pvf_debug_detect_raw": (C.c_int32, [H, H, C.c_int32, C.c_double, P, P, C.c_int32, P]),
     "pvf_debug_extract_chip": (C.c_int32, [H, H, P, C.c_double, C.c_double, C.c_int32, C.c_int32, P]),
     "pvf_debug_tracker_state": (C.c_int32, [H, H, P, P, P]),
+    "pvf_shot_dfd": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int32, P, P, P, P]),
 }
 EXPORTS = sorted(_SIGS)
 

@@ -36,6 +36,7 @@ class NpyVideo(object):
         self._size = (int(self._frames.shape[2]), int(self._frames.shape[1]))
         self._frame_size = self._size
         self.duration = len(self._frames) / self.frame_rate
+        self.step, self.start, self.end = 1.0 / self.frame_rate, 0.0, self.duration      # what structure.Shot reads (video.py:186-190)
 
     @property
     def size(self):
@@ -154,6 +155,15 @@ def cluster(embeddings, output, threshold=0.6, force=False, metric="euclidean", 
     return label
 
 
+def shot(video, output, height=50, window=2.0, threshold=1.0, ctx=None):
+    """Shot boundary detection (scripts/pyannote-structure.py:65-70): a pyannote.core.json Timeline file that `track` reads back"""
+    from .structure import Shot
+    segments = sorted(Shot(video, height=height, context=window, threshold=threshold, ctx=ctx))
+    with open(output, 'w') as fp:
+        json.dump({"pyannote": "Timeline", "content": [{"start": s.start, "end": s.end} for s in segments]}, fp)
+    return segments
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="pyannote-face", description="face tracking => feature extraction => face clustering (MI355X)")
     ap.add_argument("--fps", type=float, default=25.0, help="frame rate of a .npy / synthetic video")
@@ -169,6 +179,11 @@ def main(argv=None):
     e = sub.add_parser("extract")
     for name in ("video", "tracking", "landmark_model", "embedding_model", "landmarks", "embeddings"):
         e.add_argument(name)
+    s = sub.add_parser("shot")
+    s.add_argument("video"); s.add_argument("output")
+    s.add_argument("--height", type=int, default=50)
+    s.add_argument("--window", type=float, default=2.0)
+    s.add_argument("--threshold", type=float, default=1.0)
     c = sub.add_parser("cluster")
     c.add_argument("embeddings"); c.add_argument("labels")
     c.add_argument("--threshold", type=float, default=0.6)
@@ -182,6 +197,8 @@ def main(argv=None):
     if a.verb == "track":
         track(open_video(a.video, a.fps), a.shot, a.tracking, detect_min_size=a.min_size, detect_every=a.every,
               track_min_overlap_ratio=a.min_overlap, track_min_confidence=a.min_confidence, track_max_gap=a.max_gap, ctx=ctx)
+    elif a.verb == "shot":
+        shot(open_video(a.video, a.fps), a.output, height=a.height, window=a.window, threshold=a.threshold, ctx=ctx)
     elif a.verb == "extract":
         extract(open_video(a.video, a.fps), a.landmark_model, a.embedding_model, a.tracking, a.landmarks, a.embeddings, ctx=ctx)
     else:

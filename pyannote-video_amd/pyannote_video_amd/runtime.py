@@ -405,6 +405,27 @@ class Context(object):
         check(self._l.pvf_debug_extract_chip(self._h, f.handle, ptr(r), float(cs), float(sn), rows, cols, ptr(out)))
         return out
 
+    # ---- f4: shot boundary detection
+    def shot_dfd(self, frames, width, height, tables, want_gray=False, want_flow=False):
+        """displaced frame differences of consecutive frames (structure/shot.py:71-99): float64 [n - 1]
+        (+ the small gray images uint8 [n, height, width] and the flows float32 [n - 1, height, width, 2] on request)"""
+        n = len(frames)
+        t = np.ascontiguousarray(tables, np.float32)
+        if t.shape != (22,):
+            raise ValueError("shot tables: 22 floats (structure.shot_tables())")
+        dfd = np.zeros(max(n - 1, 0), np.float64)
+        gray = np.zeros((n, height, width), np.uint8) if want_gray else None
+        flow = np.zeros((max(n - 1, 0), height, width, 2), np.float32) if want_flow else None
+        with self._staging():
+            check(self._l.pvf_shot_dfd(self._h, ptr(self._handles(frames)), n, int(width), int(height), ptr(t), ptr(dfd) if n > 1 else None,
+                                       ptr(gray) if want_gray else None, ptr(flow) if want_flow and n > 1 else None))
+        out = (dfd,)
+        if want_gray:
+            out += (gray,)
+        if want_flow:
+            out += (flow,)
+        return out if len(out) > 1 else dfd
+
     # ---- S5
     def pair_mean_dist(self, X, row_start, metric=0):
         """T x T matrix of mean pair distances between the rows of two tracks; metric 0 = Euclidean (reference), 1 = cosine"""

@@ -118,6 +118,7 @@ class SyntheticVideo(object):
         self._frame_size = self._size
         self.n_frames = int(n_frames)
         self.duration = self.n_frames / self.frame_rate
+        self.step, self.start, self.end = 1.0 / self.frame_rate, 0.0, self.duration      # what structure.Shot reads (video.py:186-190)
         self.n_shots = int(n_shots)
         self.faces = int(faces)
         self.seed = seed
