@@ -81,8 +81,11 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
         const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
         const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, off & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, off & 3u);
         const double tl0 = (double)(lo & 0xffu), tl1 = (double)((lo >> 8) & 0xffu), tl2 = (double)((lo >> 16) & 0xffu);
-        double tr0 = (double)(lo >> 24), tr1 = (double)(hi & 0xffu), tr2 = (double)((hi >> 8) & 0xffu);
-        if (!has_right) { tr0 = tl0; tr1 = tl1; tr2 = tl2; }
+        // a lane without a right neighbour blends its own pixel with itself (oracle/pvo_image.c): the substitution is done on the packed
+        // bytes (two integer selects) instead of on the six converted doubles
+        const uint32_t lo2 = has_right ? lo : ((lo & 0x00ffffffu) | (lo << 24));
+        const uint32_t hi2 = has_right ? hi : (lo >> 8);
+        const double tr0 = (double)(lo2 >> 24), tr1 = (double)(hi2 & 0xffu), tr2 = (double)((hi2 >> 8) & 0xffu);
         hh[0] = lr1 * tl0 + lr * tr0;
         hh[1] = lr1 * tl1 + lr * tr1;
         hh[2] = lr1 * tl2 + lr * tr2;
