@@ -542,15 +542,42 @@ __global__ void __launch_bounds__(256) scale_chips_k(const TrkJob* __restrict__ 
     }
 }
 
+// the 32-point transform of fft32_seq on a register-resident line: every index is a compile-time constant after unrolling, so the 32
+// complex values never touch memory (the LDS-resident loop form spent its time on dependent LDS round trips: 0.58 ms per 2000 trackers).
+// Same permutation, stages, butterfly order and twiddles => the same bits.
+__device__ __forceinline__ void fft32_regs(double2 (&x)[NSC], const double* __restrict__ tw)
+{
+#pragma unroll
+    for (int i = 0; i < NSC; ++i) {
+        const int j = ((i & 1) << 4) | ((i & 2) << 2) | (i & 4) | ((i & 8) >> 2) | ((i & 16) >> 4);
+        if (j > i) { const double2 t = x[i]; x[i] = x[j]; x[j] = t; }
+    }
+#pragma unroll
+    for (int st = 1; st <= 5; ++st) {
+        const int m = 1 << st, half = m >> 1, tstep = NSC / m;
+#pragma unroll
+        for (int k = 0; k < NSC; k += m)
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const double wr = tw[2 * j * tstep], wi = -tw[2 * j * tstep + 1];
+                const double2 a = x[k + j], b = x[k + j + half];
+                const double tr = wr * b.x - wi * b.y;
+                const double ti = wr * b.y + wi * b.x;
+                x[k + j] = make_double2(a.x + tr, a.y + ti);
+                x[k + j + half] = make_double2(a.x - tr, a.y - ti);
+            }
+    }
+}
+
 // Fs[idx][k] = feature(idx) of scale chip k * mask_scale[k]; FFT over k; one thread per idx
 __global__ void __launch_bounds__(128) scale_fft_k(const uint8_t* __restrict__ chips, const float* __restrict__ feat,
                                                    const double* __restrict__ mask_scale, const double* __restrict__ tw32,
                                                    double2* __restrict__ Fs)
 {
-    extern __shared__ __attribute__((aligned(16))) double2 s[]; // [128][33]
     const int b = blockIdx.y, idx = blockIdx.x * 128 + threadIdx.x;
     const int cell = idx >> 5, jp = idx & 31, r = cell >> 2, c = cell & 3;
-    double2* x = s + (size_t)threadIdx.x * 33;
+    double2 x[NSC];
+#pragma unroll
     for (int k = 0; k < NSC; ++k) {
         float v;
         if (jp < 31) v = feat[(((size_t)b * NSC + k) * 16 + cell) * PVF_FHOG_STRIDE + jp];
@@ -560,8 +587,9 @@ __global__ void __launch_bounds__(128) scale_fft_k(const uint8_t* __restrict__ c
         }
         x[k] = make_double2((double)v * mask_scale[k], 0.0);
     }
-    fft32_seq(x, tw32, false);
+    fft32_regs(x, tw32);
     double2* out = Fs + ((size_t)b * SDIM + idx) * NSC;
+#pragma unroll
     for (int k = 0; k < NSC; ++k) out[k] = x[k];
 }
 
@@ -797,7 +825,7 @@ static void scale_features(Ctx* c, const DsstBuffers& b, int n)
     hipLaunchKernelGGL(scale_chips_k, dim3(NSC, n), dim3(256), 0, c->stream, b.jobs, c->ttab.alpha_pow_m16, b.chips_sc);
     float* feat = b.feat; // reuse: n*32 images of 4x4x32 floats
     fhog_device(c, b.chips_sc, n * NSC, SWIN, SWIN, 4, 1, 1, feat, c->s_hist, c->s_norm);
-    hipLaunchKernelGGL(scale_fft_k, dim3(SDIM / 128, n), dim3(128), (size_t)128 * 33 * sizeof(double2), c->stream, b.chips_sc, feat,
+    hipLaunchKernelGGL(scale_fft_k, dim3(SDIM / 128, n), dim3(128), 0, c->stream, b.chips_sc, feat,
                        c->ttab.d_mask_scale, c->ttab.d_tw32, b.Fs);
 }
 
@@ -809,7 +837,6 @@ static void ensure_fft_lds()
     HIP_CHECK(hipFuncSetAttribute((const void*)peak_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)start_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)update_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
-    HIP_CHECK(hipFuncSetAttribute((const void*)scale_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 33 * sizeof(double2))));
     done = true;
 }
 
