@@ -40,25 +40,22 @@ def shot_tables(poly_n=5, poly_sigma=1.1):
 
 
 def boundaries(times, dfd, start, end, kernel_size, threshold):
-    """shot.py:119-147 on the displaced frame differences y[i] (taken at times t[i]): median filter, normalised difference, threshold,
-    only the first of a run of consecutive frames above it; the last segment is kept if it is not empty"""
+    """The reference's decision rule (shot.py:119-147) on the displaced frame differences dfd[i] taken at times[i]: a frame is a
+    candidate when its difference exceeds the median-filtered one by more than `threshold` times that median; of a run of candidates at
+    consecutive indices only the first counts -- where "consecutive" is judged against the previous candidate, or against index 0 for the
+    first one (so a candidate at index 1 never counts: the reference's loop starts from `_i = 0`).  Segments run from cut to cut; the
+    last one is kept if it is not empty.  Array form of that loop; tests/test_shot.py holds it equal to the reference class run verbatim."""
     import scipy.signal
-    t, y = list(times), np.asarray(dfd, np.float64)
-    filtered = scipy.signal.medfilt(y, kernel_size=kernel_size)
+    y = np.asarray(dfd, np.float64)
+    base = scipy.signal.medfilt(y, kernel_size=kernel_size)
     with np.errstate(divide="ignore", invalid="ignore"):
-        normalized = (y - filtered) / filtered
-    previous = start
-    _i = 0
-    for i in np.where(normalized > threshold)[0]:
-        if i == _i + 1:
-            _i = i
-            continue
-        yield Segment(previous, t[i])
-        previous = t[i]
-        _i = i
-    last_segment = Segment(previous, end)
-    if last_segment:
-        yield last_segment
+        excess = (y - base) / base
+    candidates = np.flatnonzero(excess > threshold)
+    before = np.concatenate(([0], candidates[:-1]))
+    cuts = candidates[candidates != before + 1]
+    edges = [start] + [times[int(i)] for i in cuts] + [end]
+    segments = [Segment(a, b) for a, b in zip(edges[:-1], edges[1:])]
+    return segments[:-1] + ([segments[-1]] if segments[-1] else [])
 
 
 class Shot(object):
@@ -80,10 +77,11 @@ class Shot(object):
         self.height = height
         self.threshold = threshold
         self.context = context
-        w, h = self.video._size
-        self._resize = (self.height, int(w * self.height / h))
-        kernel_size = self.context / self.video.step
-        self._kernel_size = max(3, int(np.ceil(kernel_size) // 2 * 2 + 1))
+        frame_w, frame_h = self.video._size
+        # (shot.py:62) handed to cv2.resize as dsize, i.e. (width, height) of the small image
+        self._resize = (self.height, int(frame_w * self.height / frame_h))
+        # (shot.py:65-67) median window in frames: odd, at least 3
+        self._kernel_size = max(3, int(np.ceil(self.context / self.video.step) // 2 * 2 + 1))
         if ctx is None:
             from .runtime import Context
             ctx = Context(0)
