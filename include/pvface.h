@@ -9,8 +9,8 @@
  *   - every function returns 0 on success, <0 on error; pvf_last_error() gives the thread-local message;
  *     nothing throws or aborts across the boundary;
  *   - handles are opaque uint64_t; the caller owns every host buffer, the library owns device memory;
- *   - one HIP stream per context; a context is not re-entrant, different contexts (= different GPUs / ranks)
- *     may be driven from different threads or processes;
+ *   - one HIP stream per context; a context serialises its own compute calls (they may come from any thread), different
+ *     contexts (= different GPUs / ranks) run side by side in different threads or processes;
  *   - frames are uint8 RGB, HWC, C-contiguous (ref: pyannote/video/video.py:148-149,400-401);
  *   - there is NO CPU fallback: without a gfx950 device pvf_ctx_create fails.
  */
@@ -58,7 +58,18 @@ int32_t pvf_set_tracker_tables(pvf_handle ctx, const double* mask64, const doubl
 int32_t pvf_frame_upload(pvf_handle ctx, const uint8_t* rgb, int32_t h, int32_t w, int64_t row_stride_bytes, pvf_handle* frame);
 /* wrap a frame that already lives in HBM (no copy; the caller keeps it alive until pvf_frame_release) */
 int32_t pvf_frame_wrap_device(pvf_handle ctx, const void* dev_rgb, int32_t h, int32_t w, pvf_handle* frame);
+/* Releasing never waits for the GPU: the buffer of a frame the library allocated itself (upload, ingest ring, device resize) goes back
+ * to a pool together with an event on the compute stream, and whoever takes it next orders its first write behind that event.
+ * The frame calls (upload / wrap / release / ingest) may be made from a second thread (a decoder) while another thread runs the
+ * compute entry points of the same context; release a frame only after the calls that use it have returned. */
 int32_t pvf_frame_release(pvf_handle ctx, pvf_handle frame);
+int32_t pvf_frame_release_many(pvf_handle ctx, const pvf_handle* frames, int32_t n);
+/* ref: tracking.py:359-362,410-420 -- the reference drops a shot's frame cache when the shot is done; a streaming run here recycles
+ * the buffers of released frames, and this call gives pooled buffers beyond `keep_bytes` back to the allocator (*pooled_bytes,
+ * optional: what the pool still holds) */
+int32_t pvf_frame_pool_trim(pvf_handle ctx, int64_t keep_bytes, int64_t* pooled_bytes);
+/* free / total device memory (hipMemGetInfo): the peak-HBM figure of the streaming runs */
+int32_t pvf_mem_info(pvf_handle ctx, int64_t* free_bytes, int64_t* total_bytes);
 /* device address of a staged frame (to share it with a second context on the same GPU, e.g. a detector stream) */
 int32_t pvf_frame_device_ptr(pvf_handle ctx, pvf_handle frame, const void** dev_rgb);
 

@@ -9,19 +9,18 @@
     catch (const std::exception& e) { pvf_set_error(e.what()); return -1; } \
     catch (...) { pvf_set_error("unknown error"); return -2; }
 
-static Ctx* enter(pvf_handle h)
-{
-    Ctx* c = pvf_ctx(h);
-    HIP_CHECK(hipSetDevice(c->device));
-    return c;
-}
+// every compute entry point runs under its context's api_mu: a context serialises its own calls, whichever threads make them
+#define ENTER(c, h)                                                \
+    Ctx* c = pvf_ctx(h);                                           \
+    std::lock_guard<std::recursive_mutex> _api_lock(c->api_mu);    \
+    HIP_CHECK(hipSetDevice(c->device))
 
 // ---- S1 -------------------------------------------------------------------------------------------
 extern "C" int32_t pvf_detect_batch(pvf_handle h, const pvf_handle* frames, int32_t n_frames, int32_t upsample, double adjust,
                                     pvf_rect_i32* out, float* scores, int32_t* counts, int32_t cap)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     PVF_REQUIRE(n_frames > 0 && frames && out && counts && cap > 0, "pvf_detect_batch: bad arguments");
     PVF_REQUIRE(upsample >= 0 && upsample <= 2, "pvf_detect_batch: upsample must be 0..2");
     std::vector<Frame> fr(n_frames);
@@ -45,7 +44,7 @@ extern "C" int32_t pvf_detect_many(pvf_handle h, const pvf_handle* frames, int32
                                    pvf_rect_i32* out, float* scores, int32_t* counts, int32_t cap)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     PVF_REQUIRE(n_frames > 0 && batch > 0 && frames && out && counts && cap > 0, "pvf_detect_many: bad arguments");
     PVF_REQUIRE(upsample >= 0 && upsample <= 2, "pvf_detect_many: upsample must be 0..2");
     std::vector<Frame> fr(n_frames);
@@ -77,7 +76,7 @@ extern "C" int32_t pvf_debug_detect_raw(pvf_handle h, pvf_handle frame, int32_t 
                                         int32_t cap, int32_t* n)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     std::vector<Frame> fr{c->frame(frame)};
     std::vector<std::vector<RawDet>> raw;
     det_run_batch(c, fr, upsample, adjust, raw);
@@ -96,7 +95,7 @@ extern "C" int32_t pvf_debug_pyramid_level(pvf_handle h, pvf_handle frame, int32
                                            int32_t* ow)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     std::vector<uint8_t> buf;
     int hh = 0, ww = 0;
     det_pyramid_level(c, c->frame(frame), upsample, level, out ? &buf : nullptr, &hh, &ww);
@@ -108,7 +107,7 @@ extern "C" int32_t pvf_debug_pyramid_level(pvf_handle h, pvf_handle frame, int32
 extern "C" int32_t pvf_debug_level_features(pvf_handle h, pvf_handle frame, int32_t upsample, int32_t level, float* out, int32_t* fh, int32_t* fw)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     std::vector<float> buf;
     int a = 0, b = 0;
     det_level_features(c, c->frame(frame), upsample, level, out ? &buf : nullptr, &a, &b);
@@ -121,7 +120,7 @@ extern "C" int32_t pvf_debug_fhog(pvf_handle h, const uint8_t* img, int32_t ih, 
                                   float* out, int32_t* fh, int32_t* fw)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     int a = 0, b = 0;
     if (!out) { fhog_dims(ih, iw, cell, pad_r, pad_c, &a, &b); *fh = a; *fw = b; return 0; }
     std::vector<float> buf;
@@ -143,7 +142,7 @@ static pvf_handle tracker_new(Ctx* c)
 extern "C" int32_t pvf_tracker_create(pvf_handle h, pvf_handle* trk)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     *trk = tracker_new(c);
     API_END
 }
@@ -151,7 +150,7 @@ extern "C" int32_t pvf_tracker_create(pvf_handle h, pvf_handle* trk)
 extern "C" int32_t pvf_tracker_create_many(pvf_handle h, int32_t n, pvf_handle* trks)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     PVF_REQUIRE(n >= 0, "negative count");
     for (int i = 0; i < n; ++i) trks[i] = tracker_new(c);
     API_END
@@ -160,7 +159,7 @@ extern "C" int32_t pvf_tracker_create_many(pvf_handle h, int32_t n, pvf_handle* 
 extern "C" int32_t pvf_tracker_clone_many(pvf_handle h, const pvf_handle* src, int32_t n, pvf_handle* dst)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     PVF_REQUIRE(n >= 0, "negative count");
     std::vector<Tracker*> s(n), d(n);
     for (int i = 0; i < n; ++i) s[i] = &c->tracker(src[i]);
@@ -191,7 +190,7 @@ static void pool_tracker_state(Ctx* c, Tracker& t)
 extern "C" int32_t pvf_tracker_destroy_many(pvf_handle h, const pvf_handle* trks, int32_t n)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     for (int i = 0; i < n; ++i) {
         auto it = c->trackers.find(trks[i]);
         PVF_REQUIRE(it != c->trackers.end(), "unknown tracker handle");
@@ -204,7 +203,7 @@ extern "C" int32_t pvf_tracker_destroy_many(pvf_handle h, const pvf_handle* trks
 extern "C" int32_t pvf_tracker_destroy(pvf_handle h, pvf_handle trk)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     auto it = c->trackers.find(trk);
     PVF_REQUIRE(it != c->trackers.end(), "unknown tracker handle");
     pool_tracker_state(c, *it->second);
@@ -214,7 +213,7 @@ extern "C" int32_t pvf_tracker_destroy(pvf_handle h, pvf_handle trk)
 extern "C" int32_t pvf_tracker_start_many(pvf_handle h, const pvf_handle* trks, const pvf_handle* frames, const double* boxes, int32_t n)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     std::vector<Tracker*> t(n);
     std::vector<Frame> f(n);
     for (int i = 0; i < n; ++i) { t[i] = &c->tracker(trks[i]); f[i] = c->frame(frames[i]); }
@@ -225,7 +224,7 @@ extern "C" int32_t pvf_tracker_update_many(pvf_handle h, const pvf_handle* trks,
                                            double* boxes_out)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     std::vector<Tracker*> t(n);
     std::vector<Frame> f(n);
     for (int i = 0; i < n; ++i) { t[i] = &c->tracker(trks[i]); f[i] = c->frame(frames[i]); }
@@ -240,7 +239,7 @@ extern "C" int32_t pvf_tracker_update_many_deferred(pvf_handle h, const pvf_hand
                                                     double* boxes_out)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     std::vector<Tracker*> t(n);
     std::vector<Frame> f(n);
     for (int i = 0; i < n; ++i) { t[i] = &c->tracker(trks[i]); f[i] = c->frame(frames[i]); }
@@ -251,7 +250,7 @@ extern "C" int32_t pvf_tracker_update_many_deferred(pvf_handle h, const pvf_hand
 extern "C" int32_t pvf_tracker_commit_many(pvf_handle h, const pvf_handle* trks, const pvf_handle* frames, int32_t n)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     std::vector<Tracker*> t(n);
     std::vector<Frame> f(n);
     for (int i = 0; i < n; ++i) { t[i] = &c->tracker(trks[i]); f[i] = c->frame(frames[i]); }
@@ -266,14 +265,14 @@ extern "C" int32_t pvf_tracker_update(pvf_handle h, pvf_handle trk, pvf_handle f
 extern "C" int32_t pvf_tracker_position(pvf_handle h, pvf_handle trk, double box[4])
 {
     API_BEGIN
-    Ctx* c = pvf_ctx(h);
+    ENTER(c, h);
     memcpy(box, c->tracker(trk).pos, 4 * sizeof(double));
     API_END
 }
 extern "C" int32_t pvf_debug_tracker_state(pvf_handle h, pvf_handle trk, double* F, double* A, double* B)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     Tracker& t = c->tracker(trk);
     PVF_REQUIRE(t.d_state, "tracker has no state yet (start_track first)");
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -287,7 +286,7 @@ extern "C" int32_t pvf_shot_dfd(pvf_handle h, const pvf_handle* frames, int32_t 
                                 double* dfd, uint8_t* gray_out, float* flow_out)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     PVF_REQUIRE(n >= 1 && frames && tables && (n == 1 || dfd), "shot: frames, tables and an output array");
     std::vector<Frame> f(n);
     for (int i = 0; i < n; ++i) f[i] = c->frame(frames[i]);
@@ -496,7 +495,7 @@ extern "C" int32_t pvf_munkres(const double* cost, int32_t n, int32_t* row_to_co
 extern "C" int32_t pvf_landmarks(pvf_handle h, const pvf_handle* frames, const pvf_rect_i32* boxes, int32_t n, int32_t* pts)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     if (n == 0) return 0;
     std::vector<Frame> f(n);
     for (int i = 0; i < n; ++i) f[i] = c->frame(frames[i]);
@@ -523,7 +522,7 @@ static uint8_t* make_face_chips(Ctx* c, const pvf_handle* frames, const int32_t*
 extern "C" int32_t pvf_face_chips(pvf_handle h, const pvf_handle* frames, const int32_t* pts, int32_t n, uint8_t* chips)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     if (n == 0) return 0;
     uint8_t* d = make_face_chips(c, frames, pts, n);
     HIP_CHECK(hipMemcpyAsync(chips, d, (size_t)n * 150 * 150 * 3, hipMemcpyDeviceToHost, c->stream));
@@ -534,7 +533,7 @@ extern "C" int32_t pvf_face_chips(pvf_handle h, const pvf_handle* frames, const 
 extern "C" int32_t pvf_embed(pvf_handle h, const pvf_handle* frames, const int32_t* pts, int32_t n, float* out)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     if (n == 0) return 0;
     const int CH = 1024; // faces per chip-extraction round
     for (int i0 = 0; i0 < n; i0 += CH) {
@@ -548,7 +547,7 @@ extern "C" int32_t pvf_embed(pvf_handle h, const pvf_handle* frames, const int32
 extern "C" int32_t pvf_embed_chips(pvf_handle h, const uint8_t* chips, int32_t n, float* out)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     if (n == 0) return 0;
     const size_t bytes = (size_t)n * 150 * 150 * 3;
     c->s_trk0.ensure(bytes);
@@ -561,7 +560,7 @@ extern "C" int32_t pvf_debug_extract_chip(pvf_handle h, pvf_handle frame, const 
                                           int32_t cols, uint8_t* out)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     ChipDetails d{rect[0], rect[1], rect[2], rect[3], cs, sn, rows, cols};
     std::vector<ChipJob> jobs{chip_plan(c->frame(frame), d)};
     const size_t bytes = (size_t)rows * cols * 3;
@@ -576,7 +575,7 @@ extern "C" int32_t pvf_debug_extract_chip(pvf_handle h, pvf_handle frame, const 
 extern "C" int32_t pvf_pair_mean_dist(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T, double* D)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     pair_mean_dist_dev(c, X, N, dim, row_start, T, D, nullptr);
     API_END
 }
@@ -585,7 +584,7 @@ extern "C" int32_t pvf_pair_mean_dist_metric(pvf_handle h, const double* X, int3
                                               double* D)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     pair_mean_dist_dev(c, X, N, dim, row_start, T, D, nullptr, 0, -1, metric);
     API_END
 }
@@ -594,7 +593,7 @@ extern "C" int32_t pvf_pair_mean_dist_rows(pvf_handle h, const double* X, int32_
                                            int32_t track0, int32_t track1, double* D)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     pair_mean_dist_dev(c, X, N, dim, row_start, T, D, nullptr, track0, track1);
     API_END
 }
@@ -603,7 +602,7 @@ extern "C" int32_t pvf_cluster_dist(pvf_handle h, const double* D, const int32_t
                                     double* merge_log, int32_t* n_merges)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     PVF_REQUIRE(T > 0 && D && row_start && labels, "pvf_cluster_dist: bad arguments");
     c->s_clu1.ensure((size_t)T * T * sizeof(double) + (size_t)T * 64 + 4096);
     double* dD = c->s_clu1.as<double>();
@@ -617,7 +616,7 @@ extern "C" int32_t pvf_cluster_tracks(pvf_handle h, const double* X, int32_t N, 
                                       double threshold, int32_t* labels, double* merge_log, int32_t* n_merges)
 {
     API_BEGIN
-    Ctx* c = enter(h);
+    ENTER(c, h);
     double* dD = nullptr;
     pair_mean_dist_dev(c, X, N, dim, row_start, T, nullptr, &dD);
     const int n = hac_dev(c, dD, row_start, T, threshold, labels, merge_log);

@@ -285,7 +285,7 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
     for (int k = 0; k < 2; ++k) if (c->det_ev[k]) (void)hipEventDestroy(c->det_ev[k]);
     ml_plans_free(c);
     ingest_free_all(c);
-    for (auto& kv : c->frame_pool) for (auto q : kv.second) (void)hipFree(q);
+    for (auto& kv : c->frame_pool) for (auto q : kv.second) { if (q.free_after) (void)hipEventDestroy(q.free_after); (void)hipFree(q.p); }
     if (c->d_orient_lut) (void)hipFree(c->d_orient_lut);
     if (c->d_grad_lut) (void)hipFree(c->d_grad_lut);
     (void)hipStreamDestroy(c->stream);
@@ -298,6 +298,7 @@ extern "C" int32_t pvf_sync(pvf_handle h)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     API_END
 }
@@ -306,6 +307,7 @@ extern "C" int32_t pvf_load_detector(pvf_handle h, const char* path)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     HIP_CHECK(hipSetDevice(c->device));
     PVF_REQUIRE(path != nullptr, "pvf_load_detector: path is NULL (the Python layer passes the packaged default)");
     load_detector(c, path);
@@ -315,6 +317,7 @@ extern "C" int32_t pvf_load_shape_predictor(pvf_handle h, const char* path)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     HIP_CHECK(hipSetDevice(c->device));
     PVF_REQUIRE(path != nullptr, "path is NULL");
     load_shape(c, path);
@@ -324,6 +327,7 @@ extern "C" int32_t pvf_load_embedder(pvf_handle h, const char* path)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     HIP_CHECK(hipSetDevice(c->device));
     PVF_REQUIRE(path != nullptr, "path is NULL");
     load_embedder(c, path);
@@ -350,6 +354,7 @@ extern "C" int32_t pvf_set_tracker_tables(pvf_handle h, const double* mask64, co
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     HIP_CHECK(hipSetDevice(c->device));
     TrackerTables& t = c->ttab;
     if (!t.d_mask64) {
@@ -375,14 +380,11 @@ extern "C" int32_t pvf_frame_upload(pvf_handle h, const uint8_t* rgb, int32_t fh
     PVF_REQUIRE(rgb && fh > 0 && fw > 0, "pvf_frame_upload: bad frame");
     if (stride == 0) stride = (int64_t)fw * 3;
     PVF_REQUIRE(stride >= (int64_t)fw * 3, "pvf_frame_upload: row stride smaller than a row");
-    uint8_t* d = nullptr;
-    HIP_CHECK(hipMalloc((void**)&d, (size_t)fh * fw * 3));
-    HIP_CHECK(hipMemcpy2DAsync(d, (size_t)fw * 3, rgb, (size_t)stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
-    Frame f; f.d = d; f.h = fh; f.w = fw; f.owned = true;
-    uint64_t id = c->next_id++;
-    c->frames[id] = f;
-    *out = id;
+    uint8_t* d = c->take_frame_buffer((size_t)fh * fw * 3, nullptr);
+    // a blocking copy outside the compute stream: the frame is complete when the call returns, whatever the context is running
+    HIP_CHECK(hipMemcpy2D(d, (size_t)fw * 3, rgb, (size_t)stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice));
+    Frame f; f.d = d; f.h = fh; f.w = fw; f.owned = true; f.pooled = true;
+    *out = c->add_frame(f);
     API_END
 }
 
@@ -392,9 +394,7 @@ extern "C" int32_t pvf_frame_wrap_device(pvf_handle h, const void* dev, int32_t 
     Ctx* c = pvf_ctx(h);
     PVF_REQUIRE(dev && fh > 0 && fw > 0, "pvf_frame_wrap_device: bad frame");
     Frame f; f.d = (const uint8_t*)dev; f.h = fh; f.w = fw; f.owned = false;
-    uint64_t id = c->next_id++;
-    c->frames[id] = f;
-    *out = id;
+    *out = c->add_frame(f);
     API_END
 }
 
@@ -406,20 +406,69 @@ extern "C" int32_t pvf_frame_device_ptr(pvf_handle h, pvf_handle frame, const vo
     API_END
 }
 
+// frames_mu held.  The buffer goes back to the pool behind an event on the compute stream, so the call never waits for the kernels
+// that were queued on this frame; the next user of the buffer does (Ctx::pool_take).
+static void release_frame_locked(Ctx* c, pvf_handle frame)
+{
+    auto it = c->frames.find(frame);
+    PVF_REQUIRE(it != c->frames.end(), "unknown frame handle");
+    Frame f = it->second;
+    c->frames.erase(it);
+    if (f.ready) { (void)hipEventSynchronize(f.ready); (void)hipEventDestroy(f.ready); }     // released before any kernel read it: let the upload finish
+    if (f.owned) c->pool_give((uint8_t*)f.d, (size_t)f.h * f.w * 3);
+}
+
 extern "C" int32_t pvf_frame_release(pvf_handle h, pvf_handle frame)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
-    auto it = c->frames.find(frame);
-    PVF_REQUIRE(it != c->frames.end(), "unknown frame handle");
-    if (it->second.ready) { (void)hipEventSynchronize(it->second.ready); (void)hipEventDestroy(it->second.ready); }
-    if (it->second.owned) {
-        HIP_CHECK(hipSetDevice(c->device));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
-        if (it->second.pooled) c->frame_pool[(size_t)it->second.h * it->second.w * 3].push_back((uint8_t*)it->second.d);
-        else HIP_CHECK(hipFree((void*)it->second.d));
+    HIP_CHECK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->frames_mu);
+    release_frame_locked(c, frame);
+    API_END
+}
+
+extern "C" int32_t pvf_frame_release_many(pvf_handle h, const pvf_handle* frames, int32_t n)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    PVF_REQUIRE(n >= 0 && (frames || n == 0), "pvf_frame_release_many: bad arguments");
+    std::lock_guard<std::mutex> lk(c->frames_mu);
+    for (int i = 0; i < n; ++i) release_frame_locked(c, frames[i]);
+    API_END
+}
+
+extern "C" int32_t pvf_frame_pool_trim(pvf_handle h, int64_t keep_bytes, int64_t* pooled_bytes)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> lk(c->frames_mu);
+    for (auto& kv : c->frame_pool) {
+        auto& v = kv.second;
+        while (!v.empty() && (int64_t)c->frame_pool_bytes > keep_bytes) {
+            Ctx::PoolBuf b = v.back();
+            v.pop_back();
+            c->frame_pool_bytes -= kv.first;
+            if (b.free_after) { (void)hipEventSynchronize(b.free_after); (void)hipEventDestroy(b.free_after); }
+            HIP_CHECK(hipFree(b.p));
+        }
     }
-    c->frames.erase(it);
+    if (pooled_bytes) *pooled_bytes = (int64_t)c->frame_pool_bytes;
+    API_END
+}
+
+// free / total device memory as the driver sees it (every allocation of the process and of its neighbours on this GPU)
+extern "C" int32_t pvf_mem_info(pvf_handle h, int64_t* free_bytes, int64_t* total_bytes)
+{
+    API_BEGIN
+    Ctx* c = pvf_ctx(h);
+    HIP_CHECK(hipSetDevice(c->device));
+    size_t f = 0, t = 0;
+    HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
     API_END
 }
 
@@ -427,6 +476,7 @@ extern "C" int32_t pvf_prof_enable(pvf_handle h, int32_t on)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     if (!on && c->prof_on) prof_drain(c);
     c->prof_on = on != 0;
     API_END
@@ -435,6 +485,7 @@ extern "C" int32_t pvf_prof_reset(pvf_handle h)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     prof_drain(c);
     for (auto& kv : c->prof) { kv.second.total_ms = 0; kv.second.launches = 0; }
     API_END
@@ -443,6 +494,7 @@ extern "C" int32_t pvf_prof_get(pvf_handle h, const char* family, double* total_
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     prof_drain(c);
     auto it = c->prof.find(family);
     if (it == c->prof.end()) { *total_ms = 0; *launches = 0; }

@@ -51,7 +51,6 @@ extern "C" int32_t pvf_ingest_create(pvf_handle h, int32_t fh, int32_t fw, int32
     Ctx* c = pvf_ctx(h);
     HIP_CHECK(hipSetDevice(c->device));
     PVF_REQUIRE(fh > 0 && fw > 0 && depth > 0 && ring, "pvf_ingest_create: bad arguments");
-    if (!c->ingest_rings) c->ingest_rings = new std::unordered_map<uint64_t, std::unique_ptr<IngestRing>>();
     std::unique_ptr<IngestRing> r(new IngestRing());
     r->h = fh; r->w = fw; r->depth = depth;
     HIP_CHECK(hipHostMalloc((void**)&r->host, (size_t)depth * fh * fw * 3, hipHostMallocDefault));
@@ -60,6 +59,8 @@ extern "C" int32_t pvf_ingest_create(pvf_handle h, int32_t fh, int32_t fw, int32
     r->busy.assign(depth, 0);
     for (int i = 0; i < depth; ++i) HIP_CHECK(hipEventCreateWithFlags(&r->done[i], hipEventDisableTiming));
     const uint64_t id = c->next_id++;
+    std::lock_guard<std::mutex> lk(c->frames_mu);
+    if (!c->ingest_rings) c->ingest_rings = new std::unordered_map<uint64_t, std::unique_ptr<IngestRing>>();
     rings(c)[id] = std::move(r);
     *ring = id;
     API_END
@@ -70,13 +71,18 @@ extern "C" int32_t pvf_ingest_destroy(pvf_handle h, pvf_handle ring)
     API_BEGIN
     Ctx* c = pvf_ctx(h);
     HIP_CHECK(hipSetDevice(c->device));
-    PVF_REQUIRE(c->ingest_rings && rings(c).count(ring), "unknown ingest ring");
-    IngestRing& r = *rings(c)[ring];
+    std::unique_ptr<IngestRing> own;
+    {
+        std::lock_guard<std::mutex> lk(c->frames_mu);
+        PVF_REQUIRE(c->ingest_rings && rings(c).count(ring), "unknown ingest ring");
+        own = std::move(rings(c)[ring]);
+        rings(c).erase(ring);
+    }
+    IngestRing& r = *own;
     HIP_CHECK(hipStreamSynchronize(r.copy));
     (void)hipStreamDestroy(r.copy);
     for (auto e : r.done) (void)hipEventDestroy(e);
     (void)hipHostFree(r.host);
-    rings(c).erase(ring);
     API_END
 }
 
@@ -85,8 +91,13 @@ extern "C" int32_t pvf_ingest_acquire(pvf_handle h, pvf_handle ring, int32_t* sl
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
-    PVF_REQUIRE(c->ingest_rings && rings(c).count(ring) && slot && host_rgb, "pvf_ingest_acquire: bad arguments");
-    IngestRing& r = *rings(c)[ring];
+    IngestRing* rp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->frames_mu);
+        PVF_REQUIRE(c->ingest_rings && rings(c).count(ring) && slot && host_rgb, "pvf_ingest_acquire: bad arguments");
+        rp = rings(c)[ring].get();
+    }
+    IngestRing& r = *rp;                        // one producer per ring: its slot bookkeeping needs no lock
     const int s = r.next;
     r.next = (r.next + 1) % r.depth;
     if (r.busy[s]) { HIP_CHECK(hipEventSynchronize(r.done[s])); r.busy[s] = 0; }
@@ -100,8 +111,13 @@ extern "C" int32_t pvf_ingest_wait(pvf_handle h, pvf_handle ring)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
-    PVF_REQUIRE(c->ingest_rings && rings(c).count(ring), "unknown ingest ring");
-    HIP_CHECK(hipStreamSynchronize(rings(c)[ring]->copy));
+    hipStream_t copy = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->frames_mu);
+        PVF_REQUIRE(c->ingest_rings && rings(c).count(ring), "unknown ingest ring");
+        copy = rings(c)[ring]->copy;
+    }
+    HIP_CHECK(hipStreamSynchronize(copy));
     API_END
 }
 
@@ -111,22 +127,23 @@ extern "C" int32_t pvf_ingest_submit(pvf_handle h, pvf_handle ring, int32_t slot
     API_BEGIN
     Ctx* c = pvf_ctx(h);
     HIP_CHECK(hipSetDevice(c->device));
-    PVF_REQUIRE(c->ingest_rings && rings(c).count(ring) && frame, "pvf_ingest_submit: bad arguments");
-    IngestRing& r = *rings(c)[ring];
+    IngestRing* rp = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c->frames_mu);
+        PVF_REQUIRE(c->ingest_rings && rings(c).count(ring) && frame, "pvf_ingest_submit: bad arguments");
+        rp = rings(c)[ring].get();
+    }
+    IngestRing& r = *rp;
     PVF_REQUIRE(slot >= 0 && slot < r.depth, "pvf_ingest_submit: slot out of range");
     const size_t bytes = (size_t)r.h * r.w * 3;
-    uint8_t* d = nullptr;
-    if (!c->frame_pool[bytes].empty()) { d = c->frame_pool[bytes].back(); c->frame_pool[bytes].pop_back(); }
-    else HIP_CHECK(hipMalloc((void**)&d, bytes));
+    uint8_t* d = c->take_frame_buffer(bytes, r.copy);   // a recycled buffer: the copy waits (on the device) for the kernels that still read it
     HIP_CHECK(hipMemcpyAsync(d, r.host + (size_t)slot * bytes, bytes, hipMemcpyHostToDevice, r.copy));
     HIP_CHECK(hipEventRecord(r.done[slot], r.copy));
     r.busy[slot] = 1;
     Frame f; f.d = d; f.h = r.h; f.w = r.w; f.owned = true; f.pooled = true;
     HIP_CHECK(hipEventCreateWithFlags(&f.ready, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(f.ready, r.copy));
-    const uint64_t id = c->next_id++;
-    c->frames[id] = f;
-    *frame = id;
+    *frame = c->add_frame(f);
     API_END
 }
 
@@ -180,29 +197,33 @@ extern "C" int32_t pvf_frame_resize(pvf_handle h, pvf_handle frame, int32_t out_
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     HIP_CHECK(hipSetDevice(c->device));
     PVF_REQUIRE(out && out_w > 0 && out_h > 0, "pvf_frame_resize: bad arguments");
     const Frame f = c->frame(frame);
-    const ResizeTab tx = linear_table(f.w, out_w), ty = linear_table(f.h, out_h);
-    const size_t tb = (size_t)(out_w + out_h) * (4 + 4);
-    c->s_misc.ensure(tb + 64);
-    uint8_t* p = c->s_misc.as<uint8_t>();
-    int32_t* dxi = (int32_t*)p; int32_t* dyi = dxi + out_w;
-    int16_t* dxc = (int16_t*)(dyi + out_h); int16_t* dyc = dxc + 2 * out_w;
-    // the tables are tiny; the synchronous copies also keep the std::vectors alive long enough
-    HIP_CHECK(hipMemcpy(dxi, tx.idx.data(), (size_t)out_w * 4, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(dyi, ty.idx.data(), (size_t)out_h * 4, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(dxc, tx.coef.data(), (size_t)out_w * 4, hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(dyc, ty.coef.data(), (size_t)out_h * 4, hipMemcpyHostToDevice));
+    // coefficient tables: built and uploaded once per (source size, target size), in a buffer of their own (--min-size asks for the same
+    // resize for every frame of a video)
+    const std::vector<int> key{f.w, f.h, out_w, out_h};
+    auto it = c->resize_tabs.find(key);
+    if (it == c->resize_tabs.end()) {
+        const ResizeTab tx = linear_table(f.w, out_w), ty = linear_table(f.h, out_h);
+        std::unique_ptr<DevBuf> tab(new DevBuf());
+        tab->ensure((size_t)(out_w + out_h) * (4 + 4));
+        uint8_t* q = tab->as<uint8_t>();
+        HIP_CHECK(hipMemcpy(q, tx.idx.data(), (size_t)out_w * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(q + (size_t)out_w * 4, ty.idx.data(), (size_t)out_h * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(q + (size_t)(out_w + out_h) * 4, tx.coef.data(), (size_t)out_w * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(q + (size_t)(out_w + out_h) * 4 + (size_t)out_w * 4, ty.coef.data(), (size_t)out_h * 4, hipMemcpyHostToDevice));
+        it = c->resize_tabs.emplace(key, std::move(tab)).first;
+    }
+    uint8_t* p = it->second->as<uint8_t>();
+    const int32_t* dxi = (const int32_t*)p; const int32_t* dyi = dxi + out_w;
+    const int16_t* dxc = (const int16_t*)(dyi + out_h); const int16_t* dyc = dxc + 2 * out_w;
     const size_t bytes = (size_t)out_h * out_w * 3;
-    uint8_t* d = nullptr;
-    if (!c->frame_pool[bytes].empty()) { d = c->frame_pool[bytes].back(); c->frame_pool[bytes].pop_back(); }
-    else HIP_CHECK(hipMalloc((void**)&d, bytes));
+    uint8_t* d = c->take_frame_buffer(bytes, c->stream);
     hipLaunchKernelGGL(cv_resize_linear_k, dim3((out_w + 255) / 256, out_h), dim3(256), 0, c->stream, f.d, f.h, f.w, d, out_h, out_w, dxi, dxc, dyi, dyc);
     HIP_CHECK(hipGetLastError());
     Frame g; g.d = d; g.h = out_h; g.w = out_w; g.owned = true; g.pooled = true;
-    const uint64_t id = c->next_id++;
-    c->frames[id] = g;
-    *out = id;
+    *out = c->add_frame(g);
     API_END
 }

@@ -5,7 +5,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
@@ -85,7 +87,7 @@ struct Frame {
     const uint8_t* d = nullptr; // device, HWC RGB contiguous
     int h = 0, w = 0;
     bool owned = false;
-    bool pooled = false;        // owned memory that goes back to Ctx::frame_pool on release (ingest ring, device resize)
+    bool pooled = false;        // owned memory that goes back to Ctx::frame_pool on release (every frame the library allocated itself)
     hipEvent_t ready = nullptr; // asynchronous upload still in flight: the compute stream waits for it on first use (Ctx::frame)
 };
 
@@ -181,7 +183,12 @@ struct Ctx {
     std::unordered_map<uint64_t, Frame> frames;
     std::unordered_map<uint64_t, std::unique_ptr<Tracker>> trackers;
     std::vector<double*> tracker_pool; // freed tracker states for reuse
-    uint64_t next_id = 1;
+    std::atomic<uint64_t> next_id{1};
+    // Threads.  api_mu serialises the compute entry points of one context (they share the stream and the scratch buffers); frames_mu
+    // guards the frame table, the buffer pool and the ingest rings, which a decoder thread fills (pvf_ingest_*, pvf_frame_upload /
+    // _release) while another thread runs kernels.  Order: api_mu before frames_mu, never the other way round.
+    std::recursive_mutex api_mu;
+    std::mutex frames_mu;
     bool prof_on = false;
     std::map<std::string, ProfFamily> prof;
     std::vector<hipEvent_t> event_pool;
@@ -194,15 +201,22 @@ struct Ctx {
     hipEvent_t det_ev[2] = {nullptr, nullptr};
     int det_slot = 0;
     int n_cu = 256;
-    std::map<size_t, std::vector<uint8_t*>> frame_pool;   // released pooled frame buffers by size (ingest.hip)
+    // released frame buffers by size.  A buffer comes back with the event recorded on the compute stream at its release: whoever takes it
+    // next orders its first write behind that event (pool_take), so releasing a frame never waits for the kernels that still read it.
+    struct PoolBuf { uint8_t* p; hipEvent_t free_after; };
+    std::map<size_t, std::vector<PoolBuf>> frame_pool;
+    size_t frame_pool_bytes = 0;
     void* ingest_rings = nullptr;                          // pinned staging rings of this context (ingest.hip)
     struct MlPlanCache* ml_plans = nullptr;   // detector launch plans of this context (detect.hip); freed by ml_plans_free
+    std::map<std::vector<int>, std::unique_ptr<DevBuf>> resize_tabs;   // pvf_frame_resize coefficient tables by (in_w, in_h, out_w, out_h)
     const void* feat_ring_owner = nullptr;    // plan whose zero padding ring s_feat currently holds
     uint8_t* d_orient_lut = nullptr; // 511x511 orientation bins (fhog.hip)
     void* d_grad_lut = nullptr;          // orientation bins in 8 x 8 tiles (64^3 bytes): orientation_lut_tiled()
 
-    Frame& frame(uint64_t id)
+    // a copy of the frame record (the table may be re-hashed by another thread as soon as the lock is gone)
+    Frame frame(uint64_t id)
     {
+        std::lock_guard<std::mutex> lk(frames_mu);
         auto it = frames.find(id);
         if (it == frames.end()) throw PvfError("unknown frame handle");
         Frame& f = it->second;
@@ -212,6 +226,44 @@ struct Ctx {
             f.ready = nullptr;
         }
         return f;
+    }
+    // A buffer for a new frame: from the pool when one of that size is there.  `writer`: the stream whose work fills the buffer next (its
+    // queue waits for the previous readers on the device); nullptr: the host fills it with a blocking copy (the wait happens here,
+    // outside frames_mu).
+    uint8_t* take_frame_buffer(size_t bytes, hipStream_t writer)
+    {
+        PoolBuf b{nullptr, nullptr};
+        {
+            std::lock_guard<std::mutex> lk(frames_mu);
+            auto& v = frame_pool[bytes];
+            if (!v.empty()) { b = v.back(); v.pop_back(); frame_pool_bytes -= bytes; }
+        }
+        if (!b.p) {
+            HIP_CHECK(hipMalloc((void**)&b.p, bytes));
+            return b.p;
+        }
+        if (b.free_after) {
+            if (writer) HIP_CHECK(hipStreamWaitEvent(writer, b.free_after, 0));
+            else HIP_CHECK(hipEventSynchronize(b.free_after));
+            (void)hipEventDestroy(b.free_after);
+        }
+        return b.p;
+    }
+    // frames_mu held by the caller
+    void pool_give(uint8_t* p, size_t bytes)
+    {
+        hipEvent_t e = nullptr;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(e, stream));
+        frame_pool[bytes].push_back(PoolBuf{p, e});
+        frame_pool_bytes += bytes;
+    }
+    uint64_t add_frame(const Frame& f)
+    {
+        const uint64_t id = next_id++;
+        std::lock_guard<std::mutex> lk(frames_mu);
+        frames[id] = f;
+        return id;
     }
     Tracker& tracker(uint64_t id)
     {

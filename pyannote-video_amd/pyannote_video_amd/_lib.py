@@ -36,6 +36,9 @@ _SIGS = {
     "pvf_frame_upload": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int64, P]),
     "pvf_frame_wrap_device": (C.c_int32, [H, P, C.c_int32, C.c_int32, P]),
     "pvf_frame_release": (C.c_int32, [H, H]),
+    "pvf_frame_release_many": (C.c_int32, [H, P, C.c_int32]),
+    "pvf_frame_pool_trim": (C.c_int32, [H, C.c_int64, P]),
+    "pvf_mem_info": (C.c_int32, [H, P, P]),
     "pvf_frame_device_ptr": (C.c_int32, [H, H, P]),
     "pvf_ingest_create": (C.c_int32, [H, C.c_int32, C.c_int32, C.c_int32, P]),
     "pvf_ingest_destroy": (C.c_int32, [H, H]),
@@ -137,17 +140,25 @@ def overlap_matrix(a, b, ratio):
     return out
 
 
-_assoc_buf = {}
+import threading as _threading
+_assoc_tls = _threading.local()       # ctypes releases the GIL inside pvf_associate: the reused buffers are per thread
+_ASSOC_KEEP = 256
 
 
 def associate(trackers, detections, ratio):
     """[(tracker row, detection index)] of the reference's _associate, tracker rows ascending.
-    Called once per frame and pass by the tracking state machine (thousands of times per shot): plain ctypes arrays, reused per size."""
+    Called once per frame and pass by the tracking state machine (thousands of times per shot): plain ctypes arrays, reused per size
+    (per thread, at most _ASSOC_KEEP sizes)."""
     na, nb = len(trackers), len(detections)
     key = (na, nb)
-    buf = _assoc_buf.get(key)
+    cache = getattr(_assoc_tls, "buf", None)
+    if cache is None:
+        cache = _assoc_tls.buf = {}
+    buf = cache.get(key)
     if buf is None:
-        buf = _assoc_buf[key] = ((C.c_double * (4 * na))(), (C.c_double * (4 * nb))(), (C.c_int32 * max(na, 1))())
+        if len(cache) >= _ASSOC_KEEP:
+            cache.clear()
+        buf = cache[key] = ((C.c_double * (4 * na))(), (C.c_double * (4 * nb))(), (C.c_int32 * max(na, 1))())
     a, b, out = buf
     k = 0
     for box in trackers:

@@ -3,6 +3,7 @@
     python -m pyannote_video_amd track   [options] <video> <shot.json> <tracking>
     python -m pyannote_video_amd extract [options] <video> <tracking> <landmark_model> <embedding_model> <landmarks> <embeddings>
     python -m pyannote_video_amd cluster [options] <embeddings> <labels>
+    python -m pyannote_video_amd process [options] <video> <shot.json> <landmark_model> <embedding_model> <tracking> <landmarks> <embeddings>
 
 `track` and `extract` take the reference's arguments and options and write byte-compatible files (track.txt, landmarks.txt,
 embedding.txt: formats.py).  `cluster` is the verb BASELINE.json's north_star names; the reference offers clustering through the API
@@ -83,23 +84,44 @@ def load_shots(path):
     return [_Shot(a, b) for a, b in data]
 
 
+def auto_detect_batch(width, height):
+    """frames whose pyramids and feature maps are resident together: 128 at 1080p (18 GB), fewer for larger frames"""
+    return int(max(8, min(128, 128 * (1920 * 1080) // max(int(width) * int(height), 1))))
+
+
+def _pipeline(video, ctx, landmark_model=None, embedding_model=None, **kw):
+    from . import pipeline, runtime
+    ctx = ctx or runtime.default_context()
+    w, h = video.size
+    return pipeline.FacePipeline(ctx, landmark_model, embedding_model, detect_batch_size=auto_detect_batch(w, h), **kw)
+
+
 def track(video, shot, output, detect_min_size=0.0, detect_every=0.0, track_min_overlap_ratio=MIN_OVERLAP_RATIO,
           track_min_confidence=MIN_CONFIDENCE, track_max_gap=MAX_GAP, ctx=None):
-    """Tracking by detection (pyannote-face.py:239-269): track.txt, one line per (track, frame), flushed per track"""
-    from .face_tracking import FaceTracking
-    tracking = FaceTracking(detect_min_size=detect_min_size, detect_every=detect_every, track_min_overlap_ratio=track_min_overlap_ratio,
-                            track_min_confidence=track_min_confidence, track_max_gap=track_max_gap, ctx=ctx)
+    """Tracking by detection (pyannote-face.py:239-269): track.txt, one line per (track, frame), flushed per track.  The video is read
+    once, in a thread of its own, into the pinned ingest ring; shots go through the streaming engine (engine.py): batched detection,
+    bulk tracker work, the state machine one shot behind, frames released shot by shot."""
+    pipe = _pipeline(video, ctx, detect_min_size=detect_min_size, detect_every=detect_every, track_min_overlap_ratio=track_min_overlap_ratio,
+                     track_min_confidence=track_min_confidence, track_max_gap=track_max_gap)
     shots = load_shots(shot) if isinstance(shot, str) else shot
+    state = {"next": 0}
     with open(output, 'w') as foutput:
-        for identifier, trk in enumerate(tracking(video, shots)):
-            for line in formats.track_lines(identifier, trk):
-                foutput.write(line)
-            foutput.flush()
+        def write(tracks):
+            for trk in tracks:
+                for line in formats.track_lines(state["next"], trk):
+                    foutput.write(line)
+                foutput.flush()
+                state["next"] += 1
+        return pipe.run_stream(video, shots, extract=False, cluster=False, on_tracks=write)
 
 
-def extract(video, landmark_model, embedding_model, tracking, landmark_output, embedding_output, ctx=None, batch=256):
+def extract(video, landmark_model, embedding_model, tracking, landmark_output, embedding_output, ctx=None, batch=2048, ahead=96):
     """Facial features (pyannote-face.py:271-314): landmarks.txt and embedding.txt for every face of the track file.  The faces
-    are paired with frames by getFaceGenerator's rules (pipeline.faces_per_frame) and computed `batch` faces per library call."""
+    are paired with frames by getFaceGenerator's rules (pipeline.faces_per_frame); a reader thread pushes the frames that carry faces
+    through the pinned ingest ring (asynchronous uploads, at most `ahead` frames in flight) while this thread computes `batch` faces per
+    library call and writes the lines in the reference's order."""
+    import queue
+    import threading
     from . import pipeline, runtime
     ctx = ctx or runtime.default_context()
     ctx.load_shape_predictor(landmark_model)
@@ -111,29 +133,103 @@ def extract(video, landmark_model, embedding_model, tracking, landmark_output, e
     want = {}
     for fi, T, g in plan:
         want[fi] = (T, g)
-    with open(landmark_output, 'w') as flandmark, open(embedding_output, 'w') as fembedding:
-        pend_f, pend_b, pend_k = [], [], []
+    last_wanted = max(want) if want else -1
+    q = queue.Queue(maxsize=max(2, int(ahead)))
+    state = {"error": None}
 
-        def flush():
-            if not pend_b:
-                return
-            pts = ctx.landmarks(pend_f, pend_b)
-            emb = ctx.embed(pend_f, pts)
-            for (T, ident), p, e in zip(pend_k, pts, emb):
-                flandmark.write(formats.landmark_line(T, ident, p, frame_width, frame_height))
-                fembedding.write(formats.embedding_line(T, ident, e))
-            flandmark.flush(); fembedding.flush()
-            del pend_f[:], pend_b[:], pend_k[:]
-        for fi, (t, rgb) in enumerate(video):
-            if fi not in want:
-                continue
-            T, g = want[fi]
-            dev = ctx.upload(rgb)
-            for ident, box in g:
-                pend_f.append(dev); pend_b.append(box); pend_k.append((T, ident))
-            if len(pend_b) >= batch:
-                flush()
-        flush()
+    def reader():
+        ring = None
+        try:
+            for fi, (t, rgb) in enumerate(video):
+                if fi > last_wanted:
+                    break
+                if fi not in want:
+                    continue
+                owned = False
+                if not isinstance(rgb, runtime.DeviceFrame):
+                    if ring is None:
+                        ring = ctx.ingest_ring(rgb.shape[0], rgb.shape[1], depth=16)
+                    rgb = ring.push(rgb)
+                    owned = True
+                q.put((fi, rgb, owned))
+            if ring is not None:
+                ring.close()
+        except BaseException as e:          # noqa: BLE001 -- re-raised below
+            state["error"] = e
+        finally:
+            q.put(None)
+
+    th = threading.Thread(target=reader, name="pvface-extract-reader")
+    th.start()
+    try:
+        with open(landmark_output, 'w') as flandmark, open(embedding_output, 'w') as fembedding:
+            pend_f, pend_b, pend_k, pend_own = [], [], [], []
+
+            def flush():
+                if not pend_b:
+                    return
+                pts = ctx.landmarks(pend_f, pend_b)
+                emb = ctx.embed(pend_f, pts)
+                for (T, ident), p, e in zip(pend_k, pts, emb):
+                    flandmark.write(formats.landmark_line(T, ident, p, frame_width, frame_height))
+                    fembedding.write(formats.embedding_line(T, ident, e))
+                flandmark.flush(); fembedding.flush()
+                for f in pend_own:
+                    f.release()
+                del pend_f[:], pend_b[:], pend_k[:], pend_own[:]
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                fi, dev, owned = item
+                T, g = want[fi]
+                if owned:
+                    pend_own.append(dev)
+                for ident, box in g:
+                    pend_f.append(dev); pend_b.append(box); pend_k.append((T, ident))
+                if len(pend_b) >= batch:
+                    flush()
+            flush()
+    finally:
+        while th.is_alive():                 # an error on this side: let the reader run out
+            try:
+                q.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        th.join()
+    if state["error"] is not None:
+        raise state["error"]
+
+
+def process(video, shot, landmark_model, embedding_model, tracking_output, landmark_output, embedding_output, label_output=None,
+            detect_min_size=0.0, detect_every=0.0, track_min_overlap_ratio=MIN_OVERLAP_RATIO, track_min_confidence=MIN_CONFIDENCE,
+            track_max_gap=MAX_GAP, threshold=0.6, ctx=None):
+    """`track` + `extract` (+ `cluster`) in ONE pass over the video -- one decode, one upload per frame; the reference needs two decodes
+    (pyannote-face.py:261 and :287).  Writes the same three files as the separate verbs, line for line (the faces of one frame in the
+    order pandas' sort of the complete track table gives them: formats.file_order), plus the `identifier label` file of `cluster`."""
+    pipe = _pipeline(video, ctx, landmark_model, embedding_model, detect_min_size=detect_min_size, detect_every=detect_every,
+                     track_min_overlap_ratio=track_min_overlap_ratio, track_min_confidence=track_min_confidence, track_max_gap=track_max_gap,
+                     threshold=threshold)
+    shots = load_shots(shot) if isinstance(shot, str) else shot
+    state = {"next": 0}
+    with open(tracking_output, 'w') as foutput:
+        def write(tracks):
+            for trk in tracks:
+                for line in formats.track_lines(state["next"], trk):
+                    foutput.write(line)
+                foutput.flush()
+                state["next"] += 1
+        res = pipe.run_stream(video, shots, on_tracks=write, cluster=label_output is not None)
+    w, h = video.size
+    with open(landmark_output, 'w') as flandmark, open(embedding_output, 'w') as fembedding:
+        for T, ident, p, e in zip(res["face_T"].tolist(), res["face_id"].tolist(), res["landmarks"], res["embeddings"]):
+            flandmark.write(formats.landmark_line(T, ident, p, w, h))
+            fembedding.write(formats.embedding_line(T, ident, e))
+    if label_output is not None:
+        with open(label_output, 'w') as f:
+            for identifier in sorted(set(res["face_id"].tolist())):
+                f.write('{identifier:d} {label:d}\n'.format(identifier=identifier, label=res["labels"].get(identifier, identifier)))
+    return res
 
 
 def _times(video):
@@ -179,9 +275,20 @@ def main(argv=None):
     e = sub.add_parser("extract")
     for name in ("video", "tracking", "landmark_model", "embedding_model", "landmarks", "embeddings"):
         e.add_argument(name)
+    pr = sub.add_parser("process", help="track + extract + cluster in one pass over the video")
+    for name in ("video", "shot", "landmark_model", "embedding_model", "tracking", "landmarks", "embeddings"):
+        pr.add_argument(name)
+    pr.add_argument("--labels", default=None)
+    pr.add_argument("--min-size", type=float, default=0.0)
+    pr.add_argument("--every", type=float, default=0.0)
+    pr.add_argument("--min-overlap", type=float, default=MIN_OVERLAP_RATIO)
+    pr.add_argument("--min-confidence", type=float, default=MIN_CONFIDENCE)
+    pr.add_argument("--max-gap", type=float, default=MAX_GAP)
+    pr.add_argument("--threshold", type=float, default=0.6)
     s = sub.add_parser("shot")
     s.add_argument("video"); s.add_argument("output")
-    s.add_argument("--height", type=int, default=50)
+    s.add_argument("--height", type=int, default=50, help="height of the images the optical flow runs on (reference default 50); the "
+                   "device kernel covers the single-level flow, i.e. heights / widths below 64 pixels -- larger values are refused")
     s.add_argument("--window", type=float, default=2.0)
     s.add_argument("--threshold", type=float, default=1.0)
     c = sub.add_parser("cluster")
@@ -197,6 +304,10 @@ def main(argv=None):
     if a.verb == "track":
         track(open_video(a.video, a.fps), a.shot, a.tracking, detect_min_size=a.min_size, detect_every=a.every,
               track_min_overlap_ratio=a.min_overlap, track_min_confidence=a.min_confidence, track_max_gap=a.max_gap, ctx=ctx)
+    elif a.verb == "process":
+        process(open_video(a.video, a.fps), a.shot, a.landmark_model, a.embedding_model, a.tracking, a.landmarks, a.embeddings, a.labels,
+                detect_min_size=a.min_size, detect_every=a.every, track_min_overlap_ratio=a.min_overlap,
+                track_min_confidence=a.min_confidence, track_max_gap=a.max_gap, threshold=a.threshold, ctx=ctx)
     elif a.verb == "shot":
         shot(open_video(a.video, a.fps), a.output, height=a.height, window=a.window, threshold=a.threshold, ctx=ctx)
     elif a.verb == "extract":

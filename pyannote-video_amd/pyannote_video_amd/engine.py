@@ -1,0 +1,713 @@
+"""The streaming engine behind FacePipeline, the CLI verbs and FaceTracking.__call__: shots of one or many videos flow through
+
+    source (decoder thread) -> GPU thread: detect(k), bulk tracker work(k), landmarks + embeddings of finished shots
+                            -> caller's thread: association / graph / merging of shot k (tracking.py:184-362), track files, clustering
+
+with memory bounded the way the reference bounds it -- per shot (tracking.py:359-362,410-420: the frame cache is dropped when a shot
+has been tracked) -- instead of per video:
+
+  * frames the engine staged itself (numpy frames pushed through the pinned ingest ring, device-side --min-size copies) are released
+    as soon as the shot's passes are done and `extract` has walked past them (pvf_frame_release: the buffer is recycled behind an
+    event, nothing waits); at most the shots in flight are resident: one being read, one queued, one in detection, one in the state
+    machine, one waiting for its faces;
+  * the bulk tracker starts of a shot (HipTrackers.speculate_pair) are windowed when the shot holds more detections than
+    `speculate_limit`: trackers for the next `speculate_window` detections only, both passes (WindowedPlan).
+
+A "job" is one video: its own track numbering, its own `extract` walk, its own clustering.  Several jobs may share one engine run
+(BASELINE.json configs[3]: independent clips farmed to a GPU, no collective): the detector of clip i + 1 runs while the state
+machine of clip i is busy on the host.
+"""
+import os
+import queue
+import threading
+import time as _time
+
+import numpy as np
+
+from . import formats
+from .tracking_by_detection import get_segment_generator, HipTrackers
+
+
+class ListStore(object):
+    """frames the caller owns (resident for the whole run): nothing to release"""
+
+    def __init__(self, frames):
+        self.frames = frames
+
+    def __getitem__(self, i):
+        return self.frames[i]
+
+    def add(self, index, frame, owned):
+        pass
+
+    def release_below(self, index):
+        pass
+
+    def release_all(self):
+        pass
+
+
+class FrameStore(object):
+    """native frames of one video by global frame index; frames the engine staged itself (`owned`) go back to the buffer pool as soon
+    as `extract` has passed them"""
+
+    def __init__(self):
+        self.frames = {}
+        self.owned = set()
+        self.low = 0
+        self.peak = 0
+
+    def __getitem__(self, i):
+        return self.frames[i]
+
+    def add(self, index, frame, owned):
+        self.frames[index] = frame
+        if owned:
+            self.owned.add(index)
+        self.peak = max(self.peak, len(self.frames))
+
+    def release_below(self, index):
+        for i in range(self.low, index):
+            f = self.frames.pop(i, None)
+            if f is not None and i in self.owned:
+                self.owned.discard(i)
+                f.release()
+        self.low = max(self.low, index)
+
+    def release_all(self):
+        """the job is over: whatever `extract` never reached (the frames behind the last group it hands on) goes back too"""
+        for i in sorted(self.owned):
+            self.frames[i].release()
+        self.owned.clear()
+        self.frames.clear()
+
+
+class ExtractStream(object):
+    """`extract` (pyannote-face.py:121-175, 425-466) fed shot by shot while later shots are still being detected.
+
+    The reference reads the finished track file and walks frames and timestamp groups in step (pipeline.faces_per_frame).  Shots
+    are disjoint in time and arrive in order, so the same walk can be resumed whenever a shot's tracks exist: groups are
+    appended to a queue, the frame pointer only moves while a group is available, and the newest group is held back until a
+    later one arrives because the reference's generator never yields the last group of the file.  The faces that become
+    available are aligned and embedded immediately.  `frames` is anything indexable by global frame index (a list, a FrameStore);
+    `frame_times` may grow while the video streams in."""
+
+    def __init__(self, ctx, frames, frame_times, frame_width, frame_height):
+        self.ctx, self.frames, self.times = ctx, frames, frame_times
+        self.w, self.h = frame_width, frame_height
+        self.tracks, self.rows = [], []
+        self.file_T, self.file_id = [], []    # the track file's (T, track) column in file order (decides the row order of the outputs)
+        self.groups, self.gi, self.fi = [], 0, 0
+        self.face_boxes, self.face_T, self.face_id = [], [], []
+        self.pts, self.emb = [], []
+        self.emitted = []     # (frame index, T) of every group handed on, in order
+
+    def _emit(self, available):
+        """faces of the groups that may be handed on now: (frames, boxes, frame index below which every face has been handed on)"""
+        face_frames, boxes = [], []
+        times = self.times
+        while self.fi < len(times) and self.gi < available:
+            T, g = self.groups[self.gi]
+            if T > times[self.fi]:
+                self.fi += 1
+                continue
+            for ident, box in g:
+                face_frames.append(self.frames[self.fi]); boxes.append(box)
+                self.face_T.append(T); self.face_id.append(ident)
+            self.emitted.append((self.fi, T))
+            self.gi += 1
+            self.fi += 1
+        self.face_boxes.extend(boxes)
+        return face_frames, boxes, self.fi
+
+    def compute(self, work):
+        """GPU part: landmarks + embeddings of one batch of faces returned by prepare(); batches must arrive in order"""
+        face_frames, boxes = work[0], work[1]
+        if boxes:
+            pts = self.ctx.landmarks(face_frames, boxes)
+            self.pts.append(pts)
+            self.emb.append(self.ctx.embed(face_frames, pts))
+
+    def prepare(self, tracks):
+        """host part for the normalised tracks of the next shot (in shot order): the track-file rows, their timestamp groups,
+        and the faces that can be extracted now"""
+        base = len(self.tracks)
+        # the track file's rows: time and box with 3 decimals ('%.3f'), the box then parsed as float32 (pyannote-face.py:125-127).
+        # round(float, 3) is the correctly rounded 3-decimal value, i.e. float('%.3f' % v) -- for Python floats only (numpy scalars
+        # round differently), hence the float(); the float32 parse is one array cast.
+        flat = [round(float(v), 3) for track in tracks for _, box, _ in track for v in box]
+        q32 = np.asarray(flat, np.float64).astype(np.float32).astype(np.float64).reshape(-1, 4).tolist() if flat else []
+        rows, i = [], 0
+        for k, track in enumerate(tracks):
+            for t, _, status in track:
+                rows.append((round(float(t), 3), base + k, tuple(q32[i]), status))
+                i += 1
+        self.file_T.extend(r[0] for r in rows)
+        self.file_id.extend(r[1] for r in rows)
+        rows.sort(key=lambda r: r[0])
+        self.tracks.extend(tracks)
+        self.rows.extend(rows)
+        k, n = 0, len(rows)
+        while k < n:
+            T = rows[k][0]
+            g = []
+            while k < n and rows[k][0] == T:
+                _, ident, box, _ = rows[k]
+                g.append((ident, formats.denormalise(box, self.w, self.h)))
+                k += 1
+            if self.groups and self.groups[-1][0] == T:
+                self.groups[-1][1].extend(g)      # cannot happen for disjoint shots; keeps the grouping rule exact anyway
+            else:
+                self.groups.append((T, g))
+        return self._emit(len(self.groups) - 1)
+
+    def feed(self, tracks):
+        self.compute(self.prepare(tracks))
+
+    def plan_finish(self, drop_last=True, reorder=True):
+        """Host part of finish() that does not need the embeddings: the last faces to extract, the file order of all faces and the
+        sorted track rows.  The pipelined run calls it while the GPU still embeds the last shot's faces."""
+        self._final_work = self._emit(len(self.groups) - (1 if drop_last else 0))
+        if not drop_last and self.gi < len(self.groups):
+            # a shard that is not the end of the video must hand on ALL its groups.  A group is left over when '%.3f' rounded a frame time
+            # UP (e.g. 30 fps: t = 0.066667 -> T = 0.067 > t): the reference then serves that group one frame late and carries the lag
+            # across the shot boundary, i.e. into the next shard -- a shard cannot reproduce that on its own.  All BASELINE.json
+            # configurations run at 25 / 50 fps, whose frame times survive the rounding.
+            raise ValueError("frame-range shard ends with %d face group(s) whose rounded time lies behind the shard's last frame; cut the "
+                             "video at shots whose frame times survive 3-decimal rounding (25 / 50 fps do) or run it unsharded"
+                             % (len(self.groups) - self.gi))
+        self._perm = None
+        if reorder and len(self.face_T):
+            perm = formats.file_order(self.face_T, self.face_id, self.file_T, self.file_id)
+            self._perm = perm
+            self.face_T = [self.face_T[i] for i in perm]
+            self.face_id = [self.face_id[i] for i in perm]
+            self.face_boxes = [self.face_boxes[i] for i in perm]
+        order = formats.pandas_sort_order(self.file_T)
+        by_key = {(r[0], r[1]): r for r in self.rows}
+        self.rows = [by_key[(self.file_T[i], self.file_id[i])] for i in order]
+        self._planned = True
+
+    def finish(self, drop_last=True, reorder=True, computed=False):
+        """reorder: put the faces of one timestamp into the order the reference's `extract` writes them (formats.file_order).
+        A shard of a longer video leaves that to the step that sees the whole track table (dist.gather_rows).
+        computed: the engine's GPU thread has already run the final batch (plan_finish()'s work)."""
+        if not getattr(self, "_planned", False):
+            self.plan_finish(drop_last, reorder)
+        if not computed:
+            self.compute(self._final_work)
+        pts = np.concatenate(self.pts) if self.pts else np.zeros((0, 68, 2), np.int32)
+        emb = np.concatenate(self.emb) if self.emb else np.zeros((0, 128), np.float32)
+        if self._perm is not None:
+            pts, emb = pts[self._perm], emb[self._perm]
+        return pts, emb
+
+
+def detections_as_lists(n_frames, raw):
+    """[[(l, t, r, b) Python ints]] per frame from the arrays of Context.detect_many(arrays=True): raw = (boxes, counts, frame indices)"""
+    dets = [[] for _ in range(n_frames)]
+    if raw is not None:
+        out, cnt, idx = raw
+        rows, cnt = out.tolist(), cnt.tolist()
+        for j, i in enumerate(idx):
+            dets[i] = [tuple(b) for b in rows[j][:cnt[j]]]
+    return dets
+
+
+class ShotInput(object):
+    """one shot of one job on its way through the engine"""
+    __slots__ = ("job", "base", "cache", "flags", "natives", "owned", "resize")
+
+    def __init__(self, job, base, cache, flags, natives=None, owned=False, resize=None):
+        self.job, self.base, self.cache, self.flags = job, base, cache, flags
+        self.natives = natives          # native frames when the cache holds (or will hold) down-scaled detection frames
+        self.owned = owned              # the native frames were staged by the engine: released when extract has passed them
+        self.resize = resize            # (width, height) of the detection frames still to be made on the device (--min-size)
+
+
+class JobEnd(object):
+    """marks the end of a job's shots in the source"""
+    __slots__ = ("job",)
+
+    def __init__(self, job):
+        self.job = job
+
+
+class VideoJob(object):
+    """one video going through the engine"""
+
+    def __init__(self, ctx, width, height, det_width=None, det_height=None, frames=None, times=None, extract=True, last_shard=True,
+                 reorder=True, on_tracks=None, key=None):
+        self.ctx, self.key = ctx, key
+        self.w, self.h = int(width), int(height)
+        self.tw, self.th = int(det_width or width), int(det_height or height)
+        self.store = ListStore(frames) if frames is not None else FrameStore()
+        self.times = times if times is not None else []
+        self.streaming = times is None          # frame times (and frames) arrive with the shots
+        self.ex = ExtractStream(ctx, self.store, self.times, self.w, self.h) if extract else None
+        self.tracks = []                        # normalised tracks in yield order (the ExtractStream keeps its own list)
+        self.last_shard, self.reorder, self.on_tracks = last_shard, reorder, on_tracks
+        self.final_computed = threading.Event()
+        self.shot_ranges = []
+        self.t_tracked = None                   # when the job's last shot had its tracks
+        self.result = None
+
+    def accept(self, si):
+        """host thread, when a shot's detections arrive: the job learns the shot's frames and times (streaming sources)"""
+        n = len(si.cache)
+        self.shot_ranges.append((si.base, si.base + n))
+        if self.streaming:
+            natives = si.natives if si.natives is not None else [f for _, f in si.cache]
+            for j, f in enumerate(natives):
+                self.store.add(si.base + j, f, si.owned)
+            self.times.extend(t for t, _ in si.cache)
+
+    def shot_tracked(self, si, tracks, normalize):
+        """host thread: the shot's tracks exist.  Returns the extraction work of the faces that may be computed now (or None)."""
+        norm = [normalize(tr, self.tw, self.th) for tr in tracks]
+        if self.on_tracks is not None:
+            self.on_tracks(norm)
+        self.t_tracked = _time.perf_counter()
+        if self.ex is None:
+            self.tracks.extend(norm)
+            if self.streaming and si.owned:
+                self.store.release_below(si.base + len(si.cache))
+            return None
+        return self.ex.prepare(norm)
+
+
+class WindowedPlan(object):
+    """plan[t] of one pass over a shot (what HipTrackers.speculate_pair returns for the whole shot at once), computed for a window
+    of detections at a time when the lane gets there: the trackers that exist at any moment are those of the windows the two lanes
+    are in, not those of the whole shot.  Frames, counts and boxes are in the pass's processing order."""
+
+    def __init__(self, backend, frame_handles, times, counts, boxes, window):
+        self.backend, self.fh, self.counts, self.boxes, self.window = backend, frame_handles, counts, boxes, max(int(window), 1)
+        self.index = {t: i for i, t in enumerate(times)}
+        self.times = times
+        self.starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        self.hi = 0
+        self.cur = {}
+        self.windows = 0
+
+    def __getitem__(self, t):
+        i = self.index[t]
+        while i >= self.hi:
+            self._advance()
+        return self.cur.pop(t)
+
+    def _advance(self):
+        lo, hi, n = self.hi, self.hi, len(self.counts)
+        total = 0
+        while hi < n and (hi == lo or total + self.counts[hi] <= self.window):
+            total += self.counts[hi]
+            hi += 1
+        self.hi = hi
+        self.windows += 1
+        if total == 0:
+            return
+        k0, k1 = int(self.starts[lo]), int(self.starts[hi])
+        owner = np.repeat(np.arange(lo, hi), self.counts[lo:hi])
+        hs, psr, pos = self.backend.speculate_window(self.fh, owner, self.boxes[k0:k1], n)
+        hl = hs.tolist()
+        for i in range(lo, hi):
+            m = int(self.counts[i])
+            if m:
+                a = int(self.starts[i]) - k0
+                last = (i == n - 1)
+                self.cur[self.times[i]] = (hl[a:a + m], None if last else psr[a:a + m], None if last else pos[a:a + m])
+
+
+class _LaneBackend(object):
+    """what the lanes of the tracking thread see of the tracker context while the GPU thread owns it: on-demand updates
+    take the context lock, killed trackers are only queued (the GPU thread destroys them between its batches)"""
+
+    def __init__(self, backend, lock, dead):
+        self.backend, self.lock, self.dead = backend, lock, dead
+
+    def update_many(self, handles, frames):
+        with self.lock:
+            return self.backend.update_many(handles, frames)
+
+    def commit_many(self, handles, frames):
+        with self.lock:
+            self.backend.commit_many(handles, frames)
+
+    def start_many(self, frames, boxes):
+        with self.lock:
+            return self.backend.start_many(frames, boxes)
+
+    def speculate_window(self, fh, owner, boxes, n_frames):
+        with self.lock:
+            self.release_dead()          # the killed trackers of the previous windows make room first
+            return self.backend.speculate_window(fh, owner, boxes, n_frames)
+
+    def release_dead(self):
+        batch = []
+        while self.dead:
+            batch.append(self.dead.pop())
+        if batch:
+            self.backend.release_many(batch)
+
+    def release(self, handle):
+        self.dead.append(handle)
+
+
+class Engine(object):
+    """One pass of a source of ShotInput / JobEnd items through the GPU thread and the caller's thread (see the module text)."""
+
+    def __init__(self, ctx, tracking, detect_batch_size=8, overlap=True, speculate_limit=8192, speculate_window=4096):
+        self.ctx, self.tracking = ctx, tracking
+        self.detect_batch_size = detect_batch_size
+        self.overlap = overlap
+        self.speculate_limit, self.speculate_window = int(speculate_limit), int(speculate_window)
+        self.stats = {}
+
+    # ---- the GPU-side work of one shot ---------------------------------------------------------------------------------------
+    def _detect(self, si):
+        ctx = self.ctx
+        if si.resize is not None:
+            tw, th = si.resize
+            si.natives = [f for _, f in si.cache]
+            si.cache = [(t, ctx.resize(f, tw, th)) for t, f in si.cache]
+            si.resize = None
+        cache, flags = si.cache, si.flags
+        idx = [i for i, f in enumerate(flags) if f]
+        counts = np.zeros(len(cache), np.int64)
+        boxes = np.zeros((0, 4), np.float64)
+        raw = None
+        if idx:
+            out, _, cnt = ctx.detect_many([cache[i][1] for i in idx], max(1, int(self.detect_batch_size)), 1, arrays=True)
+            # the boxes go back to the GPU (tracker starts) as an array; the tracking thread turns them into the Python
+            # tuples its state machine works on while the GPU is busy with those starts
+            counts[idx] = cnt
+            boxes = out[np.arange(out.shape[1])[None, :] < cnt[:, None]].astype(np.float64)
+            raw = (out, cnt, idx)
+        return raw, counts, boxes
+
+    def _speculate(self, si, backend, lane_backend, raw, counts, boxes):
+        cache = si.cache
+        n = int(counts.sum())
+        if hasattr(backend, "speculate_pair"):
+            if n <= self.speculate_limit or not hasattr(backend, "speculate_window"):
+                return backend.speculate_pair(cache, None, counts=counts, boxes=boxes)
+            # a shot with more detections than the tracker budget: both passes ask for their trackers window by window
+            fh = self.ctx.frame_handles([f for _, f in cache])
+            times = [t for t, _ in cache]
+            cnt = np.asarray(counts, np.int64)
+            starts = np.concatenate([[0], np.cumsum(cnt)])
+            rev = np.concatenate([boxes[starts[i]:starts[i + 1]] for i in range(len(cnt) - 1, -1, -1)]).reshape(-1, 4) if n else boxes
+            self.stats["windowed_shots"] = self.stats.get("windowed_shots", 0) + 1
+            return (WindowedPlan(lane_backend, fh, times, cnt, boxes, self.speculate_window),
+                    WindowedPlan(lane_backend, fh[::-1].copy(), times[::-1], cnt[::-1].copy(), rev, self.speculate_window))
+        det_at = {t: d for (t, _), d in zip(cache, detections_as_lists(len(cache), raw))}
+        return backend.speculate(cache, det_at), backend.speculate(list(reversed(cache)), det_at)
+
+    # ---- sequential form (no GPU-feeding thread): every stage in the caller's thread, shot after shot --------------------------
+    def _run_sequential(self, source, backend):
+        jobs = []
+        for item in source:
+            if isinstance(item, JobEnd):
+                job = item.job
+                if job.ex is not None:
+                    job.ex.plan_finish(drop_last=job.last_shard, reorder=job.reorder)
+                    job.ex.compute(job.ex._final_work)
+                job.store.release_all()
+                job.final_computed.set()
+                jobs.append(job)
+                continue
+            si = item
+            raw, counts, boxes = self._detect(si)
+            si.job.accept(si)
+            plans = self._speculate(si, backend, backend, raw, counts, boxes)
+            dets = detections_as_lists(len(si.cache), raw)
+            jb = self.tracking.begin_shot(si.cache, si.flags, dets, backend, plans)
+            self.tracking._run_lanes(jb["lanes"], backend)
+            tracks = self.tracking.finish_shot(jb)
+            self._release_detection_frames(si)
+            work = si.job.shot_tracked(si, tracks, self.tracking._normalize_track)
+            if work is not None:
+                si.job.ex.compute(work)
+                si.job.store.release_below(work[2])
+        return jobs
+
+    @staticmethod
+    def _release_detection_frames(si):
+        if si.natives is not None:              # the cache holds down-scaled copies made by the engine: the passes are done with them
+            for _, f in si.cache:
+                f.release()
+
+    # ---- pipelined form ----------------------------------------------------------------------------------------------------------
+    def run(self, source, backend=None, n_shots=None, on_job_final=None):
+        """source: iterable of ShotInput / JobEnd (a job's JobEnd after its last shot).  n_shots: number of shots when known in advance
+        (list inputs): enables the end-of-run ordering that keeps the GPU busy during the last shot's host phase.
+        on_job_final(job): called in the caller's thread once a job's last faces have been computed, while later jobs are still running.
+        Returns the jobs in the order they ended."""
+        backend = backend if backend is not None else HipTrackers(self.ctx)
+        if not self.overlap:
+            jobs = self._run_sequential(source, backend)
+            if on_job_final is not None:
+                for job in jobs:
+                    on_job_final(job)
+            return jobs
+        import gc
+        import sys
+        was_enabled = gc.isenabled()
+        gc.disable()      # a full collection in the middle of a shot stalls both threads for tens of milliseconds
+        old_interval = sys.getswitchinterval()
+        # the GPU thread re-takes the interpreter lock after every library call; with the default 5 ms switch interval each of
+        # those hand-overs can stall the GPU queue for milliseconds while this thread runs the tracking state machine
+        sys.setswitchinterval(1e-4)
+        try:
+            return self._run_pipelined(source, backend, n_shots, on_job_final)
+        finally:
+            sys.setswitchinterval(old_interval)
+            if was_enabled:
+                gc.enable()
+
+    def _run_pipelined(self, source, backend, n, on_job_final):
+        """GPU thread: detect(k), speculate(k), extract(k-1) ...; this thread: lanes + merging of shot k as soon as its detections
+        and bulk tracker results exist.  ctypes releases the GIL inside every library call."""
+        ready, done = queue.Queue(), queue.Queue()
+        lock = threading.Lock()
+        dead = []
+        lane_backend = _LaneBackend(backend, lock, dead)
+        trace = [(_time.perf_counter(), "begin")] if os.environ.get("PVF_TRACE") else None
+
+        def note(*ev):
+            if trace is not None:
+                trace.append((_time.perf_counter(),) + ev)
+
+        def handle(msg, counters):
+            kind, job, work = msg
+            if kind == "work":
+                note("extract begin", counters["extracted"])
+                if work is not None:
+                    with lock:
+                        job.ex.compute(work)
+                    job.store.release_below(work[2])
+                counters["extracted"] += 1
+                note("extracted", counters["extracted"] - 1)
+            else:                                   # "final": the job's last faces (plan_finish has run on the host)
+                with lock:
+                    if job.ex is not None:
+                        job.ex.compute(job.ex._final_work)
+                job.store.release_all()
+                counters["finals"] += 1
+                job.final_computed.set()
+                ready.put(("final done", job))
+
+        def gpu_thread():
+            counters = {"extracted": 0, "finals": 0}
+            shots = ends = 0
+            try:
+                def drain():
+                    while True:
+                        try:
+                            msg = done.get_nowait()
+                        except queue.Empty:
+                            return True
+                        if msg is None:
+                            return False
+                        handle(msg, counters)
+
+                for item in source:
+                    if isinstance(item, JobEnd):
+                        ends += 1
+                        ready.put(("end", item.job))
+                        continue
+                    si, k = item, shots
+                    # never more than three shots ahead of the tracking thread (a slow state machine -- a crowded shot -- must not let
+                    # detected shots, i.e. their frames, pile up)
+                    while shots - counters["extracted"] >= 3:
+                        msg = done.get()
+                        if msg is None:
+                            return
+                        handle(msg, counters)
+                    note("detect begin", k)
+                    with lock:
+                        raw, counts, boxes = self._detect(si)
+                    note("detected", k)
+                    # faces of the shots the tracking thread has finished meanwhile (it is idle now, so the host side of these
+                    # calls does not compete with its state machine for the interpreter; measured better than after speculate).
+                    # Towards the end of a run of known length the order changes: the faces of the last TWO finished shots are held
+                    # back until the last shot's bulk tracker work is queued, so that its state machine (17-21 ms on the host, plus
+                    # its on-demand tracker calls) runs beside ~34 ms of embedding instead of leaving the GPU idle at the very end.
+                    if n is None or k < n - 2:
+                        if not drain():
+                            return
+                    note("speculate begin", k)
+                    with lock:
+                        lane_backend.release_dead()
+                        plans = self._speculate(si, backend, lane_backend, raw, counts, boxes)
+                    note("speculated", k)
+                    shots += 1
+                    ready.put(("shot", si, raw, plans))
+                    if n is not None and k == n - 1:
+                        if not drain():
+                            return
+                ready.put(("stop",))
+                while counters["extracted"] < shots or counters["finals"] < ends:
+                    msg = done.get()
+                    if msg is None:
+                        return
+                    handle(msg, counters)
+                with lock:
+                    lane_backend.release_dead()
+                ready.put(("idle",))
+            except BaseException as e:      # noqa: BLE001 -- handed to the caller's thread
+                ready.put(e)
+
+        th = threading.Thread(target=gpu_thread, name="pvface-gpu")
+        th.start()
+        finished, ok = [], False
+        k = 0
+        try:
+            while True:
+                item = ready.get()
+                if isinstance(item, BaseException):
+                    raise item
+                kind = item[0]
+                if kind == "idle":
+                    break
+                if kind == "stop":
+                    continue
+                if kind == "end":
+                    job = item[1]
+                    if job.ex is not None:
+                        job.ex.plan_finish(drop_last=job.last_shard, reorder=job.reorder)     # runs while the GPU embeds the last faces
+                    note("planned")
+                    done.put(("final", job, None))
+                    continue
+                if kind == "final done":
+                    job = item[1]
+                    finished.append(job)
+                    if on_job_final is not None:
+                        on_job_final(job)
+                    continue
+                _, si, raw, plans = item
+                note("host begin", k)
+                job = si.job
+                job.accept(si)
+                dets = detections_as_lists(len(si.cache), raw)
+                jb = self.tracking.begin_shot(si.cache, si.flags, dets, lane_backend, plans)
+                self.tracking._run_lanes(jb["lanes"], lane_backend)
+                note("lanes done", k)
+                tracks = self.tracking.finish_shot(jb)
+                note("tracked", k)
+                self._release_detection_frames(si)
+                done.put(("work", job, job.shot_tracked(si, tracks, self.tracking._normalize_track)))
+                note("prepared", k)
+                k += 1
+            ok = True
+        finally:
+            if not ok:
+                done.put(None)
+            th.join()
+        while not ready.empty():
+            item = ready.get()
+            if isinstance(item, BaseException):
+                raise item
+        if trace is not None:
+            import json
+            note("finish")
+            with open(os.environ["PVF_TRACE"], "w") as f:
+                json.dump(trace, f)
+        return finished
+
+
+# ---- sources ----------------------------------------------------------------------------------------------------------------------
+def split_into_shots(times, shots):
+    """frame index ranges per shot, using the reference's flush rule: a frame at t >= segment.end opens the next shot
+    (tracking.py:44-58,406-417).  Returns [(i0, i1)] (possibly empty ranges are dropped like empty caches would be)."""
+    gen = get_segment_generator(shots)
+    gen.send(None)
+    out, start = [], 0
+    for i, t in enumerate(times):
+        if gen.send(t):
+            out.append((start, i))
+            start = i
+    out.append((start, len(times)))
+    return out
+
+
+def resident_source(job, frames, times, shots, every, resize=None):
+    """shots of a video whose frames the caller holds (DeviceFrames / arrays, all of them, for the whole run)"""
+    for i0, i1 in split_into_shots(times, shots):
+        yield ShotInput(job, i0, [(times[i], frames[i]) for i in range(i0, i1)], [(i % every == 0) for i in range(i0, i1)], resize=resize)
+    yield JobEnd(job)
+
+
+class StreamSource(object):
+    """Reads `video` (an iterable of (t, frame): numpy uint8 [H, W, 3] or DeviceFrame) in a thread of its own, cuts it into shots by the
+    reference's flush rule and hands complete shots to the engine through a bounded queue.  numpy frames reach HBM through a pinned
+    ingest ring (one asynchronous copy each on the copy stream; the reference's `Video.__iter__` + `np.fromstring`, video.py:368-406);
+    the frames it staged are the engine's to release."""
+
+    def __init__(self, ctx, jobs, depth=1, ring_depth=24):
+        """jobs: [(job, video iterable, shots, every, resize or None)] read one after the other"""
+        self.ctx, self.jobs = ctx, jobs
+        self.q = queue.Queue(maxsize=max(1, int(depth)))
+        self.ring_depth = int(ring_depth)
+        self.error = None
+        self.frames_read = 0
+        self._stop = False
+        self.th = threading.Thread(target=self._produce, name="pvface-ingest")
+        self.th.start()
+
+    def _produce(self):
+        try:
+            for job, video, shots, every, resize in self.jobs:
+                seg = get_segment_generator(shots)
+                seg.send(None)
+                ring = None
+                cache, flags, base, i, owned = [], [], 0, 0, False
+                for t, frame in video:
+                    if self._stop:
+                        return
+                    if seg.send(t):
+                        self.q.put(ShotInput(job, base, cache, flags, owned=owned, resize=resize))
+                        cache, flags, base = [], [], i
+                    if isinstance(frame, np.ndarray):
+                        if ring is None or (ring.h, ring.w) != frame.shape[:2]:
+                            if ring is not None:
+                                ring.close()
+                            ring = self.ctx.ingest_ring(frame.shape[0], frame.shape[1], depth=self.ring_depth)
+                        frame = ring.push(frame)
+                        owned = True
+                    cache.append((t, frame))
+                    flags.append(i % every == 0)
+                    i += 1
+                    self.frames_read += 1
+                self.q.put(ShotInput(job, base, cache, flags, owned=owned, resize=resize))
+                self.q.put(JobEnd(job))
+                if ring is not None:
+                    ring.close()              # waits for the last uploads
+        except BaseException as e:              # noqa: BLE001 -- re-raised in the consumer
+            self.error = e
+        finally:
+            self.q.put(None)
+
+    def __iter__(self):
+        while True:
+            try:
+                item = self.q.get(timeout=0.1)
+            except queue.Empty:
+                if not self.th.is_alive() and self.q.empty():      # the producer is gone and so is its end mark (close() took it)
+                    return
+                continue
+            if item is None:
+                if self.error is not None:
+                    raise self.error
+                return
+            yield item
+
+    def close(self):
+        """stop reading (an error downstream, a consumer that went away) and wait for the reader thread"""
+        self._stop = True
+        while self.th.is_alive():
+            try:
+                self.q.get(timeout=0.05)
+            except queue.Empty:
+                pass
+        self.th.join()

@@ -16,6 +16,7 @@ The passes only communicate through the graph, and each lane's graph mutations a
 (forward pass first, then backward), so the resulting graph is identical.
 """
 from __future__ import division
+import contextlib
 import itertools
 import numpy as np
 import networkx as nx
@@ -130,6 +131,13 @@ class HipTrackers(object):
         else:
             counts = [int(v) for v in counts]
             boxes = np.ascontiguousarray(boxes, np.float64).reshape(-1, 4)
+        # numpy frames are staged on first sight and cached by identity; the handles looked up here are used by every batched call
+        # below, so nothing staged may be evicted until the last of them has run (a shot longer than the cache's capacity)
+        hold = ctx._staging() if hasattr(ctx, "_staging") else contextlib.nullcontext()
+        with hold:
+            return self._speculate_pair(ctx, cache, counts, boxes, chunk)
+
+    def _speculate_pair(self, ctx, cache, counts, boxes, chunk):
         n = sum(counts)
         fh = ctx.frame_handles([f for _, f in cache])
         owner = np.repeat(np.arange(len(cache)), counts)
@@ -158,6 +166,27 @@ class HipTrackers(object):
                     plan[t] = (hl[k:k + m], psr[k:k + m] if i != edge else None, pos[k:k + m] if i != edge else None)
             plans.append(plan)
         return plans[0], plans[1]
+
+    def speculate_window(self, fh, owner, boxes, n_frames, chunk=4096):
+        """One window of ONE pass (engine.WindowedPlan): trackers for the detections `boxes` (row k lives on the frame with processing
+        index owner[k]; `fh` = the shot's frame handles in processing order), started and -- unless their frame is the pass's last --
+        updated once on the next frame, filter update deferred.  Returns (handles, psr, positions) as arrays.  A long shot (or a crowded
+        one) asks for its trackers window by window, so that the 2.39 MB of filters per detection exist for a window, not for the shot."""
+        ctx = self.ctx
+        n = len(owner)
+        boxes = np.ascontiguousarray(boxes, np.float64).reshape(-1, 4)
+        hs = ctx.tracker_create_many(n, as_array=True)
+        for o in range(0, n, chunk):
+            ctx.tracker_start_many(hs[o:o + chunk], fh[owner[o:o + chunk]], boxes[o:o + chunk])
+        psr = np.zeros(n, np.float64)
+        pos = np.zeros((n, 4), np.float64)
+        upd = np.nonzero(owner != n_frames - 1)[0]
+        for o in range(0, len(upd), chunk):
+            ks = upd[o:o + chunk]
+            p, b = ctx.tracker_update_many(hs[ks], fh[owner[ks] + 1], True)
+            psr[ks] = p
+            pos[ks] = b
+        return hs, psr, pos
 
 
 class ObjectTrackers(object):
@@ -556,7 +585,9 @@ class TrackingByDetection(object):
         return self._trackers_backend
 
     def __call__(self, video, segmentation):
-        """Yield normalised tracks, shot after shot, in the reference's order (tracking.py:374-434)."""
+        """Yield normalised tracks, shot after shot, in the reference's order (tracking.py:374-434).  With the GPU tracker backend the
+        video goes through the streaming engine (engine.py: one reader thread + pinned ingest ring, batched detection, bulk tracker
+        work, frames released shot by shot); the tracks are the same, they just exist sooner."""
         every_x_frames = int(self.detect_every * video.frame_rate) if self.detect_every > 0.0 else 1
         if every_x_frames < 1:
             every_x_frames = 1
@@ -567,23 +598,66 @@ class TrackingByDetection(object):
         old_frame_size = video.frame_size
         frame_width, frame_height = int(width * ratio), int(height * ratio)
         video.frame_size = (frame_width, frame_height)
-        segment_generator = get_segment_generator(segmentation)
-        segment_generator.send(None)
         backend = self._backend()
-        cache, flags = [], []
-        for i, (t, frame) in enumerate(video):
-            # the reference's Video hands out frames already resized to frame_size (video.py:402-403: cv2.resize per frame on the host);
-            # a source that yields native frames gets them resized on the device, where they are staged anyway
-            if (frame.shape[1], frame.shape[0]) != (frame_width, frame_height):
-                frame = self._detection_frame(frame, frame_width, frame_height, backend)
-            segment = segment_generator.send(t)
-            if segment:
-                for track in self.process_shots([(cache, flags)], backend)[0]:
-                    yield self._normalize_track(track, frame_width, frame_height)
-                cache, flags = [], []
-            cache.append((t, frame))
-            flags.append(i % every_x_frames == 0)
-        for track in self.process_shots([(cache, flags)], backend)[0]:
-            yield self._normalize_track(track, frame_width, frame_height)
-        if self.detect_min_size > 0.0:
-            video.frame_size = old_frame_size
+        try:
+            if isinstance(backend, HipTrackers) and hasattr(backend.ctx, "detect_many"):
+                for track in self._call_streaming(video, segmentation, backend, every_x_frames, (width, height), (frame_width, frame_height)):
+                    yield track
+                return
+            segment_generator = get_segment_generator(segmentation)
+            segment_generator.send(None)
+            cache, flags = [], []
+            for i, (t, frame) in enumerate(video):
+                # the reference's Video hands out frames already resized to frame_size (video.py:402-403: cv2.resize per frame on the host);
+                # a source that yields native frames gets them resized on the device, where they are staged anyway
+                if (frame.shape[1], frame.shape[0]) != (frame_width, frame_height):
+                    frame = self._detection_frame(frame, frame_width, frame_height, backend)
+                segment = segment_generator.send(t)
+                if segment:
+                    for track in self.process_shots([(cache, flags)], backend)[0]:
+                        yield self._normalize_track(track, frame_width, frame_height)
+                    cache, flags = [], []
+                cache.append((t, frame))
+                flags.append(i % every_x_frames == 0)
+            for track in self.process_shots([(cache, flags)], backend)[0]:
+                yield self._normalize_track(track, frame_width, frame_height)
+        finally:
+            if self.detect_min_size > 0.0:
+                video.frame_size = old_frame_size
+
+    def _call_streaming(self, video, segmentation, backend, every, native_size, detection_size):
+        import queue
+        import threading
+        from . import engine
+        ctx = backend.ctx
+        out = queue.Queue()
+        job = engine.VideoJob(ctx, native_size[0], native_size[1], detection_size[0], detection_size[1], extract=False,
+                              on_tracks=lambda tracks: out.put(tracks))
+        w, h = native_size
+        batch = int(max(8, min(128, 128 * (1920 * 1080) // max(w * h, 1))))
+        eng = engine.Engine(ctx, self, detect_batch_size=max(batch, int(self.detect_batch_size)))
+        src = engine.StreamSource(ctx, [(job, video, segmentation, every, detection_size if detection_size != native_size else None)])
+        state = {}
+
+        def work():
+            try:
+                eng.run(src, backend)
+            except BaseException as e:          # noqa: BLE001 -- re-raised in the consumer
+                state["error"] = e
+            finally:
+                out.put(None)
+
+        th = threading.Thread(target=work, name="pvface-tracking")
+        th.start()
+        try:
+            while True:
+                tracks = out.get()
+                if tracks is None:
+                    break
+                for track in tracks:
+                    yield track
+        finally:
+            src.close()
+            th.join()
+        if "error" in state:
+            raise state["error"]
