@@ -9,6 +9,13 @@ shot boundaries) of one N x 1000-frame video.
 
 Prints ONE JSON line on rank 0 with `roofline` (dominant kernel = HOG filter scoring, HIP-event timed on the library's
 stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample of the same frames, N = 1 only).
+
+`--config` selects one of BASELINE.json's other configurations (the default, c2, is the one the metric is quoted on):
+  c3  one long 1080p video streamed through the bounded-memory engine (configs[2]: --frames per rank, e.g. 22500 = 2 h / 8), frames
+      delivered one by one from a resident 1000-frame clip played in a loop, released shot by shot; all-gather + one global clustering
+  c4  64 independent 720p clips of 250 frames farmed over the ranks (configs[3]): per-clip clustering, no collective
+  c5  4K, 50 fps, 40 faces per frame (configs[4]): the c2 step on 3840x2160 frames, with the peak HBM use of the run
+Each prints its own JSON line (same contract, its own `metric` label).
 """
 import argparse
 import json
@@ -29,12 +36,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--faces", type=int, default=8)
-    ap.add_argument("--shots", type=int, default=4)
-    ap.add_argument("--detect-batch", type=int, default=128, help="frames whose pyramids, features and scores are resident together (one scoring launch per batch)")
+    ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2", help="BASELINE.json configuration (default c2 = configs[1], the one the metric is quoted on)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (c2: 1000, c3: 22500, c4: 250 per clip, c5: 500)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--fps", type=float, default=None)
+    ap.add_argument("--faces", type=int, default=None)
+    ap.add_argument("--shots", type=int, default=None)
+    ap.add_argument("--clips", type=int, default=64, help="c4: number of clips in the farm")
+    ap.add_argument("--detect-batch", type=int, default=None, help="frames whose pyramids, features and scores are resident together (one scoring launch per batch; 128 up to 1080p, 32 at 4K)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the extra passes through the pyannote-face verbs (track / extract / cluster / process)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): every rank owns --frames frames of an N x --frames video; strong: ONE video of --frames frames "
                          "(BASELINE.json configs[2]'s shape: a fixed video cut into N frame ranges at shot boundaries)")
@@ -44,6 +55,15 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="no GPU-feeding thread: every stage runs in the caller's thread, shot after shot")
     ap.add_argument("--small-models", action="store_true", help="debug only: reduced landmark model")
     args = ap.parse_args()
+    defaults = {"c2": dict(frames=1000, width=1920, height=1080, fps=25.0, faces=8, shots=4, detect_batch=128),
+                "c3": dict(frames=22500, width=1920, height=1080, fps=25.0, faces=8, shots=4, detect_batch=128),
+                "c4": dict(frames=250, width=1280, height=720, fps=25.0, faces=8, shots=2, detect_batch=128),
+                "c5": dict(frames=500, width=3840, height=2160, fps=50.0, faces=40, shots=2, detect_batch=32)}[args.config]
+    for k, v in defaults.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    if args.config == "c5" and args.cpu_frames == 32:
+        args.cpu_frames, args.cpu_frames_1t = 8, 0          # a 4K frame costs the CPU oracle four 1080p frames
 
     import numpy as np
     import torch
@@ -62,11 +82,17 @@ def main():
 
     model_dir = os.path.join(tempfile.gettempdir(), "pvface_models_rank%d" % rank)
     lp, ep = models.ensure_synthetic_models(model_dir, small=args.small_models)
+    if world > 1:
+        os.environ.setdefault("PVF_DIST_STRICT", "1")        # a C-ABI collective that fails must fail the run, not fall back silently
+    if args.config == "c4":
+        return bench_farm(args, rank, local_rank, world, device, lp, ep)
+    if args.config == "c3":
+        return bench_stream(args, rank, local_rank, world, device, lp, ep)
 
     if args.scaling == "strong" and world > 1:
         # ONE video of --frames frames; the ranks take contiguous shot ranges (dist.shard_shots), each rendering only its own frames
         whole = synth.SyntheticVideo(width=args.width, height=args.height, n_frames=args.frames, n_shots=max(args.shots, world),
-                                     faces=args.faces, seed=20260925)
+                                     faces=args.faces, seed=20260925, frame_rate=args.fps)
         all_times = [whole.timestamp(i) for i in range(whole.n_frames)]
         ranges = pipeline.split_into_shots(all_times, whole.shots())
         s0, s1 = pdist.shard_shots(ranges, world)[rank]
@@ -82,7 +108,7 @@ def main():
     else:
         # this rank's frame range of the long video: its own faces/backgrounds (seed), timestamps continue across ranks
         video = synth.SyntheticVideo(width=args.width, height=args.height, n_frames=args.frames, n_shots=args.shots,
-                                     faces=args.faces, seed=20260925 + rank)
+                                     faces=args.faces, seed=20260925 + rank, frame_rate=args.fps)
         t_gen = time.time()
         frames_t = video.frames_torch(device)
         torch.cuda.synchronize()
@@ -123,6 +149,7 @@ def main():
         c.prof_reset()
         c.prof_enable(True)
     barrier()
+    hbm = HbmSampler(ctx)
     t0 = time.perf_counter()
     last = None
     prof_path = os.environ.get("PVF_PYPROF")
@@ -139,6 +166,7 @@ def main():
             pstats.Stats(pr, stream=f).sort_stats("cumulative").print_stats(45)
     barrier()
     elapsed = time.perf_counter() - t0
+    hbm.stop()
     for c in ctxs:
         c.prof_enable(False)
     if world > 1:
@@ -193,32 +221,389 @@ def main():
     if world == 1 and args.cpu_frames > 0:
         cpu, parity = cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args)
     host = None
-    if world == 1 and not args.no_host_ingest:
+    if world == 1 and not args.no_host_ingest and args.config == "c2":
         host = host_ingest_pass(ctx, pipe, frames_t, times, video, shots, args)
+    dropin = None
+    if world == 1 and not args.no_dropin and args.config == "c2":
+        dropin = dropin_cli_pass(ctx, frames, video, lp, ep, fps, res, labels)
 
     n_clusters = len(set(labels.values()))
+    label = "1080p@25fps" if args.config == "c2" else "%dx%d@%gfps (BASELINE.json configs[4])" % (args.width, args.height, args.fps)
     out = {
-        "metric": "frames/sec end-to-end detect->embed->cluster, 1080p@25fps",
+        "metric": "frames/sec end-to-end detect->embed->cluster, %s" % label,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None, "dtype": "f32 (detector, embedder) / f64 (tracker, clustering) / u8 frames",
         "data": "synthetic (procedural faces on low-pass backgrounds, seeded; synthetic model weights of dlib's shapes)",
-        "config": {"workload": "configs[1]: synthetic %dx%d 25 fps, %d frames, %d shots, %d faces/frame %s, frames resident in HBM"
-                               % (args.width, args.height, args.frames, args.shots, args.faces,
+        "config": {"workload": "configs[%d]: synthetic %dx%d %g fps, %d frames, %d shots, %d faces/frame %s, frames resident in HBM"
+                               % (1 if args.config == "c2" else 4, args.width, args.height, args.fps, args.frames, args.shots, args.faces,
                                   "in total, one video cut into shot ranges" if (args.scaling == "strong" and world > 1) else "per GPU"),
                    "detect_every": 0, "upsample": 1, "tracking": "forward+backward DSST, CLI defaults (overlap 0.5, conf 10, gap 1.0)",
                    "parallelism": "shot-range sharding x%d + all-gather of track embeddings" % world if world > 1 else "single GPU",
-                   "detect_batch": args.detect_batch},
+                   "detect_batch": args.detect_batch, "collective": pdist.collective_name()},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity": parity,
         "host_ingest": host,
+        "dropin_cli": dropin,
+        "hbm": hbm.report(frames_bytes=int(frames_t.numel()), engine=pipe.last_engine),
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
         "kernel_families_ms": fam,
         "results": {"tracks": len(res["tracks"]), "faces_embedded": int(len(res["face_T"])), "clusters": n_clusters,
                     "identities_in_video": len(set(tr["ident"] for shot in video.tracks for tr in shot))},
         "setup_seconds": {"generate_frames_in_hbm": round(t_gen, 1)},
     }
+    print(json.dumps(out))
+
+
+class HbmSampler(object):
+    """device memory in use (hipMemGetInfo through the library: every allocation on this GPU) sampled every 10 ms while the timed steps run"""
+
+    def __init__(self, ctx, period=0.01):
+        import threading
+        self.ctx, self.period = ctx, period
+        free, total = ctx.mem_info()
+        self.total, self.before, self.min_free = total, total - free, free
+        self._run = True
+        self.th = threading.Thread(target=self._loop, name="hbm-sampler")
+        self.th.start()
+
+    def _loop(self):
+        while self._run:
+            free, _ = self.ctx.mem_info()
+            self.min_free = min(self.min_free, free)
+            time.sleep(self.period)
+
+    def stop(self):
+        self._run = False
+        self.th.join()
+
+    def report(self, frames_bytes=None, engine=None):
+        peak = self.total - self.min_free
+        out = {"peak_bytes_in_use": int(peak), "in_use_before_timed_region": int(self.before), "device_total_bytes": int(self.total),
+               "note": "hipMemGetInfo sampled every 10 ms during the timed steps; includes the resident input frames, the models, the "
+                       "batch's pyramids and feature maps, tracker filters, chips and activations"}
+        if frames_bytes is not None:
+            out["resident_input_frames_bytes"] = int(frames_bytes)
+        if engine is not None:
+            out["windowed_shots_last_step"] = int(engine.stats.get("windowed_shots", 0))
+        return out
+
+
+class ResidentVideo(object):
+    """frames resident in HBM behind the iteration contract of the reference's Video (video.py:411-464): yields (t, DeviceFrame)"""
+
+    def __init__(self, frames, frame_rate, size, t0_index=0):
+        self.frames, self.frame_rate, self._size, self._frame_size, self.t0 = frames, float(frame_rate), size, size, int(t0_index)
+
+    size = property(lambda self: self._size)
+
+    @property
+    def frame_size(self):
+        return self._frame_size
+
+    @frame_size.setter
+    def frame_size(self, v):
+        self._frame_size = tuple(int(x) for x in v)
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __iter__(self):
+        for i, f in enumerate(self.frames):
+            yield (self.t0 + i) / self.frame_rate, f
+
+
+def dropin_cli_pass(ctx, frames, video, lp, ep, fps_pipeline, res, labels):
+    """Outside the timed region: the same clip through the reference-named entry points -- the `track`, `extract` and `cluster` verbs one
+    after the other (three passes over the frames, files in between, like scripts/pyannote-face.py:239-314), and the one-pass `process`
+    verb -- with the frames resident in HBM as for `value`.  Their files must say what the timed step computed."""
+    import numpy as np
+    from pyannote_video_amd import cli, formats
+    from pyannote_video_amd._core import Segment
+    d = tempfile.mkdtemp(prefix="pvface_dropin_")
+    n = len(frames)
+    rv = ResidentVideo(frames, video.frame_rate, video.frame_size)
+    shots = [Segment(a, b) for a, b in video.shots()]
+    paths = {k: os.path.join(d, k + ".txt") for k in ("track", "landmarks", "embedding", "labels", "track1", "landmarks1", "embedding1", "labels1")}
+    best = None
+    for _ in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        cli.track(rv, shots, paths["track"], ctx=ctx)
+        t1 = time.perf_counter()
+        cli.extract(rv, lp, ep, paths["track"], paths["landmarks"], paths["embedding"], ctx=ctx)
+        t2 = time.perf_counter()
+        lab = cli.cluster(paths["embedding"], paths["labels"], ctx=ctx)
+        t3 = time.perf_counter()
+        cur = (t3 - t0, t1 - t0, t2 - t1, t3 - t2)
+        best = cur if best is None or cur[0] < best[0] else best
+    one = None
+    for _ in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        r1 = cli.process(rv, shots, lp, ep, paths["track1"], paths["landmarks1"], paths["embedding1"], paths["labels1"], ctx=ctx)
+        dt = time.perf_counter() - t0
+        one = dt if one is None else min(one, dt)
+    same = open(paths["track"]).read() == open(paths["track1"]).read() and open(paths["landmarks"]).read() == open(paths["landmarks1"]).read()
+    track_same = [l for i, tr in enumerate(res["tracks"]) for l in formats.track_lines(i, tr)] == open(paths["track"]).readlines()
+    return {"verbs_track_extract_cluster": {"value": round(n / best[0], 2), "unit": "frames/s", "seconds": {"track": round(best[1], 4), "extract": round(best[2], 4), "cluster": round(best[3], 4)},
+                                            "passes_over_the_frames": 2},
+            "verb_process_one_pass": {"value": round(n / one, 2), "unit": "frames/s"},
+            "fraction_of_value": {"three_verbs": round(n / best[0] / fps_pipeline, 3), "process": round(n / one / fps_pipeline, 3)},
+            "files": {"track_file_equals_timed_step": bool(track_same), "three_verbs_equal_one_pass": bool(same), "labels_equal_timed_step": lab == labels and r1["labels"] == labels},
+            "frames_start_in": "HBM (resident, as for `value`); text files written with the reference's formats"}
+
+
+def _models_for_oracle(lp, ep):
+    from pyannote_video_amd import models
+    from oracle import oracle
+    return (oracle.Detector(models.load_container(models.DEFAULT_DETECTOR)), oracle.ShapePredictor(models.load_model_file(lp, "shape_predictor")),
+            oracle.Embedder(models.load_model_file(ep, "embedder")), models.dsst_tables())
+
+
+def oracle_window_parity(frames_np, times, shots, frame_rate, size, res, lp, ep, threads=None, label=""):
+    """the CPU oracle flow on a window of frames against the product's result on the same window: the parity dictionary + oracle seconds"""
+    import concurrent.futures
+    import numpy as np
+    from pyannote_video_amd import pipeline
+    from oracle import oracle, ref_flow
+    det, sp, emb, tabs = _models_for_oracle(lp, ep)
+    threads = threads or oracle.usable_cpus(cap=1024)
+    oracle.lib().pvo_set_threads(threads)
+    pool = concurrent.futures.ThreadPoolExecutor(min(threads, 32)) if threads > 1 else None
+    t0 = time.perf_counter()
+    tracks = ref_flow.track_video(frames_np, times, shots, det, lambda: oracle.Tracker(tabs), frame_rate,
+                                  min_conf=pipeline.CLI_MIN_CONFIDENCE, ratio=pipeline.CLI_MIN_OVERLAP_RATIO, max_gap=pipeline.CLI_MAX_GAP, pool=pool)
+    lm, em = ref_flow.extract(ref_flow.track_text(tracks), frames_np, times, sp, emb, pool=pool)
+    labels = ref_flow.cluster(em, 0.6)
+    dt = time.perf_counter() - t0
+    if pool is not None:
+        pool.shutdown()
+    ref_e = np.array([[float(x) for x in line.split()[2:]] for line in em]).reshape(-1, 128)
+    ref_pts = np.array([[float(x) for x in line.split()[2:]] for line in lm]).reshape(-1, 68, 2)
+    w, h = size
+    ref_int = np.rint(ref_pts * np.array([w, h], np.float64)).astype(np.int64)
+    same_rows = len(ref_e) == len(res["embeddings"]) and [int(l.split()[1]) for l in em] == res["face_id"].tolist()
+    parity = {"sample": label,
+              "boxes": "exact" if res["tracks"] == tracks else "MISMATCH",
+              "track_ids": "exact" if [len(t) for t in res["tracks"]] == [len(t) for t in tracks] and same_rows else "MISMATCH",
+              "landmarks": "exact" if same_rows and np.array_equal(res["landmarks"].astype(np.int64), ref_int) else "MISMATCH",
+              "embed_l2_max": float(np.linalg.norm(ref_e - res["embeddings"].astype(np.float64), axis=1).max()) if same_rows and len(ref_e) else None,
+              "labels": "exact" if res["labels"] == labels else "MISMATCH",
+              "tracks": len(tracks), "faces": int(len(ref_e))}
+    return parity, dt, threads
+
+
+def bench_farm(args, rank, local_rank, world, device, lp, ep):
+    """BASELINE.json configs[3]: a batch of independent 720p clips farmed over the GPUs (round robin), every clip tracked, embedded and
+    clustered on its own; no collective anywhere.  One step = this rank's clips through ONE engine run (FacePipeline.run_many)."""
+    import numpy as np
+    import torch
+    from pyannote_video_amd import synth, pipeline
+    from pyannote_video_amd.runtime import Context
+    ctx = Context(device=local_rank)
+    mine = list(range(rank, args.clips, world))
+    t_gen = time.time()
+    clips, videos, tensors = [], [], []
+    for i in mine:
+        v = synth.SyntheticVideo(width=args.width, height=args.height, n_frames=args.frames, n_shots=args.shots, faces=args.faces,
+                                 seed=20260925 + i, frame_rate=args.fps)
+        ft = v.frames_torch(device)
+        tensors.append(ft); videos.append(v)
+        clips.append(dict(frames=[ctx.wrap_torch(ft[k]) for k in range(v.n_frames)], times=[v.timestamp(k) for k in range(v.n_frames)],
+                          frame_rate=v.frame_rate, shots=v.shots()))
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap)
+
+    def barrier():
+        ctx.sync(); torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+    for _ in range(args.warmup):
+        pipe.run_many(clips)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    barrier()
+    hbm = HbmSampler(ctx)
+    t0 = time.perf_counter()
+    results = None
+    for _ in range(args.steps):
+        results = pipe.run_many(clips)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hbm.stop()
+    ctx.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fam = {}
+    for name in ("pyramid", "fhog", "score", "chip", "ert", "conv", "dsst", "pdist", "hac"):
+        ms, n = ctx.prof_get(name)
+        fam[name] = {"ms": round(ms, 3), "launches": int(n)}
+    if rank != 0:
+        return
+    total_frames = args.clips * args.frames * args.steps
+    fps = total_frames / elapsed
+    geo = pipeline.detector_geometry(args.height, args.width)
+    flop_per_frame = sum(g[4] for g in geo) * 3100 * 5 * 2.0
+    score_ms, launches = fam["score"]["ms"], max(fam["score"]["launches"], 1)
+    achieved = (flop_per_frame * len(mine) * args.frames * args.steps / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
+    parity, cpu = None, None
+    if args.cpu_frames > 0:
+        # parity gate: clip 0, a window around its shot cut, product (frames resident) vs the CPU oracle flow
+        v, ft = videos[0], tensors[0]
+        n = min(16, v.n_frames)
+        cut = v.shot_bounds[1] if v.n_shots > 1 else v.n_frames // 2
+        i0 = max(0, min(cut - n // 2, v.n_frames - n))
+        idx = list(range(i0, i0 + n))
+        times = [v.timestamp(i) for i in idx]
+        shots = [(a, b) for a, b in v.shots() if b > times[0] and a <= times[-1]]
+        res = pipe.run([ctx.wrap_torch(ft[i]) for i in idx], times, v.frame_rate, shots)
+        parity, dt, threads = oracle_window_parity([np.ascontiguousarray(ft[i].cpu().numpy()) for i in idx], times, shots, v.frame_rate, v.frame_size, res, lp, ep,
+                                                   label="clip 0, frames %d..%d (a window around its cut), product vs CPU oracle flow" % (idx[0], idx[-1]))
+        cpu = {"value": round(n / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port", "sample": "the same %d-frame 720p window, whole flow" % n}
+    out = {"metric": "frames/sec end-to-end detect->embed->cluster, %d independent %dx%d clips farmed one per GPU (BASELINE.json configs[3])" % (args.clips, args.width, args.height),
+           "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32 (detector, embedder) / f64 (tracker, clustering) / u8 frames",
+           "data": "synthetic (seeds 20260925 + clip index)",
+           "config": {"workload": "configs[3]: %d clips x %d frames %dx%d %g fps, %d shots and %d faces/frame each, clips round robin over %d GPU(s), frames resident in HBM, "
+                                  "per-clip clustering, no collective" % (args.clips, args.frames, args.width, args.height, args.fps, args.shots, args.faces, world),
+                      "parallelism": "farm: clip i on rank i %% %d; one engine run per rank (detector of clip i + 1 beside the state machine of clip i)" % world,
+                      "detect_batch": args.detect_batch, "collective": "none"},
+           "roofline": {"kernel": "score_mfma_rows_ml_k<4>", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(score_ms / launches, 4)},
+           "cpu_baseline": cpu, "parity": parity,
+           "kernel_families_ms": fam,
+           "hbm": hbm.report(frames_bytes=sum(int(t.numel()) for t in tensors)),
+           "results": {"clips": len(results), "tracks": sum(len(r["tracks"]) for r in results), "faces_embedded": sum(int(len(r["face_T"])) for r in results),
+                       "clusters_per_clip": [len(set(r["labels"].values())) for r in results][:8]},
+           "setup_seconds": {"generate_frames_in_hbm": round(t_gen, 1)}}
+    print(json.dumps(out))
+
+
+class LoopedVideo(object):
+    """A long video = a resident clip played in a loop, delivered the way a decoder that writes into HBM would deliver it: every frame
+    is copied into a fresh buffer of the library's (pvf_frame_upload from a device address) that the engine releases when it is done with
+    it.  Timestamps continue (frame i of the long video at i / frame_rate); the shot cuts repeat with the clip."""
+
+    def __init__(self, ctx, frames_t, n_frames, frame_rate, first_index=0):
+        self.ctx, self.ft, self.n, self.frame_rate, self.first = ctx, frames_t, int(n_frames), float(frame_rate), int(first_index)
+        self.size = self.frame_size = (int(frames_t.shape[2]), int(frames_t.shape[1]))
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        m, h, w = int(self.ft.shape[0]), int(self.ft.shape[1]), int(self.ft.shape[2])
+        base, stride = self.ft.data_ptr(), h * w * 3
+        for i in range(self.n):
+            yield (self.first + i) / self.frame_rate, self.ctx.upload_device(base + ((self.first + i) % m) * stride, h, w, transient=True)
+
+
+def bench_stream(args, rank, local_rank, world, device, lp, ep):
+    """BASELINE.json configs[2]: one long 1080p video cut into frame ranges at shot boundaries, one range per GPU, streamed through the
+    bounded-memory engine (FacePipeline.run_stream): frames arrive one by one, shots are detected / tracked / extracted in flight and
+    their frames released, then ONE all-gather of the (time, track, 128-D) rows and one global clustering."""
+    import numpy as np
+    import torch
+    from pyannote_video_amd import synth, pipeline, dist as pdist
+    from pyannote_video_amd.runtime import Context
+    clip_n = 1000
+    video = synth.SyntheticVideo(width=args.width, height=args.height, n_frames=clip_n, n_shots=args.shots, faces=args.faces, seed=20260925, frame_rate=args.fps)
+    t_gen = time.time()
+    frames_t = video.frames_torch(device)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    ctx = Context(device=local_rank)
+    pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap)
+    n = args.frames
+    first = rank * n                                        # this rank's frame range of the world * n frame video
+    per_shot = clip_n // args.shots
+    assert n % per_shot == 0, "--frames must be a multiple of the shot length (%d) so that the ranges are cut at shot boundaries" % per_shot
+    shots = [((first + k * per_shot) / args.fps, (first + (k + 1) * per_shot) / args.fps) for k in range(n // per_shot)]
+
+    def step(frames=n):
+        tm = {}
+        t_step = time.perf_counter()
+        src = LoopedVideo(ctx, frames_t, frames, args.fps, first_index=first)
+        res = pipe.run_stream(src, shots[:frames // per_shot], timings=tm, cluster=False, last_shard=(rank == world - 1), reorder=(world == 1))
+        T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["X"], len(res["tracks"]), device=device,
+                                               file_T=res["file_T"] if world > 1 else None, file_id=res["file_id"] if world > 1 else None)
+        t0 = time.perf_counter()
+        labels = pdist.global_cluster(pipe.clustering, T, ids, X)
+        tm["cluster_s"] = time.perf_counter() - t0
+        tm["step_wall_s"] = time.perf_counter() - t_step
+        return res, labels, tm
+
+    def barrier():
+        ctx.sync(); torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+    for _ in range(args.warmup):
+        step(min(n, 4 * per_shot))                          # plans, scratch buffers and the buffer pool exist after four shots
+    ctx.prof_reset(); ctx.prof_enable(True)
+    barrier()
+    hbm = HbmSampler(ctx)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hbm.stop()
+    ctx.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    res, labels, tm = last
+    fam = {}
+    for name in ("pyramid", "fhog", "score", "chip", "ert", "conv", "dsst", "pdist", "hac"):
+        ms, k = ctx.prof_get(name)
+        fam[name] = {"ms": round(ms, 3), "launches": int(k)}
+    if rank != 0:
+        return
+    fps = n * world * args.steps / elapsed
+    geo = pipeline.detector_geometry(args.height, args.width)
+    flop_per_frame = sum(g[4] for g in geo) * 3100 * 5 * 2.0
+    score_ms, launches = fam["score"]["ms"], max(fam["score"]["launches"], 1)
+    achieved = (flop_per_frame * n * args.steps / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
+    parity, cpu = None, None
+    if world == 1 and args.cpu_frames > 0:
+        # parity gate through the STREAMING path: a window across the seam of the loop (last frames of the clip's last shot, first
+        # frames of its first shot: a cut), product (run_stream, frames delivered one by one) vs the CPU oracle flow
+        m = min(8, args.cpu_frames)
+        i0 = clip_n - m // 2
+        idx = list(range(i0, i0 + m))
+        times = [i / args.fps for i in idx]
+        wshots = [(a, b) for a, b in shots if b > times[0] and a <= times[-1]]
+        r = pipe.run_stream(LoopedVideo(ctx, frames_t, m, args.fps, first_index=i0), wshots)
+        parity, dt, threads = oracle_window_parity([np.ascontiguousarray(frames_t[i % clip_n].cpu().numpy()) for i in idx], times, wshots, args.fps, video.frame_size, r, lp, ep,
+                                                   label="frames %d..%d of the long video (across the seam of the loop: a cut), streamed product vs CPU oracle flow" % (idx[0], idx[-1]))
+        cpu = {"value": round(m / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port", "sample": "the same %d-frame window, whole flow" % m}
+    peak_frames = res.get("peak_frames_resident")
+    out = {"metric": "frames/sec end-to-end detect->embed->cluster, one long 1080p@25fps video in frame ranges (BASELINE.json configs[2])",
+           "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (detector, embedder) / f64 (tracker, clustering) / u8 frames",
+           "data": "synthetic: the 1000-frame configs[1] clip played in a loop (timestamps and track numbers continue; every loop adds its tracks to the global clustering)",
+           "config": {"workload": "configs[2]: %d frames per GPU (%.1f min of 1080p 25 fps video; %d GPUs x that = the whole video), %d-frame shots, %d faces/frame; frames delivered one by one "
+                                  "into HBM buffers of the library (device-to-device from the resident clip), released shot by shot" % (n, n / args.fps / 60.0, world, per_shot, args.faces),
+                      "parallelism": "frame ranges cut at shot boundaries x%d + all-gather of track embeddings + one global clustering" % world if world > 1 else "single GPU (one range)",
+                      "detect_batch": args.detect_batch, "collective": pdist.collective_name()},
+           "roofline": {"kernel": "score_mfma_rows_ml_k<4>", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(score_ms / launches, 4)},
+           "cpu_baseline": cpu, "parity": parity,
+           "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
+           "kernel_families_ms": fam,
+           "hbm": dict(hbm.report(frames_bytes=int(frames_t.numel())), peak_frames_resident=peak_frames,
+                       whole_range_resident_would_be_bytes=int(n) * args.width * args.height * 3),
+           "results": {"tracks": len(res["tracks"]), "faces_embedded": int(len(res["face_T"])), "clusters": len(set(labels.values())),
+                       "identities_in_video": len(set(tr["ident"] for shot in video.tracks for tr in shot))},
+           "setup_seconds": {"generate_clip_in_hbm": round(t_gen, 1)}}
     print(json.dumps(out))
 
 
@@ -311,7 +696,7 @@ def cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args):
     idx, times, shots = window(min(args.cpu_frames, video.n_frames))
     tracks, lm, em, labels, dt, t_track = oracle_flow(idx, times, shots, nproc)
     cpu = {"value": round(len(idx) / dt, 4), "unit": "frames/s", "cores": int(nproc), "kind": "port",
-           "sample": "frames %d..%d of the same 1080p video (a window around the shot cut at frame %d), whole flow: detect + fwd/bwd tracking %.1f s "
+           "sample": "frames %d..%d of the same video (a window around the shot cut at frame %d), whole flow: detect + fwd/bwd tracking %.1f s "
                      "of %.1f s, then landmarks, embedding, clustering; OpenMP over pyramid rows, FHOG cell rows and scoring rows, trackers and "
                      "faces of a frame in a thread pool" % (idx[0], idx[-1], cut, t_track, dt)}
     if args.cpu_frames_1t > 0:
@@ -329,7 +714,7 @@ def cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args):
     ref_int = np.rint(ref_pts * np.array([w, h], np.float64)).astype(np.int64)      # 5 decimals of x / width resolve the integer point
     same_rows = len(ref_e) == len(res["embeddings"]) and [int(l.split()[1]) for l in em] == res["face_id"].tolist()
     parity = {
-        "sample": "product pipeline vs CPU oracle flow on frames %d..%d (1080p, full landmark model, detect batch %d)" % (idx[0], idx[-1], args.detect_batch),
+        "sample": "product pipeline vs CPU oracle flow on frames %d..%d (%dx%d, full landmark model, detect batch %d)" % (idx[0], idx[-1], args.width, args.height, args.detect_batch),
         "boxes": "exact" if res["tracks"] == tracks else "MISMATCH",           # every track row: time, detector / tracker box, status string
         "track_ids": "exact" if [len(t) for t in res["tracks"]] == [len(t) for t in tracks] and same_rows else "MISMATCH",
         "landmarks": "exact" if same_rows and np.array_equal(res["landmarks"].astype(np.int64), ref_int) else "MISMATCH",
@@ -337,6 +722,16 @@ def cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args):
         "labels": "exact" if res["labels"] == labels else "MISMATCH",
         "tracks": len(tracks), "faces": int(len(ref_e)),
     }
+    if video.n_shots >= 4 and args.config == "c2":
+        # a second, smaller window at the LAST cut of the clip (shots 3 | 4): other faces, other backgrounds, other tracker histories
+        cut2 = video.shot_bounds[video.n_shots - 1]
+        idx2 = list(range(cut2 - 4, cut2 + 4))
+        times2 = [video.timestamp(i) for i in idx2]
+        shots2 = [(a, b) for a, b in video.shots() if b > times2[0] and a <= times2[-1]]
+        res2 = pipe.run([ctx.wrap_torch(frames_t[i]) for i in idx2], times2, video.frame_rate, shots2)
+        p2, _, _ = oracle_window_parity([np.ascontiguousarray(frames_t[i].cpu().numpy()) for i in idx2], times2, shots2, video.frame_rate, video.frame_size, res2, lp, ep,
+                                        label="frames %d..%d (the cut between the last two shots)" % (idx2[0], idx2[-1]))
+        parity["second_window"] = p2
     return cpu, parity
 
 

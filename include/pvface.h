@@ -56,6 +56,8 @@ int32_t pvf_set_tracker_tables(pvf_handle ctx, const double* mask64, const doubl
 /* stage a host frame into HBM once; detection, trackers, landmarks and embedding all reuse it
  * (the reference re-reads the host array for every dlib call: tracking.py:203,251,426; pyannote-face.py:296-297) */
 int32_t pvf_frame_upload(pvf_handle ctx, const uint8_t* rgb, int32_t h, int32_t w, int64_t row_stride_bytes, pvf_handle* frame);
+/* `rgb` may also be a device address (a decoder that delivers into HBM): the frame is copied into a buffer of the library's own, so
+ * the source may be overwritten as soon as the call returns */
 /* wrap a frame that already lives in HBM (no copy; the caller keeps it alive until pvf_frame_release) */
 int32_t pvf_frame_wrap_device(pvf_handle ctx, const void* dev_rgb, int32_t h, int32_t w, pvf_handle* frame);
 /* Releasing never waits for the GPU: the buffer of a frame the library allocated itself (upload, ingest ring, device resize) goes back
@@ -178,6 +180,13 @@ int32_t pvf_cluster_dist(pvf_handle ctx, const double* D, const int32_t* row_sta
                          int32_t* labels, double* merge_log, int32_t* n_merges);
 int32_t pvf_cluster_tracks(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start,
                            int32_t T, double threshold, int32_t* labels, double* merge_log, int32_t* n_merges);
+
+/* ---- file formats (host) ------------------------------------------------------------------------------ */
+/* ref: scripts/pyannote-face.py:299-311  the lines of landmarks.txt / embedding.txt: "{t:.3f} {identifier:d}" + n_cols x " {v:.<decimals>f}"
+ * + newline per row, byte for byte what Python's format writes (both are the correctly rounded decimal).  values [n_rows][n_cols];
+ * out needs 64 + 42 * n_cols bytes per row; *written = bytes produced. */
+int32_t pvf_format_rows(const double* t, const int64_t* identifier, const double* values, int64_t n_rows, int32_t n_cols,
+                        int32_t decimals, char* out, int64_t cap, int64_t* written);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */
 /* HIP-event timing of each kernel family on the context's stream ("pyramid","fhog","score","ert","chip","conv",

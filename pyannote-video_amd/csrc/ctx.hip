@@ -382,7 +382,7 @@ extern "C" int32_t pvf_frame_upload(pvf_handle h, const uint8_t* rgb, int32_t fh
     PVF_REQUIRE(stride >= (int64_t)fw * 3, "pvf_frame_upload: row stride smaller than a row");
     uint8_t* d = c->take_frame_buffer((size_t)fh * fw * 3, nullptr);
     // a blocking copy outside the compute stream: the frame is complete when the call returns, whatever the context is running
-    HIP_CHECK(hipMemcpy2D(d, (size_t)fw * 3, rgb, (size_t)stride, (size_t)fw * 3, fh, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy2D(d, (size_t)fw * 3, rgb, (size_t)stride, (size_t)fw * 3, fh, hipMemcpyDefault));    // host or device source
     Frame f; f.d = d; f.h = fh; f.w = fw; f.owned = true; f.pooled = true;
     *out = c->add_frame(f);
     API_END

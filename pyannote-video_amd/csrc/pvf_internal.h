@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <atomic>
 #include <memory>
@@ -204,7 +205,7 @@ struct Ctx {
     // released frame buffers by size.  A buffer comes back with the event recorded on the compute stream at its release: whoever takes it
     // next orders its first write behind that event (pool_take), so releasing a frame never waits for the kernels that still read it.
     struct PoolBuf { uint8_t* p; hipEvent_t free_after; };
-    std::map<size_t, std::vector<PoolBuf>> frame_pool;
+    std::map<size_t, std::deque<PoolBuf>> frame_pool;      // oldest release first: its event is the most likely to have passed
     size_t frame_pool_bytes = 0;
     void* ingest_rings = nullptr;                          // pinned staging rings of this context (ingest.hip)
     struct MlPlanCache* ml_plans = nullptr;   // detector launch plans of this context (detect.hip); freed by ml_plans_free
@@ -236,7 +237,7 @@ struct Ctx {
         {
             std::lock_guard<std::mutex> lk(frames_mu);
             auto& v = frame_pool[bytes];
-            if (!v.empty()) { b = v.back(); v.pop_back(); frame_pool_bytes -= bytes; }
+            if (!v.empty()) { b = v.front(); v.pop_front(); frame_pool_bytes -= bytes; }
         }
         if (!b.p) {
             HIP_CHECK(hipMalloc((void**)&b.p, bytes));

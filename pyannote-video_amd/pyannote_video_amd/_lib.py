@@ -73,6 +73,7 @@ _SIGS = {
     "pvf_pair_mean_dist_rows": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P]),
     "pvf_cluster_dist": (C.c_int32, [H, P, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_cluster_tracks": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
+    "pvf_format_rows": (C.c_int32, [P, P, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "pvf_prof_enable": (C.c_int32, [H, C.c_int32]),
     "pvf_prof_reset": (C.c_int32, [H]),
     "pvf_prof_get": (C.c_int32, [H, C.c_char_p, P, P]),
@@ -170,6 +171,19 @@ def associate(trackers, detections, ratio):
         k += 4
     check(lib().pvf_associate(a, na, b, nb, float(ratio), out))
     return [(t, d) for t, d in enumerate(out[:na]) if d >= 0]
+
+
+def format_rows(t, identifier, values, decimals=5):
+    """bytes of the lines "{t:.3f} {identifier:d}" + " {v:.<decimals>f}" per value (landmarks.txt / embedding.txt rows)"""
+    t = np.ascontiguousarray(t, np.float64)
+    ident = np.ascontiguousarray(identifier, np.int64)
+    v = np.ascontiguousarray(values, np.float64)
+    v = v.reshape(len(t), -1) if len(t) else v.reshape(0, max(v.shape[-1], 1) if v.ndim else 1)
+    cap = len(t) * (64 + 42 * v.shape[1])
+    buf = np.empty(max(cap, 1), np.uint8)
+    n = C.c_int64(0)
+    check(lib().pvf_format_rows(ptr(t), ptr(ident), ptr(v), len(t), v.shape[1], int(decimals), ptr(buf), cap, C.byref(n)))
+    return buf[:n.value].tobytes()
 
 
 def munkres(cost):

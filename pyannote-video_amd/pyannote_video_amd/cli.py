@@ -162,7 +162,7 @@ def extract(video, landmark_model, embedding_model, tracking, landmark_output, e
     th = threading.Thread(target=reader, name="pvface-extract-reader")
     th.start()
     try:
-        with open(landmark_output, 'w') as flandmark, open(embedding_output, 'w') as fembedding:
+        with open(landmark_output, 'wb') as flandmark, open(embedding_output, 'wb') as fembedding:
             pend_f, pend_b, pend_k, pend_own = [], [], [], []
 
             def flush():
@@ -170,9 +170,9 @@ def extract(video, landmark_model, embedding_model, tracking, landmark_output, e
                     return
                 pts = ctx.landmarks(pend_f, pend_b)
                 emb = ctx.embed(pend_f, pts)
-                for (T, ident), p, e in zip(pend_k, pts, emb):
-                    flandmark.write(formats.landmark_line(T, ident, p, frame_width, frame_height))
-                    fembedding.write(formats.embedding_line(T, ident, e))
+                T, ident = [k[0] for k in pend_k], [k[1] for k in pend_k]
+                flandmark.write(formats.landmark_rows(T, ident, pts, frame_width, frame_height))
+                fembedding.write(formats.embedding_rows(T, ident, emb))
                 flandmark.flush(); fembedding.flush()
                 for f in pend_own:
                     f.release()
@@ -221,10 +221,9 @@ def process(video, shot, landmark_model, embedding_model, tracking_output, landm
                 state["next"] += 1
         res = pipe.run_stream(video, shots, on_tracks=write, cluster=label_output is not None)
     w, h = video.size
-    with open(landmark_output, 'w') as flandmark, open(embedding_output, 'w') as fembedding:
-        for T, ident, p, e in zip(res["face_T"].tolist(), res["face_id"].tolist(), res["landmarks"], res["embeddings"]):
-            flandmark.write(formats.landmark_line(T, ident, p, w, h))
-            fembedding.write(formats.embedding_line(T, ident, e))
+    with open(landmark_output, 'wb') as flandmark, open(embedding_output, 'wb') as fembedding:
+        flandmark.write(formats.landmark_rows(res["face_T"], res["face_id"], res["landmarks"], w, h))
+        fembedding.write(formats.embedding_rows(res["face_T"], res["face_id"], res["embeddings"]))
     if label_output is not None:
         with open(label_output, 'w') as f:
             for identifier in sorted(set(res["face_id"].tolist())):

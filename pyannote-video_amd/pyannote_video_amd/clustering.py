@@ -35,9 +35,13 @@ class _Model(object):
             time, track, X = embedding
         data = Features(np.asarray(time, np.float64), np.asarray(track, np.int64), np.asarray(X, np.float64))
         starting_point = Annotation(modality='face')
-        for trk in np.unique(data.track):
-            t = data.time[data.track == trk]
-            segment = Segment(np.min(t), np.max(t))
+        # rows are sorted by (track, time): a track's extent is its first and last row (the reference takes np.min / np.max of the
+        # track's rows, clustering.py:76-77 -- the same two values, without a pass over all rows per track)
+        tracks, first, count = np.unique(data.track, return_index=True, return_counts=True)
+        t_min = data.time[first].tolist()
+        t_max = data.time[first + count - 1].tolist()
+        for trk, a, b in zip(tracks.tolist(), t_min, t_max):
+            segment = Segment(a, b)
             if not segment:          # single-timestamp tracks are skipped (clustering.py:78-79)
                 continue
             starting_point[segment, int(trk)] = int(trk)
@@ -77,7 +81,7 @@ class FaceClustering(object):
         rows = order[keep]
         rt = row_track[rows]
         Xs = np.ascontiguousarray(X[rows], np.float64)
-        counts = np.array([(rt == t).sum() for t in track_ids], np.int64)
+        counts = np.searchsorted(rt, track_ids, side="right") - np.searchsorted(rt, track_ids, side="left")     # rt is sorted (stable argsort above)
         row_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         cut = float("inf") if self.force else self.threshold
         if self.metric == "cosine":

@@ -105,15 +105,28 @@ def rccl_rows():
     except Exception as e:                      # noqa: BLE001 -- any failure means: use the torch path, together
         import sys
         sys.stderr.write("[pvface] libpvface_dist unavailable on rank %d (%s); using torch.distributed collectives\n" % (rank, e))
-        ok = 0
+        ok, err = 0, e
     flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) != 1:
         if comm is not None:
             comm.close()
         comm = None
+        if os.environ.get("PVF_DIST_STRICT", "0") == "1":
+            # a job that asked for the C-ABI collective (bench.py --gpus N > 1 does) must not measure something else in its place
+            raise RuntimeError("libpvface_dist.so: the RCCL communicator could not be set up on every rank and PVF_DIST_STRICT=1 forbids "
+                               "the torch.distributed fallback (set PVF_DIST_COLLECTIVE=torch to ask for it explicitly)")
     _rccl["comm"] = comm
     return comm
+
+
+def collective_name():
+    """which exchange step a multi-GPU run uses: 'libpvface_dist' (RCCL behind the C ABI), 'torch' (torch.distributed collectives) or
+    'none' (a single process)"""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return "none"
+    return "libpvface_dist" if rccl_rows() is not None else "torch"
 
 
 def shard_shots(shot_ranges, world_size):

@@ -259,7 +259,7 @@ class VideoJob(object):
         if self.streaming:
             natives = si.natives if si.natives is not None else [f for _, f in si.cache]
             for j, f in enumerate(natives):
-                self.store.add(si.base + j, f, si.owned)
+                self.store.add(si.base + j, f, si.owned or getattr(f, "transient", False))
             self.times.extend(t for t, _ in si.cache)
 
     def shot_tracked(self, si, tracks, normalize):
@@ -270,7 +270,7 @@ class VideoJob(object):
         self.t_tracked = _time.perf_counter()
         if self.ex is None:
             self.tracks.extend(norm)
-            if self.streaming and si.owned:
+            if self.streaming:
                 self.store.release_below(si.base + len(si.cache))
             return None
         return self.ex.prepare(norm)

@@ -42,7 +42,9 @@ def quantise_track_box(box, frame_width, frame_height):
 
 
 def quantise_time(t):
-    return round(t, 3)       # == float("%.3f" % t): both are the correctly rounded 3-decimal value (tests/test_host_logic.py)
+    # == float("%.3f" % t): both are the correctly rounded 3-decimal value (tests/test_host_logic.py) -- for Python floats; round() of a
+    # numpy scalar goes through numpy's scale / rint / divide and is not (np.float64(0.1125) -> 0.112), hence the float()
+    return round(float(t), 3)
 
 
 def pandas_sort_order(times):
@@ -89,6 +91,20 @@ def embedding_line(T, identifier, embedding):
     for x in embedding:
         s += ' {x:.5f}'.format(x=float(x))
     return s + '\n'
+
+
+def landmark_rows(T, identifier, pts, frame_width, frame_height):
+    """bytes of many landmarks.txt lines at once (== landmark_line per face, formatted by the library: pvf_format_rows)"""
+    from . import _lib
+    pts = np.asarray(pts).reshape(len(T), -1, 2)
+    vals = np.stack([pts[:, :, 0].astype(np.float64) / frame_width, pts[:, :, 1].astype(np.float64) / frame_height], 2)
+    return _lib.format_rows(T, identifier, vals.reshape(len(T), -1), 5)
+
+
+def embedding_rows(T, identifier, embeddings):
+    """bytes of many embedding.txt lines at once (== embedding_line per face)"""
+    from . import _lib
+    return _lib.format_rows(T, identifier, np.asarray(embeddings).astype(np.float64).reshape(len(T), 128 if len(T) == 0 else -1), 5)
 
 
 def quantise_embedding(embedding):

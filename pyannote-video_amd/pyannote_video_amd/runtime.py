@@ -9,10 +9,11 @@ from . import models as _models
 
 class DeviceFrame(object):
     """A frame resident in HBM (uint8 RGB HWC).  `keep` pins whatever owns the memory (e.g. a torch tensor)."""
-    __slots__ = ("ctx", "handle", "height", "width", "keep", "__weakref__")
+    __slots__ = ("ctx", "handle", "height", "width", "keep", "transient", "__weakref__")
 
-    def __init__(self, ctx, handle, height, width, keep=None):
+    def __init__(self, ctx, handle, height, width, keep=None, transient=False):
         self.ctx, self.handle, self.height, self.width, self.keep = ctx, handle, height, width, keep
+        self.transient = transient      # a streaming source made it for one pass: the engine releases it when `extract` has passed it
 
     @property
     def shape(self):
@@ -97,6 +98,7 @@ class Context(object):
         self.stage_capacity = 1024
         self._hold = 0         # > 0 while a call is collecting frame handles: nothing staged may be evicted until it has run
         self._tables = False
+        self._models = {}
         if detector:
             self.load_detector(detector)
         if landmarks:
@@ -125,11 +127,27 @@ class Context(object):
     def load_detector(self, path):
         check(self._l.pvf_load_detector(self._h, str(path).encode()))
 
+    def _model_key(self, path):
+        import os
+        try:
+            st = os.stat(str(path))
+        except OSError:
+            return object()          # never equal: the loader reports the missing file
+        return (os.path.abspath(str(path)), st.st_size, st.st_mtime_ns)
+
     def load_shape_predictor(self, path):
-        check(self._l.pvf_load_shape_predictor(self._h, str(path).encode()))
+        """(a model file that is already loaded -- same path, size and modification time -- is not read again: every CLI verb and
+        every FacePipeline names its models)"""
+        key = self._model_key(path)
+        if self._models.get("sp") != key:
+            check(self._l.pvf_load_shape_predictor(self._h, str(path).encode()))
+            self._models["sp"] = key
 
     def load_embedder(self, path):
-        check(self._l.pvf_load_embedder(self._h, str(path).encode()))
+        key = self._model_key(path)
+        if self._models.get("emb") != key:
+            check(self._l.pvf_load_embedder(self._h, str(path).encode()))
+            self._models["emb"] = key
 
     def ensure_tracker_tables(self):
         if not self._tables:
@@ -149,6 +167,24 @@ class Context(object):
         h = C.c_uint64(0)
         check(self._l.pvf_frame_upload(self._h, ptr(rgb), rgb.shape[0], rgb.shape[1], rgb.strides[0], C.byref(h)))
         return DeviceFrame(self, h.value, rgb.shape[0], rgb.shape[1])
+
+    def upload_device(self, data_ptr, height, width, transient=False):
+        """copy of a frame that already lies in HBM (a decoder's output surface) into a buffer of the library's own"""
+        h = C.c_uint64(0)
+        check(self._l.pvf_frame_upload(self._h, C.c_void_p(int(data_ptr)), int(height), int(width), int(width) * 3, C.byref(h)))
+        return DeviceFrame(self, h.value, int(height), int(width), transient=transient)
+
+    def mem_info(self):
+        """(free, total) bytes of device memory as the driver sees them"""
+        f, t = C.c_int64(0), C.c_int64(0)
+        check(self._l.pvf_mem_info(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def pool_trim(self, keep_bytes=0):
+        """give pooled frame buffers beyond keep_bytes back to the allocator; returns what the pool still holds"""
+        n = C.c_int64(0)
+        check(self._l.pvf_frame_pool_trim(self._h, int(keep_bytes), C.byref(n)))
+        return n.value
 
     def wrap_device(self, data_ptr, height, width, keep=None):
         h = C.c_uint64(0)

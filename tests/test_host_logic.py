@@ -345,6 +345,35 @@ def test_round3_equals_text_round_trip():
     box = (0.123456, 0.5, 0.987654, 0.75)
     q = np.asarray([round(v, 3) for v in box], np.float64).astype(np.float32).astype(np.float64).tolist()
     assert q == [float(np.float32("%.3f" % v)) for v in box]
+    # numpy scalars (times = np.arange(n) / fps): round() of an np.float64 is numpy's scale / rint / divide, not the correctly rounded
+    # value -- np.float64(0.1125) gives 0.112 where '%.3f' gives 0.113 -- so the product converts to a Python float first
+    assert round(np.float64(0.1125), 3) != float("%.3f" % 0.1125)
+    for fps in (29.97, 23.976, 25.0, 30.0):
+        for t in np.arange(3000) / fps:
+            assert formats.quantise_time(t) == float("%.3f" % t)
+    ex = pipeline.ExtractStream(None, [None] * 4, [0.0, 0.1125, 0.2, 0.3], 100, 100)
+    ex.prepare([[(np.float64(0.1125), tuple(np.float64(v) for v in (0.1125, 0.2, 0.3125, 0.4)), "detection"), (np.float64(0.2), (0.1, 0.2, 0.3, 0.4), "detection")]])
+    assert ex.file_T == [0.113, 0.2] and ex.rows[0][2][0] == float(np.float32("0.113"))
+
+
+def test_text_rows_formatted_by_the_library_equal_python_formatting():
+    """formats.landmark_rows / embedding_rows (pvf_format_rows) == the reference's per-value '{:.5f}' formatting (pyannote-face.py:299-311),
+    byte for byte, rounding ties and negative zeros included"""
+    rng = np.random.default_rng(4)
+    emb = rng.normal(0, 0.1, (300, 128)).astype(np.float32)
+    emb[0, :8] = [0.000005, -0.000005, 0.123455, 1e-9, -1e-9, 0.0, -0.0, 123456.7]
+    emb[1, :4] = [0.5e-5, 1.5e-5, 2.5e-5, -2.5e-5]
+    T = np.round(rng.random(300) * 40, 3)
+    ids = rng.integers(0, 500, 300)
+    want = "".join(formats.embedding_line(float(T[i]), int(ids[i]), emb[i]) for i in range(300)).encode()
+    assert formats.embedding_rows(T, ids, emb) == want
+    pts = rng.integers(0, 1920, (300, 68, 2)).astype(np.int32)
+    want = "".join(formats.landmark_line(float(T[i]), int(ids[i]), pts[i], 1920, 1080) for i in range(300)).encode()
+    assert formats.landmark_rows(T, ids, pts, 1920, 1080) == want
+    from pyannote_video_amd import _lib
+    x = np.concatenate([(rng.integers(-10**7, 10**7, 20000) + 0.5) / 1e5, rng.normal(0, 1, 20000), rng.normal(0, 1e3, 10000), [1e12, -3e15]])
+    assert _lib.format_rows(np.zeros(1), np.zeros(1, np.int64), x.reshape(1, -1)) == ("0.000 0" + "".join(" %.5f" % v for v in x.tolist()) + "\n").encode()
+    assert formats.embedding_rows([], [], np.zeros((0, 128))) == b""
 
 
 @pytest.mark.parametrize("seed", range(6))
