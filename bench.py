@@ -167,6 +167,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     hbm.stop()
+    timed_engine = pipe.last_engine
     for c in ctxs:
         c.prof_enable(False)
     if world > 1:
@@ -246,7 +247,7 @@ def main():
         "parity": parity,
         "host_ingest": host,
         "dropin_cli": dropin,
-        "hbm": hbm.report(frames_bytes=int(frames_t.numel()), engine=pipe.last_engine),
+        "hbm": hbm.report(frames_bytes=int(frames_t.numel()), engine=timed_engine),
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
         "kernel_families_ms": fam,
         "results": {"tracks": len(res["tracks"]), "faces_embedded": int(len(res["face_T"])), "clusters": n_clusters,

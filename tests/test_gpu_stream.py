@@ -117,16 +117,19 @@ def _oracle_flow(oracle, frames_np, times, shots, fps, model_paths, every=0.0, t
     tabs = models.dsst_tables()
     pool = concurrent.futures.ThreadPoolExecutor(16)
     tracks = ref_flow.track_video(frames_np, times, shots, det, lambda: oracle.Tracker(tabs), fps, detect_every=every, min_conf=10., ratio=0.5, max_gap=1.0, pool=pool)
-    pts = []
-    lm, em = ref_flow.extract(ref_flow.track_text(tracks), frames_np, times, lambda f, b: pts.append(sp(f, b)) or pts[-1], emb, pool=pool)
+    lm, em = ref_flow.extract(ref_flow.track_text(tracks), frames_np, times, sp, emb, pool=pool)
     pool.shutdown()
+    # the landmark lines hold x / width, y / height with 5 decimals: that resolves the integer point (the faces of a frame run in a
+    # thread pool, so the lines -- written in order -- are the record, not the order of the calls)
+    h, w = frames_np[0].shape[:2]
+    pts = np.rint(np.array([[float(x) for x in l.split()[2:]] for l in lm]).reshape(-1, 68, 2) * np.array([w, h], np.float64)).astype(np.int64)
     return tracks, pts, em, ref_flow.cluster(em, 0.6)
 
 
 def _check_against_oracle(res, ref):
     tracks, pts, em, labels = ref
     assert res["tracks"] == tracks
-    assert len(pts) == len(res["landmarks"]) > 0 and np.array_equal(np.stack(pts), res["landmarks"])
+    assert len(pts) == len(res["landmarks"]) > 0 and np.array_equal(pts, res["landmarks"].astype(np.int64))
     ref_e = np.array([[float(x) for x in line.split()[2:]] for line in em]).reshape(-1, 128)
     assert [int(l.split()[1]) for l in em] == res["face_id"].tolist()
     assert np.linalg.norm(ref_e - res["embeddings"], axis=1).max() <= 1e-4 + 128 ** 0.5 * 5e-6        # bar 1e-4 + the text rounding of the reference side
