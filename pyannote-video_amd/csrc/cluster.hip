@@ -8,6 +8,7 @@
 // whole agglomeration is ONE persistent workgroup (row minima in LDS, no launches inside the loop).
 #include "pvf_internal.h"
 #include <cmath>
+#include <cstdlib>
 
 __global__ void __launch_bounds__(256) transpose_k(const double* __restrict__ X, int N, int dim, double* __restrict__ Xt)
 {
@@ -70,19 +71,26 @@ __global__ void __launch_bounds__(256) track_pair_mean_k(const double* __restric
 // hold nothing else), shorter tracks are packed whole, several to a block.  The blocking depends on the track sizes only, never on
 // which rank computes which rows, so every D entry is formed by the same additions wherever it is computed.
 // A wave owns one row block (its 16 x 128 values stay in registers as 32 A fragments) and sweeps a range of column blocks, which
-// its workgroup stages through LDS (one copy serves 4 row blocks).  Per 16 x 16 tile: 32 MFMAs give x_a . x_b,
-//   d = sqrt(|a|^2 + |b|^2 - 2 a.b)     (recomputed as sum (a_k - b_k)^2 where the Gram form would cancel; cosine: 1 - a.b / (|a| |b|)),
-// lane r adds the tile's row r to a running sum over b that restarts whenever a column track ends (sequential in b, across tiles),
-// and for every finished column track the sums of the rows of each row track are added in row order:
-//   whole row tracks  ->  D[i][j] = sum / (n_i n_j) written at once;   chunks of a long track -> P[chunk][j], summed in chunk order by
-// pair_chunks_k.  D[i][i] = 0 like scipy's squareform diagonal.
+// its workgroup stages through LDS (one copy serves 4 row blocks).  Per 16 x 16 tile:
+//   32 MFMAs give x_a . x_b;  d = sqrt(|a|^2 + |b|^2 - 2 a.b)  (recomputed as sum (a_k - b_k)^2 where the Gram form would cancel;
+//   cosine: 1 - a.b / (|a| |b|)) -- the tile of distances sits in the C layout, 4 values per lane;
+//   the reduction to track pairs runs on the matrix cores as well: with the 0/1 matrices Rind[row segment][row] (which rows of this
+//   row block form which track) and Cind[column][column segment],
+//       R' = d^T . Rind^T   (4 MFMAs: the C layout of d IS the A layout of d^T)      sums over the rows of every row track, per column
+//       T2 += R'^T . Cind   (4 MFMAs: the C layout of R' IS the A layout of R'^T)    ... and over the columns of every column track
+//   (products with 1.0 and sums with 0.0 are exact; the order of the additions is the matrix core's, the same for every launch
+//   shape).  T2 keeps accumulating while consecutive column blocks are chunks of ONE long track and is written when the track ends:
+//   whole row tracks -> D[i][j] = sum / (n_i n_j);  chunks of a long row track -> P[chunk][j], summed in chunk order by pair_chunks_k.
+// D[i][i] = 0 like scipy's squareform diagonal.  Round 2 reduced the tile with LDS round trips and lane-serial running sums (16
+// dependent steps per tile on 16 lanes): 10-16 TFLOP/s; the matrix-core reduction removes every serial step from the tile.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define PT_PITCH 130                      // doubles per staged row: (2 j + k) mod 32 distinct bank pairs for the B fragment reads
 
 struct PtArgs {
     const double* X; const double* nrm; int N, T;
-    const int* row_track; const int* row_last; const int* row_seg_len;   // per row: track, 1 on a track's last row, rows of its block segment if it starts one else 0
-    const int* blk_r0; const int* blk_nr; const int* blk_chunk;          // per block: first row, rows, chunk index (-1: packed whole tracks)
+    const int* row_track; const int* row_segidx;                         // per row: track, index of its track's segment inside its block
+    const int* blk_r0; const int* blk_nr; const int* blk_chunk; const int* blk_last;   // per block: first row, rows, chunk index (-1: packed whole tracks), 1 = its tracks end here
+    const int* seg_track;                                                  // [block][16]: track of each segment of the block (-1: none)
     const int* range_b0;                                                   // column ranges: block index bounds [n_ranges + 1]
     const int* row_start; double* D; double* P;
     int n_blocks, n_ranges, t0, t1, metric;
@@ -97,14 +105,14 @@ __global__ void __launch_bounds__(256) row_norms_k(const double* __restrict__ X,
     nrm[a] = s;
 }
 
-__global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
+__device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
 {
     constexpr int DIM = 128, KS = DIM / 4;
     __shared__ __attribute__((aligned(16))) double Bs[2][16 * PT_PITCH];
-    __shared__ double tileD[4][16][17];
-    __shared__ double colS[4][16][17];
-    __shared__ int colInfo[2][16][2];                 // per staged column: track (or -1 for padding), last-row flag
-    __shared__ double colNrm[2][16];                  // ... and |b|^2
+    __shared__ int colSeg[2][16];                     // per staged column: segment index inside its block (-1: padding)
+    __shared__ int colSegTrack[2][16];                // per segment of the staged block: its track (-1: none)
+    __shared__ double colNrm[2][16];                  // |b|^2 per staged column
+    __shared__ int blkLast[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ab = blockIdx.x * 4 + wave;             // row block of this wave
     const bool have = ab < a.n_blocks;
@@ -121,10 +129,21 @@ __global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
 #pragma unroll
         for (int s = 0; s < KS; ++s) af[s] = ok ? xa[4 * s] : 0.0;
     }
-    double na4[4];
+    double na4[4], rb[4], rcnt[4];
+    int rt[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const int row = k4 + 4 * r; na4[r] = (have && row < anr) ? a.nrm[ar0 + row] : 0.0; }
-    double run = 0.0;                                  // lane r < 16: running sum of row r over the columns of the current column track
+    for (int r = 0; r < 4; ++r) {
+        const int row = k4 + 4 * r;                    // C-layout row of register r == K index of step r in the row reduction
+        const bool ok = have && row < anr;
+        na4[r] = ok ? a.nrm[ar0 + row] : 0.0;
+        rb[r] = (ok && a.row_segidx[ar0 + row] == i16) ? 1.0 : 0.0;          // Rind^T[row][segment i16]
+        // T2's C layout: register r of this lane holds row segment k4 + 4 r, column segment i16
+        const int seg = k4 + 4 * r;
+        int t = have ? a.seg_track[ab * 16 + seg] : -1;
+        if (t >= 0 && !(t >= a.t0 && t < a.t1)) t = -1;                       // rows of another rank's share
+        rt[r] = t;
+        rcnt[r] = t >= 0 ? (double)(a.row_start[t + 1] - a.row_start[t]) : 1.0;
+    }
     // staging role: thread t moves 8 doubles (64 bytes) of row t >> 4
     const int srow = tid >> 4, sch = tid & 15;
     auto stage = [&](int cb, int buf) {
@@ -138,23 +157,13 @@ __global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
 #pragma unroll
         for (int q = 0; q < 8; ++q) dst[q] = v[q];
         if (tid < 16) {
-            colInfo[buf][tid][0] = tid < nr ? a.row_track[r0 + tid] : -1;
-            colInfo[buf][tid][1] = tid < nr ? a.row_last[r0 + tid] : 0;
+            colSeg[buf][tid] = tid < nr ? a.row_segidx[r0 + tid] : -1;
+            colSegTrack[buf][tid] = a.seg_track[cb * 16 + tid];
             colNrm[buf][tid] = tid < nr ? a.nrm[r0 + tid] : 0.0;
+            if (tid == 0) blkLast[buf] = a.blk_last[cb];
         }
     };
-    // row side of the reduction, fixed for the whole sweep: lane + 64 q <-> (row r, column c); a row that starts a row track carries
-    // the number of rows of that track inside this block
-    int seg_len[4], seg_track[4];
-    double seg_cnt[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = (lane + 64 * q) >> 4;
-        seg_len[q] = (have && r < anr) ? a.row_seg_len[ar0 + r] : 0;
-        seg_track[q] = seg_len[q] > 0 ? a.row_track[ar0 + r] : -1;
-        if (seg_track[q] >= 0 && !(seg_track[q] >= a.t0 && seg_track[q] < a.t1)) seg_len[q] = 0;    // rows of another rank's share
-        seg_cnt[q] = seg_track[q] >= 0 ? (double)(a.row_start[seg_track[q] + 1] - a.row_start[seg_track[q]]) : 1.0;
-    }
+    f64x4 t2 = (f64x4){0.0, 0.0, 0.0, 0.0};          // sums per (row segment, column segment), carried across the chunks of a long column track
     if (cb0 < cb1) stage(cb0, 0);
     __syncthreads();
     for (int cb = cb0; cb < cb1; ++cb) {
@@ -167,15 +176,16 @@ __global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
 #pragma unroll
             for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bp[4 * s], acc, 0, 0, 0);
             // C/D of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
-            const int ct = colInfo[buf][i16][0];
+            const bool col_ok = colSeg[buf][i16] >= 0;
             const double nb = colNrm[buf][i16];
+            double d[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = k4 + 4 * r;
-                double d = 0.0;
-                if (row < anr && ct >= 0) {
+                d[r] = 0.0;
+                if (row < anr && col_ok) {
                     const double g = acc[r], sum = na4[r] + nb;
-                    if (a.metric == 1) d = 1.0 - g / sqrt(na4[r] * nb);
+                    if (a.metric == 1) d[r] = 1.0 - g / sqrt(na4[r] * nb);
                     else {
                         double d2 = sum - 2.0 * g;
                         // the Gram form cancels for close rows: its absolute error in d is ~1e-16 (|a|^2 + |b|^2) / d, i.e. below 1e-13 down
@@ -186,42 +196,44 @@ __global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a)
                             d2 = 0.0;
                             for (int k = 0; k < DIM; ++k) { const double t = xa[k] - xb[k]; d2 += t * t; }
                         }
-                        d = sqrt(d2 > 0.0 ? d2 : 0.0);
+                        d[r] = sqrt(d2 > 0.0 ? d2 : 0.0);
                     }
                 }
-                tileD[wave][row][i16] = d;
             }
-            __builtin_amdgcn_wave_barrier();        // tileD is written and read by different lanes of this wave (LDS is in order per wave)
-            // running sums over b, one lane per row; a finished column track leaves its sum in colS[row][column]
-            if (lane < 16) {
+            // rows of every row track: R'[column][row segment] = sum_row d[row][column] Rind[segment][row]; this lane's d[s] is
+            // element (column i16, row 4 s + k4) of d^T, i.e. the A operand of step s
+            f64x4 rp = (f64x4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (colInfo[buf][c][0] >= 0) {
-                        run += tileD[wave][lane][c];
-                        if (colInfo[buf][c][1]) { colS[wave][lane][c] = run; run = 0.0; }
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // sums over the rows of each row track, in row order, for every finished column track
+            for (int s = 0; s < 4; ++s) rp = __builtin_amdgcn_mfma_f64_16x16x4f64(d[s], rb[s], rp, 0, 0, 0);
+            // columns of every column track: T2[row segment][column segment] += sum_col R'[col][row segment] Cind[col][column segment];
+            // rp[q] is element (row segment i16, column 4 q + k4) of R'^T: the A operand of step q
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int idx = lane + 64 * q, r = idx >> 4, c = idx & 15;
-                if (seg_len[q] > 0 && colInfo[buf][c][1]) {
-                    const int i = seg_track[q], j = colInfo[buf][c][0];
-                    double s = 0.0;
-                    for (int rr = r; rr < r + seg_len[q]; ++rr) s += colS[wave][rr][c];
-                    if (achunk >= 0) a.P[(size_t)achunk * a.T + j] = s;
-                    else {
-                        const double cnt = seg_cnt[q] * (double)(a.row_start[j + 1] - a.row_start[j]);
-                        a.D[(size_t)i * a.T + j] = (i == j) ? 0.0 : s / cnt;
+                const double cind = (colSeg[buf][4 * q + k4] == i16) ? 1.0 : 0.0;
+                t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[q], cind, t2, 0, 0, 0);
+            }
+            if (blkLast[buf]) {                        // (uniform) the column tracks of this block are complete
+                const int j = colSegTrack[buf][i16];
+                if (j >= 0) {
+                    const double ccnt = (double)(a.row_start[j + 1] - a.row_start[j]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int i = rt[q];
+                        if (i < 0) continue;
+                        if (achunk >= 0) a.P[(size_t)achunk * a.T + j] = t2[q];
+                        else a.D[(size_t)i * a.T + j] = (i == j) ? 0.0 : t2[q] / (rcnt[q] * ccnt);
                     }
                 }
+                t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
             }
         }
         __syncthreads();
     }
 }
+
+__global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a) { pair_tiles_body(a); }
+// EXPERIMENT (round 3 measurement session): the same body limited to 168 registers = three waves per SIMD instead of two
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) pair_tiles_occ3_k(PtArgs a) { pair_tiles_body(a); }
 
 // long tracks: D[i][j] = (P[c0][j] + P[c0+1][j] + ...) / (n_i n_j), chunks in order
 __global__ void __launch_bounds__(256) pair_chunks_k(const double* __restrict__ P, const int* __restrict__ big_track, const int* __restrict__ big_c0,
@@ -241,11 +253,11 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
 {
     constexpr int DIM = 128;
     // ---- blocking (host, O(N))
-    std::vector<int> row_track(N), row_last(N, 0), row_seg(N, 0), blk_r0, blk_nr, blk_chunk, big_track, big_c0, big_nc;
+    std::vector<int> row_track(N), row_segidx(N, 0), blk_r0, blk_nr, blk_chunk, blk_last, seg_track, big_track, big_c0, big_nc;
     std::vector<int> blk_first_track;
     int n_chunks = 0;
     for (int t = 0; t < T; ++t) for (int r = row_start[t]; r < row_start[t + 1]; ++r) row_track[r] = t;
-    for (int t = 0; t < T; ++t) if (row_start[t + 1] > row_start[t]) row_last[row_start[t + 1] - 1] = 1;
+    auto new_block = [&]() { seg_track.insert(seg_track.end(), 16, -1); };
     int t = 0;
     while (t < T) {
         const int n = row_start[t + 1] - row_start[t];
@@ -256,28 +268,36 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
             for (int r = row_start[t]; r < row_start[t + 1]; r += 16, ++k) {
                 const int nr = std::min(16, row_start[t + 1] - r);
                 blk_r0.push_back(r); blk_nr.push_back(nr); blk_chunk.push_back(n_chunks + k); blk_first_track.push_back(t);
-                row_seg[r] = nr;
+                blk_last.push_back(r + 16 >= row_start[t + 1] ? 1 : 0);
+                new_block();
+                seg_track[seg_track.size() - 16] = t;          // one segment (index 0, the rows' default)
             }
             big_nc.push_back(k);
             n_chunks += k;
             ++t;
         } else {
             const int r0 = row_start[t];
-            int rows = 0;
+            int rows = 0, segs = 0;
             blk_first_track.push_back(t);
+            new_block();
             while (t < T && rows + (row_start[t + 1] - row_start[t]) <= 16 && (row_start[t + 1] - row_start[t]) < 16) {
                 const int m = row_start[t + 1] - row_start[t];
-                if (m > 0) row_seg[row_start[t]] = m;
+                if (m > 0) {
+                    for (int r = row_start[t]; r < row_start[t + 1]; ++r) row_segidx[r] = segs;
+                    seg_track[seg_track.size() - 16 + segs] = t;
+                    ++segs;
+                }
                 rows += m;
                 ++t;
             }
-            blk_r0.push_back(r0); blk_nr.push_back(rows); blk_chunk.push_back(-1);
+            blk_r0.push_back(r0); blk_nr.push_back(rows); blk_chunk.push_back(-1); blk_last.push_back(1);
         }
     }
     const int nb = (int)blk_r0.size();
-    // column ranges: about 4 x 256 workgroups in total, cut only where a block starts a new track (never inside a long track)
+    // column ranges: about six rounds of workgroups over the chip (4 resident per CU), cut only where a block starts a new track (never
+    // inside a long track: the sums of a long column track are carried from chunk to chunk)
     const int row_groups = (nb + 3) / 4;
-    int want_ranges = std::max(1, std::min(nb, (4 * 256 + row_groups - 1) / row_groups));
+    int want_ranges = std::max(1, std::min(nb, (6 * 4 * c->n_cu + row_groups - 1) / row_groups));
     std::vector<int> range_b0{0};
     for (int k = 1; k < want_ranges; ++k) {
         int b = (int)((long long)nb * k / want_ranges);
@@ -290,21 +310,23 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t xb = al((size_t)N * DIM * 8), nbz = al((size_t)N * 8), ib = al((size_t)N * 4), bb = al((size_t)nb * 4), pb = al((size_t)std::max(n_chunks, 1) * T * 8);
     const size_t rsb = al((size_t)(T + 1) * 4), rgb = al((size_t)(n_ranges + 1) * 4), bigb = al((size_t)std::max<size_t>(big_track.size(), 1) * 4);
-    c->s_clu0.ensure(xb + nbz + 3 * ib + 3 * bb + pb + rsb + rgb + 3 * bigb + 1024);
+    c->s_clu0.ensure(xb + nbz + 2 * ib + 4 * bb + 16 * bb + pb + rsb + rgb + 3 * bigb + 4096);
     c->s_clu1.ensure((size_t)T * T * sizeof(double) + (size_t)T * 64 + 4096);
     uint8_t* p = c->s_clu0.as<uint8_t>();
     auto take = [&](size_t bytes) { uint8_t* q = p; p += bytes; return q; };
     double* dX = (double*)take(xb); double* dN = (double*)take(nbz);
-    int* dRT = (int*)take(ib); int* dRL = (int*)take(ib); int* dRS = (int*)take(ib);
-    int* dB0 = (int*)take(bb); int* dBN = (int*)take(bb); int* dBC = (int*)take(bb);
+    int* dRT = (int*)take(ib); int* dRS = (int*)take(ib);
+    int* dB0 = (int*)take(bb); int* dBN = (int*)take(bb); int* dBC = (int*)take(bb); int* dBL = (int*)take(bb);
+    int* dST = (int*)take(al((size_t)nb * 16 * 4));
     double* dP = (double*)take(pb);
     int* dRow = (int*)take(rsb); int* dRange = (int*)take(rgb);
     int* dBigT = (int*)take(bigb); int* dBigC0 = (int*)take(bigb); int* dBigNc = (int*)take(bigb);
     double* dD = c->s_clu1.as<double>();
     auto up = [&](void* d, const void* h, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream)); };
     up(dX, X, (size_t)N * DIM * 8);
-    up(dRT, row_track.data(), (size_t)N * 4); up(dRL, row_last.data(), (size_t)N * 4); up(dRS, row_seg.data(), (size_t)N * 4);
+    up(dRT, row_track.data(), (size_t)N * 4); up(dRS, row_segidx.data(), (size_t)N * 4);
     up(dB0, blk_r0.data(), (size_t)nb * 4); up(dBN, blk_nr.data(), (size_t)nb * 4); up(dBC, blk_chunk.data(), (size_t)nb * 4);
+    up(dBL, blk_last.data(), (size_t)nb * 4); up(dST, seg_track.data(), (size_t)nb * 16 * 4);
     up(dRow, row_start, (size_t)(T + 1) * 4); up(dRange, range_b0.data(), (size_t)(n_ranges + 1) * 4);
     up(dBigT, big_track.data(), big_track.size() * 4); up(dBigC0, big_c0.data(), big_c0.size() * 4); up(dBigNc, big_nc.data(), big_nc.size() * 4);
     // the staging buffers above are std::vectors: the copies must have run before they go out of scope
@@ -313,10 +335,11 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
         ProfScope ps(c, "pdist");
         hipLaunchKernelGGL(row_norms_k, dim3((N + 255) / 256), dim3(256), 0, c->stream, dX, N, DIM, dN);
         PtArgs a;
-        a.X = dX; a.nrm = dN; a.N = N; a.T = T; a.row_track = dRT; a.row_last = dRL; a.row_seg_len = dRS;
-        a.blk_r0 = dB0; a.blk_nr = dBN; a.blk_chunk = dBC; a.range_b0 = dRange; a.row_start = dRow; a.D = dD; a.P = dP;
+        a.X = dX; a.nrm = dN; a.N = N; a.T = T; a.row_track = dRT; a.row_segidx = dRS;
+        a.blk_r0 = dB0; a.blk_nr = dBN; a.blk_chunk = dBC; a.blk_last = dBL; a.seg_track = dST; a.range_b0 = dRange; a.row_start = dRow; a.D = dD; a.P = dP;
         a.n_blocks = nb; a.n_ranges = n_ranges; a.t0 = t0; a.t1 = t1; a.metric = metric;
-        hipLaunchKernelGGL(pair_tiles_k, dim3(row_groups, n_ranges), dim3(256), 0, c->stream, a);
+        if (getenv("PVF_K10_OCC3")) hipLaunchKernelGGL(pair_tiles_occ3_k, dim3(row_groups, n_ranges), dim3(256), 0, c->stream, a);
+        else hipLaunchKernelGGL(pair_tiles_k, dim3(row_groups, n_ranges), dim3(256), 0, c->stream, a);
         // long tracks of the requested range
         std::vector<int> sel;
         for (size_t k = 0; k < big_track.size(); ++k) if (big_track[k] >= t0 && big_track[k] < t1) sel.push_back((int)k);
@@ -550,16 +573,24 @@ __global__ void __launch_bounds__(1024) hac_persist_k(HacState h)
         }
         __syncthreads();
         const int nd = s_nd;
-        for (int q = 0; q < nd; ++q) {                   // re-scan row r: first minimum over the alive columns j > r
+        // re-scan the rows whose cached minimum died (and row mi): first minimum over the alive columns j > r.  One WAVE per row, the
+        // sixteen waves working on different rows at once -- in clustered data a merge kills the minimum of many rows (every member of the
+        // cluster that pointed at mi or mj), and round 2 scanned them one after the other with the whole workgroup (two barriers per row)
+        for (int q = tid >> 6; q < nd; q += 16) {
             const int r = dlist[q];
             double v0 = INFINITY; int j0 = 0x7fffffff;
-            for (int j = r + 1 + tid; j < T; j += 1024) {
+            for (int j = r + 1 + (tid & 63); j < T; j += 64) {
                 if (!h.alive[j]) continue;
                 const double v = h.D[(size_t)r * T + j];
-                if (v < v0) { v0 = v; j0 = j; }
+                if (v < v0) { v0 = v; j0 = j; }             // ascending j per lane: first occurrence kept
             }
-            block_argmin(v0, j0, wv, wi);
-            if (tid == 0) { rmin[r] = v0; rarg[r] = j0; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ov = __shfl_down(v0, off, 64);
+                const int oi = __shfl_down(j0, off, 64);
+                if (ov < v0 || (ov == v0 && oi < j0)) { v0 = ov; j0 = oi; }
+            }
+            if ((tid & 63) == 0) { rmin[r] = v0; rarg[r] = j0; }
         }
         __syncthreads();
         ++merges;

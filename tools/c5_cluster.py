@@ -32,7 +32,7 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else None
     ctx = Context(device=0, detector=None)
     res = []
-    for T, rows in ((10000, 1), (10000, 10), (2000, 50)):
+    for T, rows in ((10000, 1), (10000, 10), (2000, 50), (720, 250)):      # the last: one GPU's share of configs[2] (22 500 frames, 250-row tracks)
         X, rs, ident = make(T, rows)
         N = len(X)
         ctx.cluster_tracks(X[:rs[64]], rs[:65], 0.6)                  # warm-up (module load, buffers)
