@@ -8,7 +8,6 @@
 // whole agglomeration is ONE persistent workgroup (row minima in LDS, no launches inside the loop).
 #include "pvf_internal.h"
 #include <cmath>
-#include <cstdlib>
 
 __global__ void __launch_bounds__(256) transpose_k(const double* __restrict__ X, int N, int dim, double* __restrict__ Xt)
 {
@@ -231,9 +230,9 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
     }
 }
 
-__global__ void __launch_bounds__(256) pair_tiles_k(PtArgs a) { pair_tiles_body(a); }
-// EXPERIMENT (round 3 measurement session): the same body limited to 168 registers = three waves per SIMD instead of two
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) pair_tiles_occ3_k(PtArgs a) { pair_tiles_body(a); }
+// 168 registers = three waves per SIMD (the compiler's own choice, 232 registers and two waves, was measured 11 % slower at N = 180 000:
+// 33.0 vs 37.2 TFLOP/s; a wave's epilogue -- four IEEE square roots per lane -- needs other waves' MFMAs to hide behind)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) pair_tiles_k(PtArgs a) { pair_tiles_body(a); }
 
 // long tracks: D[i][j] = (P[c0][j] + P[c0+1][j] + ...) / (n_i n_j), chunks in order
 __global__ void __launch_bounds__(256) pair_chunks_k(const double* __restrict__ P, const int* __restrict__ big_track, const int* __restrict__ big_c0,
@@ -338,8 +337,7 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
         a.X = dX; a.nrm = dN; a.N = N; a.T = T; a.row_track = dRT; a.row_segidx = dRS;
         a.blk_r0 = dB0; a.blk_nr = dBN; a.blk_chunk = dBC; a.blk_last = dBL; a.seg_track = dST; a.range_b0 = dRange; a.row_start = dRow; a.D = dD; a.P = dP;
         a.n_blocks = nb; a.n_ranges = n_ranges; a.t0 = t0; a.t1 = t1; a.metric = metric;
-        if (getenv("PVF_K10_OCC3")) hipLaunchKernelGGL(pair_tiles_occ3_k, dim3(row_groups, n_ranges), dim3(256), 0, c->stream, a);
-        else hipLaunchKernelGGL(pair_tiles_k, dim3(row_groups, n_ranges), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL(pair_tiles_k, dim3(row_groups, n_ranges), dim3(256), 0, c->stream, a);
         // long tracks of the requested range
         std::vector<int> sel;
         for (size_t k = 0; k < big_track.size(); ++k) if (big_track[k] >= t0 && big_track[k] < t1) sel.push_back((int)k);
@@ -573,24 +571,18 @@ __global__ void __launch_bounds__(1024) hac_persist_k(HacState h)
         }
         __syncthreads();
         const int nd = s_nd;
-        // re-scan the rows whose cached minimum died (and row mi): first minimum over the alive columns j > r.  One WAVE per row, the
-        // sixteen waves working on different rows at once -- in clustered data a merge kills the minimum of many rows (every member of the
-        // cluster that pointed at mi or mj), and round 2 scanned them one after the other with the whole workgroup (two barriers per row)
-        for (int q = tid >> 6; q < nd; q += 16) {
+        // re-scan row r: first minimum over the alive columns j > r.  (One wave per row, sixteen rows at a time, was measured 2.3 x slower at
+        // T = 10 000: a lane then walks 156 dependent load pairs instead of 10.)
+        for (int q = 0; q < nd; ++q) {
             const int r = dlist[q];
             double v0 = INFINITY; int j0 = 0x7fffffff;
-            for (int j = r + 1 + (tid & 63); j < T; j += 64) {
+            for (int j = r + 1 + tid; j < T; j += 1024) {
                 if (!h.alive[j]) continue;
                 const double v = h.D[(size_t)r * T + j];
-                if (v < v0) { v0 = v; j0 = j; }             // ascending j per lane: first occurrence kept
+                if (v < v0) { v0 = v; j0 = j; }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ov = __shfl_down(v0, off, 64);
-                const int oi = __shfl_down(j0, off, 64);
-                if (ov < v0 || (ov == v0 && oi < j0)) { v0 = ov; j0 = oi; }
-            }
-            if ((tid & 63) == 0) { rmin[r] = v0; rarg[r] = j0; }
+            block_argmin(v0, j0, wv, wi);
+            if (tid == 0) { rmin[r] = v0; rarg[r] = j0; }
         }
         __syncthreads();
         ++merges;

@@ -258,19 +258,17 @@ __device__ __forceinline__ int ml_level(const MlStarts& st, int g)
 #define FUSED_OUT 61
 // value of the lane to the right / left (v_mov_b32_dpp wave_shl:1 / wave_shr:1; the last / first lane, which has no source, gets 0).
 // The direction is checked once per context on the device (dpp_probe_k): a mismatch is an error, not a fallback.
-// (bound_ctrl: the lane without a source is written with 0 by the instruction itself -- no zeroed destination register to set up)
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xf, 0xf, true); }
-__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 
 
 __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
                                                        float* __restrict__ feat_base, const uint8_t* __restrict__ lut2, int oy, int ox)
 {
     constexpr int RSRC_FLAGS = 0x00020000;
-    // the bins of the two cell rows a pixel row votes into: [even / odd cell row][wave][bin][lane].  One array: the two bins a vote
-    // touches sit at ONE lane address plus two constant offsets (a multiple of 256 bytes apart), so a vote is one ds_read2st64_b32,
-    // one packed multiply, one packed add and one ds_write2st64_b32 for both cells
-    __shared__ float s_acc[2][4][18][64];
+    // the bins of the two cell rows a pixel row votes into: two arrays, so that the compiler knows their updates never alias
+    __shared__ float s_even[4][18][64];                            // cell rows with even index
+    __shared__ float s_odd[4][18][64];                             // cell rows with odd index
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = ml_block(st);
@@ -297,10 +295,10 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
     // give negative offsets, which are huge as unsigned: out of range for the row's buffer descriptor => zeros.  Both offsets go
     // through the VGPR: the range check does not see an SGPR offset, so -16 + an SGPR 16 would be rejected although it is byte 0.
     const int voff = 3 * x_first - 4, voff2 = voff + 16;
-    constexpr int PAR = 4 * 18 * 64;                               // floats between the even and the odd cell row's bins
-    float* accE = &s_acc[0][wave][0][lane];                        // bin k of this lane: accE[64 * k] (even cell rows), accE[PAR + 64 * k] (odd)
+    float* accE = &s_even[wave][0][lane];                          // bin k of this lane: accE[64 * k]
+    float* accO = &s_odd[wave][0][lane];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accE[PAR + 64 * k] = 0.0f; }
+    for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accO[64 * k] = 0.0f; }
 
     // image rows as 8 dwords per lane: bytes [3 x_first - 4, 3 x_first + 28) -- pixel p, channel k at byte 4 + 3 p + k;
     // a row outside the image, or bytes outside a row, read as 0 (such pixels are never valid)
@@ -353,8 +351,7 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
     // The first band's lower half (cell row y0) and the last band's upper half (cell row y0 + R + 3) belong to cells this chunk
     // does not need; they are accumulated all the same (no branches in the vote loop): the first is read and dropped, the last
     // is never read.  Rows without gradients vote with magnitude 0 (x + 0 = x: nothing changes).
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    auto band = [&](int gb, const int offU, const int offL) {          // offsets (floats) of the upper / lower cell row's bins: 0 or PAR
+    auto band = [&](int gb, float* accU, float* accL) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int y = 8 * gb + i - 12;                         // the row whose votes are cast in this step (gradients in mc / bc)
@@ -369,7 +366,7 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
             int bn[8];
             const float fy = ((float)i + 0.5f) / 8.0f;
             // the 16 columns of the window, left to right: own 8 (weights rising), then the right neighbour's 8 (falling).
-            // Each vote is a read-add-write on the lane's own two bins in LDS (lower cell, upper cell), both halves of one instruction.
+            // Each vote is a read-add-write on the lane's own bin in LDS; the two cells' chains are independent.
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int p = j & 7;
@@ -381,13 +378,10 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
                 }
                 const float fx = ((float)p + 0.5f) / 8.0f;
                 const float wx = (j < 8) ? fx : 1.0f - fx;
-                float* cell = accE + bv;
-                const f32x2 cur = (f32x2){cell[offL], cell[offU]};
+                const float vl = accL[bv], vu = accU[bv];
                 if ((j & 1) == 0) grad_px(nu, nc, nd, j >> 1, nok, &mn[j >> 1], &bn[j >> 1]);
-                const f32x2 w = (f32x2){(1.0f - fy) * wx, fy * wx};                 // (constants after unrolling)
-                const f32x2 nxt = cur + w * (f32x2){mv, mv};                          // v_pk_mul_f32, v_pk_add_f32: each half the plain IEEE product and sum
-                cell[offL] = nxt.x;
-                cell[offU] = nxt.y;
+                accL[bv] = vl + ((1.0f - fy) * wx) * mv;
+                accU[bv] = vu + (fy * wx) * mv;
             }
 #pragma unroll
             for (int p = 0; p < 8; ++p) { mc[p] = mn[p]; bc[p] = bn[p]; }
@@ -395,7 +389,6 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
         // cell row c = gb - 1 is complete (for c = y0: a half-filled cell that only has to be cleared; its energy is shifted out of
         // e0..e2 before the first feature row is formed): energy in the oracle's order (straight from LDS: the new bins and the
         // previous row's never sit in registers together)
-        float* accL = accE + offL;
         const int c = gb - 1;
         float e = 0.0f;
 #pragma unroll
@@ -422,8 +415,8 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
         for (int k = 0; k < 18; ++k) { hprev[k] = accL[64 * k]; accL[64 * k] = 0.0f; }
     };
     for (int gb = g_first; gb <= g_last; ++gb) {
-        if (gb & 1) band(gb, PAR, 0);                               // upper half -> the odd cell row gb, lower half -> the even row gb - 1
-        else band(gb, 0, PAR);
+        if (gb & 1) band(gb, accO, accE);                           // upper half -> the odd cell row gb, lower half -> the even row gb - 1
+        else band(gb, accE, accO);
     }
 #undef BYTE_OF
 }

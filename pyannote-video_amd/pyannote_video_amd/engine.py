@@ -96,7 +96,8 @@ class ExtractStream(object):
         self.ctx, self.frames, self.times = ctx, frames, frame_times
         self.w, self.h = frame_width, frame_height
         self.tracks, self.rows = [], []
-        self.file_T, self.file_id = [], []    # the track file's (T, track) column in file order (decides the row order of the outputs)
+        self.rows_file = []                   # the track file's rows, in file order
+        self.file_T, self.file_id = [], []    # ... and their (T, track) columns (they decide the row order of the outputs)
         self.groups, self.gi, self.fi = [], 0, 0
         self.face_boxes, self.face_T, self.face_id = [], [], []
         self.pts, self.emb = [], []
@@ -144,9 +145,9 @@ class ExtractStream(object):
                 i += 1
         self.file_T.extend(r[0] for r in rows)
         self.file_id.extend(r[1] for r in rows)
-        rows.sort(key=lambda r: r[0])
+        self.rows_file.extend(rows)
+        rows = sorted(rows, key=lambda r: r[0])
         self.tracks.extend(tracks)
-        self.rows.extend(rows)
         k, n = 0, len(rows)
         while k < n:
             T = rows[k][0]
@@ -183,9 +184,8 @@ class ExtractStream(object):
             self.face_T = [self.face_T[i] for i in perm]
             self.face_id = [self.face_id[i] for i in perm]
             self.face_boxes = [self.face_boxes[i] for i in perm]
-        order = formats.pandas_sort_order(self.file_T)
-        by_key = {(r[0], r[1]): r for r in self.rows}
-        self.rows = [by_key[(self.file_T[i], self.file_id[i])] for i in order]
+        rows_file = self.rows_file
+        self.rows = [rows_file[i] for i in formats.pandas_sort_order(self.file_T).tolist()]
         self._planned = True
 
     def finish(self, drop_last=True, reorder=True, computed=False):

@@ -69,14 +69,26 @@ def read_tracks(path):
     return [rows[i] for i in pandas_sort_order([r[0] for r in rows])]
 
 
+def _row_key(T, identifier):
+    """one integer per (3-decimal time, track): a track has at most one row per timestamp"""
+    return np.rint(np.asarray(T, np.float64) * 1000.0).astype(np.int64) * (1 << 24) + np.asarray(identifier, np.int64)
+
+
 def file_order(face_T, face_id, file_T, file_id):
     """permutation that puts extracted faces (any order within a timestamp) into the order the reference's `extract` writes them:
     the order of the (T, track) rows in the pandas-sorted track table.  file_T / file_id: the track file's rows in file order."""
-    rank = {}
-    for k, i in enumerate(pandas_sort_order(file_T)):
-        rank[(float(file_T[i]), int(file_id[i]))] = k
-    keys = [rank[(float(t), int(i))] for t, i in zip(face_T, face_id)]
-    return np.argsort(np.asarray(keys, np.int64), kind="stable")
+    file_T = np.asarray(file_T, np.float64)
+    order = pandas_sort_order(file_T)
+    rank_of_row = np.empty(len(order), np.int64)
+    rank_of_row[order] = np.arange(len(order))                  # position of every file row in the sorted table
+    fkey = _row_key(file_T, file_id)
+    sorter = np.argsort(fkey, kind="stable")
+    want = _row_key(face_T, face_id)
+    pos = np.searchsorted(fkey[sorter], want)
+    rows = sorter[np.minimum(pos, len(sorter) - 1)] if len(sorter) else np.zeros(0, np.int64)
+    if len(want) and not (len(sorter) and np.array_equal(fkey[rows], want)):
+        raise KeyError("a face whose (time, track) is not a row of the track table")
+    return np.argsort(rank_of_row[rows], kind="stable")
 
 
 def landmark_line(T, identifier, pts, frame_width, frame_height):

@@ -21,11 +21,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 CLIP = dict(width=640, height=360, n_frames=12, n_shots=2, faces=3, min_face=50, max_face=110, seed=7)   # == conftest.small_video
 
 
-def run_reference_cli(outdir, dlib_module, landmarks_path, embedding_path, clip=CLIP, every=0.0):
-    """the reference's track() and extract() on the clip -> paths of the three files"""
+def run_reference_cli(outdir, dlib_module, landmarks_path, embedding_path, clip=CLIP, every=0.0, record=None):
+    """the reference's track() and extract() on the clip -> paths of the three files.  record: path of a dlib_trace.json to write
+    (every call the reference makes into `dlib`, with the arguments and what came back: tests/dlib_trace.py)"""
     import refhost
     from pyannote_video_amd import synth
     video = synth.SyntheticVideo(**clip)
+    if record:
+        import dlib_trace
+        dlib_module = dlib_trace.Recorder(dlib_module, [video.frame(i) for i in range(video.n_frames)])
     shot_path = os.path.join(outdir, "shots.json")
     with open(shot_path, "w") as f:
         json.dump(video.shots(), f)
@@ -33,6 +37,9 @@ def run_reference_cli(outdir, dlib_module, landmarks_path, embedding_path, clip=
     with refhost.reference_modules(dlib_module, video_cls=synth.SyntheticVideo) as ref:
         ref.cli.track(video, shot_path, track_path, detect_every=every)           # CLI defaults: overlap 0.5, confidence 10, gap 1.0
         ref.cli.extract(video, landmarks_path, embedding_path, track_path, lm_path, emb_path)
+    if record:
+        dlib_module.save(record, {"clip": clip, "every": every, "what": "calls of /root/reference/scripts/pyannote-face.py track() + extract() into dlib "
+                                                                          "(dlib = the CPU oracle), in order"})
     return track_path, lm_path, emb_path
 
 
@@ -44,7 +51,7 @@ def main():
     for name, every in (("reference_cli_small", 0.0), ("reference_cli_small_every3", 0.12)):     # --every=0.12 s = every 3rd frame
         out = os.path.join(HERE, name)
         os.makedirs(out, exist_ok=True)
-        paths = run_reference_cli(out, oracle_dlib, lp, ep, every=every)
+        paths = run_reference_cli(out, oracle_dlib, lp, ep, every=every, record=os.path.join(out, "dlib_trace.json"))
         os.remove(os.path.join(out, "shots.json"))
         for p in paths:
             print(p, os.path.getsize(p), "bytes", sum(1 for _ in open(p)), "lines")

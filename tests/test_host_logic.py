@@ -353,7 +353,7 @@ def test_round3_equals_text_round_trip():
             assert formats.quantise_time(t) == float("%.3f" % t)
     ex = pipeline.ExtractStream(None, [None] * 4, [0.0, 0.1125, 0.2, 0.3], 100, 100)
     ex.prepare([[(np.float64(0.1125), tuple(np.float64(v) for v in (0.1125, 0.2, 0.3125, 0.4)), "detection"), (np.float64(0.2), (0.1, 0.2, 0.3, 0.4), "detection")]])
-    assert ex.file_T == [0.113, 0.2] and ex.rows[0][2][0] == float(np.float32("0.113"))
+    assert ex.file_T == [0.113, 0.2] and ex.rows_file[0][2][0] == float(np.float32("0.113"))
 
 
 def test_text_rows_formatted_by_the_library_equal_python_formatting():

@@ -109,3 +109,52 @@ def test_reference_cli_runs_on_the_hip_shim(tmp_path, ctx, model_paths):
     a = np.array([[float(x) for x in l.split()] for l in _canon(_lines(paths[2]))])
     b = np.array([[float(x) for x in l.split()] for l in _canon(_lines(os.path.join(GOLD[0.0], "embedding.txt")))])
     assert np.abs(a - b).max() <= 1e-4 + 1e-5
+
+
+# ---- the reference's call sequence into dlib, recorded where /root/reference exists, replayed where the GPU is ----------------------
+def _trace(every):
+    import json
+    with open(os.path.join(GOLD[every], "dlib_trace.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("every", [0.0, 0.12])
+def test_recorded_reference_calls_replay_on_the_oracle_dlib(every, oracle, model_paths):
+    """the trace is self-consistent (replayed against the look-alike it was recorded from it reproduces every return value) and holds
+    what the reference does: one detector call per detection frame (face.py:66 via tracking.py:426), one tracker object per (detection,
+    pass) started once (tracking.py:250-251) and updated frame by frame (:203), positions read after updates (:231), one landmark and
+    one descriptor call per extracted face (pyannote-face.py:296-297)"""
+    import dlib_trace
+    import oracle_dlib
+    from pyannote_video_amd import models
+    oracle_dlib.configure(models.load_container(models.DEFAULT_DETECTOR), models.dsst_tables())
+    t = _trace(every)
+    assert t["meta"]["clip"] == mrg.CLIP and t["meta"]["every"] == every
+    v, frames, _ = _clip()
+    n = dlib_trace.replay(oracle_dlib, t["calls"], frames, model_paths[0], model_paths[1], embed_tol=0.0)
+    n_faces = len(_lines(os.path.join(GOLD[every], "landmarks.txt")))
+    assert n["detector.call"] == (12 if every == 0.0 else 4)
+    assert n["shape_predictor.call"] == n["face_recognition.call"] == n_faces
+    assert n["tracker.new"] == n["tracker.start_track"] == 2 * sum(len(c[3]) for c in t["calls"] if c[0] == "detector.call")
+    # every tracker is updated at least once except those started on the last frame of their pass (3 faces x 2 shots x 2 passes)
+    assert n["tracker.update"] >= n["tracker.new"] - 12 and n["tracker.get_position"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("every", [0.0, 0.12])
+def test_recorded_reference_calls_replay_on_the_hip_shim(every, ctx, model_paths):
+    """INTEGRATION.md section 1 without the reference files: the exact dlib calls the reference's track() + extract() made (recorded in
+    the build container, tests/golden/make_reference_golden.py) go through pyannote_video_amd.shim -> C ABI -> HIP kernels one by one --
+    per-object trackers, single-frame detector calls, landmark objects handed on to the embedder -- and every return value equals what
+    the CPU oracle returned to the reference: boxes, tracker confidences and positions, 68 points bit for bit, descriptors within 1e-4"""
+    import dlib_trace
+    from pyannote_video_amd import shim, runtime
+    v, frames, _ = _clip()
+    old = runtime._default
+    runtime._default = ctx
+    try:
+        n = dlib_trace.replay(shim, _trace(every)["calls"], frames, model_paths[0], model_paths[1], embed_tol=1e-4)
+    finally:
+        runtime._default = old
+        ctx.unstage_all()
+    assert n["tracker.update"] > 20 and n["face_recognition.call"] > 20
