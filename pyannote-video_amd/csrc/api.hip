@@ -18,6 +18,23 @@
     HIP_CHECK(hipSetDevice(c->device))
 
 // ---- S1 -------------------------------------------------------------------------------------------
+// a frame with more raw candidates than the candidate slots hold (a threshold lowered far below the operating point, a pathological
+// image): the slots are enlarged to what the frame asked for and the call runs again -- the scanner itself has no limit (dlib collects
+// every window above the threshold)
+template <class F>
+static void with_candidate_room(Ctx* c, F&& run)
+{
+    for (;;) {
+        try { run(); return; }
+        catch (const CandOverflow& e) {
+            PVF_REQUIRE(e.needed <= (1 << 22), "detector: more than 4M candidates in one frame");
+            int cap = c->det_cand_cap;
+            while (cap < e.needed) cap *= 2;
+            c->det_cand_cap = cap;
+        }
+    }
+}
+
 extern "C" int32_t pvf_detect_batch(pvf_handle h, const pvf_handle* frames, int32_t n_frames, int32_t upsample, double adjust,
                                     pvf_rect_i32* out, float* scores, int32_t* counts, int32_t cap)
 {
@@ -28,7 +45,7 @@ extern "C" int32_t pvf_detect_batch(pvf_handle h, const pvf_handle* frames, int3
     std::vector<Frame> fr(n_frames);
     for (int i = 0; i < n_frames; ++i) fr[i] = c->frame(frames[i]);
     std::vector<std::vector<RawDet>> raw;
-    det_run_batch(c, fr, upsample, adjust, raw);
+    with_candidate_room(c, [&]() { det_run_batch(c, fr, upsample, adjust, raw); });
     std::vector<RawDet> kept;
     for (int i = 0; i < n_frames; ++i) {
         det_nms(c->det, raw[i], kept);
@@ -52,7 +69,7 @@ extern "C" int32_t pvf_detect_many(pvf_handle h, const pvf_handle* frames, int32
     std::vector<Frame> fr(n_frames);
     for (int i = 0; i < n_frames; ++i) fr[i] = c->frame(frames[i]);
     std::vector<std::vector<RawDet>> kept_all;
-    det_run_many(c, fr, batch, upsample, adjust, kept_all, true);
+    with_candidate_room(c, [&]() { det_run_many(c, fr, batch, upsample, adjust, kept_all, true); });
     for (int i = 0; i < n_frames; ++i) {
         const std::vector<RawDet>& kept = kept_all[i];
         const int n = std::min<int>((int)kept.size(), cap);
@@ -81,7 +98,7 @@ extern "C" int32_t pvf_debug_detect_raw(pvf_handle h, pvf_handle frame, int32_t 
     ENTER(c, h);
     std::vector<Frame> fr{c->frame(frame)};
     std::vector<std::vector<RawDet>> raw;
-    det_run_batch(c, fr, upsample, adjust, raw);
+    with_candidate_room(c, [&]() { det_run_batch(c, fr, upsample, adjust, raw); });
     const int k = std::min<int>((int)raw[0].size(), cap);
     *n = (int)raw[0].size();
     for (int i = 0; i < k; ++i) {

@@ -147,8 +147,10 @@ void transform_batch(Ctx* c, const std::vector<ChipJob>& jobs, uint8_t* d_out)
         memcpy(x.m, j.m, sizeof x.m); memcpy(x.b, j.b, sizeof x.b);
     }
     c->s_chip.ensure(n * sizeof(DevXfJob));
-    HIP_CHECK(hipMemcpyAsync(c->s_chip.p, xf.data(), n * sizeof(DevXfJob), hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream)); // xf is a stack vector
+    void* hb = c->stage.take(n * sizeof(DevXfJob));
+    memcpy(hb, xf.data(), n * sizeof(DevXfJob));
+    HIP_CHECK(hipMemcpyAsync(c->s_chip.p, hb, n * sizeof(DevXfJob), hipMemcpyHostToDevice, c->stream));
+    c->stage.sent(c->stream);
     ProfScope ps(c, "chip");
     hipLaunchKernelGGL(transform_k, dim3((cols + 63) / 64, rows, n), dim3(64), 0, c->stream, c->s_chip.as<DevXfJob>(), d_out, rows, cols);
 }
@@ -216,12 +218,12 @@ void chip_extract_batch(Ctx* c, const std::vector<ChipJob>& jobs, uint8_t* d_out
     const size_t pyr_bytes = (size_t)max_levels * n * sizeof(DevPyrJob);
     const size_t total = pyr_bytes + n * sizeof(DevXfJob) + 64;
     c->s_chip.ensure(total);
-    c->h_misc.ensure(total);
-    uint8_t* hb = c->h_misc.as<uint8_t>();
+    uint8_t* hb = reinterpret_cast<uint8_t*>(c->stage.take(total));
     for (int l = 0; l < max_levels; ++l) memcpy(hb + (size_t)l * n * sizeof(DevPyrJob), pj[l].data(), n * sizeof(DevPyrJob));
     const size_t xf_off = (pyr_bytes + 15) / 16 * 16;
     memcpy(hb + xf_off, xf.data(), n * sizeof(DevXfJob));
     HIP_CHECK(hipMemcpyAsync(c->s_chip.p, hb, xf_off + n * sizeof(DevXfJob), hipMemcpyHostToDevice, c->stream));
+    c->stage.sent(c->stream);
     ProfScope ps(c, "chip");
     for (int l = 0; l < max_levels; ++l) {
         if (max_h[l] <= 0 || max_w[l] <= 0) continue;
@@ -230,5 +232,5 @@ void chip_extract_batch(Ctx* c, const std::vector<ChipJob>& jobs, uint8_t* d_out
     }
     hipLaunchKernelGGL(transform_k, dim3((cols + 63) / 64, rows, n), dim3(64), 0, c->stream,
                        reinterpret_cast<const DevXfJob*>(c->s_chip.as<uint8_t>() + xf_off), d_out, rows, cols);
-    HIP_CHECK(hipStreamSynchronize(c->stream)); // h_misc is reused by the next call
+    // (no synchronisation: the descriptors went through a staging buffer of their own, the device scratch is reused in stream order)
 }

@@ -871,7 +871,7 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     PVF_REQUIRE(m.loaded, "detector not loaded");
     PVF_REQUIRE(!frames.empty(), "no frames");
     const int B = (int)frames.size();
-    const int cap = 8192;
+    const int cap = c->det_cand_cap;
     c->s_cand.ensure((size_t)B * cap * sizeof(CandRec) + (size_t)B * sizeof(int) + 64);
     int* d_counts = c->s_cand.as<int>();
     CandRec* d_cands = reinterpret_cast<CandRec*>(c->s_cand.as<uint8_t>() + (((size_t)B * sizeof(int) + 63) / 64) * 64);
@@ -889,7 +889,7 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     raw_sorted.assign(B, {});
     for (int b = 0; b < B; ++b) {
         const int n = h_counts[b];
-        if (n > cap) throw PvfError("detector: candidate buffer overflow (threshold far too low for this input)");
+        if (n > cap) throw CandOverflow(n);
         if (n == 0) continue;
         HIP_CHECK(hipMemcpyAsync(h_cands + (size_t)b * cap, d_cands + (size_t)b * cap, (size_t)n * sizeof(CandRec), hipMemcpyDeviceToHost,
                                  c->stream));
@@ -941,7 +941,7 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
         }
         return;
     }
-    const int cap = 8192, PF = DET_PREFETCH;
+    const int cap = c->det_cand_cap, PF = DET_PREFETCH;
     ScoreParams sp;
     for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
     sp.n_filters = m.n_filters; sp.cap = cap;
@@ -976,7 +976,10 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
         std::vector<CandRec> big;
         for (int b = 0; b < B; ++b) {
             const int n = h_counts[b];
-            if (n > cap) throw PvfError("detector: candidate buffer overflow (threshold far too low for this input)");
+            if (n > cap) {
+                HIP_CHECK(hipStreamSynchronize(c->stream));         // the next batch is in flight on the shared scratch: let it finish before the call is repeated
+                throw CandOverflow(n);
+            }
             std::vector<RawDet> sorted_raw;
             std::vector<RawDet>& dst = nms ? sorted_raw : raw_sorted[o + b];
             if (n <= PF) decode_candidates(m, upsample, h_cands + (size_t)b * PF, n, dst);

@@ -803,8 +803,10 @@ static DsstBuffers prepare(Ctx* c, const std::vector<Tracker*>& t, const std::ve
     b.pos = reinterpret_cast<double*>(q); q += (size_t)n * 4 * sizeof(double);
     b.jobs = reinterpret_cast<TrkJob*>(q);
     for (int i = 0; i < n; ++i) jobs[i].pos = b.pos + 4 * (size_t)i;
-    HIP_CHECK(hipMemcpyAsync(b.jobs, jobs.data(), (size_t)n * sizeof(TrkJob), hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    void* hj = c->stage.take((size_t)n * sizeof(TrkJob));
+    memcpy(hj, jobs.data(), (size_t)n * sizeof(TrkJob));
+    HIP_CHECK(hipMemcpyAsync(b.jobs, hj, (size_t)n * sizeof(TrkJob), hipMemcpyHostToDevice, c->stream));
+    c->stage.sent(c->stream);
     hipLaunchKernelGGL(init_pos_k, dim3((4 * n + 255) / 256), dim3(256), 0, c->stream, b.jobs, n);
     return b;
 }
@@ -865,7 +867,8 @@ void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<F
         hipLaunchKernelGGL(scale_start_k, dim3(n), dim3(256), 0, c->stream, b.jobs, b.Fs, c->ttab.d_tw32);
     }
     HIP_CHECK(hipGetLastError());
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    // start_track returns nothing: the call ends with its kernels queued, and the host work of the next call (the first updates of
+    // these trackers, usually) runs beside them
 }
 
 // mode 0: dlib's update().  mode 1 (deferred): the same response, peak, position and confidence, but the translation and

@@ -18,6 +18,8 @@
 #define PVF_FHOG_STRIDE 32
 
 struct PvfError : std::runtime_error { using std::runtime_error::runtime_error; };
+// a frame produced more raw candidates than the context's candidate slots hold: the entry point enlarges them and runs the call again
+struct CandOverflow : PvfError { int needed; explicit CandOverflow(int n) : PvfError("detector: candidate buffer overflow"), needed(n) {} };
 
 #define HIP_CHECK(expr)                                                                              \
     do {                                                                                             \
@@ -68,6 +70,32 @@ struct HostBuf {
     }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
     ~HostBuf() { if (p) (void)hipHostFree(p); }
+};
+
+// Pinned staging buffers for the small descriptor tables a batched call uploads (tracker jobs, chip plans): a call takes the next
+// buffer of the ring, fills it, queues the copy and moves on -- no stream synchronisation just to keep a host vector alive.  A buffer
+// is handed out again only after the copy that read it has run (its event).
+struct StageRing {
+    static constexpr int N = 8;
+    HostBuf buf[N];
+    hipEvent_t ev[N] = {};
+    bool busy[N] = {};
+    int next = 0, cur = 0;
+    void* take(size_t bytes)
+    {
+        cur = next;
+        next = (next + 1) % N;
+        if (busy[cur]) { HIP_CHECK(hipEventSynchronize(ev[cur])); busy[cur] = false; }
+        buf[cur].ensure(bytes);
+        return buf[cur].p;
+    }
+    void sent(hipStream_t st)      // the copy out of the buffer taken last has been queued on `st`
+    {
+        if (!ev[cur]) HIP_CHECK(hipEventCreateWithFlags(&ev[cur], hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(ev[cur], st));
+        busy[cur] = true;
+    }
+    ~StageRing() { for (auto e : ev) if (e) (void)hipEventDestroy(e); }
 };
 
 struct Tensor {
@@ -196,11 +224,13 @@ struct Ctx {
     // scratch (grow only)
     DevBuf s_grad, s_pyr, s_hist, s_norm, s_feat, s_cand, s_misc, s_chip, s_chip_pyr, s_act0, s_act1, s_act2, s_trk0, s_trk1, s_trk2, s_clu0, s_clu1;
     HostBuf h_cand, h_misc;
+    StageRing stage;
     // det_run_many: alternating candidate buffers / frame-pointer tables / completion events of the two batches in flight
     DevBuf s_cand2[2], s_fptr[2];
     HostBuf h_cand2[2], h_fptr[2];
     hipEvent_t det_ev[2] = {nullptr, nullptr};
     int det_slot = 0;
+    int det_cand_cap = 8192;                  // raw candidates per frame the scoring kernel can record (grown on demand, api.hip)
     int n_cu = 256;
     // released frame buffers by size.  A buffer comes back with the event recorded on the compute stream at its release: whoever takes it
     // next orders its first write behind that event (pool_take), so releasing a frame never waits for the kernels that still read it.

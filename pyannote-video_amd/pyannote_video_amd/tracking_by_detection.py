@@ -147,16 +147,25 @@ class HipTrackers(object):
         hs_b = ctx.tracker_clone_many(hs_f, as_array=True)          # before any update touches the originals
         last = len(cache) - 1
         starts = np.concatenate([[0], np.cumsum(counts)])
-        plans = []
-        for hs, step, edge in ((hs_f, 1, last), (hs_b, -1, 0)):
-            upd = np.nonzero(owner != edge)[0]
+        # the first updates of both passes in ONE batched call per chunk (forward trackers on frame i + 1, their clones on frame i - 1):
+        # one set of launches and one wait for results instead of two
+        sides = ((hs_f, 1, last), (hs_b, -1, 0))
+        upd = [np.nonzero(owner != edge)[0] for _, _, edge in sides]
+        all_h = np.concatenate([hs[u] for (hs, _, _), u in zip(sides, upd)]) if n else np.zeros(0, np.uint64)
+        all_f = np.concatenate([fh[owner[u] + step] for (_, step, _), u in zip(sides, upd)]) if n else np.zeros(0, np.uint64)
+        all_p = np.zeros(len(all_h), np.float64)
+        all_b = np.zeros((len(all_h), 4), np.float64)
+        for o in range(0, len(all_h), chunk):
+            p, b = ctx.tracker_update_many(all_h[o:o + chunk], all_f[o:o + chunk], True)
+            all_p[o:o + chunk] = p
+            all_b[o:o + chunk] = b
+        plans, o = [], 0
+        for (hs, step, edge), u in zip(sides, upd):
             psr = np.zeros(n, np.float64)
             pos = np.zeros((n, 4), np.float64)
-            for o in range(0, len(upd), chunk):
-                ks = upd[o:o + chunk]
-                p, b = ctx.tracker_update_many(hs[ks], fh[owner[ks] + step], True)
-                psr[ks] = p
-                pos[ks] = b
+            psr[u] = all_p[o:o + len(u)]
+            pos[u] = all_b[o:o + len(u)]
+            o += len(u)
             hl = hs.tolist()
             plan = {}
             for i, (t, _) in enumerate(cache):

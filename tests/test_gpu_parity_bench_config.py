@@ -120,3 +120,31 @@ def test_detector_other_configs_single_frame(ctx_full, oracle, size):
     want = det.detect(f, 1)
     assert boxes == [tuple(d[5]) for d in want] and len(boxes) >= (6 if w < 3000 else 25)
     assert np.array_equal(scores, np.array([d[0] for d in want], np.float32))
+
+
+def test_crowded_frame_overflows_the_default_slots_and_dense_nms(ctx_full, oracle):
+    """A 1080p frame with 96 faces: more detections than the 64 result slots per frame `detect_many` starts with (the call repeats itself
+    with room for every detection), and -- with the threshold lowered by 0.5 -- thousands of raw candidates (beyond the 512 per frame
+    copied back ahead: the on-demand fetch) whose overlapping boxes the greedy suppression has to walk in the canonical order.  Boxes,
+    scores and their order == the CPU oracle, also in batches where crowded and ordinary frames alternate."""
+    from pyannote_video_amd import synth
+    crowd = synth.SyntheticVideo(width=1920, height=1080, n_frames=2, n_shots=1, faces=96, min_face=60, max_face=120, seed=77)
+    plain = synth.SyntheticVideo(width=1920, height=1080, n_frames=2, n_shots=1, faces=8, seed=20260925)
+    fc, fp = crowd.frame(1), plain.frame(0)
+    det = _oracle_detector(oracle)
+    want_c, want_p = det.detect(fc, 1), det.detect(fp, 1)
+    assert len(want_c) > 64 and len(want_p) >= 6
+    dev = [ctx_full.upload(fc), ctx_full.upload(fp)]
+    res = ctx_full.detect_many([dev[i % 2] for i in range(12)], 4, 1)              # cap = 64 slots -> repeated with 512
+    for i, (boxes, scores) in enumerate(res):
+        w = want_c if i % 2 == 0 else want_p
+        assert boxes == [tuple(d[5]) for d in w]
+        assert np.array_equal(scores, np.array([d[0] for d in w], np.float32))
+    # lowered threshold: a dense candidate cloud, more than the 8192 candidate slots a frame starts with (they grow on demand)
+    raw = det.detect_raw(fc, 1, -0.5)
+    assert len(raw) > 8192
+    low = det.detect(fc, 1, -0.5)
+    out, sc, cnt = ctx_full.detect_many([dev[0], dev[1], dev[0]], 2, 1, adjust_threshold=-0.5, arrays=True)
+    assert cnt[0] == cnt[2] == len(low) > len(want_c)
+    assert out[0, :cnt[0]].tolist() == [list(d[5]) for d in low] and np.array_equal(out[2, :cnt[2]], out[0, :cnt[0]])
+    assert np.array_equal(sc[0, :cnt[0]], np.array([d[0] for d in low], np.float32))
