@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--shots", type=int, default=None)
     ap.add_argument("--clips", type=int, default=64, help="c4: number of clips in the farm")
     ap.add_argument("--detect-batch", type=int, default=None, help="frames whose pyramids, features and scores are resident together (one scoring launch per batch; 128 up to 1080p, 32 at 4K)")
+    ap.add_argument("--detect-every", type=float, default=0.0, help="`--every` of the track verb: run the detector every that many seconds only (reference "
+                    "tracking.py:383-386,425; 0 = every frame, the benched configuration); the trackers carry the faces in between")
     ap.add_argument("--no-dropin", action="store_true", help="skip the extra passes through the pyannote-face verbs (track / extract / cluster / process)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): every rank owns --frames frames of an N x --frames video; strong: ONE video of --frames frames "
@@ -120,7 +122,7 @@ def main():
 
     ctx = Context(device=local_rank)
     frames = [ctx.wrap_torch(frames_t[i]) for i in range(n_local)]
-    pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap)
+    pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap, detect_every=args.detect_every)
 
     def step():
         tm = {}
@@ -207,11 +209,14 @@ def main():
                 "avg_launch_ms": round(score_ms / launches, 4),
                 "flop_per_launch": flop_per_frame * n_score_frames / launches}
 
-    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read inside this process);
-    # the committed measurement is attached when it was taken on this configuration.
+    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read inside this process); the
+    # committed measurement is attached only when it was taken on this configuration AND on this source of the kernel (hash of
+    # csrc/detect.hip): a changed kernel drops the figure instead of carrying a stale one.
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_score.json")))
-        if pm["detect_batch"] == args.detect_batch and pm["frame"] == "%dx%d" % (args.width, args.height):
+        import hashlib
+        src_hash = hashlib.sha256(open(os.path.join(ROOT, "pyannote-video_amd", "csrc", "detect.hip"), "rb").read()).hexdigest()[:16]
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_score.json")))
+        if pm["detect_batch"] == args.detect_batch and pm["frame"] == "%dx%d" % (args.width, args.height) and pm.get("detect_hip_sha256_16") == src_hash:
             roofline["traffic"] = pm["traffic_bytes_per_launch"]
             roofline["traffic_source"] = pm["source"]
             roofline["algorithmic_bytes_per_launch"] = sum(g[2] * g[3] for g in geo) * 128.0 * n_score_frames / launches   # features read once
@@ -225,7 +230,7 @@ def main():
     if world == 1 and not args.no_host_ingest and args.config == "c2":
         host = host_ingest_pass(ctx, pipe, frames_t, times, video, shots, args)
     dropin = None
-    if world == 1 and not args.no_dropin and args.config == "c2":
+    if world == 1 and not args.no_dropin and args.config == "c2" and args.detect_every == 0.0:
         dropin = dropin_cli_pass(ctx, frames, video, lp, ep, fps, res, labels)
 
     n_clusters = len(set(labels.values()))
@@ -239,7 +244,7 @@ def main():
         "config": {"workload": "configs[%d]: synthetic %dx%d %g fps, %d frames, %d shots, %d faces/frame %s, frames resident in HBM"
                                % (1 if args.config == "c2" else 4, args.width, args.height, args.fps, args.frames, args.shots, args.faces,
                                   "in total, one video cut into shot ranges" if (args.scaling == "strong" and world > 1) else "per GPU"),
-                   "detect_every": 0, "upsample": 1, "tracking": "forward+backward DSST, CLI defaults (overlap 0.5, conf 10, gap 1.0)",
+                   "detect_every": args.detect_every, "upsample": 1, "tracking": "forward+backward DSST, CLI defaults (overlap 0.5, conf 10, gap 1.0)",
                    "parallelism": "shot-range sharding x%d + all-gather of track embeddings" % world if world > 1 else "single GPU",
                    "detect_batch": args.detect_batch, "collective": pdist.collective_name()},
         "roofline": roofline,
@@ -682,7 +687,7 @@ def cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args):
         pool = concurrent.futures.ThreadPoolExecutor(min(threads, 32)) if threads > 1 else None
         note("oracle flow on %d frames, %d threads" % (len(idx), threads))
         t0 = time.perf_counter()
-        tracks = ref_flow.track_video(frames, times, shots, det, lambda: oracle.Tracker(tabs), video.frame_rate,
+        tracks = ref_flow.track_video(frames, times, shots, det, lambda: oracle.Tracker(tabs), video.frame_rate, detect_every=args.detect_every,
                                       min_conf=pipeline.CLI_MIN_CONFIDENCE, ratio=pipeline.CLI_MIN_OVERLAP_RATIO, max_gap=pipeline.CLI_MAX_GAP, pool=pool)
         t_track = time.perf_counter() - t0
         note("  detect + tracking done (%.1f s)" % t_track)
@@ -723,7 +728,7 @@ def cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args):
         "labels": "exact" if res["labels"] == labels else "MISMATCH",
         "tracks": len(tracks), "faces": int(len(ref_e)),
     }
-    if video.n_shots >= 4 and args.config == "c2":
+    if video.n_shots >= 4 and args.config == "c2" and args.detect_every == 0.0:
         # a second, smaller window at the LAST cut of the clip (shots 3 | 4): other faces, other backgrounds, other tracker histories
         cut2 = video.shot_bounds[video.n_shots - 1]
         idx2 = list(range(cut2 - 4, cut2 + 4))

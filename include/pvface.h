@@ -154,6 +154,10 @@ int32_t pvf_landmarks(pvf_handle ctx, const pvf_handle* frames, const pvf_rect_i
 /* ref: face.py:73-76  face_recognition_.compute_face_descriptor(rgb, landmarks) -> 128 floats */
 int32_t pvf_embed(pvf_handle ctx, const pvf_handle* frames, const int32_t* pts /* n*68*2 */, int32_t n,
                   float* out /* n*128 */);
+/* ref: pyannote-face.py:296-297  landmarks = face.get_landmarks(rgb, face); embedding = face.get_embedding(rgb, landmarks) -- both for a
+ * batch of faces in one call (same results as pvf_landmarks followed by pvf_embed) */
+int32_t pvf_landmarks_embed(pvf_handle ctx, const pvf_handle* frames, const pvf_rect_i32* boxes, int32_t n,
+                            int32_t* pts /* n*68*2 */, float* out /* n*128 */);
 /* the network alone on ready-made 150x150x3 chips (host buffer), for testing K7 in isolation */
 int32_t pvf_embed_chips(pvf_handle ctx, const uint8_t* chips, int32_t n, float* out /* n*128 */);
 /* the aligned chips alone (get_face_chip_details + extract_image_chips), for testing K6 in isolation */

@@ -563,6 +563,29 @@ extern "C" int32_t pvf_embed(pvf_handle h, const pvf_handle* frames, const int32
     API_END
 }
 
+// landmarks and descriptors of n faces in one call: what `extract` does per face (pyannote-face.py:296-297: get_landmarks, then
+// get_embedding on the result), for a whole batch, without a trip through the caller between the two (the caller's thread may be busy:
+// the tracking state machine of the next shot runs in the same interpreter)
+extern "C" int32_t pvf_landmarks_embed(pvf_handle h, const pvf_handle* frames, const pvf_rect_i32* boxes, int32_t n, int32_t* pts, float* out)
+{
+    API_BEGIN
+    ENTER(c, h);
+    if (n == 0) return 0;
+    PVF_REQUIRE(frames && boxes && pts && out, "pvf_landmarks_embed: bad arguments");
+    {
+        std::vector<Frame> f(n);
+        for (int i = 0; i < n; ++i) f[i] = c->frame(frames[i]);
+        ert_run(c, f, boxes, n, pts);
+    }
+    const int CH = 1024; // faces per chip-extraction round
+    for (int i0 = 0; i0 < n; i0 += CH) {
+        const int m = std::min(CH, n - i0);
+        uint8_t* d = make_face_chips(c, frames + i0, pts + (size_t)i0 * 136, m);
+        resnet_forward(c, d, m, out + (size_t)i0 * 128);
+    }
+    API_END
+}
+
 extern "C" int32_t pvf_embed_chips(pvf_handle h, const uint8_t* chips, int32_t n, float* out)
 {
     API_BEGIN

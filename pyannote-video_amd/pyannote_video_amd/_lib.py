@@ -66,6 +66,7 @@ _SIGS = {
     "pvf_associate": (C.c_int32, [P, C.c_int32, P, C.c_int32, C.c_double, P]),
     "pvf_landmarks": (C.c_int32, [H, P, P, C.c_int32, P]),
     "pvf_embed": (C.c_int32, [H, P, P, C.c_int32, P]),
+    "pvf_landmarks_embed": (C.c_int32, [H, P, P, C.c_int32, P, P]),
     "pvf_embed_chips": (C.c_int32, [H, P, C.c_int32, P]),
     "pvf_face_chips": (C.c_int32, [H, P, P, C.c_int32, P]),
     "pvf_pair_mean_dist": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, P]),

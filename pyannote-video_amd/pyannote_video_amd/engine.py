@@ -125,9 +125,13 @@ class ExtractStream(object):
         """GPU part: landmarks + embeddings of one batch of faces returned by prepare(); batches must arrive in order"""
         face_frames, boxes = work[0], work[1]
         if boxes:
-            pts = self.ctx.landmarks(face_frames, boxes)
+            if hasattr(self.ctx, "landmarks_embed"):
+                pts, emb = self.ctx.landmarks_embed(face_frames, boxes)      # one library call: no interpreter between the two stages
+            else:
+                pts = self.ctx.landmarks(face_frames, boxes)
+                emb = self.ctx.embed(face_frames, pts)
             self.pts.append(pts)
-            self.emb.append(self.ctx.embed(face_frames, pts))
+            self.emb.append(emb)
 
     def prepare(self, tracks):
         """host part for the normalised tracks of the next shot (in shot order): the track-file rows, their timestamp groups,

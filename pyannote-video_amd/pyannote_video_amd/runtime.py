@@ -420,6 +420,18 @@ class Context(object):
             check(self._l.pvf_embed(self._h, ptr(self._handles(frames)), ptr(pts), n, ptr(out)))
         return out
 
+    def landmarks_embed(self, frames, boxes):
+        """landmarks() then embed() of the same faces in one library call: (int32 [n, 68, 2], float32 [n, 128])"""
+        n = len(boxes)
+        pts = np.zeros((n, 68, 2), np.int32)
+        out = np.zeros((n, 128), np.float32)
+        if n == 0:
+            return pts, out
+        r = np.ascontiguousarray(np.asarray(boxes).astype(np.int64).astype(np.int32)).reshape(n, 4)
+        with self._staging():
+            check(self._l.pvf_landmarks_embed(self._h, ptr(self._handles(frames)), ptr(r), n, ptr(pts), ptr(out)))
+        return pts, out
+
     def face_chips(self, frames, pts):
         pts = np.ascontiguousarray(pts, np.int32).reshape(-1, 68, 2)
         n = len(pts)

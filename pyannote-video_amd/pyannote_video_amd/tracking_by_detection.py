@@ -160,20 +160,14 @@ class HipTrackers(object):
             all_p[o:o + chunk] = p
             all_b[o:o + chunk] = b
         plans, o = [], 0
+        times = [t for t, _ in cache]
         for (hs, step, edge), u in zip(sides, upd):
             psr = np.zeros(n, np.float64)
             pos = np.zeros((n, 4), np.float64)
             psr[u] = all_p[o:o + len(u)]
             pos[u] = all_b[o:o + len(u)]
             o += len(u)
-            hl = hs.tolist()
-            plan = {}
-            for i, (t, _) in enumerate(cache):
-                m = counts[i]
-                if m:
-                    k = int(starts[i])
-                    plan[t] = (hl[k:k + m], psr[k:k + m] if i != edge else None, pos[k:k + m] if i != edge else None)
-            plans.append(plan)
+            plans.append(ArrayPlan(times, counts, starts, hs, psr, pos, edge))
         return plans[0], plans[1]
 
     def speculate_window(self, fh, owner, boxes, n_frames, chunk=4096):
@@ -196,6 +190,29 @@ class HipTrackers(object):
             psr[ks] = p
             pos[ks] = b
         return hs, psr, pos
+
+
+class ArrayPlan(object):
+    """plan[t] -> (handles, psr or None, positions or None) of the trackers started on the detections of the frame at time t, read out
+    of the arrays a bulk call filled.  The per-frame views are made when the lane asks for them, i.e. in the tracking thread: the
+    thread that feeds the GPU hands the arrays over and goes on to the next batch."""
+
+    def __init__(self, times, counts, starts, handles, psr, pos, edge):
+        self.times, self.counts, self.starts, self.hs, self.psr, self.pos, self.edge = times, counts, starts, handles, psr, pos, edge
+        self._index = self._hl = None
+
+    def __getitem__(self, t):
+        if self._index is None:
+            self._index = {t: i for i, t in enumerate(self.times)}
+            self._hl = self.hs.tolist()
+        i = self._index[t]
+        m = self.counts[i]
+        if not m:
+            raise KeyError(t)
+        k = int(self.starts[i])
+        if i == self.edge:
+            return self._hl[k:k + m], None, None
+        return self._hl[k:k + m], self.psr[k:k + m], self.pos[k:k + m]
 
 
 class ObjectTrackers(object):
