@@ -192,6 +192,10 @@ int32_t pvf_cluster_tracks(pvf_handle ctx, const double* X, int32_t N, int32_t d
 int32_t pvf_format_rows(const double* t, const int64_t* identifier, const double* values, int64_t n_rows, int32_t n_cols,
                         int32_t decimals, char* out, int64_t cap, int64_t* written);
 
+/* ref: scripts/pyannote-face.py:307-311, face/clustering.py:70-75  the float64 values `preprocess` reads back from the 5-decimal text of
+ * embedding.txt, computed in memory: out[i] = rint((double)x[i] * 10^decimals) / 10^decimals (== np.round of the float64 value) */
+int32_t pvf_round_rows(const float* x, int64_t n, int32_t decimals, double* out);
+
 /* ---- measurement ----------------------------------------------------------------------------------- */
 /* HIP-event timing of each kernel family on the context's stream ("pyramid","fhog","score","ert","chip","conv",
  * "dsst","pdist","hac"); off by default */

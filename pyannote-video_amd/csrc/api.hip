@@ -554,7 +554,7 @@ extern "C" int32_t pvf_embed(pvf_handle h, const pvf_handle* frames, const int32
     API_BEGIN
     ENTER(c, h);
     if (n == 0) return 0;
-    const int CH = 1024; // faces per chip-extraction round
+    const int CH = 4096; // faces per chip-extraction round = the network's largest forward (resnet_forward: MAXB)
     for (int i0 = 0; i0 < n; i0 += CH) {
         const int m = std::min(CH, n - i0);
         uint8_t* d = make_face_chips(c, frames + i0, pts + (size_t)i0 * 136, m);
@@ -577,7 +577,7 @@ extern "C" int32_t pvf_landmarks_embed(pvf_handle h, const pvf_handle* frames, c
         for (int i = 0; i < n; ++i) f[i] = c->frame(frames[i]);
         ert_run(c, f, boxes, n, pts);
     }
-    const int CH = 1024; // faces per chip-extraction round
+    const int CH = 4096; // faces per chip-extraction round = the network's largest forward (resnet_forward: MAXB)
     for (int i0 = 0; i0 < n; i0 += CH) {
         const int m = std::min(CH, n - i0);
         uint8_t* d = make_face_chips(c, frames + i0, pts + (size_t)i0 * 136, m);
@@ -727,5 +727,37 @@ extern "C" int32_t pvf_format_rows(const double* t, const int64_t* identifier, c
         w += len[r];
     }
     *written = w;
+    API_END
+}
+
+
+// ref: scripts/pyannote-face.py:307-311 + face/clustering.py:70-75: a descriptor reaches the clustering through embedding.txt, i.e. as the
+// float64 value of its 5-decimal text.  In memory: x (float32) -> double -> np.round(x, 5), which numpy evaluates as rint(x * 1e5) / 1e5
+// (three correctly rounded double operations; the same three here, on a few threads -- numpy's own np.round spends 10-28 ms on 8000 x 128
+// values, at the very end of a run, when the GPU has nothing left to do).
+extern "C" int32_t pvf_round_rows(const float* x, int64_t n, int32_t decimals, double* out)
+{
+    API_BEGIN
+    PVF_REQUIRE(n >= 0 && decimals >= 0 && decimals <= 15 && (n == 0 || (x && out)), "pvf_round_rows: bad arguments");
+    double scale = 1.0;
+    for (int d = 0; d < decimals; ++d) scale *= 10.0;
+    auto work = [&](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) {
+            double v = (double)x[i];
+            v = v * scale;
+            // round half to even, like np.rint: below 2^51 adding and subtracting 1.5 * 2^52 IS that rounding (one IEEE addition in the
+            // default mode), and it vectorises; larger magnitudes are integers already or go through nearbyint
+            const double big = 6755399441055744.0;
+            v = (std::fabs(v) < 2251799813685248.0) ? std::copysign((v + big) - big, v) : std::nearbyint(v);      // (copysign: rint keeps -0.0)
+            out[i] = v / scale;
+        }
+    };
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, n / 65536));
+    if (nt == 1) work(0, n);
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nt; ++i) th.emplace_back(work, n * i / nt, n * (i + 1) / nt);
+        for (auto& t : th) t.join();
+    }
     API_END
 }

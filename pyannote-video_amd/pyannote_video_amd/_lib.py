@@ -75,6 +75,7 @@ _SIGS = {
     "pvf_cluster_dist": (C.c_int32, [H, P, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_cluster_tracks": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_format_rows": (C.c_int32, [P, P, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64, P]),
+    "pvf_round_rows": (C.c_int32, [P, C.c_int64, C.c_int32, P]),
     "pvf_prof_enable": (C.c_int32, [H, C.c_int32]),
     "pvf_prof_reset": (C.c_int32, [H]),
     "pvf_prof_get": (C.c_int32, [H, C.c_char_p, P, P]),
@@ -185,6 +186,14 @@ def format_rows(t, identifier, values, decimals=5):
     n = C.c_int64(0)
     check(lib().pvf_format_rows(ptr(t), ptr(ident), ptr(v), len(t), v.shape[1], int(decimals), ptr(buf), cap, C.byref(n)))
     return buf[:n.value].tobytes()
+
+
+def round_rows(x, decimals=5):
+    """np.round(x.astype(float64), decimals) for a float32 array, by the library (pvf_round_rows)"""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape, np.float64)
+    check(lib().pvf_round_rows(ptr(x), x.size, int(decimals), ptr(out)))
+    return out
 
 
 def munkres(cost):

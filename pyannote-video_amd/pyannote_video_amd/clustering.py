@@ -18,7 +18,10 @@ class Features(object):
 
     def __init__(self, time, track, X):
         order = np.lexsort((time, track))
-        self.time, self.track, self.X = time[order], track[order], np.ascontiguousarray(X[order])
+        if len(order) and np.array_equal(order, np.arange(len(order))):
+            self.time, self.track, self.X = time, track, np.ascontiguousarray(X)          # already in (track, time) order: no copy
+        else:
+            self.time, self.track, self.X = time[order], track[order], np.ascontiguousarray(X[order])
 
     def __len__(self):
         return len(self.time)
@@ -80,7 +83,8 @@ class FaceClustering(object):
         keep = np.isin(row_track[order], track_ids)
         rows = order[keep]
         rt = row_track[rows]
-        Xs = np.ascontiguousarray(X[rows], np.float64)
+        # (features that come from preprocess() are in (track, time) order already: when every track takes part nothing moves)
+        Xs = np.ascontiguousarray(X, np.float64) if len(rows) == len(X) and np.array_equal(rows, np.arange(len(X))) else np.ascontiguousarray(X[rows], np.float64)
         counts = np.searchsorted(rt, track_ids, side="right") - np.searchsorted(rt, track_ids, side="left")     # rt is sorted (stable argsort above)
         row_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         cut = float("inf") if self.force else self.threshold

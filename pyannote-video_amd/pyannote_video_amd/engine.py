@@ -506,14 +506,31 @@ class Engine(object):
             shots = ends = 0
             try:
                 def drain():
+                    """everything the tracking thread has handed back so far; the faces of several shots of one job that are waiting
+                    together go through the landmark / embedding kernels as ONE batch (a forward of 4000 faces fills the chip better than
+                    two of 2000: the deep layers' grids are small)"""
+                    msgs = []
                     while True:
                         try:
                             msg = done.get_nowait()
                         except queue.Empty:
-                            return True
+                            break
                         if msg is None:
                             return False
-                        handle(msg, counters)
+                        msgs.append(msg)
+                    i = 0
+                    while i < len(msgs):
+                        kind, job, work = msgs[i]
+                        j = i + 1
+                        if kind == "work" and work is not None:
+                            while j < len(msgs) and msgs[j][0] == "work" and msgs[j][1] is job and msgs[j][2] is not None and len(work[1]) + len(msgs[j][2][1]) <= 4096:
+                                work = (work[0] + msgs[j][2][0], work[1] + msgs[j][2][1], max(work[2], msgs[j][2][2]))
+                                j += 1
+                        handle((kind, job, work), counters)
+                        for _ in range(i + 1, j):
+                            handle(("work", job, None), counters)          # (the merged shots still count as extracted)
+                        i = j
+                    return True
 
                 for item in source:
                     if isinstance(item, JobEnd):

@@ -12,6 +12,7 @@ import time as _time
 import os
 import numpy as np
 from . import formats
+from . import _lib
 from . import runtime as _runtime
 from .face_tracking import FaceTracking
 from .tracking_by_detection import HipTrackers
@@ -113,11 +114,8 @@ class FacePipeline(object):
         face_T = np.asarray(ex.face_T, np.float64)
         face_id = np.asarray(ex.face_id, np.int64)
         # np.round(x, 5) of the float64 value (== parsing the '%.5f' text for these magnitudes; formats.quantise_embedding is the literal
-        # form) written as the three passes numpy makes of it, in place: np.round itself spends 10-28 ms on 8000 x 128 values
-        Xq = emb.astype(np.float64) if len(emb) else np.zeros((0, 128))
-        Xq *= 1e5
-        np.rint(Xq, out=Xq)
-        Xq /= 1e5
+        # form), computed by the library: numpy's own np.round spends 10-28 ms on 8000 x 128 values at the very end of the run
+        Xq = _lib.round_rows(emb, 5) if len(emb) else np.zeros((0, 128))
         labels = {}
         if len(face_T) and cluster:
             starting_point, data = self.clustering.model.preprocess((face_T, face_id, Xq))
