@@ -360,8 +360,12 @@ class _LaneBackend(object):
 class Engine(object):
     """One pass of a source of ShotInput / JobEnd items through the GPU thread and the caller's thread (see the module text)."""
 
-    def __init__(self, ctx, tracking, detect_batch_size=8, overlap=True, speculate_limit=8192, speculate_window=4096):
+    def __init__(self, ctx, tracking, detect_batch_size=8, overlap=True, speculate_limit=8192, speculate_window=4096, group=1):
         self.ctx, self.tracking = ctx, tracking
+        # shots whose passes run in lock-step as ONE set of lanes (tracking.py:359-362: shots are independent).  With detection on every
+        # frame a shot's trackers live for one frame and the bulk calls cover them; with `--every` they live for many frames, updated
+        # frame after frame in small batches -- a latency-bound chain per shot -- and several shots side by side share each of those calls.
+        self.group = max(1, int(group))
         self.detect_batch_size = detect_batch_size
         self.overlap = overlap
         self.speculate_limit, self.speculate_window = int(speculate_limit), int(speculate_window)
@@ -532,15 +536,25 @@ class Engine(object):
                         i = j
                     return True
 
+                group = []
+
+                def flush():
+                    if group:
+                        ready.put(("shots", list(group)))
+                        del group[:]
+
                 for item in source:
                     if isinstance(item, JobEnd):
+                        flush()
                         ends += 1
                         ready.put(("end", item.job))
                         continue
                     si, k = item, shots
-                    # never more than three shots ahead of the tracking thread (a slow state machine -- a crowded shot -- must not let
-                    # detected shots, i.e. their frames, pile up)
-                    while shots - counters["extracted"] >= 3:
+                    if group and group[-1][0].job is not si.job:
+                        flush()
+                    # never more than three shots (or two groups) ahead of the tracking thread (a slow state machine -- a crowded shot --
+                    # must not let detected shots, i.e. their frames, pile up)
+                    while shots - counters["extracted"] >= max(3, 2 * self.group):
                         msg = done.get()
                         if msg is None:
                             return
@@ -563,10 +577,13 @@ class Engine(object):
                         plans = self._speculate(si, backend, lane_backend, raw, counts, boxes)
                     note("speculated", k)
                     shots += 1
-                    ready.put(("shot", si, raw, plans))
+                    group.append((si, raw, plans))
+                    if len(group) >= self.group or (n is not None and k == n - 1):
+                        flush()
                     if n is not None and k == n - 1:
                         if not drain():
                             return
+                flush()
                 ready.put(("stop",))
                 while counters["extracted"] < shots or counters["finals"] < ends:
                     msg = done.get()
@@ -606,20 +623,21 @@ class Engine(object):
                     if on_job_final is not None:
                         on_job_final(job)
                     continue
-                _, si, raw, plans = item
+                members = item[1]
                 note("host begin", k)
-                job = si.job
-                job.accept(si)
-                dets = detections_as_lists(len(si.cache), raw)
-                jb = self.tracking.begin_shot(si.cache, si.flags, dets, lane_backend, plans)
-                self.tracking._run_lanes(jb["lanes"], lane_backend)
+                jbs = []
+                for si, raw, plans in members:
+                    si.job.accept(si)
+                    jbs.append(self.tracking.begin_shot(si.cache, si.flags, detections_as_lists(len(si.cache), raw), lane_backend, plans))
+                self.tracking._run_lanes([lane for jb in jbs for lane in jb["lanes"]], lane_backend)
                 note("lanes done", k)
-                tracks = self.tracking.finish_shot(jb)
-                note("tracked", k)
-                self._release_detection_frames(si)
-                done.put(("work", job, job.shot_tracked(si, tracks, self.tracking._normalize_track)))
-                note("prepared", k)
-                k += 1
+                for (si, _, _), jb in zip(members, jbs):
+                    tracks = self.tracking.finish_shot(jb)
+                    note("tracked", k)
+                    self._release_detection_frames(si)
+                    done.put(("work", si.job, si.job.shot_tracked(si, tracks, self.tracking._normalize_track)))
+                    note("prepared", k)
+                    k += 1
             ok = True
         finally:
             if not ok:

@@ -83,6 +83,7 @@ class FacePipeline(object):
         self.detect_min_size = detect_min_size
         # trackers a shot may hold at once before its bulk starts are windowed (2.39 MB of filters each): engine.WindowedPlan
         self.speculate_limit, self.speculate_window = speculate_limit, speculate_window
+        self.shot_group = 8              # with --every: shots whose passes share their frame-by-frame tracker calls (engine.Engine.group)
         self.last_engine = None
 
     # ---- geometry of one video -------------------------------------------------------------------------------------------------
@@ -100,7 +101,8 @@ class FacePipeline(object):
 
     def _engine(self):
         e = _engine.Engine(self.ctx, self.tracking, detect_batch_size=self.detect_batch_size, overlap=self.overlap,
-                           speculate_limit=self.speculate_limit, speculate_window=self.speculate_window)
+                           speculate_limit=self.speculate_limit, speculate_window=self.speculate_window,
+                           group=(self.shot_group if self.detect_every > 0.0 else 1))
         self.last_engine = e
         return e
 

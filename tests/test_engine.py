@@ -44,12 +44,17 @@ class FakeContext(FakeTrackerContext):
 
     def __init__(self, frames, dets):
         FakeTrackerContext.__init__(self, ModelScriptTracker)
+        self.update_calls = 0
         self.script_of = {f.i: f for f in frames}
         self.dets_of = {f.i: d for f, d in zip(frames, dets)}
         self.detect_calls = 0
 
     def ingest_ring(self, h, w, depth=8):
         return FakeRing(self, h, w)
+
+    def tracker_update_many(self, trks, frames, defer=False):
+        self.update_calls += 1
+        return FakeTrackerContext.tracker_update_many(self, trks, frames, defer)
 
     def detect_many(self, frames, batch, upsample=1, adjust_threshold=0.0, cap=64, arrays=False):
         self.detect_calls += 1
@@ -99,10 +104,10 @@ def make_video(seed, n_shots=4, n=30, **kw):
     return frames, dets, times, shots
 
 
-def run_engine(frames, dets, times, shots, mode, overlap=True, limit=8192, window=4096, extract=True):
+def run_engine(frames, dets, times, shots, mode, overlap=True, limit=8192, window=4096, extract=True, group=1):
     ctx = FakeContext(frames, dets)
     tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0, trackers=HipTrackers(ctx))
-    eng = engine.Engine(ctx, tbd, detect_batch_size=7, overlap=overlap, speculate_limit=limit, speculate_window=window)
+    eng = engine.Engine(ctx, tbd, detect_batch_size=7, overlap=overlap, speculate_limit=limit, speculate_window=window, group=group)
     if mode == "resident":
         job = engine.VideoJob(ctx, 640, 360, frames=frames, times=times, extract=extract)
         src = engine.resident_source(job, frames, times, shots, 1)
@@ -185,6 +190,21 @@ def test_windowed_bulk_tracker_starts_equal_whole_shot_ones(window):
     eng.run(engine.resident_source(job, frames, times, shots, 1), HipTrackers(ctx))
     n_max_shot = max(sum(len(d) for d in dets[i0:i1]) for i0, i1 in engine.split_into_shots(times, shots))
     assert Counting.peak <= 2 * (window + 5) + 12 < n_max_shot
+
+
+def test_shots_grouped_into_one_set_of_lanes_equal_shot_by_shot():
+    """Engine.group (what `--every` uses): the passes of several shots advance in lock-step and share their tracker calls; tracks, faces
+    and descriptors are those of the shot-by-shot run, with fewer (larger) on-demand update calls"""
+    frames, dets, times, shots = make_video(31, n_shots=7, n=24, faces=4, p_miss=0.6, p_false=0.05)      # many misses: trackers live on
+    base = run_engine(frames, dets, times, shots, "resident")
+    calls = []
+    for group in (1, 3, 8):
+        for mode in ("resident", "stream"):
+            got = run_engine(frames, dets, times, shots, mode, group=group)
+            assert got[0] == base[0] and got[1] == base[1], (group, mode)
+            assert np.array_equal(got[2][1], base[2][1])
+        calls.append(got[3].update_calls)
+    assert calls[0] > calls[1] > calls[2]
 
 
 def test_many_jobs_through_one_engine_run_equal_one_run_each():

@@ -47,4 +47,9 @@ timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFM
 DB=$(find /tmp/pmcc -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_mfma_busy.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS -d /tmp/pmcd -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin --steps 1 --warmup 0 > /tmp/pd.log 2>&1
 DB=$(find /tmp/pmcd -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_sq_valu.txt 2>&1
+# the tracker's fused kernels and the clustering kernels, each in the micro-bench that isolates them
+timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CU_CYCLES -d /tmp/pmce -- python $R/tools/bench_dsst.py 2000 2 > /tmp/pe.log 2>&1
+DB=$(find /tmp/pmce -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB | grep -v "at::native\|rocclr" | head -14 > $R/$O/pmc_tracker_sq.txt 2>&1
+rm -rf /tmp/pmcf; timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmcf -- python $R/tools/c5_cluster.py > /tmp/pf.log 2>&1
+DB=$(find /tmp/pmcf -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB | grep -v "at::native\|rocclr" | head -8 > $R/$O/pmc_cluster_mfma.txt 2>&1
 cd $R; grep -h "passed\|failed" $O/tests.log; cat $O/summary.log | cut -c1-400; head -c 700 $O/bench.json; echo; head -14 $O/rocprof_kernel_stats.txt; head -4 $O/pmc_fetch_size.txt; head -3 $O/pmc_mfma_busy.txt
