@@ -119,7 +119,23 @@ static void load_shape(Ctx* c, const char* path)
     s.n_cascades = q[0]; s.n_trees = q[1]; s.n_parts = q[2]; s.n_pix = q[3]; s.depth = q[4];
     PVF_REQUIRE(s.n_parts == 68, "shape predictor: 68 parts expected");
     PVF_REQUIRE(s.depth >= 1 && s.depth <= 6, "shape predictor: tree depth 1..6");
-    PVF_REQUIRE(s.n_pix <= 1024, "shape predictor: at most 1024 feature pixels per cascade");
+    PVF_REQUIRE(s.n_pix >= 1 && s.n_pix <= 1024, "shape predictor: 1..1024 feature pixels per cascade");
+    PVF_REQUIRE(s.n_cascades >= 1 && s.n_trees >= 1, "shape predictor: no cascades / trees");
+    {
+        // the kernel indexes with what the file says: sizes and indices are checked here, once (a corrupt or crafted model file must
+        // not turn into out-of-range device reads)
+        const size_t splits = (size_t)s.n_cascades * s.n_trees * (((size_t)1 << s.depth) - 1), leaves = (size_t)s.n_cascades * s.n_trees * ((size_t)1 << s.depth);
+        PVF_REQUIRE(need(m, "sp.initial_shape").numel() == 136 && need(m, "sp.anchor_idx").numel() == (size_t)s.n_cascades * s.n_pix &&
+                    need(m, "sp.deltas").numel() == (size_t)s.n_cascades * s.n_pix * 2 && need(m, "sp.split_idx1").numel() == splits &&
+                    need(m, "sp.split_idx2").numel() == splits && need(m, "sp.split_thresh").numel() == splits &&
+                    need(m, "sp.leaves").numel() == leaves * 136, "shape predictor: tensor sizes do not match sp.meta");
+        const int32_t* a = need(m, "sp.anchor_idx").i32();
+        for (size_t k = 0; k < (size_t)s.n_cascades * s.n_pix; ++k) PVF_REQUIRE(a[k] >= 0 && a[k] < s.n_parts, "shape predictor: anchor index out of range");
+        const int32_t* i1 = need(m, "sp.split_idx1").i32();
+        const int32_t* i2 = need(m, "sp.split_idx2").i32();
+        for (size_t k = 0; k < splits; ++k)
+            PVF_REQUIRE(i1[k] >= 0 && i1[k] < s.n_pix && i2[k] >= 0 && i2[k] < s.n_pix, "shape predictor: split feature index out of range");
+    }
     auto up_f = [&](const char* k) { const Tensor& t = need(m, k); return upload<float>(t.f32(), t.numel()); };
     auto up_i = [&](const char* k) { const Tensor& t = need(m, k); return upload<int32_t>(t.i32(), t.numel()); };
     s.d_initial = up_f("sp.initial_shape");

@@ -46,7 +46,11 @@ struct DlibStream {
     void matrix_f32(std::vector<float>& out, int64_t* nr, int64_t* nc)
     {
         *nr = -integer(); *nc = -integer();
-        if (*nr < 0 || *nc < 0 || (uint64_t)(*nr) * (uint64_t)(*nc) > ((uint64_t)1 << 32)) fail("matrix header");
+        // every element takes at least two bytes in the stream (mantissa and exponent integers of one byte each plus their control
+        // bytes are four; two is a safe floor): a header that promises more elements than the remaining bytes can hold is corrupt, and
+        // is refused BEFORE anything is allocated for it
+        const uint64_t left = (uint64_t)(b.size() - o);
+        if (*nr < 0 || *nc < 0 || (uint64_t)(*nr) > left || (uint64_t)(*nc) > left || (uint64_t)(*nr) * (uint64_t)(*nc) > left / 2) fail("matrix header");
         const size_t n = (size_t)(*nr) * (size_t)(*nc);
         const size_t base = out.size();
         out.resize(base + n);
@@ -56,8 +60,14 @@ struct DlibStream {
     {
         if (integer() != 2) fail("tensor version");
         uint64_t n = 1;
-        for (int i = 0; i < 4; ++i) { dims[i] = integer(); if (dims[i] < 0) fail("tensor dims"); n *= (uint64_t)dims[i]; }
-        if (o + 4 * n > b.size()) fail("tensor data");
+        const uint64_t left = (uint64_t)(b.size() - o);
+        for (int i = 0; i < 4; ++i) {
+            dims[i] = integer();
+            if (dims[i] < 0 || (uint64_t)dims[i] > left) fail("tensor dims");
+            n *= (uint64_t)dims[i];                                  // each factor <= left < 2^63 / 4 only after the check below: test as we go
+            if (n > left / 4 + 1) fail("tensor dims");
+        }
+        if (n > (uint64_t)(b.size() - o) / 4) fail("tensor data");
         out.resize(n);
         if (n) memcpy(out.data(), b.data() + o, 4 * n);     // little-endian host
         o += 4 * n;
@@ -103,14 +113,16 @@ std::map<std::string, Tensor> read_shape_predictor(const char* path)
     for (int64_t c = 0; c < n_casc; ++c) {
         const int64_t nt = s.integer();
         if (n_trees < 0) n_trees = nt;
-        if (nt != n_trees || nt <= 0) s.fail("tree count");
+        if (nt != n_trees || nt <= 0 || nt > 100000) s.fail("tree count");
         for (int64_t t = 0; t < nt; ++t) {
             const int64_t ns = s.integer();
             if (n_split < 0) n_split = ns;
-            if (ns != n_split || ns <= 0) s.fail("split count");
+            if (ns != n_split || ns <= 0 || ns > 63) s.fail("split count");
             for (int64_t k = 0; k < ns; ++k) {
-                idx1.push_back((int32_t)s.integer());
-                idx2.push_back((int32_t)s.integer());
+                const int64_t i1 = s.integer(), i2 = s.integer();
+                if (i1 < 0 || i2 < 0 || i1 > 0x7fffffff || i2 > 0x7fffffff) s.fail("split feature index");     // (< n_pix is checked once n_pix is known)
+                idx1.push_back((int32_t)i1);
+                idx2.push_back((int32_t)i2);
                 thresh.push_back((float)s.real());
             }
             const int64_t nl = s.integer();
@@ -130,8 +142,12 @@ std::map<std::string, Tensor> read_shape_predictor(const char* path)
     for (int64_t c = 0; c < n_casc; ++c) {
         const int64_t n = s.integer();
         if (n_pix < 0) n_pix = n;
-        if (n != n_pix || n <= 0) s.fail("anchor count");
-        for (int64_t k = 0; k < n; ++k) anchor.push_back((int32_t)s.integer());
+        if (n != n_pix || n <= 0 || n > 1024) s.fail("anchor count");
+        for (int64_t k = 0; k < n; ++k) {
+            const int64_t a = s.integer();
+            if (a < 0 || 2 * a >= (int64_t)initial.size()) s.fail("anchor index beyond the shape's parts");
+            anchor.push_back((int32_t)a);
+        }
     }
     std::vector<float> deltas;
     if (s.integer() != n_casc) s.fail("deltas size");
@@ -139,6 +155,8 @@ std::map<std::string, Tensor> read_shape_predictor(const char* path)
         if (s.integer() != n_pix) s.fail("delta count");
         for (int64_t k = 0; k < 2 * n_pix; ++k) deltas.push_back((float)s.real());
     }
+    for (size_t k = 0; k < idx1.size(); ++k)
+        if (idx1[k] >= n_pix || idx2[k] >= n_pix) s.fail("split feature index beyond the cascade's feature pixels");
     int depth = 0;
     while (((int64_t)1 << depth) < n_leaf) ++depth;
     if (((int64_t)1 << depth) != n_leaf) s.fail("trees are not complete binary trees");
@@ -189,6 +207,7 @@ std::map<std::string, Tensor> read_embedder(const char* path)
         if (buf[o] == 'c') tag_at(o, "con_", 0);
         else if (buf[o] == 'a') tag_at(o, "affine_", 1);
         else if (buf[o] == 'f') tag_at(o, "fc_", 2);
+        else if (buf[o] == 'b') tag_at(o, "bn_con", 3);          // "bn_con2": a model serialised from the TRAINING net (see below)
     }
     struct Conv { std::vector<float> p; int64_t nf, nr, nc; };
     std::vector<Conv> cons;
@@ -201,7 +220,26 @@ std::map<std::string, Tensor> read_embedder(const char* path)
             if (r.kind == 2) { s.integer(); s.integer(); }     // num_outputs, bias_mode
             std::vector<float> p;
             s.tensor(p, dims);
-            if (r.kind == 0) {
+            if (r.kind == 3) {
+                // [EXT] bn_ (dlib/dnn/layers.h, "bn_con2"): params (gamma then beta), then the tensors means, invstds, running_means,
+                // running_variances, then num_updates, running_stats_window_size, learning-rate / weight-decay multipliers and eps.
+                // dlib's affine_ deserialiser accepts such a record and turns it into gamma' = gamma / sqrt(var + eps),
+                // beta' = beta - mean * gamma'; the same here, in float like dlib.
+                std::vector<float> means, invstds, rmean, rvar;
+                s.tensor(means, dims); s.tensor(invstds, dims); s.tensor(rmean, dims); s.tensor(rvar, dims);
+                s.integer(); s.integer();                                  // num_updates, running_stats_window_size
+                s.real(); s.real(); s.real(); s.real();                    // learning_rate / weight_decay multipliers (+ bias ones)
+                const double eps = s.real();
+                const size_t ch = p.size() / 2;
+                if (p.size() % 2 || rmean.size() != ch || rvar.size() != ch || !(eps > 0 && eps < 1)) throw PvfError("bn record");
+                std::vector<float> gb(2 * ch);
+                for (size_t k = 0; k < ch; ++k) {
+                    const float g = p[k] / std::sqrt(rvar[k] + (float)eps);
+                    gb[k] = g;
+                    gb[ch + k] = p[ch + k] - rmean[k] * g;
+                }
+                affs.push_back(std::move(gb));
+            } else if (r.kind == 0) {
                 Conv c;
                 c.nf = s.integer(); c.nr = s.integer(); c.nc = s.integer();
                 c.p = std::move(p);

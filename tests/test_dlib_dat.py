@@ -70,3 +70,29 @@ def test_c_loader_rejects_garbage(tmp_path):
         _lib.model_tensor(p, 1, "sp.meta", np.int32)
     with pytest.raises(_lib.PvfError):
         _lib.model_tensor(p, 2, "emb.blob", np.float32)
+
+
+def test_c_loader_bounds_what_a_file_may_ask_for(dat_files, tmp_path):
+    """a corrupt or crafted model file must be refused while it is parsed: sizes are bounded by the bytes that are there (nothing is
+    allocated for a header that promises 2^31 elements), and feature / anchor indices outside the model never reach the device"""
+    sp, _, _, _ = dat_files
+    # a matrix header of 2^31 x 2^31 elements in a 40-byte file
+    w = models.DlibWriter(); w.int(1); w.int(-(2 ** 31)); w.int(-(2 ** 31))
+    p = str(tmp_path / "huge.dat")
+    open(p, "wb").write(w.bytes() + b"\x01\x01" * 16)
+    with pytest.raises(_lib.PvfError, match="matrix header"):
+        _lib.model_tensor(p, 1, "sp.meta", np.int32)
+    # a split that reads feature pixel n_pix (one past the end), an anchor that names part 68
+    for key, bad, what in (("sp.split_idx1", 120, "split feature index"), ("sp.split_idx2", 7000, "split feature index"), ("sp.anchor_idx", 68, "anchor index")):
+        broken = {k: v.copy() for k, v in sp.items()}
+        broken[key].reshape(-1)[5] = bad
+        p = str(tmp_path / ("bad_%s.dat" % key))
+        models.write_dlib_shape_predictor(p, broken)
+        with pytest.raises(_lib.PvfError, match=what):
+            _lib.model_tensor(p, 1, "sp.meta", np.int32)
+    # a tensor record whose dimensions multiply past the end of the file
+    w = models.DlibWriter(); w.string("con_1"); w.int(2); w.int(2 ** 20); w.int(2 ** 20); w.int(2 ** 20); w.int(1)
+    p = str(tmp_path / "tensor.dat")
+    open(p, "wb").write(b"\x00\x00" + w.bytes() + b"\x00" * 64)
+    with pytest.raises(_lib.PvfError, match="expected 29 con"):          # the record is skipped as a look-alike, the file then lacks its layers
+        _lib.model_tensor(p, 2, "emb.blob", np.float32)
