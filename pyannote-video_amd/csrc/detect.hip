@@ -22,13 +22,20 @@
 // bytes, lanes 0..47 collect the two packed pixels their dword straddles through the LDS crossbar (ds_bpermute) and store once.
 // Needs 4-byte aligned output rows (level images of the batched path have a padded row pitch).
 #define RESIZE_MAXS 22
+// per output row of a resize stage, computed once on the host with the oracle's double arithmetic (y = r * y_scale; top = floor(y);
+// bottom = min(top + 1, ih - 1); tb = y - top; tb1 = 1 - tb): the row loop reads it through the scalar cache instead of redoing
+// wave-uniform double arithmetic in every lane.  32 bytes = one aligned s_load_dwordx8.
+struct RowTab { int32_t top, bottom; double tb, tb1, pad; };
+
 template <int RS>
 __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
                                                      size_t in_stride, int in_rb, int ih, int iw, uint8_t* __restrict__ out,
-                                                     size_t out_stride, int out_rb, int oh, int ow, double x_scale, double y_scale)
+                                                     size_t out_stride, int out_rb, int oh, int ow, double x_scale,
+                                                     const RowTab* __restrict__ rows)
 {
     constexpr int MAXS = RESIZE_MAXS;
     __shared__ uint32_t s_rows[4][MAXS][64];
+    __shared__ __attribute__((aligned(16))) float s_cvt[4][256 + 8];     // one source row's window as floats (exact: bytes), per wave
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = blockIdx.x * 256 + wave * 64;               // first column of this wave's segment
@@ -44,8 +51,8 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     const bool has_right = (left + 1 <= iw - 1);
     const double lr = x - left, lr1 = 1 - lr;
     const int r_end = min(r0 + RS, oh);
-    const int s_first = (int)floor(r0 * y_scale);
-    const int s_last = min((int)floor((r_end - 1) * y_scale) + 1, ih - 1);
+    const int s_first = rows[r0].top;
+    const int s_last = rows[r_end - 1].bottom;
     // stage the source rows: dword `lane` of the 256-byte window that starts at the aligned address below the wave's first pixel.
     // Branch-free so that all loads are in flight together: a dword that lies wholly past the frame is redirected to the frame's
     // last word (never used; an aligned dword cannot straddle a page, so the word holding the last byte is always readable).
@@ -72,29 +79,36 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     const int bp0 = 4 * min(pa_lane, 63), bp1 = 4 * min(pa_lane + 1, 63);
     const int seg_bytes = min(ow - c0, 64) * 3;
     const bool stores = (4 * lane < seg_bytes);
+    // this lane's two source pixels inside the window: `dl` floats from the window's first byte to the left pixel's first channel
+    // (without the row's alignment offset, added per row); a lane without a right neighbour blends its own pixel with itself
+    // (oracle/pvo_image.c): its "right" pixel is read from the left one's slots
+    const int dl = 3 * (left - left0), ro = has_right ? 3 : 0;
+    float* cv = s_cvt[wave];
     int s0 = -1, s1 = -1;              // cached source rows
     double h0[3], h1[3];
+    // The horizontal blend of a source row.  Round 2 had every lane dig its six bytes out of three staged dwords (12 shift / mask / select
+    // instructions) and convert each to double (6): per OUTPUT pixel.  Now the wave converts the row's 256-byte window once -- a lane
+    // turns its dword into four floats (v_cvt_f32_ubyte0..3, exact) and parks them -- and a lane reads its six values back by index.
     auto hblend = [&](int srow, double* hh) {
-        const uint8_t* a0 = in + (size_t)srow * in_rb + 3 * left0;
-        const unsigned off = ((unsigned)(uintptr_t)a0 & 3u) + 3u * (unsigned)(left - left0);     // byte offset of this lane's pixel in the window
-        const uint32_t* w = &s_rows[wave][srow - s_first][off >> 2];
-        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
-        const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, off & 3u), hi = __builtin_amdgcn_alignbyte(w2, w1, off & 3u);
-        const double tl0 = (double)(lo & 0xffu), tl1 = (double)((lo >> 8) & 0xffu), tl2 = (double)((lo >> 16) & 0xffu);
-        // a lane without a right neighbour blends its own pixel with itself (oracle/pvo_image.c): the substitution is done on the packed
-        // bytes (two integer selects) instead of on the six converted doubles
-        const uint32_t lo2 = has_right ? lo : ((lo & 0x00ffffffu) | (lo << 24));
-        const uint32_t hi2 = has_right ? hi : (lo >> 8);
-        const double tr0 = (double)(lo2 >> 24), tr1 = (double)(hi2 & 0xffu), tr2 = (double)((hi2 >> 8) & 0xffu);
+        const uint32_t w = s_rows[wave][srow - s_first][lane];
+        f32x4 f;
+        f.x = (float)(w & 0xffu); f.y = (float)((w >> 8) & 0xffu);         // (the compiler emits v_cvt_f32_ubyte0 .. 3)
+        f.z = (float)((w >> 16) & 0xffu); f.w = (float)(w >> 24);
+        *reinterpret_cast<f32x4*>(cv + 4 * lane) = f;
+        __builtin_amdgcn_wave_barrier();                        // (LDS serves a wave's accesses in order; this only pins the compiler's order)
+        const unsigned al = (unsigned)((uintptr_t)(in + (size_t)srow * in_rb + 3 * left0) & 3u);   // wave-uniform
+        const float* q = cv + al + dl;
+        const double tl0 = (double)q[0], tl1 = (double)q[1], tl2 = (double)q[2];
+        const double tr0 = (double)q[ro], tr1 = (double)q[ro + 1], tr2 = (double)q[ro + 2];
+        __builtin_amdgcn_wave_barrier();
         hh[0] = lr1 * tl0 + lr * tr0;
         hh[1] = lr1 * tl1 + lr * tr1;
         hh[2] = lr1 * tl2 + lr * tr2;
     };
     for (int r = r0; r < r_end; ++r) {
-        const double y = r * y_scale;
-        const int top = (int)floor(y);
-        const int bottom = min(top + 1, ih - 1);
-        const double tb = y - top, tb1 = 1 - tb;
+        const RowTab rt = rows[r];                              // wave-uniform: scalar loads
+        const int top = rt.top, bottom = rt.bottom;
+        const double tb = rt.tb, tb1 = rt.tb1;
         if (s1 == top) { s0 = s1; h0[0] = h1[0]; h0[1] = h1[1]; h0[2] = h1[2]; s1 = -1; }
         if (s0 != top) { hblend(top, h0); s0 = top; }
         if (s1 != bottom) {
@@ -114,8 +128,24 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     }
 }
 
+static void fill_row_table(std::vector<RowTab>& t, int ih, int oh)
+{
+    const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
+    const size_t base = t.size();
+    t.resize(base + oh);
+    for (int r = 0; r < oh; ++r) {
+        const double y = r * y_scale;
+        RowTab& e = t[base + r];
+        e.top = (int)std::floor(y);
+        e.bottom = std::min(e.top + 1, ih - 1);
+        e.tb = y - e.top;
+        e.tb1 = 1 - e.tb;
+        e.pad = 0;
+    }
+}
+
 static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* in_base, size_t in_stride, int in_rb, int ih, int iw,
-                               uint8_t* out, size_t out_stride, int out_rb, int oh, int ow, int batch)
+                               uint8_t* out, size_t out_stride, int out_rb, int oh, int ow, int batch, const RowTab* d_rows)
 {
     const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
     const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
@@ -124,7 +154,7 @@ static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint
     PVF_REQUIRE(out_rb % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)out & 3) == 0 && out_rb >= (ow * 3 + 3) / 4 * 4, "resize: output rows must be 4-byte aligned");
     dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
     hipLaunchKernelGGL((resize_rows_k<RS>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb,
-                       oh, ow, x_scale, y_scale);
+                       oh, ow, x_scale, d_rows);
 }
 
 static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
@@ -651,8 +681,10 @@ struct MlPlan {
     int feat_blocks = 0, score_blocks = 0, fused_blocks = 0;
     size_t img_bytes = 0, feat_floats = 0, up_bytes = 0;
     LvDesc* d_lv = nullptr;
+    RowTab* d_rowtab = nullptr;                // row tables of every resize stage: upsampling stages first, then level l from level l - 1
+    std::vector<size_t> up_tab, lv_tab;        // offsets (entries) into d_rowtab
     const void* ring_valid_for = nullptr;      // feature buffer whose zero border was written for this plan (fused FHOG)
-    ~MlPlan() { if (d_lv) (void)hipFree(d_lv); }
+    ~MlPlan() { if (d_lv) (void)hipFree(d_lv); if (d_rowtab) (void)hipFree(d_rowtab); }
     MlPlan() = default;
     MlPlan(const MlPlan&) = delete;
     MlPlan& operator=(const MlPlan&) = delete;
@@ -718,6 +750,15 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
     p.fused.b0[nl] = p.fused_blocks;
     HIP_CHECK(hipMalloc((void**)&p.d_lv, sizeof(LvDesc) * nl));
     HIP_CHECK(hipMemcpy(p.d_lv, p.lv.data(), sizeof(LvDesc) * nl, hipMemcpyHostToDevice));
+    {
+        std::vector<RowTab> tab;
+        int ch = h;
+        for (size_t u = 0; u < p.ups.size(); ++u) { p.up_tab.push_back(tab.size()); fill_row_table(tab, ch, p.ups[u].h); ch = p.ups[u].h; }
+        p.lv_tab.push_back(0);
+        for (int l = 1; l < nl; ++l) { p.lv_tab.push_back(tab.size()); fill_row_table(tab, p.lv[l - 1].h, p.lv[l].h); }
+        HIP_CHECK(hipMalloc((void**)&p.d_rowtab, sizeof(RowTab) * std::max<size_t>(tab.size(), 1)));
+        if (!tab.empty()) HIP_CHECK(hipMemcpy(p.d_rowtab, tab.data(), sizeof(RowTab) * tab.size(), hipMemcpyHostToDevice));
+    }
     MlPlan* raw = pp.get();
     c->ml_plans->plans[key] = std::move(pp);
     return raw;
@@ -745,7 +786,7 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
         uint8_t* dst = last ? base + p->lv[0].img_off : up_tmp;
         const int drb = (int)al((size_t)p->ups[u].w * 3, 64);
         const size_t dstride = (size_t)p->ups[u].h * drb;
-        launch_resize_rows(c, cur ? nullptr : d_ptrs, cur, cstride, crb, ch, cw, dst, dstride, drb, p->ups[u].h, p->ups[u].w, B);
+        launch_resize_rows(c, cur ? nullptr : d_ptrs, cur, cstride, crb, ch, cw, dst, dstride, drb, p->ups[u].h, p->ups[u].w, B, p->d_rowtab + p->up_tab[u]);
         cur = dst; cstride = dstride; crb = drb; ch = p->ups[u].h; cw = p->ups[u].w;
     }
     if (!cur) {
@@ -755,7 +796,7 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
     }
     for (size_t l = 1; l < p->lv.size(); ++l)
         launch_resize_rows(c, nullptr, base + p->lv[l - 1].img_off, (size_t)p->lv[l - 1].img_stride, p->lv[l - 1].rb, p->lv[l - 1].h, p->lv[l - 1].w,
-                           base + p->lv[l].img_off, (size_t)p->lv[l].img_stride, p->lv[l].rb, p->lv[l].h, p->lv[l].w, B);
+                           base + p->lv[l].img_off, (size_t)p->lv[l].img_stride, p->lv[l].rb, p->lv[l].h, p->lv[l].w, B, p->d_rowtab + p->lv_tab[l]);
     return p;
 }
 
