@@ -27,7 +27,7 @@
 // wave-uniform double arithmetic in every lane.  32 bytes = one aligned s_load_dwordx8.
 struct RowTab { int32_t top, bottom; double tb, tb1, pad; };
 
-template <int RS>
+template <int RS, int NSTRIP>
 __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
                                                      size_t in_stride, int in_rb, int ih, int iw, uint8_t* __restrict__ out,
                                                      size_t out_stride, int out_rb, int oh, int ow, double x_scale,
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = blockIdx.x * 256 + wave * 64;               // first column of this wave's segment
-    const int r0 = blockIdx.y * RS, b = blockIdx.z;
+    const int b = blockIdx.z;
     if (c0 >= ow) return;                                      // wave-uniform
     const int c = min(c0 + lane, ow - 1);                      // lanes past the row end recompute the last column (never stored)
     const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
@@ -50,30 +50,6 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     const int left0 = __builtin_amdgcn_readfirstlane(left);    // lane 0 holds column c0: the smallest source column of the wave
     const bool has_right = (left + 1 <= iw - 1);
     const double lr = x - left, lr1 = 1 - lr;
-    const int r_end = min(r0 + RS, oh);
-    const int s_first = rows[r0].top;
-    const int s_last = rows[r_end - 1].bottom;
-    // stage the source rows: dword `lane` of the 256-byte window that starts at the aligned address below the wave's first pixel.
-    // Branch-free so that all loads are in flight together: a dword that lies wholly past the frame is redirected to the frame's
-    // last word (never used; an aligned dword cannot straddle a page, so the word holding the last byte is always readable).
-    {
-        typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
-        const uintptr_t last_word = ((uintptr_t)in_end - 1) & ~(uintptr_t)3;
-        const int nrows = s_last - s_first + 1;
-        uint32_t t[MAXS];
-#pragma unroll
-        for (int k = 0; k < MAXS; ++k) {
-            t[k] = 0;
-            if (k < nrows) {                                   // wave-uniform
-                const uintptr_t a = (uintptr_t)(in + (size_t)(s_first + k) * in_rb + 3 * left0);
-                uintptr_t q = (a & ~(uintptr_t)3) + 4 * lane;
-                q = q < last_word ? q : last_word;
-                t[k] = *(gptr_t)q;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < MAXS; ++k) s_rows[wave][k][lane] = t[k];
-    }
     // output dword d of the segment (lane d < 48) straddles packed pixels a = 4d / 3 and a + 1, starting at byte 4d - 3a of pixel a
     const int pa_lane = (4 * lane) / 3, phase = 4 * lane - 3 * pa_lane;
     const int bp0 = 4 * min(pa_lane, 63), bp1 = 4 * min(pa_lane + 1, 63);
@@ -84,47 +60,80 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     // (oracle/pvo_image.c): its "right" pixel is read from the left one's slots
     const int dl = 3 * (left - left0), ro = has_right ? 3 : 0;
     float* cv = s_cvt[wave];
-    int s0 = -1, s1 = -1;              // cached source rows
-    double h0[3], h1[3];
-    // The horizontal blend of a source row.  Round 2 had every lane dig its six bytes out of three staged dwords (12 shift / mask / select
-    // instructions) and convert each to double (6): per OUTPUT pixel.  Now the wave converts the row's 256-byte window once -- a lane
-    // turns its dword into four floats (v_cvt_f32_ubyte0..3, exact) and parks them -- and a lane reads its six values back by index.
-    auto hblend = [&](int srow, double* hh) {
-        const uint32_t w = s_rows[wave][srow - s_first][lane];
-        f32x4 f;
-        f.x = (float)(w & 0xffu); f.y = (float)((w >> 8) & 0xffu);         // (the compiler emits v_cvt_f32_ubyte0 .. 3)
-        f.z = (float)((w >> 16) & 0xffu); f.w = (float)(w >> 24);
-        *reinterpret_cast<f32x4*>(cv + 4 * lane) = f;
-        __builtin_amdgcn_wave_barrier();                        // (LDS serves a wave's accesses in order; this only pins the compiler's order)
-        const unsigned al = (unsigned)((uintptr_t)(in + (size_t)srow * in_rb + 3 * left0) & 3u);   // wave-uniform
-        const float* q = cv + al + dl;
-        const double tl0 = (double)q[0], tl1 = (double)q[1], tl2 = (double)q[2];
-        const double tr0 = (double)q[ro], tr1 = (double)q[ro + 1], tr2 = (double)q[ro + 2];
-        __builtin_amdgcn_wave_barrier();
-        hh[0] = lr1 * tl0 + lr * tr0;
-        hh[1] = lr1 * tl1 + lr * tr1;
-        hh[2] = lr1 * tl2 + lr * tr2;
-    };
-    for (int r = r0; r < r_end; ++r) {
-        const RowTab rt = rows[r];                              // wave-uniform: scalar loads
-        const int top = rt.top, bottom = rt.bottom;
-        const double tb = rt.tb, tb1 = rt.tb1;
-        if (s1 == top) { s0 = s1; h0[0] = h1[0]; h0[1] = h1[1]; h0[2] = h1[2]; s1 = -1; }
-        if (s0 != top) { hblend(top, h0); s0 = top; }
-        if (s1 != bottom) {
-            if (bottom == top) { h1[0] = h0[0]; h1[1] = h0[1]; h1[2] = h0[2]; }
-            else hblend(bottom, h1);
-            s1 = bottom;
-        }
-        uint32_t P = 0;
+    typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
+    const uintptr_t last_word = ((uintptr_t)in_end - 1) & ~(uintptr_t)3;
+    // A wave walks NSTRIP strips of RS output rows, top to bottom.  The source rows of a strip are requested as one burst (one coalesced
+    // dword per lane and row: the 64 columns of a wave span < 256 source bytes for scales <= 1.25; branch-free: a dword that lies wholly
+    // past the frame is redirected to the frame's last word, never used) -- and the burst of strip k + 1 is in flight while strip k is
+    // computed, so only the first burst's latency is exposed (round 2: one strip per wave, every wave waited for its burst).
+    uint32_t t[MAXS];
+    auto request = [&](int r0) {
+        const int r_end = min(r0 + RS, oh);
+        const int s_first = rows[r0].top, nrows = rows[r_end - 1].bottom - s_first + 1;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double v = tb1 * h0[k] + tb * h1[k];
-            P |= (uint32_t)(uint8_t)(v + 0.5) << (8 * k);
+        for (int k = 0; k < MAXS; ++k) {
+            t[k] = 0;
+            if (k < nrows) {                                   // wave-uniform
+                const uintptr_t a = (uintptr_t)(in + (size_t)(s_first + k) * in_rb + 3 * left0);
+                uintptr_t q = (a & ~(uintptr_t)3) + 4 * lane;
+                q = q < last_word ? q : last_word;
+                t[k] = *(gptr_t)q;
+            }
         }
-        const uint32_t Pa = (uint32_t)__builtin_amdgcn_ds_bpermute(bp0, (int)P), Pb = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)P);
-        const uint32_t dw = __builtin_amdgcn_alignbyte(Pb >> 8, Pa | (Pb << 24), (unsigned)phase);
-        if (stores) *reinterpret_cast<uint32_t*>(ob + (size_t)r * out_rb + 4 * lane) = dw;
+    };
+    const int r_first = blockIdx.y * (RS * NSTRIP);
+    request(r_first);
+#pragma unroll 1
+    for (int st = 0; st < NSTRIP; ++st) {
+        const int r0 = r_first + st * RS;
+        if (r0 >= oh) break;                                   // wave-uniform
+        const int r_end = min(r0 + RS, oh);
+        const int s_first = rows[r0].top;
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) s_rows[wave][k][lane] = t[k];
+        if (st + 1 < NSTRIP && r0 + RS < oh) request(r0 + RS);
+        int s0 = -1, s1 = -1;              // cached source rows
+        double h0[3], h1[3];
+        // The horizontal blend of a source row.  Round 2 had every lane dig its six bytes out of three staged dwords (12 shift / mask / select
+        // instructions) and convert each to double (6): per OUTPUT pixel.  Now the wave converts the row's 256-byte window once -- a lane
+        // turns its dword into four floats (v_cvt_f32_ubyte0..3, exact) and parks them -- and a lane reads its six values back by index.
+        auto hblend = [&](int srow, double* hh) {
+            const uint32_t w = s_rows[wave][srow - s_first][lane];
+            f32x4 f;
+            f.x = (float)(w & 0xffu); f.y = (float)((w >> 8) & 0xffu);         // (the compiler emits v_cvt_f32_ubyte0 .. 3)
+            f.z = (float)((w >> 16) & 0xffu); f.w = (float)(w >> 24);
+            *reinterpret_cast<f32x4*>(cv + 4 * lane) = f;
+            __builtin_amdgcn_wave_barrier();                        // (LDS serves a wave's accesses in order; this only pins the compiler's order)
+            const unsigned al = (unsigned)((uintptr_t)(in + (size_t)srow * in_rb + 3 * left0) & 3u);   // wave-uniform
+            const float* q = cv + al + dl;
+            const double tl0 = (double)q[0], tl1 = (double)q[1], tl2 = (double)q[2];
+            const double tr0 = (double)q[ro], tr1 = (double)q[ro + 1], tr2 = (double)q[ro + 2];
+            __builtin_amdgcn_wave_barrier();
+            hh[0] = lr1 * tl0 + lr * tr0;
+            hh[1] = lr1 * tl1 + lr * tr1;
+            hh[2] = lr1 * tl2 + lr * tr2;
+        };
+        for (int r = r0; r < r_end; ++r) {
+            const RowTab rt = rows[r];                              // wave-uniform: scalar loads
+            const int top = rt.top, bottom = rt.bottom;
+            const double tb = rt.tb, tb1 = rt.tb1;
+            if (s1 == top) { s0 = s1; h0[0] = h1[0]; h0[1] = h1[1]; h0[2] = h1[2]; s1 = -1; }
+            if (s0 != top) { hblend(top, h0); s0 = top; }
+            if (s1 != bottom) {
+                if (bottom == top) { h1[0] = h0[0]; h1[1] = h0[1]; h1[2] = h0[2]; }
+                else hblend(bottom, h1);
+                s1 = bottom;
+            }
+            uint32_t P = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double v = tb1 * h0[k] + tb * h1[k];
+                P |= (uint32_t)(uint8_t)(v + 0.5) << (8 * k);
+            }
+            const uint32_t Pa = (uint32_t)__builtin_amdgcn_ds_bpermute(bp0, (int)P), Pb = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)P);
+            const uint32_t dw = __builtin_amdgcn_alignbyte(Pb >> 8, Pa | (Pb << 24), (unsigned)phase);
+            if (stores) *reinterpret_cast<uint32_t*>(ob + (size_t)r * out_rb + 4 * lane) = dw;
+        }
     }
 }
 
@@ -152,9 +161,18 @@ static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint
     constexpr int RS = 16;
     PVF_REQUIRE(x_scale <= 1.25 && (RS - 1) * y_scale + 3 <= RESIZE_MAXS, "resize_rows: scale outside the pyramid's range (2x up, 6/5 down)");
     PVF_REQUIRE(out_rb % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)out & 3) == 0 && out_rb >= (ow * 3 + 3) / 4 * 4, "resize: output rows must be 4-byte aligned");
-    dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
-    hipLaunchKernelGGL((resize_rows_k<RS>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb,
-                       oh, ow, x_scale, d_rows);
+    // EXPERIMENT (measurement session): strips per wave
+    static const int nstrip = getenv("PVF_RESIZE_NSTRIP") ? atoi(getenv("PVF_RESIZE_NSTRIP")) : 4;
+    if (nstrip == 1) {
+        dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
+        hipLaunchKernelGGL((resize_rows_k<RS, 1>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
+    } else if (nstrip == 2) {
+        dim3 grid((ow + 255) / 256, (oh + 2 * RS - 1) / (2 * RS), batch);
+        hipLaunchKernelGGL((resize_rows_k<RS, 2>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
+    } else {
+        dim3 grid((ow + 255) / 256, (oh + 4 * RS - 1) / (4 * RS), batch);
+        hipLaunchKernelGGL((resize_rows_k<RS, 4>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
+    }
 }
 
 static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)

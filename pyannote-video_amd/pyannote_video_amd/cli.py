@@ -112,7 +112,10 @@ def track(video, shot, output, detect_min_size=0.0, detect_every=0.0, track_min_
                     foutput.write(line)
                 foutput.flush()
                 state["next"] += 1
-        return pipe.run_stream(video, shots, extract=False, cluster=False, on_tracks=write)
+        tm = {}
+        res = pipe.run_stream(video, shots, extract=False, cluster=False, on_tracks=write, timings=tm)
+        res["timings"] = tm
+        return res
 
 
 def extract(video, landmark_model, embedding_model, tracking, landmark_output, embedding_output, ctx=None, batch=2048, ahead=96):
@@ -219,7 +222,9 @@ def process(video, shot, landmark_model, embedding_model, tracking_output, landm
                     foutput.write(line)
                 foutput.flush()
                 state["next"] += 1
-        res = pipe.run_stream(video, shots, on_tracks=write, cluster=label_output is not None)
+        tm = {}
+        res = pipe.run_stream(video, shots, on_tracks=write, cluster=label_output is not None, timings=tm)
+        res["timings"] = tm
     w, h = video.size
     with open(landmark_output, 'wb') as flandmark, open(embedding_output, 'wb') as fembedding:
         flandmark.write(formats.landmark_rows(res["face_T"], res["face_id"], res["landmarks"], w, h))
@@ -263,6 +268,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="pyannote-face", description="face tracking => feature extraction => face clustering (MI355X)")
     ap.add_argument("--fps", type=float, default=25.0, help="frame rate of a .npy / synthetic video")
     ap.add_argument("--device", type=int, default=None, help="GPU index (default: LOCAL_RANK or 0)")
+    ap.add_argument("--metrics", default=None, help="write a JSON file with the run's timings and counts (frames, tracks, faces, seconds per stage, "
+                    "frames resident at peak, device memory in use) next to the outputs")
     sub = ap.add_subparsers(dest="verb", required=True)
     t = sub.add_parser("track")
     t.add_argument("video"); t.add_argument("shot"); t.add_argument("tracking")
@@ -296,15 +303,18 @@ def main(argv=None):
     c.add_argument("--force", action="store_true")
     c.add_argument("--metric", choices=("euclidean", "cosine"), default="euclidean")
     a = ap.parse_args(argv)
+    import time
     ctx = None
     if a.device is not None:
         from .runtime import Context
         ctx = Context(device=a.device)
+    t_begin = time.perf_counter()
+    res = None
     if a.verb == "track":
-        track(open_video(a.video, a.fps), a.shot, a.tracking, detect_min_size=a.min_size, detect_every=a.every,
-              track_min_overlap_ratio=a.min_overlap, track_min_confidence=a.min_confidence, track_max_gap=a.max_gap, ctx=ctx)
+        res = track(open_video(a.video, a.fps), a.shot, a.tracking, detect_min_size=a.min_size, detect_every=a.every,
+                    track_min_overlap_ratio=a.min_overlap, track_min_confidence=a.min_confidence, track_max_gap=a.max_gap, ctx=ctx)
     elif a.verb == "process":
-        process(open_video(a.video, a.fps), a.shot, a.landmark_model, a.embedding_model, a.tracking, a.landmarks, a.embeddings, a.labels,
+        res = process(open_video(a.video, a.fps), a.shot, a.landmark_model, a.embedding_model, a.tracking, a.landmarks, a.embeddings, a.labels,
                 detect_min_size=a.min_size, detect_every=a.every, track_min_overlap_ratio=a.min_overlap,
                 track_min_confidence=a.min_confidence, track_max_gap=a.max_gap, threshold=a.threshold, ctx=ctx)
     elif a.verb == "shot":
@@ -313,6 +323,20 @@ def main(argv=None):
         extract(open_video(a.video, a.fps), a.landmark_model, a.embedding_model, a.tracking, a.landmarks, a.embeddings, ctx=ctx)
     else:
         cluster(a.embeddings, a.labels, threshold=a.threshold, force=a.force, metric=a.metric, ctx=ctx)
+    if a.metrics:
+        from . import runtime
+        m = {"verb": a.verb, "seconds": round(time.perf_counter() - t_begin, 4)}
+        if isinstance(res, dict):
+            m.update(frames=res.get("frames"), tracks=len(res.get("tracks", ())), faces=int(len(res["face_T"])) if "face_T" in res else None,
+                     clusters=len(set(res["labels"].values())) if res.get("labels") else None, peak_frames_resident=res.get("peak_frames_resident"),
+                     stage_seconds={k: round(v, 4) for k, v in res.get("timings", {}).items()})
+        try:
+            free, total = (ctx or runtime.default_context()).mem_info()
+            m["device_memory_in_use_bytes"] = total - free
+        except Exception:          # noqa: BLE001 -- the figure is optional
+            pass
+        with open(a.metrics, "w") as f:
+            json.dump(m, f, indent=1)
     return 0
 
 

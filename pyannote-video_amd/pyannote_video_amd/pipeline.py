@@ -109,6 +109,8 @@ class FacePipeline(object):
     def _result(self, job, tm, cluster, t0):
         """a finished job -> the result dictionary (`extract`'s arrays in file order, clustering on request)"""
         if job.ex is None:
+            if tm is not None:
+                tm["track_s"] = tm["total_s"] = _time.perf_counter() - t0
             return {"tracks": job.tracks, "shot_ranges": job.shot_ranges, "labels": {}}
         ex = job.ex
         pts, emb = ex.finish(drop_last=job.last_shard, reorder=job.reorder, computed=True)
