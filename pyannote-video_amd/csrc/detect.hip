@@ -302,14 +302,13 @@ __device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_
 __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
 
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) fhog_fused_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
+__global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
                                                        float* __restrict__ feat_base, const uint8_t* __restrict__ lut2, int oy, int ox)
 {
     constexpr int RSRC_FLAGS = 0x00020000;
     // the bins of the two cell rows a pixel row votes into: two arrays, so that the compiler knows their updates never alias
     __shared__ float s_even[4][18][64];                            // cell rows with even index
     __shared__ float s_odd[4][18][64];                             // cell rows with odd index
-    __shared__ float s_prev[4][18][64];                            // the finished cell row that is the centre of the next feature row
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = ml_block(st);
@@ -338,9 +337,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int voff = 3 * x_first - 4, voff2 = voff + 16;
     float* accE = &s_even[wave][0][lane];                          // bin k of this lane: accE[64 * k]
     float* accO = &s_odd[wave][0][lane];
-    float* prevp = &s_prev[wave][0][lane];
 #pragma unroll
-    for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accO[64 * k] = 0.0f; prevp[64 * k] = 0.0f; }
+    for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accO[64 * k] = 0.0f; }
 
     // image rows as 8 dwords per lane: bytes [3 x_first - 4, 3 x_first + 28) -- pixel p, channel k at byte 4 + 3 p + k;
     // a row outside the image, or bytes outside a row, read as 0 (such pixels are never valid)
@@ -360,7 +358,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     load_row(y_begin + 1, rw[2]);
     load_row(y_begin + 2, rw[3]);
 
+    float hprev[18];
     float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) hprev[k] = 0.f;
 
 #define BYTE_OF(w, i) (int)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
     // (magnitude, bin offset) of pixel p of image row y from the three row buffers; rows / columns without a gradient give magnitude 0
@@ -372,9 +373,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             l3[k] = BYTE_OF(ce, 1 + 3 * p + k); r3[k] = BYTE_OF(ce, 7 + 3 * p + k);
         }
         float v; int o;
-        grad_lookup(u3, d3, l3, r3, lut2, &v, &o);                 // o: float offset of the bin's row of 64 lanes
+        grad_lookup(u3, d3, l3, r3, lut2, &v, &o);
         *mo = (row_ok && ((xmask >> p) & 1u)) ? v : 0.0f;
-        *bof = o;
+        *bof = o << 6;                                             // float offset of the bin's row of 64 lanes
     };
     // the votes of a row are a chain of LDS read-add-writes (latency bound); the gradients of the NEXT row are pure VALU work plus a table
     // look-up: they are computed in between, one pixel per two votes, so that a wave fills its own LDS waits and the look-ups of a row are
@@ -442,20 +443,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             n[6] = __uint_as_float(from_prev_lane(__float_as_uint(e0))); n[8] = __uint_as_float(from_next_lane(__float_as_uint(e0)));
             const int x = FUSED_OUT * sx + lane - 1, yh = c - 3;
             if (lane >= 1 && lane <= FUSED_OUT && x < d.hog_nc) {
-                // (the centre row's bins wait in LDS, not in 18 registers held across the vote loop: with the 8-byte gradient entries in
-                // flight the loop would otherwise need more than the 256 registers that two waves per SIMD leave a lane)
-                float hp[18], o[32];
-#pragma unroll
-                for (int k = 0; k < 18; ++k) hp[k] = prevp[64 * k];
-                cell_features(hp, n, o);
+                float o[32];
+                cell_features(hprev, n, o);
                 float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)(yh + oy) * d.fw + (x + ox)) * PVF_FHOG_STRIDE);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
             }
         }
-        // the finished cell row becomes the centre of the next feature row: its bins move aside, the vote words are cleared
+        // the finished cell row becomes the centre of the next feature row: its bins move to registers, the LDS words are cleared
 #pragma unroll
-        for (int k = 0; k < 18; ++k) { prevp[64 * k] = accL[64 * k]; accL[64 * k] = 0.0f; }
+        for (int k = 0; k < 18; ++k) { hprev[k] = accL[64 * k]; accL[64 * k] = 0.0f; }
     };
     for (int gb = g_first; gb <= g_last; ++gb) {
         if (gb & 1) band(gb, accO, accE);                           // upper half -> the odd cell row gb, lower half -> the even row gb - 1

@@ -46,22 +46,12 @@ const uint8_t* orientation_lut_tiled(Ctx* c)
     orientation_lut(c);
     std::vector<uint8_t> ol((size_t)511 * 511);
     HIP_CHECK(hipMemcpy(ol.data(), c->d_orient_lut, ol.size(), hipMemcpyDeviceToHost));
-    // round 3: an entry is 8 bytes -- the gradient's magnitude, sqrtf(gx^2 + gy^2) correctly rounded (the host's sqrtf; the device's
-    // v_sqrt_f32 is not: tools/probes/sqrt_probe.hip), and the bin's offset in the vote arrays (bin << 6) -- so that one 8-byte gather
-    // per pixel replaces the byte gather plus ten instructions of exact square root.  2 MB; the entries of small gradients, the ones
-    // every image hits, are a few 512-byte tiles around the centre.
-    struct Entry { float mag; uint32_t bin_off; };
-    std::vector<Entry> lut((size_t)64 * 64 * 64, Entry{0.0f, 0u});
+    std::vector<uint8_t> lut((size_t)64 * 64 * 64, 0);
     for (int Y = 0; Y < 511; ++Y)
-        for (int X = 0; X < 511; ++X) {
-            const int gx = X - 255, gy = Y - 255;
-            Entry e;
-            e.mag = sqrtf((float)(gx * gx + gy * gy));
-            e.bin_off = (uint32_t)ol[(size_t)Y * 511 + X] << 6;
-            lut[((size_t)(Y >> 3) << 12) | ((size_t)(X >> 3) << 6) | ((Y & 7) << 3) | (X & 7)] = e;
-        }
-    HIP_CHECK(hipMalloc((void**)&c->d_grad_lut, lut.size() * sizeof(Entry)));
-    HIP_CHECK(hipMemcpy(c->d_grad_lut, lut.data(), lut.size() * sizeof(Entry), hipMemcpyHostToDevice));
+        for (int X = 0; X < 511; ++X)
+            lut[((size_t)(Y >> 3) << 12) | ((size_t)(X >> 3) << 6) | ((Y & 7) << 3) | (X & 7)] = ol[(size_t)Y * 511 + X];
+    HIP_CHECK(hipMalloc((void**)&c->d_grad_lut, lut.size()));
+    HIP_CHECK(hipMemcpy(c->d_grad_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
     return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
 }
 

@@ -24,10 +24,9 @@ __device__ __forceinline__ float sqrt_exact_small(float x)
     return r;
 }
 
-// colour channel with the largest |g|^2 (first wins); its magnitude and its bin's offset in the vote arrays (bin << 6) come out of the
-// tiled gradient table (fhog.hip: orientation_lut_tiled) with ONE 8-byte gather
+// colour channel with the largest |g|^2 (first wins); magnitude by arithmetic, orientation bin from the tiled table
 __device__ __forceinline__ void grad_lookup(const int u[3], const int d[3], const int l[3], const int r[3],
-                                            const uint8_t* __restrict__ lut_t, float* v, int* bin_off)
+                                            const uint8_t* __restrict__ lut_t, float* v, int* o)
 {
     int bx = r[0] - l[0], by = d[0] - u[0];
     int bv = bx * bx + by * by;
@@ -40,11 +39,10 @@ __device__ __forceinline__ void grad_lookup(const int u[3], const int d[3], cons
         if (cv > bv) { bv = cv; bi = ci; }
     }
     const unsigned P = (unsigned)(bi + 255 * 512 + 255);           // Y << 9 | X
-    const unsigned off = ((P & 0x3F007u) | ((P & 0x1F8u) << 3) | ((P >> 6) & 0x38u)) << 3;     // tiled entry index x 8 bytes
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lut_t, 0, 64 * 64 * 64 * 8, 0x00020000);
-    const u32x2 e = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
-    *v = __uint_as_float(e.x);
-    *bin_off = (int)e.y;
+    const unsigned off = (P & 0x3F007u) | ((P & 0x1F8u) << 3) | ((P >> 6) & 0x38u);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lut_t, 0, 64 * 64 * 64, 0x00020000);
+    *o = (int)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
+    *v = sqrt_exact_small((float)bv);
 }
 
 __device__ __forceinline__ void cell_features(const float* h, const float* n, float* o)
