@@ -143,18 +143,21 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
         rt[r] = t;
         rcnt[r] = t >= 0 ? (double)(a.row_start[t + 1] - a.row_start[t]) : 1.0;
     }
-    // staging role: thread t moves 8 doubles (64 bytes) of row t >> 4
-    const int srow = tid >> 4, sch = tid & 15;
+    // staging: a wave moves rows wave, wave + 4, ... of the column block straight from HBM into LDS (buffer_load_dwordx4 ... lds: 64 lanes x
+    // 16 bytes = one row of 128 doubles, no registers in between), asynchronously: the block for step cb + 1 is requested before the
+    // MFMAs of step cb and only waited for at the end of the step.  (Round 2 / early round 3 loaded into registers and parked them in LDS
+    // BEFORE computing: every step began with a full memory latency.)  Rows past the block's last one are requested beyond the buffer's
+    // end, which returns zeros.
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, a.N * DIM * 8, 0x00020000);
     auto stage = [&](int cb, int buf) {
         const int r0 = a.blk_r0[cb], nr = a.blk_nr[cb];
-        double v[8];
-        const bool ok = srow < nr;
-        const double* src = a.X + (size_t)(r0 + (ok ? srow : 0)) * DIM + 8 * sch;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = ok ? src[q] : 0.0;
-        double* dst = &Bs[buf][srow * PT_PITCH + 8 * sch];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) dst[q] = v[q];
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave + 4 * q;
+            const int voff = (r < nr) ? lane * 16 : 0x7ffffff0;                  // (wave-uniform choice; out of range -> zeros)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)&Bs[buf][r * PT_PITCH], 16, voff,
+                                                     (r0 + (r < nr ? r : 0)) * (DIM * 8), 0, 0);
+        }
         if (tid < 16) {
             colSeg[buf][tid] = tid < nr ? a.row_segidx[r0 + tid] : -1;
             colSegTrack[buf][tid] = a.seg_track[cb * 16 + tid];
@@ -164,6 +167,7 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
     };
     f64x4 t2 = (f64x4){0.0, 0.0, 0.0, 0.0};          // sums per (row segment, column segment), carried across the chunks of a long column track
     if (cb0 < cb1) stage(cb0, 0);
+    __builtin_amdgcn_s_waitcnt(0);                     // the rows requested above are in LDS
     __syncthreads();
     for (int cb = cb0; cb < cb1; ++cb) {
         const int buf = (cb - cb0) & 1;
@@ -226,7 +230,8 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
                 t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0);                 // this wave's share of the next block has arrived ...
+        __syncthreads();                               // ... and so has everybody else's
     }
 }
 

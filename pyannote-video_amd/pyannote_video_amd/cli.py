@@ -171,8 +171,7 @@ def extract(video, landmark_model, embedding_model, tracking, landmark_output, e
             def flush():
                 if not pend_b:
                     return
-                pts = ctx.landmarks(pend_f, pend_b)
-                emb = ctx.embed(pend_f, pts)
+                pts, emb = ctx.landmarks_embed(pend_f, pend_b)
                 T, ident = [k[0] for k in pend_k], [k[1] for k in pend_k]
                 flandmark.write(formats.landmark_rows(T, ident, pts, frame_width, frame_height))
                 fembedding.write(formats.embedding_rows(T, ident, emb))
