@@ -66,20 +66,23 @@ __global__ void __launch_bounds__(256) track_pair_mean_k(const double* __restric
 // ---------------------------------------------------------------------------------------------------
 // K10 on the f64 matrix cores.
 //
-// Rows are grouped into ROW BLOCKS of at most 16 consecutive rows: a track with >= 16 rows is cut into chunks of 16 (blocks that
-// hold nothing else), shorter tracks are packed whole, several to a block.  The blocking depends on the track sizes only, never on
-// which rank computes which rows, so every D entry is formed by the same additions wherever it is computed.
+// Rows (sorted by track) are cut into ROW BLOCKS of 16 consecutive rows wherever the tracks begin and end: a block holds up to 16
+// SEGMENTS (runs of rows of one track), a track longer than what is left of its first block continues in the next ones.  The blocking
+// depends on the track sizes only, never on which rank computes which rows, so every D entry is formed by the same additions wherever
+// it is computed.  (Round 2 / early round 3 started every track >= 16 rows on a block of its own and packed shorter tracks whole:
+// 16-row blocks 39 % full at 10 rows per track.)
 // A wave owns one row block (its 16 x 128 values stay in registers as 32 A fragments) and sweeps a range of column blocks, which
 // its workgroup stages through LDS (one copy serves 4 row blocks).  Per 16 x 16 tile:
 //   32 MFMAs give x_a . x_b;  d = sqrt(|a|^2 + |b|^2 - 2 a.b)  (recomputed as sum (a_k - b_k)^2 where the Gram form would cancel;
 //   cosine: 1 - a.b / (|a| |b|)) -- the tile of distances sits in the C layout, 4 values per lane;
 //   the reduction to track pairs runs on the matrix cores as well: with the 0/1 matrices Rind[row segment][row] (which rows of this
-//   row block form which track) and Cind[column][column segment],
-//       R' = d^T . Rind^T   (4 MFMAs: the C layout of d IS the A layout of d^T)      sums over the rows of every row track, per column
-//       T2 += R'^T . Cind   (4 MFMAs: the C layout of R' IS the A layout of R'^T)    ... and over the columns of every column track
+//   row block form which segment) and Cind[column][column segment],
+//       R' = d^T . Rind^T   (4 MFMAs: the C layout of d IS the A layout of d^T)      sums over the rows of every row segment, per column
+//       T2 += R'^T . Cind   (4 MFMAs: the C layout of R' IS the A layout of R'^T)    ... and over the columns of every column segment
 //   (products with 1.0 and sums with 0.0 are exact; the order of the additions is the matrix core's, the same for every launch
-//   shape).  T2 keeps accumulating while consecutive column blocks are chunks of ONE long track and is written when the track ends:
-//   whole row tracks -> D[i][j] = sum / (n_i n_j);  chunks of a long row track -> P[chunk][j], summed in chunk order by pair_chunks_k.
+//   shape).  A column segment whose track goes on in the next block hands its column of T2 on to segment 0 of the next tile (a lane
+//   shuffle); complete ones are written: row segments that are a whole track -> D[i][j] = sum / (n_i n_j); row segments of a track
+//   that spans several blocks -> P[part][j], summed in part order by pair_chunks_k.
 // D[i][i] = 0 like scipy's squareform diagonal.  Round 2 reduced the tile with LDS round trips and lane-serial running sums (16
 // dependent steps per tile on 16 lanes): 10-16 TFLOP/s; the matrix-core reduction removes every serial step from the tile.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -87,9 +90,9 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct PtArgs {
     const double* X; const double* nrm; int N, T;
-    const int* row_track; const int* row_segidx;                         // per row: track, index of its track's segment inside its block
-    const int* blk_r0; const int* blk_nr; const int* blk_chunk; const int* blk_last;   // per block: first row, rows, chunk index (-1: packed whole tracks), 1 = its tracks end here
-    const int* seg_track;                                                  // [block][16]: track of each segment of the block (-1: none)
+    const int* row_track; const int* row_segidx;                         // per row: track, index of its segment inside its block
+    const int* blk_cont;                                                   // per block: the segment that goes on in the next block, or -1
+    const int* seg_track; const int* seg_part;                             // [block][16]: track of each segment (-1: none); its row in P (-1: the segment is its whole track)
     const int* range_b0;                                                   // column ranges: block index bounds [n_ranges + 1]
     const int* row_start; double* D; double* P;
     int n_blocks, n_ranges, t0, t1, metric;
@@ -111,12 +114,12 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
     __shared__ int colSeg[2][16];                     // per staged column: segment index inside its block (-1: padding)
     __shared__ int colSegTrack[2][16];                // per segment of the staged block: its track (-1: none)
     __shared__ double colNrm[2][16];                  // |b|^2 per staged column
-    __shared__ int blkLast[2];
+    __shared__ int colCont[2];                        // the staged block's segment that goes on in the next block (-1: none)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ab = blockIdx.x * 4 + wave;             // row block of this wave
     const bool have = ab < a.n_blocks;
     const int cb0 = a.range_b0[blockIdx.y], cb1 = a.range_b0[blockIdx.y + 1];
-    const int ar0 = have ? a.blk_r0[ab] : 0, anr = have ? a.blk_nr[ab] : 0, achunk = have ? a.blk_chunk[ab] : -1;
+    const int ar0 = have ? ab * 16 : 0, anr = have ? min(16, a.N - ab * 16) : 0;
     // a wave whose rows all lie outside [t0, t1) has nothing to write (row tracks are contiguous in a block)
     bool wanted = false;
     if (have) { const int ta = a.row_track[ar0], tb = a.row_track[ar0 + anr - 1]; wanted = (tb >= a.t0 && ta < a.t1); }
@@ -129,7 +132,7 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
         for (int s = 0; s < KS; ++s) af[s] = ok ? xa[4 * s] : 0.0;
     }
     double na4[4], rb[4], rcnt[4];
-    int rt[4];
+    int rt[4], rpart[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = k4 + 4 * r;                    // C-layout row of register r == K index of step r in the row reduction
@@ -141,6 +144,7 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
         int t = have ? a.seg_track[ab * 16 + seg] : -1;
         if (t >= 0 && !(t >= a.t0 && t < a.t1)) t = -1;                       // rows of another rank's share
         rt[r] = t;
+        rpart[r] = t >= 0 ? a.seg_part[ab * 16 + seg] : -1;
         rcnt[r] = t >= 0 ? (double)(a.row_start[t + 1] - a.row_start[t]) : 1.0;
     }
     // staging: a wave moves rows wave, wave + 4, ... of the column block straight from HBM into LDS (buffer_load_dwordx4 ... lds: 64 lanes x
@@ -148,21 +152,23 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
     // MFMAs of step cb and only waited for at the end of the step.  (Round 2 / early round 3 loaded into registers and parked them in LDS
     // BEFORE computing: every step began with a full memory latency.)  Rows past the block's last one are requested beyond the buffer's
     // end, which returns zeros.
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, a.N * DIM * 8, 0x00020000);
+    // (the descriptor covers this workgroup's column range only: 32-bit offsets, whatever N is)
+    const int range_rows = min(a.N - cb0 * 16, (cb1 - cb0) * 16);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (size_t)cb0 * 16 * DIM), 0, range_rows * DIM * 8, 0x00020000);
     auto stage = [&](int cb, int buf) {
-        const int r0 = a.blk_r0[cb], nr = a.blk_nr[cb];
+        const int r0 = cb * 16, nr = min(16, a.N - r0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = wave + 4 * q;
             const int voff = (r < nr) ? lane * 16 : 0x7ffffff0;                  // (wave-uniform choice; out of range -> zeros)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)&Bs[buf][r * PT_PITCH], 16, voff,
-                                                     (r0 + (r < nr ? r : 0)) * (DIM * 8), 0, 0);
+                                                     (r0 - cb0 * 16 + (r < nr ? r : 0)) * (DIM * 8), 0, 0);
         }
         if (tid < 16) {
             colSeg[buf][tid] = tid < nr ? a.row_segidx[r0 + tid] : -1;
             colSegTrack[buf][tid] = a.seg_track[cb * 16 + tid];
             colNrm[buf][tid] = tid < nr ? a.nrm[r0 + tid] : 0.0;
-            if (tid == 0) blkLast[buf] = a.blk_last[cb];
+            if (tid == 0) colCont[buf] = a.blk_cont[cb];
         }
     };
     f64x4 t2 = (f64x4){0.0, 0.0, 0.0, 0.0};          // sums per (row segment, column segment), carried across the chunks of a long column track
@@ -173,7 +179,7 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
         const int buf = (cb - cb0) & 1;
         if (cb + 1 < cb1) stage(cb + 1, buf ^ 1);
         if (wanted) {
-            const int br0 = a.blk_r0[cb];
+            const int br0 = cb * 16;
             f64x4 acc = (f64x4){0.0, 0.0, 0.0, 0.0};
             const double* bp = &Bs[buf][i16 * PT_PITCH + k4];
 #pragma unroll
@@ -215,20 +221,29 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
                 const double cind = (colSeg[buf][4 * q + k4] == i16) ? 1.0 : 0.0;
                 t2 = __builtin_amdgcn_mfma_f64_16x16x4f64(rp[q], cind, t2, 0, 0, 0);
             }
-            if (blkLast[buf]) {                        // (uniform) the column tracks of this block are complete
-                const int j = colSegTrack[buf][i16];
-                if (j >= 0) {
-                    const double ccnt = (double)(a.row_start[j + 1] - a.row_start[j]);
+            // complete column segments are written; the one that goes on in the next block (at most one, the block's last) hands its sums to
+            // segment 0 of the next tile
+            const int cont = colCont[buf];                 // (uniform)
+            const int j = colSegTrack[buf][i16];
+            if (j >= 0 && i16 != cont) {
+                const double ccnt = (double)(a.row_start[j + 1] - a.row_start[j]);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int i = rt[q];
-                        if (i < 0) continue;
-                        if (achunk >= 0) a.P[(size_t)achunk * a.T + j] = t2[q];
-                        else a.D[(size_t)i * a.T + j] = (i == j) ? 0.0 : t2[q] / (rcnt[q] * ccnt);
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const int i = rt[q];
+                    if (i < 0) continue;
+                    if (rpart[q] >= 0) a.P[(size_t)rpart[q] * a.T + j] = t2[q];
+                    else a.D[(size_t)i * a.T + j] = (i == j) ? 0.0 : t2[q] / (rcnt[q] * ccnt);
                 }
-                t2 = (f64x4){0.0, 0.0, 0.0, 0.0};
             }
+            f64x4 carry = (f64x4){0.0, 0.0, 0.0, 0.0};
+            if (cont >= 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double v = __shfl(t2[q], (lane & 48) | cont, 64);
+                    carry[q] = (i16 == 0) ? v : 0.0;
+                }
+            }
+            t2 = carry;
         }
         __builtin_amdgcn_s_waitcnt(0);                 // this wave's share of the next block has arrived ...
         __syncthreads();                               // ... and so has everybody else's
@@ -256,72 +271,58 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
                                 int metric)
 {
     constexpr int DIM = 128;
-    // ---- blocking (host, O(N))
-    std::vector<int> row_track(N), row_segidx(N, 0), blk_r0, blk_nr, blk_chunk, blk_last, seg_track, big_track, big_c0, big_nc;
-    std::vector<int> blk_first_track;
-    int n_chunks = 0;
+    // ---- blocking (host, O(N)): blocks of 16 consecutive rows; segments = runs of one track inside a block
+    const int nb = (N + 15) / 16;
+    std::vector<int> row_track(N), row_segidx(N, 0), blk_cont(nb, -1), blk_clean(nb, 1), seg_track((size_t)nb * 16, -1), seg_part((size_t)nb * 16, -1);
+    std::vector<int> big_track, big_c0, big_nc;
     for (int t = 0; t < T; ++t) for (int r = row_start[t]; r < row_start[t + 1]; ++r) row_track[r] = t;
-    auto new_block = [&]() { seg_track.insert(seg_track.end(), 16, -1); };
-    int t = 0;
-    while (t < T) {
-        const int n = row_start[t + 1] - row_start[t];
-        if (n == 0) { ++t; continue; }
-        if (n >= 16) {
-            big_track.push_back(t); big_c0.push_back(n_chunks);
-            int k = 0;
-            for (int r = row_start[t]; r < row_start[t + 1]; r += 16, ++k) {
-                const int nr = std::min(16, row_start[t + 1] - r);
-                blk_r0.push_back(r); blk_nr.push_back(nr); blk_chunk.push_back(n_chunks + k); blk_first_track.push_back(t);
-                blk_last.push_back(r + 16 >= row_start[t + 1] ? 1 : 0);
-                new_block();
-                seg_track[seg_track.size() - 16] = t;          // one segment (index 0, the rows' default)
-            }
-            big_nc.push_back(k);
-            n_chunks += k;
-            ++t;
-        } else {
-            const int r0 = row_start[t];
-            int rows = 0, segs = 0;
-            blk_first_track.push_back(t);
-            new_block();
-            while (t < T && rows + (row_start[t + 1] - row_start[t]) <= 16 && (row_start[t + 1] - row_start[t]) < 16) {
-                const int m = row_start[t + 1] - row_start[t];
-                if (m > 0) {
-                    for (int r = row_start[t]; r < row_start[t + 1]; ++r) row_segidx[r] = segs;
-                    seg_track[seg_track.size() - 16 + segs] = t;
-                    ++segs;
-                }
-                rows += m;
-                ++t;
-            }
-            blk_r0.push_back(r0); blk_nr.push_back(rows); blk_chunk.push_back(-1); blk_last.push_back(1);
+    for (int b = 0; b < nb; ++b) {
+        const int r0 = b * 16, nr = std::min(16, N - r0);
+        int seg = 0;
+        for (int r = r0; r < r0 + nr; ++r) {
+            if (r > r0 && row_track[r] != row_track[r - 1]) ++seg;
+            row_segidx[r] = seg;
+            seg_track[(size_t)b * 16 + seg] = row_track[r];
         }
+        if (r0 + nr < N && row_track[r0 + nr] == row_track[r0 + nr - 1]) blk_cont[b] = seg;      // the last segment's track goes on
+        if (b > 0 && row_track[r0] == row_track[r0 - 1]) blk_clean[b] = 0;                         // ... and this block takes it over
     }
-    const int nb = (int)blk_r0.size();
-    // column ranges: about six rounds of workgroups over the chip (4 resident per CU), cut only where a block starts a new track (never
-    // inside a long track: the sums of a long column track are carried from chunk to chunk)
+    // tracks that span several blocks: one row of P per (track, block), summed in block order afterwards
+    int n_chunks = 0;
+    for (int t = 0; t < T; ++t) {
+        if (row_start[t + 1] <= row_start[t]) continue;
+        const int b_first = row_start[t] / 16, b_last = (row_start[t + 1] - 1) / 16;
+        if (b_last == b_first) continue;
+        big_track.push_back(t); big_c0.push_back(n_chunks); big_nc.push_back(b_last - b_first + 1);
+        for (int b = b_first; b <= b_last; ++b)
+            seg_part[(size_t)b * 16 + (b == b_first ? row_segidx[row_start[t]] : 0)] = n_chunks++;
+    }
+    // column ranges: about six rounds of workgroups over the chip (4 resident per CU), cut only at blocks that do not take a segment over
+    // from their predecessor (the sums of a track that spans blocks are carried from tile to tile inside a range)
     const int row_groups = (nb + 3) / 4;
     int want_ranges = std::max(1, std::min(nb, (6 * 4 * c->n_cu + row_groups - 1) / row_groups));
+    want_ranges = std::max(want_ranges, (nb >> 16) + 1);            // a range is addressed with 32-bit byte offsets: at most 2^20 rows
     std::vector<int> range_b0{0};
     for (int k = 1; k < want_ranges; ++k) {
         int b = (int)((long long)nb * k / want_ranges);
-        while (b < nb && blk_chunk[b] >= 0 && b > 0 && blk_first_track[b] == blk_first_track[b - 1]) ++b;   // move past the chunks of one track
+        while (b < nb && !blk_clean[b]) ++b;
         if (b > range_b0.back() && b < nb) range_b0.push_back(b);
     }
     range_b0.push_back(nb);
     const int n_ranges = (int)range_b0.size() - 1;
+    for (int k = 0; k < n_ranges; ++k) PVF_REQUIRE(range_b0[k + 1] - range_b0[k] <= (1 << 17), "pair_mean_dist: a track of more than a million rows");
     // ---- device buffers
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t xb = al((size_t)N * DIM * 8), nbz = al((size_t)N * 8), ib = al((size_t)N * 4), bb = al((size_t)nb * 4), pb = al((size_t)std::max(n_chunks, 1) * T * 8);
     const size_t rsb = al((size_t)(T + 1) * 4), rgb = al((size_t)(n_ranges + 1) * 4), bigb = al((size_t)std::max<size_t>(big_track.size(), 1) * 4);
-    c->s_clu0.ensure(xb + nbz + 2 * ib + 4 * bb + 16 * bb + pb + rsb + rgb + 3 * bigb + 4096);
+    c->s_clu0.ensure(xb + nbz + 2 * ib + bb + 2 * al((size_t)nb * 16 * 4) + pb + rsb + rgb + 3 * bigb + 4096);
     c->s_clu1.ensure((size_t)T * T * sizeof(double) + (size_t)T * 64 + 4096);
     uint8_t* p = c->s_clu0.as<uint8_t>();
     auto take = [&](size_t bytes) { uint8_t* q = p; p += bytes; return q; };
     double* dX = (double*)take(xb); double* dN = (double*)take(nbz);
     int* dRT = (int*)take(ib); int* dRS = (int*)take(ib);
-    int* dB0 = (int*)take(bb); int* dBN = (int*)take(bb); int* dBC = (int*)take(bb); int* dBL = (int*)take(bb);
-    int* dST = (int*)take(al((size_t)nb * 16 * 4));
+    int* dBC = (int*)take(bb);
+    int* dST = (int*)take(al((size_t)nb * 16 * 4)); int* dSP = (int*)take(al((size_t)nb * 16 * 4));
     double* dP = (double*)take(pb);
     int* dRow = (int*)take(rsb); int* dRange = (int*)take(rgb);
     int* dBigT = (int*)take(bigb); int* dBigC0 = (int*)take(bigb); int* dBigNc = (int*)take(bigb);
@@ -329,8 +330,8 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
     auto up = [&](void* d, const void* h, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream)); };
     up(dX, X, (size_t)N * DIM * 8);
     up(dRT, row_track.data(), (size_t)N * 4); up(dRS, row_segidx.data(), (size_t)N * 4);
-    up(dB0, blk_r0.data(), (size_t)nb * 4); up(dBN, blk_nr.data(), (size_t)nb * 4); up(dBC, blk_chunk.data(), (size_t)nb * 4);
-    up(dBL, blk_last.data(), (size_t)nb * 4); up(dST, seg_track.data(), (size_t)nb * 16 * 4);
+    up(dBC, blk_cont.data(), (size_t)nb * 4);
+    up(dST, seg_track.data(), (size_t)nb * 16 * 4); up(dSP, seg_part.data(), (size_t)nb * 16 * 4);
     up(dRow, row_start, (size_t)(T + 1) * 4); up(dRange, range_b0.data(), (size_t)(n_ranges + 1) * 4);
     up(dBigT, big_track.data(), big_track.size() * 4); up(dBigC0, big_c0.data(), big_c0.size() * 4); up(dBigNc, big_nc.data(), big_nc.size() * 4);
     // the staging buffers above are std::vectors: the copies must have run before they go out of scope
@@ -340,14 +341,14 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
         hipLaunchKernelGGL(row_norms_k, dim3((N + 255) / 256), dim3(256), 0, c->stream, dX, N, DIM, dN);
         PtArgs a;
         a.X = dX; a.nrm = dN; a.N = N; a.T = T; a.row_track = dRT; a.row_segidx = dRS;
-        a.blk_r0 = dB0; a.blk_nr = dBN; a.blk_chunk = dBC; a.blk_last = dBL; a.seg_track = dST; a.range_b0 = dRange; a.row_start = dRow; a.D = dD; a.P = dP;
+        a.blk_cont = dBC; a.seg_track = dST; a.seg_part = dSP; a.range_b0 = dRange; a.row_start = dRow; a.D = dD; a.P = dP;
         a.n_blocks = nb; a.n_ranges = n_ranges; a.t0 = t0; a.t1 = t1; a.metric = metric;
         hipLaunchKernelGGL(pair_tiles_k, dim3(row_groups, n_ranges), dim3(256), 0, c->stream, a);
-        // long tracks of the requested range
+        // tracks of the requested range that span several blocks
         std::vector<int> sel;
         for (size_t k = 0; k < big_track.size(); ++k) if (big_track[k] >= t0 && big_track[k] < t1) sel.push_back((int)k);
         if (!sel.empty()) {
-            const int k0 = sel.front(), nsel = (int)sel.size();     // long tracks inside [t0, t1) are consecutive entries
+            const int k0 = sel.front(), nsel = (int)sel.size();     // (big_track is sorted: those inside [t0, t1) are consecutive entries)
             hipLaunchKernelGGL(pair_chunks_k, dim3((T + 255) / 256, nsel), dim3(256), 0, c->stream, dP, dBigT + k0, dBigC0 + k0, dBigNc + k0, dRow, T, dD);
         }
     }
