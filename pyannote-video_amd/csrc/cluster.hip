@@ -184,30 +184,42 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
             const double* bp = &Bs[buf][i16 * PT_PITCH + k4];
 #pragma unroll
             for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bp[4 * s], acc, 0, 0, 0);
-            // C/D of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg
-            const bool col_ok = colSeg[buf][i16] >= 0;
+            // C/D of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 * reg.  Rows past the block's last one and padding columns need
+            // no masking here: their distances are finite (their fragments are zeros) and the 0/1 matrices of the two reductions leave them out.
             const double nb = colNrm[buf][i16];
             double d[4];
+            if (a.metric == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = k4 + 4 * r;
-                d[r] = 0.0;
-                if (row < anr && col_ok) {
-                    const double g = acc[r], sum = na4[r] + nb;
-                    if (a.metric == 1) d[r] = 1.0 - g / sqrt(na4[r] * nb);
-                    else {
-                        double d2 = sum - 2.0 * g;
-                        // the Gram form cancels for close rows: its absolute error in d is ~1e-16 (|a|^2 + |b|^2) / d, i.e. below 1e-13 down
-                        // to d ~ 3e-3 |x|; closer pairs (identical or near-identical rows) take the differences instead
-                        if (d2 < 1e-5 * sum) {
+                for (int r = 0; r < 4; ++r) {
+                    const double den = sqrt(na4[r] * nb);
+                    d[r] = den > 0.0 ? 1.0 - acc[r] / den : 0.0;
+                }
+            } else {
+                double d2[4];
+                bool fix = false;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double sum = na4[r] + nb;
+                    d2[r] = sum - 2.0 * acc[r];
+                    // the Gram form cancels for close rows: its absolute error in d is ~1e-16 (|a|^2 + |b|^2) / d, i.e. below 1e-13 down
+                    // to d ~ 3e-3 |x|; closer pairs (identical or near-identical rows) take the differences instead
+                    fix = fix || (d2[r] < 1e-5 * sum && k4 + 4 * r < anr && colSeg[buf][i16] >= 0);
+                }
+                if (__builtin_amdgcn_ballot_w64(fix) != 0) {           // rare: some lane of the wave holds such a pair
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = k4 + 4 * r;
+                        if (d2[r] < 1e-5 * (na4[r] + nb) && row < anr && colSeg[buf][i16] >= 0) {
                             const double* xa = a.X + (size_t)(ar0 + row) * DIM;
                             const double* xb = a.X + (size_t)(br0 + i16) * DIM;
-                            d2 = 0.0;
-                            for (int k = 0; k < DIM; ++k) { const double t = xa[k] - xb[k]; d2 += t * t; }
+                            double e = 0.0;
+                            for (int k = 0; k < DIM; ++k) { const double t = xa[k] - xb[k]; e += t * t; }
+                            d2[r] = e;
                         }
-                        d[r] = sqrt(d2 > 0.0 ? d2 : 0.0);
                     }
                 }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = sqrt(d2[r] > 0.0 ? d2[r] : 0.0);
             }
             // rows of every row track: R'[column][row segment] = sum_row d[row][column] Rind[segment][row]; this lane's d[s] is
             // element (column i16, row 4 s + k4) of d^T, i.e. the A operand of step s
