@@ -516,23 +516,48 @@ __global__ void __launch_bounds__(256) hac_init_k(HacState h, const int32_t* __r
     h.alive[k] = 1; h.dirty[k] = 0; h.size[k] = (double)(row_start[k + 1] - row_start[k]);
 }
 
-// The whole agglomeration in ONE workgroup: row minima and their arguments live in LDS (12 bytes per track: up to 10 240 tracks), a merge
-// is argmin over LDS -> size-weighted update of row / column bi in HBM -> re-scan of the rows whose cached minimum died.  Same decisions
-// as the kernels above (first minimum in row-major order, rows re-scanned from scratch), no launch or host round trip inside the loop.
-#define HAC_PERSIST_MAX_T 10200          // 16 bytes of LDS per track + the reduction scratch <= 160 KiB
-// (value, index) minimum over the workgroup, smaller index on equal values: wave reduction by shuffles, 16 partial results through LDS
-__device__ __forceinline__ void block_argmin(double& v, int& i, double* wv, int* wi)
+// The whole agglomeration in ONE workgroup: row minima and their arguments live in LDS (14 bytes per track + one alive bit: up to 10 240
+// tracks), a merge is argmin over LDS -> size-weighted update of row / column mi in HBM -> re-scan of the rows whose cached minimum died.
+// Same decisions as the kernels above (first minimum in row-major order, rows re-scanned from scratch), no launch or host round trip
+// inside the loop.  A merge is two dependent trips to HBM, whatever T: a thread requests the <= U entries it owns of rows mi and mj (and
+// the two sizes) in one batch before it uses any, the new minimum of row mi comes out of that same pass (its new entries are in
+// registers), and the other rows to re-scan are read HAC_G - 1 at a time, again one batch per thread, and reduced together.
+#define HAC_PERSIST_MAX_T 10200
+#define HAC_G 3                          // rows reduced together after a merge (row mi + 2 re-scanned rows; then 3 at a time)
+static inline size_t hac_persist_lds(int T) { return ((size_t)T * 14 + 3) / 4 * 4 + (size_t)((T + 31) / 32) * 4; }
+
+// (value, index) minimum over a wave, smaller index on equal values, left in every lane.  Two DPP reductions (row_shr 1 / 2 / 4 / 8 inside
+// the rows of 16 lanes, then row_bcast:15 and row_bcast:31 carry the row results up to lane 63): first the value, then the smallest index
+// among the lanes that hold it -- no trips through the LDS crossbar, no compare-and-select chains.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); }
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_down(v, off, 64);
-        const int oi = __shfl_down(i, off, 64);
-        if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();                                     // the previous round's readers are done with wv / wi
-    if (lane == 0) { wv[wave] = v; wi[wave] = i; }
-    __syncthreads();
+    return __hiloint2double(dpp_i32<CTRL, ROWS>(__double2hiint(v)), dpp_i32<CTRL, ROWS>(__double2loint(v)));
+}
+__device__ __forceinline__ void wave_argmin(double& v, int& i)
+{
+    double m = v;
+    m = __builtin_fmin(m, dpp_f64<0x111, 0xf>(m));
+    m = __builtin_fmin(m, dpp_f64<0x112, 0xf>(m));
+    m = __builtin_fmin(m, dpp_f64<0x114, 0xf>(m));
+    m = __builtin_fmin(m, dpp_f64<0x118, 0xf>(m));
+    m = __builtin_fmin(m, dpp_f64<0x142, 0xa>(m));
+    m = __builtin_fmin(m, dpp_f64<0x143, 0xc>(m));
+    const double vmin = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 63), __builtin_amdgcn_readlane(__double2loint(m), 63));
+    int c = (v == vmin) ? i : 0x7fffffff;
+    c = min(c, dpp_i32<0x111, 0xf>(c));
+    c = min(c, dpp_i32<0x112, 0xf>(c));
+    c = min(c, dpp_i32<0x114, 0xf>(c));
+    c = min(c, dpp_i32<0x118, 0xf>(c));
+    c = min(c, dpp_i32<0x142, 0xa>(c));
+    c = min(c, dpp_i32<0x143, 0xc>(c));
+    v = vmin;
+    i = __builtin_amdgcn_readlane(c, 63);
+}
+__device__ __forceinline__ void pick16(const double* wv, const int* wi, double& v, int& i)
+{
     v = wv[0]; i = wi[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) {
@@ -541,68 +566,140 @@ __device__ __forceinline__ void block_argmin(double& v, int& i, double* wv, int*
     }
 }
 
+template <int U>
 __global__ void __launch_bounds__(1024) hac_persist_k(HacState h)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
-    const int T = h.T, tid = threadIdx.x;
+    const int T = h.T, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* rmin = reinterpret_cast<double*>(hsm);
     int* rarg = reinterpret_cast<int*>(hsm + (size_t)T * 8);
-    int* dlist = rarg + T;                              // rows to re-scan after this merge
-    __shared__ double wv[16];
-    __shared__ int wi[16];
+    uint16_t* dlist = reinterpret_cast<uint16_t*>(rarg + T);                     // rows to re-scan after this merge
+    uint32_t* abits = reinterpret_cast<uint32_t*>(hsm + ((size_t)T * 14 + 3) / 4 * 4);   // bit k: track k has not been merged away
+    __shared__ double wvA[16];
+    __shared__ int wiA[16];
+    __shared__ double wvB[HAC_G][16];
+    __shared__ int wiB[HAC_G][16];
     __shared__ int s_nd;
+    double* const D = h.D;
     for (int r = tid; r < T; r += 1024) { rmin[r] = h.rmin[r]; rarg[r] = h.rarg[r]; }
+    for (int w = tid; w < (T + 31) / 32; w += 1024) abits[w] = (32 * w + 32 <= T) ? 0xffffffffu : ((1u << (T - 32 * w)) - 1u);
     __syncthreads();
+    auto alive = [&](int k) { return (abits[k >> 5] >> (k & 31)) & 1u; };
     int merges = 0;
     while (merges < T - 1) {
+        // ---- the closest pair: first minimum of the row minima
         double bv = INFINITY; int bi = 0x7fffffff;
-        for (int r = tid; r < T; r += 1024) {
-            const double v = rmin[r];
-            if (v < bv) { bv = v; bi = r; }             // ascending r per thread: first occurrence kept
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = tid + 1024 * u;
+            if (r < T) { const double v = rmin[r]; if (v < bv) { bv = v; bi = r; } }   // ascending r per thread: first occurrence kept
         }
-        block_argmin(bv, bi, wv, wi);
+        wave_argmin(bv, bi);
+        if (lane == 0) { wvA[wave] = bv; wiA[wave] = bi; }
+        if (tid == 0) s_nd = 0;
+        __syncthreads();
+        pick16(wvA, wiA, bv, bi);
         if (bi == 0x7fffffff || !(bv <= h.threshold)) break;      // uniform: every thread holds the same (bv, bi)
         const int mi = bi, mj = rarg[bi];
+        // ---- row / column mi <- size-weighted mean of rows mi and mj; everything a thread needs is requested before anything is used
+        double a[U], b[U];
+        uint32_t live = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = tid + 1024 * u;
+            if (k < T && k != mi && k != mj && alive(k)) live |= 1u << u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = tid + 1024 * u;
+            a[u] = 0.0; b[u] = 0.0;
+            if (live >> u & 1) {
+                a[u] = D[(size_t)mi * T + k];
+                b[u] = D[(size_t)mj * T + k];
+            }
+        }
         const double szi = h.size[mi], szj = h.size[mj];
         if (tid == 0) {
-            s_nd = 0;
             h.log[4 * merges] = mi; h.log[4 * merges + 1] = mj; h.log[4 * merges + 2] = bv; h.log[4 * merges + 3] = szi + szj;
         }
-        __syncthreads();                                 // sizes and rarg[bi] are read by everyone before anything changes
-        for (int k = tid; k < T; k += 1024) {
-            if (k == mi || k == mj || !h.alive[k]) continue;
-            const double v = (szi * h.D[(size_t)mi * T + k] + szj * h.D[(size_t)mj * T + k]) / (szi + szj);
-            h.D[(size_t)mi * T + k] = v;
-            h.D[(size_t)k * T + mi] = v;
+        // the quotient by the (uniform) sum of the sizes: reciprocal once, then q = n y corrected twice through the exact residual
+        // n - den q (Markstein: with y the correctly rounded reciprocal the result is the correctly rounded quotient, i.e. what the
+        // division instruction sequence returns -- 35 instructions per entry otherwise; checked on 1e8 cases, tests/test_host_logic.py)
+        const double den = szi + szj, yrc = 1.0 / den;
+        double v0 = INFINITY; int j0 = 0x7fffffff;             // the new first minimum of row mi over its alive columns k > mi
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!(live >> u & 1)) continue;
+            const int k = tid + 1024 * u;
+            const double num = szi * a[u] + szj * b[u];
+            double v = num * yrc;
+            v = __builtin_fma(__builtin_fma(-den, v, num), yrc, v);
+            v = __builtin_fma(__builtin_fma(-den, v, num), yrc, v);
+            D[(size_t)mi * T + k] = v;
+            D[(size_t)k * T + mi] = v;
             if (k < mi) {
                 const int ra = rarg[k];
-                if (ra == mi || ra == mj) dlist[atomicAdd(&s_nd, 1)] = k;
+                if (ra == mi || ra == mj) dlist[atomicAdd(&s_nd, 1)] = (uint16_t)k;
                 else if (v < rmin[k] || (v == rmin[k] && mi < ra)) { rmin[k] = v; rarg[k] = mi; }
-            } else if (k < mj) {
-                if (rarg[k] == mj) dlist[atomicAdd(&s_nd, 1)] = k;
+            } else {
+                if (k < mj && rarg[k] == mj) dlist[atomicAdd(&s_nd, 1)] = (uint16_t)k;
+                if (v < v0) { v0 = v; j0 = k; }
             }
         }
         if (tid == 0) {
-            h.size[mi] = szi + szj; h.alive[mj] = 0;
+            atomicAnd(&abits[mj >> 5], ~(1u << (mj & 31)));
             rmin[mj] = INFINITY; rarg[mj] = 0x7fffffff;
-            dlist[atomicAdd(&s_nd, 1)] = mi;
         }
         __syncthreads();
         const int nd = s_nd;
-        // re-scan row r: first minimum over the alive columns j > r.  (One wave per row, sixteen rows at a time, was measured 2.3 x slower at
-        // T = 10 000: a lane then walks 156 dependent load pairs instead of 10.)
-        for (int q = 0; q < nd; ++q) {
-            const int r = dlist[q];
-            double v0 = INFINITY; int j0 = 0x7fffffff;
-            for (int j = r + 1 + tid; j < T; j += 1024) {
-                if (!h.alive[j]) continue;
-                const double v = h.D[(size_t)r * T + j];
-                if (v < v0) { v0 = v; j0 = j; }
-            }
-            block_argmin(v0, j0, wv, wi);
-            if (tid == 0) { rmin[r] = v0; rarg[r] = j0; }
+        if (tid == 0) h.size[mi] = szi + szj;               // (after the barrier: every thread has read the two sizes)
+        // ---- row mi (from registers) and the rows whose cached minimum died: first minimum over the alive columns j > r
+        uint32_t am = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = tid + 1024 * u;
+            if (j < T && alive(j)) am |= 1u << u;
         }
-        __syncthreads();
+        int q = 0;
+        bool first = true;
+        do {
+            int row[HAC_G];
+            double sv[HAC_G]; int sj[HAC_G];
+            int nrow = 0;
+            row[0] = mi; nrow = 1;                                              // slot 0: row mi in the first round, unused afterwards
+            while (nrow < HAC_G && q < nd) row[nrow++] = dlist[q++];            // (uniform)
+            double ld[HAC_G - 1][U];                                            // (slot 0 is row mi's, never loaded)
+#pragma unroll
+            for (int g = 1; g < HAC_G; ++g)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = tid + 1024 * u;
+                    ld[g - 1][u] = INFINITY;
+                    if (g < nrow && (am >> u & 1) && j > row[g]) ld[g - 1][u] = D[(size_t)row[g] * T + j];
+                }
+#pragma unroll
+            for (int g = 0; g < HAC_G; ++g) {
+                if (g >= nrow) continue;
+                if (g == 0) { if (!first) continue; sv[g] = v0; sj[g] = j0; }
+                else {
+                    sv[g] = INFINITY; sj[g] = 0x7fffffff;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) if (ld[g - 1][u] < sv[g]) { sv[g] = ld[g - 1][u]; sj[g] = tid + 1024 * u; }
+                }
+                wave_argmin(sv[g], sj[g]);
+                if (lane == 0) { wvB[g][wave] = sv[g]; wiB[g][wave] = sj[g]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < HAC_G; ++g)
+                if (g < nrow && tid == g && (g > 0 || first)) {
+                    double v; int i;
+                    pick16(wvB[g], wiB[g], v, i);
+                    rmin[row[g]] = v; rarg[row[g]] = i;
+                }
+            __syncthreads();
+            first = false;
+        } while (q < nd);
         ++merges;
     }
     if (tid == 0) *h.n_merges = merges;
@@ -636,13 +733,17 @@ int hac_dev(Ctx* c, double* d_D, const int32_t* row_start, int T, double thresho
     hipLaunchKernelGGL(hac_row_min_k, dim3(T), dim3(256), 0, c->stream, h, 0);
     double hbest[4];
     if (T <= HAC_PERSIST_MAX_T) {
-        const size_t lds = (size_t)T * 16;               // rmin f64, rarg i32, re-scan list i32
+        const size_t lds = hac_persist_lds(T);           // rmin f64, rarg i32, re-scan list u16, alive bits
         static bool attr_set = false;
         if (!attr_set) {
-            HIP_CHECK(hipFuncSetAttribute((const void*)hac_persist_k, hipFuncAttributeMaxDynamicSharedMemorySize, HAC_PERSIST_MAX_T * 16));
+            HIP_CHECK(hipFuncSetAttribute((const void*)hac_persist_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hac_persist_lds(1024)));
+            HIP_CHECK(hipFuncSetAttribute((const void*)hac_persist_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hac_persist_lds(3072)));
+            HIP_CHECK(hipFuncSetAttribute((const void*)hac_persist_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hac_persist_lds(HAC_PERSIST_MAX_T)));
             attr_set = true;
         }
-        hipLaunchKernelGGL(hac_persist_k, dim3(1), dim3(1024), lds, c->stream, h);
+        if (T <= 1024) hipLaunchKernelGGL(hac_persist_k<1>, dim3(1), dim3(1024), lds, c->stream, h);
+        else if (T <= 3072) hipLaunchKernelGGL(hac_persist_k<3>, dim3(1), dim3(1024), lds, c->stream, h);
+        else hipLaunchKernelGGL(hac_persist_k<10>, dim3(1), dim3(1024), lds, c->stream, h);
     } else
     for (int it = 0; it < T - 1; ++it) {
         hipLaunchKernelGGL(hac_argmin_k, dim3(1), dim3(1024), 0, c->stream, h);

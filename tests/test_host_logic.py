@@ -1,6 +1,7 @@
 """CPU: the product's lock-step tracking state machine against the sequential restatement of the reference
 (oracle/ref_flow.py), with scripted detections and a scripted tracker plugged into the reference's own seams
 (detect_func: tracking.py:104,112,426; tracker object start_track/update/get_position: :203,231,250-251)."""
+import os
 import numpy as np
 import pytest
 from pyannote_video_amd.tracking_by_detection import TrackingByDetection, ObjectTrackers, get_segment_generator
@@ -479,3 +480,18 @@ def test_bulk_pair_path_on_handle_arrays_equals_sequential_reference(seed):
     assert got == ref
     assert ctx.clones == sum(len(d) for d in dets) and ctx.commits > 0
     assert not ctx.trk                      # every tracker was released
+
+
+def test_hac_quotient_by_reciprocal_is_the_ieee_quotient(tmp_path):
+    """hac_persist_k divides by the (merge-uniform) sum of two sizes through one reciprocal and two fused corrections: 9.6e7 cases against
+    the division itself (tests/csrc/exact_quotient_check.c)"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "exact_quotient_check")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "exact_quotient_check.c")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", exe, src, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout[-400:]
+    assert " 0 differ" in out.stdout
