@@ -196,6 +196,11 @@ int32_t pvf_format_rows(const double* t, const int64_t* identifier, const double
  * embedding.txt, computed in memory: out[i] = rint((double)x[i] * 10^decimals) / 10^decimals (== np.round of the float64 value) */
 int32_t pvf_round_rows(const float* x, int64_t n, int32_t decimals, double* out);
 
+/* ref: face/clustering.py:70-75 (`read_table` of embedding.txt), scripts/pyannote-face.py:223-233 (track.txt)  whitespace-separated numeric
+ * text -> float64 [n_rows][n_cols], row-major, the values strtod returns (one IEEE division for plain decimals of <= 15 digits, strtod for
+ * the rest); rows of different lengths or a token that is not a number are errors.  cap = doubles `out` can hold (len / 2 + 1 suffices). */
+int32_t pvf_parse_rows(const char* text, int64_t len, double* out, int64_t cap, int64_t* n_rows, int32_t* n_cols);
+
 /* ---- measurement ----------------------------------------------------------------------------------- */
 /* HIP-event timing of each kernel family on the context's stream ("pyramid","fhog","score","ert","chip","conv",
  * "dsst","pdist","hac"); off by default */

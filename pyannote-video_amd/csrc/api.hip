@@ -2,6 +2,8 @@
 #include "pvf_internal.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <string>
 #include <thread>
 
 #define API_BEGIN try {
@@ -759,5 +761,91 @@ extern "C" int32_t pvf_round_rows(const float* x, int64_t n, int32_t decimals, d
         for (int i = 0; i < nt; ++i) th.emplace_back(work, n * i / nt, n * (i + 1) / nt);
         for (auto& t : th) t.join();
     }
+    API_END
+}
+
+// ---- text rows back into float64 (what np.loadtxt / pandas.read_table return for the files the writers above produce) --------------------
+// A token "[-]digits[.digits]" with at most 15 significant digits is mantissa / 10^k with both operands exact in binary64, so ONE IEEE
+// division gives the correctly rounded value of the decimal -- the value strtod returns; anything else (exponents, inf, nan, longer digit
+// strings) goes through strtod itself.  Rows end at '\n'; every row must hold the same number of values.
+extern "C" int32_t pvf_parse_rows(const char* text, int64_t len, double* out, int64_t cap, int64_t* n_rows, int32_t* n_cols)
+{
+    API_BEGIN
+    PVF_REQUIRE(len >= 0 && (len == 0 || text) && cap >= 0 && (cap == 0 || out) && n_rows && n_cols, "pvf_parse_rows: bad arguments");
+    static const double p10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+    // rows are independent: cut the text at line ends into a few pieces, parse them on threads, then check the shapes and pack
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, len / (1 << 20)));
+    std::vector<int64_t> cut(nt + 1, len);
+    cut[0] = 0;
+    for (int i = 1; i < nt; ++i) {
+        int64_t q = len * i / nt;
+        while (q < len && text[q] != '\n') ++q;
+        cut[i] = std::min(len, q + 1);
+    }
+    struct Piece { std::vector<double> v; int64_t rows = 0; int cols = -1; bool ragged = false; bool bad = false; };
+    std::vector<Piece> pc(nt);
+    auto work = [&](int pi) {
+        Piece& P = pc[pi];
+        const char* s = text + cut[pi];
+        const char* const e = text + cut[pi + 1];
+        P.v.reserve((size_t)(e - s) / 8 + 16);
+        int in_row = 0;
+        auto end_row = [&]() {
+            if (in_row == 0) return;                               // blank line
+            if (P.cols < 0) P.cols = in_row; else if (P.cols != in_row) P.ragged = true;
+            ++P.rows; in_row = 0;
+        };
+        while (s < e) {
+            const char c = *s;
+            if (c == '\n') { end_row(); ++s; continue; }
+            if (c == ' ' || c == '\t' || c == '\r') { ++s; continue; }
+            const char* tok = s;
+            bool neg = false;
+            if (*s == '-' || *s == '+') { neg = (*s == '-'); ++s; }
+            uint64_t m = 0; int nd = 0, frac = 0; bool simple = (s < e) && ((*s >= '0' && *s <= '9') || *s == '.'), seen_digit = false;
+            while (s < e && *s >= '0' && *s <= '9') { m = m * 10 + (uint64_t)(*s - '0'); nd += (m != 0); ++s; seen_digit = true; }
+            if (s < e && *s == '.') {
+                ++s;
+                while (s < e && *s >= '0' && *s <= '9') { m = m * 10 + (uint64_t)(*s - '0'); nd += (m != 0); ++frac; ++s; seen_digit = true; }
+            }
+            const bool ends = (s == e) || *s == ' ' || *s == '\n' || *s == '\t' || *s == '\r';
+            double val;
+            if (simple && seen_digit && ends && nd <= 15 && frac <= 15) {
+                val = (double)m / p10[frac];
+                if (neg) val = -val;
+            } else {
+                // the general case: let strtod read a bounded copy of the token
+                const char* t2 = tok;
+                while (t2 < e && !(*t2 == ' ' || *t2 == '\n' || *t2 == '\t' || *t2 == '\r')) ++t2;
+                std::string tmp(tok, t2);
+                char* endp = nullptr;
+                val = std::strtod(tmp.c_str(), &endp);
+                if (tmp.empty() || endp != tmp.c_str() + tmp.size()) { P.bad = true; return; }
+                s = t2;
+            }
+            P.v.push_back(val);
+            ++in_row;
+        }
+        end_row();
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nt; ++i) th.emplace_back(work, i);
+        for (auto& t : th) t.join();
+    }
+    int64_t rows = 0, total = 0; int cols = -1;
+    for (auto& P : pc) {
+        PVF_REQUIRE(!P.bad, "pvf_parse_rows: not a number");
+        PVF_REQUIRE(!P.ragged, "pvf_parse_rows: rows of different lengths");
+        if (P.rows == 0) continue;
+        if (cols < 0) cols = P.cols;
+        PVF_REQUIRE(cols == P.cols, "pvf_parse_rows: rows of different lengths");
+        rows += P.rows; total += (int64_t)P.v.size();
+    }
+    PVF_REQUIRE(total <= cap, "pvf_parse_rows: output buffer too small");
+    int64_t o = 0;
+    for (auto& P : pc) { if (!P.v.empty()) memcpy(out + o, P.v.data(), P.v.size() * sizeof(double)); o += (int64_t)P.v.size(); }
+    *n_rows = rows; *n_cols = cols < 0 ? 0 : cols;
     API_END
 }

@@ -76,6 +76,7 @@ _SIGS = {
     "pvf_cluster_tracks": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_format_rows": (C.c_int32, [P, P, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "pvf_round_rows": (C.c_int32, [P, C.c_int64, C.c_int32, P]),
+    "pvf_parse_rows": (C.c_int32, [C.c_char_p, C.c_int64, P, C.c_int64, P, P]),
     "pvf_prof_enable": (C.c_int32, [H, C.c_int32]),
     "pvf_prof_reset": (C.c_int32, [H]),
     "pvf_prof_get": (C.c_int32, [H, C.c_char_p, P, P]),
@@ -194,6 +195,19 @@ def round_rows(x, decimals=5):
     out = np.empty(x.shape, np.float64)
     check(lib().pvf_round_rows(ptr(x), x.size, int(decimals), ptr(out)))
     return out
+
+
+def parse_rows(text):
+    """float64 [rows, cols] of whitespace-separated numeric text (bytes): np.loadtxt(..., ndmin=2) for the files format_rows writes"""
+    n = len(text)
+    rows, cols = C.c_int64(0), C.c_int32(0)
+    for cap in (n // 6 + 16, n // 2 + 1):             # (a value and its separator take >= 2 bytes; the files here use >= 8)
+        out = np.empty(cap, np.float64)
+        if lib().pvf_parse_rows(text, n, ptr(out), out.size, C.byref(rows), C.byref(cols)) == 0:
+            return out[:rows.value * cols.value].reshape(rows.value, cols.value)
+        if b"too small" not in lib().pvf_last_error():
+            break
+    raise PvfError(lib().pvf_last_error().decode("utf-8", "replace"))
 
 
 def munkres(cost):

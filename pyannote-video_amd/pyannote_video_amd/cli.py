@@ -167,31 +167,54 @@ def extract(video, landmark_model, embedding_model, tracking, landmark_output, e
     try:
         with open(landmark_output, 'wb') as flandmark, open(embedding_output, 'wb') as fembedding:
             pend_f, pend_b, pend_k, pend_own = [], [], [], []
+            wq = queue.Queue(maxsize=4)
+
+            def writer():
+                # the text of batch i is formatted (in the library, outside the GIL) and written while the GPU computes batch i + 1
+                try:
+                    while True:
+                        item = wq.get()
+                        if item is None:
+                            return
+                        if state["error"] is not None:
+                            continue
+                        T, ident, pts, emb = item
+                        flandmark.write(formats.landmark_rows(T, ident, pts, frame_width, frame_height))
+                        fembedding.write(formats.embedding_rows(T, ident, emb))
+                except BaseException as e:          # noqa: BLE001 -- re-raised below
+                    state["error"] = e
+                    while wq.get() is not None:
+                        pass
+
+            wth = threading.Thread(target=writer, name="pvface-extract-writer")
+            wth.start()
 
             def flush():
                 if not pend_b:
                     return
                 pts, emb = ctx.landmarks_embed(pend_f, pend_b)
-                T, ident = [k[0] for k in pend_k], [k[1] for k in pend_k]
-                flandmark.write(formats.landmark_rows(T, ident, pts, frame_width, frame_height))
-                fembedding.write(formats.embedding_rows(T, ident, emb))
-                flandmark.flush(); fembedding.flush()
+                wq.put(([k[0] for k in pend_k], [k[1] for k in pend_k], pts, emb))
                 for f in pend_own:
                     f.release()
                 del pend_f[:], pend_b[:], pend_k[:], pend_own[:]
-            while True:
-                item = q.get()
-                if item is None:
-                    break
-                fi, dev, owned = item
-                T, g = want[fi]
-                if owned:
-                    pend_own.append(dev)
-                for ident, box in g:
-                    pend_f.append(dev); pend_b.append(box); pend_k.append((T, ident))
-                if len(pend_b) >= batch:
+            try:
+                while state["error"] is None:
+                    item = q.get()
+                    if item is None:
+                        break
+                    fi, dev, owned = item
+                    T, g = want[fi]
+                    if owned:
+                        pend_own.append(dev)
+                    for ident, box in g:
+                        pend_f.append(dev); pend_b.append(box); pend_k.append((T, ident))
+                    if len(pend_b) >= batch:
+                        flush()
+                if state["error"] is None:
                     flush()
-            flush()
+            finally:
+                wq.put(None)
+                wth.join()
     finally:
         while th.is_alive():                 # an error on this side: let the reader run out
             try:

@@ -495,3 +495,46 @@ def test_hac_quotient_by_reciprocal_is_the_ieee_quotient(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout[-400:]
     assert " 0 differ" in out.stdout
+
+
+def test_parse_rows_returns_what_loadtxt_returns():
+    """pvf_parse_rows (the embedding.txt reader behind FaceClustering's preprocess) against np.loadtxt: the writers' 5-decimal rows bit for
+    bit, exponents / inf / nan / long digit strings through strtod, blank lines skipped, ragged rows and non-numbers refused"""
+    import io
+    from pyannote_video_amd import _lib
+    rng = np.random.default_rng(3)
+    n = 300
+    t = np.round(rng.uniform(0, 4000, n), 3)
+    ident = rng.integers(0, 5000, n)
+    v = rng.normal(size=(n, 128)) * rng.choice([1e-6, 1e-2, 1.0, 1e3], size=(n, 1))
+    v[0, :4] = [0.0, -0.0, -1e-7, 12345.678901]
+    for decimals in (5, 3, 9):
+        txt = _lib.format_rows(t, ident, v, decimals)
+        a = _lib.parse_rows(txt)
+        b = np.loadtxt(io.BytesIO(txt), dtype=np.float64, ndmin=2)
+        assert a.shape == b.shape == (n, 130)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    txt = b"1e-3 2.5E+2 -inf nan +3\n\n0.1234567890123456789 7 .5 9. 123456789012345678\r\n"
+    a, b = _lib.parse_rows(txt), np.loadtxt(io.BytesIO(txt), ndmin=2)
+    assert a.shape == (2, 5) and np.array_equal(a, b, equal_nan=True)
+    assert _lib.parse_rows(b"").shape == (0, 0)
+    assert _lib.parse_rows(b"1 2 3 4 5 6 7 8 9\n").shape == (1, 9)          # (more values than the first buffer guess holds)
+    for bad in (b"1 2\n3\n", b"1 x\n", b"1 2-3\n"):
+        with pytest.raises(_lib.PvfError):
+            _lib.parse_rows(bad)
+
+
+def test_read_embeddings_round_trip(tmp_path):
+    from pyannote_video_amd import _lib
+    rng = np.random.default_rng(4)
+    t = np.round(rng.uniform(0, 40, 50), 3)
+    ident = rng.integers(0, 9, 50)
+    v = rng.normal(size=(50, 128)) * 0.1
+    p = tmp_path / "embedding.txt"
+    p.write_bytes(_lib.format_rows(t, ident, v, 5))
+    tt, ii, xx = formats.read_embeddings(str(p))
+    assert np.array_equal(tt, t) and np.array_equal(ii, ident) and xx.flags.c_contiguous
+    assert np.array_equal(xx, np.round(v, 5))
+    (tmp_path / "empty.txt").write_bytes(b"")
+    tt, ii, xx = formats.read_embeddings(str(tmp_path / "empty.txt"))
+    assert len(tt) == 0 and xx.shape == (0, 128)
