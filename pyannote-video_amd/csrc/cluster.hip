@@ -523,7 +523,7 @@ __global__ void __launch_bounds__(256) hac_init_k(HacState h, const int32_t* __r
 // the two sizes) in one batch before it uses any, the new minimum of row mi comes out of that same pass (its new entries are in
 // registers), and the other rows to re-scan are read HAC_G - 1 at a time, again one batch per thread, and reduced together.
 #define HAC_PERSIST_MAX_T 10200
-#define HAC_G 3                          // rows reduced together after a merge (row mi + 2 re-scanned rows; then 3 at a time)
+#define HAC_G 4                          // rows reduced together after a merge: row mi + 3 re-scanned rows, then 3 per further round
 static inline size_t hac_persist_lds(int T) { return ((size_t)T * 14 + 3) / 4 * 4 + (size_t)((T + 31) / 32) * 4; }
 
 // (value, index) minimum over a wave, smaller index on equal values, left in every lane.  Two DPP reductions (row_shr 1 / 2 / 4 / 8 inside
@@ -600,7 +600,8 @@ __global__ void __launch_bounds__(1024) hac_persist_k(HacState h)
         __syncthreads();
         pick16(wvA, wiA, bv, bi);
         if (bi == 0x7fffffff || !(bv <= h.threshold)) break;      // uniform: every thread holds the same (bv, bi)
-        const int mi = bi, mj = rarg[bi];
+        // (the pair comes out of LDS: tell the compiler it is wave-uniform, so that row addresses are scalar arithmetic)
+        const int mi = __builtin_amdgcn_readfirstlane(bi), mj = __builtin_amdgcn_readfirstlane(rarg[bi]);
         // ---- row / column mi <- size-weighted mean of rows mi and mj; everything a thread needs is requested before anything is used
         double a[U], b[U];
         uint32_t live = 0;
@@ -651,7 +652,7 @@ __global__ void __launch_bounds__(1024) hac_persist_k(HacState h)
             rmin[mj] = INFINITY; rarg[mj] = 0x7fffffff;
         }
         __syncthreads();
-        const int nd = s_nd;
+        const int nd = __builtin_amdgcn_readfirstlane(s_nd);
         if (tid == 0) h.size[mi] = szi + szj;               // (after the barrier: every thread has read the two sizes)
         // ---- row mi (from registers) and the rows whose cached minimum died: first minimum over the alive columns j > r
         uint32_t am = 0;
@@ -667,7 +668,7 @@ __global__ void __launch_bounds__(1024) hac_persist_k(HacState h)
             double sv[HAC_G]; int sj[HAC_G];
             int nrow = 0;
             row[0] = mi; nrow = 1;                                              // slot 0: row mi in the first round, unused afterwards
-            while (nrow < HAC_G && q < nd) row[nrow++] = dlist[q++];            // (uniform)
+            while (nrow < HAC_G && q < nd) row[nrow++] = __builtin_amdgcn_readfirstlane((int)dlist[q++]);
             double ld[HAC_G - 1][U];                                            // (slot 0 is row mi's, never loaded)
 #pragma unroll
             for (int g = 1; g < HAC_G; ++g)

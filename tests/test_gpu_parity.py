@@ -350,3 +350,22 @@ def test_hac_persistent_kernel_3000_tracks_equals_oracle(ctx, oracle):
     assert np.allclose(log[:, 2], logr[:, 2], rtol=1e-11)
     for t in range(T):
         assert ident[labels[t]] == ident[t]
+
+
+@pytest.mark.parametrize("T", [40, 700, 3200])
+def test_hac_tie_order_equals_oracle(ctx, oracle, T):
+    """K11 on distance matrices made of a handful of values: almost every minimum is tied, so the merge order is decided by the
+    first-minimum-in-row-major-order rule alone (in the wave reductions, in the re-scans, in the cached row minima); T = 40 / 700 / 3200
+    run the three instantiations of the persistent kernel (<= 1024, <= 3072, <= 10 240 tracks)"""
+    rng = np.random.default_rng(100 + T)
+    lv = np.array([0.125, 0.25, 0.5, 0.75, 1.0, 1.25, 1.5])
+    D = lv[rng.integers(0, len(lv), (T, T))]
+    D = np.triu(D, 1); D = D + D.T
+    sizes = rng.integers(1, 5, T)
+    rs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    labels, log = ctx.cluster_dist(D, rs, 0.6)
+    lr, logr = oracle.hac(D, sizes, 0.6)
+    assert len(log) == len(logr) and T // 2 < len(log) < T - 1
+    assert np.array_equal(log[:, :2], logr[:, :2])
+    assert np.array_equal(log[:, 2:], logr[:, 2:])           # distances and sizes: the same operations in the same order
+    assert np.array_equal(labels, lr)
