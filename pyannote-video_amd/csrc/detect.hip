@@ -3,6 +3,7 @@
 // oracle/pvo_detect.c so that boxes are bit-identical; the code itself is written for gfx950 (wave64, LDS tiles).
 #include "fhog_dev.h"
 #include <algorithm>
+#include <thread>
 #include <cmath>
 #include <cstdlib>
 
@@ -980,18 +981,6 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
     PVF_REQUIRE(!frames.empty() && batch > 0, "no frames");
     const int N = (int)frames.size();
     raw_sorted.assign(N, {});
-    if (N <= batch) {
-        for (int o = 0; o < N; o += batch) {                   // plain batch-by-batch form
-            std::vector<Frame> fr(frames.begin() + o, frames.begin() + std::min(N, o + batch));
-            std::vector<std::vector<RawDet>> part;
-            det_run_batch(c, fr, upsample, adjust, part);
-            for (size_t i = 0; i < part.size(); ++i) {
-                if (nms) det_nms(m, part[i], raw_sorted[o + i]);
-                else raw_sorted[o + i] = std::move(part[i]);
-            }
-        }
-        return;
-    }
     const int cap = c->det_cand_cap, PF = DET_PREFETCH;
     ScoreParams sp;
     for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
@@ -1024,23 +1013,38 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
         const int* h_counts = reinterpret_cast<const int*>(hb);
         const CandRec* h_cands = reinterpret_cast<const CandRec*>(hb + cnt_bytes);
         const CandRec* d_cands = reinterpret_cast<const CandRec*>(c->s_cand2[slot].as<uint8_t>() + cnt_bytes);
-        std::vector<CandRec> big;
-        for (int b = 0; b < B; ++b) {
-            const int n = h_counts[b];
-            if (n > cap) {
+        for (int b = 0; b < B; ++b)
+            if (h_counts[b] > cap) {
                 HIP_CHECK(hipStreamSynchronize(c->stream));         // the next batch is in flight on the shared scratch: let it finish before the call is repeated
-                throw CandOverflow(n);
+                throw CandOverflow(h_counts[b]);
             }
+        // rare: frames with more candidates than were copied back ahead are fetched whole, one after the other
+        std::vector<std::vector<CandRec>> big(B);
+        bool any_big = false;
+        for (int b = 0; b < B; ++b)
+            if (h_counts[b] > PF) {
+                big[b].resize(h_counts[b]);
+                HIP_CHECK(hipMemcpyAsync(big[b].data(), d_cands + (size_t)b * cap, (size_t)h_counts[b] * sizeof(CandRec), hipMemcpyDeviceToHost, c->stream));
+                any_big = true;
+            }
+        if (any_big) HIP_CHECK(hipStreamSynchronize(c->stream));
+        // rectangles, order and suppression per frame: independent, so the frames of a batch are shared out over a few threads.  For every
+        // batch but a call's last this runs while the next batch's kernels are queued; the last one's is what the GPU waits for
+        auto frames_of = [&](int b0, int b1) {
             std::vector<RawDet> sorted_raw;
-            std::vector<RawDet>& dst = nms ? sorted_raw : raw_sorted[o + b];
-            if (n <= PF) decode_candidates(m, upsample, h_cands + (size_t)b * PF, n, dst);
-            else {
-                big.resize(n);                                  // rare: more candidates than were copied back ahead
-                HIP_CHECK(hipMemcpyAsync(big.data(), d_cands + (size_t)b * cap, (size_t)n * sizeof(CandRec), hipMemcpyDeviceToHost, c->stream));
-                HIP_CHECK(hipStreamSynchronize(c->stream));
-                decode_candidates(m, upsample, big.data(), n, dst);
+            for (int b = b0; b < b1; ++b) {
+                const int n = h_counts[b];
+                std::vector<RawDet>& dst = nms ? sorted_raw : raw_sorted[o + b];
+                decode_candidates(m, upsample, n <= PF ? h_cands + (size_t)b * PF : big[b].data(), n, dst);
+                if (nms) det_nms(m, sorted_raw, raw_sorted[o + b]);
             }
-            if (nms) det_nms(m, sorted_raw, raw_sorted[o + b]);  // the suppression too runs while the next batch's kernels are queued
+        };
+        const int nt = std::max(1, std::min(8, B / 12));
+        if (nt == 1) frames_of(0, B);
+        else {
+            std::vector<std::thread> th;
+            for (int i = 0; i < nt; ++i) th.emplace_back(frames_of, B * i / nt, B * (i + 1) / nt);
+            for (auto& t : th) t.join();
         }
     };
     submit(0, 0);

@@ -123,15 +123,7 @@ class ExtractStream(object):
 
     def compute(self, work):
         """GPU part: landmarks + embeddings of one batch of faces returned by prepare(); batches must arrive in order"""
-        face_frames, boxes = work[0], work[1]
-        if boxes:
-            if hasattr(self.ctx, "landmarks_embed"):
-                pts, emb = self.ctx.landmarks_embed(face_frames, boxes)      # one library call: no interpreter between the two stages
-            else:
-                pts = self.ctx.landmarks(face_frames, boxes)
-                emb = self.ctx.embed(face_frames, pts)
-            self.pts.append(pts)
-            self.emb.append(emb)
+        compute_many(self.ctx, [(self, work)])
 
     def prepare(self, tracks):
         """host part for the normalised tracks of the next shot (in shot order): the track-file rows, their timestamp groups,
@@ -207,6 +199,31 @@ class ExtractStream(object):
         return pts, emb
 
 
+def compute_many(ctx, items):
+    """landmarks + embeddings of several batches -- [(ExtractStream, work)], possibly of different videos -- in ONE library call (a call
+    costs 2-4 ms of idle GPU around its kernels whatever its size, and the deep layers of the network fill the chip only from a
+    few thousand faces on); every stream receives its own rows, in order"""
+    frames, boxes, cuts = [], [], []
+    for ex, work in items:
+        if work is not None and work[1]:
+            frames.extend(work[0]); boxes.extend(work[1])
+            cuts.append((ex, len(work[1])))
+    if not boxes:
+        return
+    if hasattr(ctx, "landmarks_embed"):
+        pts, emb = ctx.landmarks_embed(frames, boxes)      # one library call: no interpreter between the two stages
+    else:
+        pts = ctx.landmarks(frames, boxes)
+        emb = ctx.embed(frames, pts)
+    if len(cuts) == 1:
+        cuts[0][0].pts.append(pts); cuts[0][0].emb.append(emb)
+        return
+    a = 0
+    for ex, m in cuts:
+        ex.pts.append(pts[a:a + m]); ex.emb.append(emb[a:a + m])
+        a += m
+
+
 def detections_as_lists(n_frames, raw):
     """[[(l, t, r, b) Python ints]] per frame from the arrays of Context.detect_many(arrays=True): raw = (boxes, counts, frame indices)"""
     dets = [[] for _ in range(n_frames)]
@@ -280,6 +297,45 @@ class VideoJob(object):
         return self.ex.prepare(norm)
 
 
+class _NoLock(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+class FairLock(object):
+    """first come, first served (threading.Lock hands itself to whoever runs next: a thread that releases it and asks again at once keeps
+    it, and the GPU thread's back-to-back library calls would starve the tracking thread's on-demand calls for whole shots)"""
+
+    def __init__(self):
+        self._c = threading.Condition(threading.Lock())
+        self._next = self._serving = 0
+
+    def acquire(self):
+        with self._c:
+            me = self._next
+            self._next += 1
+            while self._serving != me:
+                self._c.wait()
+
+    def release(self):
+        with self._c:
+            self._serving += 1
+            self._c.notify_all()
+
+    def waiting(self):
+        return self._next - self._serving - 1
+
+    def __enter__(self):
+        self.acquire()
+        return self
+
+    def __exit__(self, *exc):
+        self.release()
+
+
 class WindowedPlan(object):
     """plan[t] of one pass over a shot (what HipTrackers.speculate_pair returns for the whole shot at once), computed for a window
     of detections at a time when the lane gets there: the trackers that exist at any moment are those of the windows the two lanes
@@ -326,8 +382,9 @@ class _LaneBackend(object):
     """what the lanes of the tracking thread see of the tracker context while the GPU thread owns it: on-demand updates
     take the context lock, killed trackers are only queued (the GPU thread destroys them between its batches)"""
 
-    def __init__(self, backend, lock, dead):
+    def __init__(self, backend, lock, dead, note=None):
         self.backend, self.lock, self.dead = backend, lock, dead
+        self.note = note or (lambda *ev: None)
 
     def update_many(self, handles, frames):
         with self.lock:
@@ -342,9 +399,14 @@ class _LaneBackend(object):
             return self.backend.start_many(frames, boxes)
 
     def speculate_window(self, fh, owner, boxes, n_frames):
+        self.note("window wanted", len(owner))
         with self.lock:
+            self.note("window begin")
             self.release_dead()          # the killed trackers of the previous windows make room first
-            return self.backend.speculate_window(fh, owner, boxes, n_frames)
+            try:
+                return self.backend.speculate_window(fh, owner, boxes, n_frames)
+            finally:
+                self.note("window done")
 
     def release_dead(self):
         batch = []
@@ -360,7 +422,7 @@ class _LaneBackend(object):
 class Engine(object):
     """One pass of a source of ShotInput / JobEnd items through the GPU thread and the caller's thread (see the module text)."""
 
-    def __init__(self, ctx, tracking, detect_batch_size=8, overlap=True, speculate_limit=8192, speculate_window=4096, group=1):
+    def __init__(self, ctx, tracking, detect_batch_size=8, overlap=True, speculate_limit=8192, speculate_window=4096, group=1, extract_min=0):
         self.ctx, self.tracking = ctx, tracking
         # shots whose passes run in lock-step as ONE set of lanes (tracking.py:359-362: shots are independent).  With detection on every
         # frame a shot's trackers live for one frame and the bulk calls cover them; with `--every` they live for many frames, updated
@@ -369,23 +431,46 @@ class Engine(object):
         self.detect_batch_size = detect_batch_size
         self.overlap = overlap
         self.speculate_limit, self.speculate_window = int(speculate_limit), int(speculate_window)
+        # faces that must be waiting before the GPU thread runs an extraction call while it still has shots to detect (0: run what
+        # is there).  A run over many short videos sets it: their per-shot and end-of-video batches are small, and a call's fixed
+        # cost is paid per call (compute_many)
+        self.extract_min = int(extract_min)
         self.stats = {}
 
     # ---- the GPU-side work of one shot ---------------------------------------------------------------------------------------
-    def _detect(self, si):
+    def _detect(self, si, lock=None):
+        """detections of a shot's flagged frames.  lock: the engine's context lock (pipelined run).  A shot of four or more detector
+        batches (4K frames: 32 per batch) is detected batch by batch with the lock given up in between, so that the tracking thread's
+        bulk tracker calls for the PREVIOUS shot are served while this one is still being detected (a whole-shot call holds the context
+        for a quarter of a second there); shorter shots go through in one call, whose batches hide each other's host work."""
         ctx = self.ctx
-        if si.resize is not None:
-            tw, th = si.resize
-            si.natives = [f for _, f in si.cache]
-            si.cache = [(t, ctx.resize(f, tw, th)) for t, f in si.cache]
-            si.resize = None
+        if lock is None:
+            lock = _NoLock()
+        with lock:
+            if si.resize is not None:
+                tw, th = si.resize
+                si.natives = [f for _, f in si.cache]
+                si.cache = [(t, ctx.resize(f, tw, th)) for t, f in si.cache]
+                si.resize = None
         cache, flags = si.cache, si.flags
         idx = [i for i, f in enumerate(flags) if f]
         counts = np.zeros(len(cache), np.int64)
         boxes = np.zeros((0, 4), np.float64)
         raw = None
         if idx:
-            out, _, cnt = ctx.detect_many([cache[i][1] for i in idx], max(1, int(self.detect_batch_size)), 1, arrays=True)
+            batch = max(1, int(self.detect_batch_size))
+            chunk = batch if len(idx) >= 4 * batch else len(idx)
+            outs, cnts = [], []
+            for o in range(0, len(idx), chunk):
+                with lock:
+                    out, _, cnt = ctx.detect_many([cache[i][1] for i in idx[o:o + chunk]], batch, 1, arrays=True)
+                outs.append(out); cnts.append(cnt)
+            if len(outs) == 1:
+                out, cnt = outs[0], cnts[0]
+            else:
+                m = max(o.shape[1] for o in outs)
+                out = np.concatenate([np.pad(o, ((0, 0), (0, m - o.shape[1]), (0, 0))) for o in outs])
+                cnt = np.concatenate(cnts)
             # the boxes go back to the GPU (tracker starts) as an array; the tracking thread turns them into the Python
             # tuples its state machine works on while the GPU is busy with those starts
             counts[idx] = cnt
@@ -477,43 +562,66 @@ class Engine(object):
         """GPU thread: detect(k), speculate(k), extract(k-1) ...; this thread: lanes + merging of shot k as soon as its detections
         and bulk tracker results exist.  ctypes releases the GIL inside every library call."""
         ready, done = queue.Queue(), queue.Queue()
-        lock = threading.Lock()
+        lock = FairLock()
         dead = []
-        lane_backend = _LaneBackend(backend, lock, dead)
         trace = [(_time.perf_counter(), "begin")] if os.environ.get("PVF_TRACE") else None
 
         def note(*ev):
             if trace is not None:
                 trace.append((_time.perf_counter(),) + ev)
 
-        def handle(msg, counters):
+        lane_backend = _LaneBackend(backend, lock, dead, note)
+
+        pending = []                                # messages of the tracking thread whose faces have not been computed yet, in order
+
+        def faces_of(msg):
             kind, job, work = msg
-            if kind == "work":
+            if kind == "final":
+                work = job.ex._final_work if job.ex is not None else None
+            return work
+
+        def receive(msg, counters):
+            pending.append(msg)
+            if msg[0] == "work":
+                counters["received"] += 1
+
+        def run_pending(counters, force):
+            """the faces that are waiting go through the landmark / embedding kernels, <= 4096 per library call (the network's largest
+            forward), whichever shots and videos they belong to (compute_many); unless `force`, only once extract_min faces wait"""
+            while pending:
+                if not force and sum(len(w[1]) for w in map(faces_of, pending) if w is not None) < self.extract_min:
+                    return
+                take, faces = [], 0
+                while pending:
+                    w = faces_of(pending[0])
+                    m = len(w[1]) if w is not None else 0
+                    if take and faces + m > 4096:
+                        break
+                    take.append(pending.pop(0))
+                    faces += m
                 note("extract begin", counters["extracted"])
-                if work is not None:
+                if faces:
                     with lock:
-                        job.ex.compute(work)
-                    job.store.release_below(work[2])
-                counters["extracted"] += 1
+                        compute_many(self.ctx, [(msg[1].ex, faces_of(msg)) for msg in take if msg[1].ex is not None])
+                for kind, job, work in take:
+                    if kind == "work":
+                        if work is not None:
+                            job.store.release_below(work[2])
+                        counters["extracted"] += 1
+                    else:                           # "final": the job's last faces (plan_finish has run on the host)
+                        job.store.release_all()
+                        counters["finals"] += 1
+                        job.final_computed.set()
+                        ready.put(("final done", job))
                 note("extracted", counters["extracted"] - 1)
-            else:                                   # "final": the job's last faces (plan_finish has run on the host)
-                with lock:
-                    if job.ex is not None:
-                        job.ex.compute(job.ex._final_work)
-                job.store.release_all()
-                counters["finals"] += 1
-                job.final_computed.set()
-                ready.put(("final done", job))
 
         def gpu_thread():
-            counters = {"extracted": 0, "finals": 0}
+            counters = {"received": 0, "extracted": 0, "finals": 0}
             shots = ends = 0
+            eager = self.extract_min <= 0
             try:
                 def drain():
-                    """everything the tracking thread has handed back so far; the faces of several shots of one job that are waiting
-                    together go through the landmark / embedding kernels as ONE batch (a forward of 4000 faces fills the chip better than
-                    two of 2000: the deep layers' grids are small)"""
-                    msgs = []
+                    """everything the tracking thread has handed back so far"""
                     while True:
                         try:
                             msg = done.get_nowait()
@@ -521,19 +629,8 @@ class Engine(object):
                             break
                         if msg is None:
                             return False
-                        msgs.append(msg)
-                    i = 0
-                    while i < len(msgs):
-                        kind, job, work = msgs[i]
-                        j = i + 1
-                        if kind == "work" and work is not None:
-                            while j < len(msgs) and msgs[j][0] == "work" and msgs[j][1] is job and msgs[j][2] is not None and len(work[1]) + len(msgs[j][2][1]) <= 4096:
-                                work = (work[0] + msgs[j][2][0], work[1] + msgs[j][2][1], max(work[2], msgs[j][2][2]))
-                                j += 1
-                        handle((kind, job, work), counters)
-                        for _ in range(i + 1, j):
-                            handle(("work", job, None), counters)          # (the merged shots still count as extracted)
-                        i = j
+                        receive(msg, counters)
+                    run_pending(counters, eager)
                     return True
 
                 group = []
@@ -554,14 +651,14 @@ class Engine(object):
                         flush()
                     # never more than three shots (or two groups) ahead of the tracking thread (a slow state machine -- a crowded shot --
                     # must not let detected shots, i.e. their frames, pile up)
-                    while shots - counters["extracted"] >= max(3, 2 * self.group):
+                    while shots - counters["received"] >= max(3, 2 * self.group):
                         msg = done.get()
                         if msg is None:
                             return
-                        handle(msg, counters)
+                        receive(msg, counters)
+                        run_pending(counters, eager)
                     note("detect begin", k)
-                    with lock:
-                        raw, counts, boxes = self._detect(si)
+                    raw, counts, boxes = self._detect(si, lock)
                     note("detected", k)
                     # faces of the shots the tracking thread has finished meanwhile (it is idle now, so the host side of these
                     # calls does not compete with its state machine for the interpreter; measured better than after speculate).
@@ -586,10 +683,15 @@ class Engine(object):
                 flush()
                 ready.put(("stop",))
                 while counters["extracted"] < shots or counters["finals"] < ends:
+                    if pending and done.empty():
+                        run_pending(counters, True)          # nothing else to do: what waits goes now, whatever its size
+                        continue
                     msg = done.get()
                     if msg is None:
                         return
-                    handle(msg, counters)
+                    receive(msg, counters)
+                    if not drain():
+                        return
                 with lock:
                     lane_backend.release_dead()
                 ready.put(("idle",))

@@ -84,6 +84,7 @@ class FacePipeline(object):
         # trackers a shot may hold at once before its bulk starts are windowed (2.39 MB of filters each): engine.WindowedPlan
         self.speculate_limit, self.speculate_window = speculate_limit, speculate_window
         self.shot_group = 8              # with --every: shots whose passes share their frame-by-frame tracker calls (engine.Engine.group)
+        self.farm_extract_min = 3072        # run_many: faces that wait together before an extraction call is made (at most 4096 go into one)
         self.last_engine = None
 
     # ---- geometry of one video -------------------------------------------------------------------------------------------------
@@ -99,10 +100,10 @@ class FacePipeline(object):
             return int(w * ratio), int(h * ratio)
         return w, h
 
-    def _engine(self):
+    def _engine(self, extract_min=0):
         e = _engine.Engine(self.ctx, self.tracking, detect_batch_size=self.detect_batch_size, overlap=self.overlap,
                            speculate_limit=self.speculate_limit, speculate_window=self.speculate_window,
-                           group=(self.shot_group if self.detect_every > 0.0 else 1))
+                           group=(self.shot_group if self.detect_every > 0.0 else 1), extract_min=extract_min)
         self.last_engine = e
         return e
 
@@ -220,7 +221,9 @@ class FacePipeline(object):
                         yield item
             source = source_gen()
         try:
-            self._engine().run(source, HipTrackers(self.ctx), n_shots=(n_shots if not streamed else None), on_job_final=complete)
+            # many short videos: their faces are extracted a few thousand at a time, whichever clips they belong to (engine.compute_many)
+            self._engine(extract_min=(self.farm_extract_min if len(jobs) > 1 else 0)).run(
+                source, HipTrackers(self.ctx), n_shots=(n_shots if not streamed else None), on_job_final=complete)
         finally:
             if src is not None:
                 src.close()

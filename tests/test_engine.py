@@ -207,11 +207,12 @@ def test_shots_grouped_into_one_set_of_lanes_equal_shot_by_shot():
     assert calls[0] > calls[1] > calls[2]
 
 
-def test_many_jobs_through_one_engine_run_equal_one_run_each():
+@pytest.mark.parametrize("extract_min", [0, 40, 100000])
+def test_many_jobs_through_one_engine_run_equal_one_run_each(extract_min):
+    """several videos as jobs of ONE engine run (run_many / the clip farm); extract_min > 0: their faces wait for each other and go through
+    the landmark / embedding calls together, across shots and videos (engine.compute_many) -- same rows per video, fewer calls"""
     clips = [make_video(20 + k, n_shots=2, n=18, faces=3) for k in range(4)]
     singles = [run_engine(*c, mode="resident") for c in clips]
-    frames = [f for c in clips for f in c[0]]
-    dets = [d for c in clips for d in c[1]]
     ctx = FakeContext([], [])
     for k, c in enumerate(clips):                     # frame indices restart per clip: key the scripted detections by object
         for f, d in zip(c[0], c[1]):
@@ -222,8 +223,14 @@ def test_many_jobs_through_one_engine_run_equal_one_run_each():
             def __init__(s, f): s.i = id(f)
         return ctx.detect_many_orig([W(f) for f in frs], batch, upsample, adjust_threshold, cap, arrays)
     ctx.detect_many = detect_many
+    landmark_calls = []
+    landmarks_orig = ctx.landmarks
+    def landmarks(frs, boxes):
+        landmark_calls.append(len(boxes))
+        return landmarks_orig(frs, boxes)
+    ctx.landmarks = landmarks
     tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0, trackers=HipTrackers(ctx))
-    eng = engine.Engine(ctx, tbd, detect_batch_size=7)
+    eng = engine.Engine(ctx, tbd, detect_batch_size=7, extract_min=extract_min)
     jobs = [engine.VideoJob(ctx, 640, 360, frames=c[0], times=c[2], key=k) for k, c in enumerate(clips)]
     def source():
         for job, c in zip(jobs, clips):
@@ -232,11 +239,18 @@ def test_many_jobs_through_one_engine_run_equal_one_run_each():
     order = []
     done = eng.run(source(), HipTrackers(ctx), n_shots=8, on_job_final=lambda job: order.append(job.key))
     assert order == [0, 1, 2, 3] and [j.key for j in done] == order
+    n_faces = 0
     for job, single in zip(jobs, singles):
         pts, emb = job.ex.finish(computed=True)
         assert job.ex.tracks == single[0]
         assert (job.ex.face_T, job.ex.face_id, job.ex.face_boxes) == single[1]
-        assert np.array_equal(pts, single[2][0])
+        assert np.array_equal(pts, single[2][0]) and np.array_equal(emb, single[2][1])
+        n_faces += len(pts)
+    assert sum(landmark_calls) == n_faces
+    if extract_min == 100000:
+        assert len(landmark_calls) < 12               # everything waited until the GPU thread had no shot left to detect (12 batches exist)
+    if extract_min == 40:
+        assert len(landmark_calls) < 12               # (12 batches exist: two shots and the end of each of the four videos)
 
 
 def test_engine_hands_errors_of_either_thread_to_the_caller():
@@ -266,3 +280,24 @@ def test_engine_hands_errors_of_either_thread_to_the_caller():
             engine.Engine(ctx2, tbd2).run(src, HipTrackers(ctx2))
         finally:
             src.close()
+
+
+def test_fair_lock_serves_in_order_of_arrival():
+    """the engine's context lock: a thread that releases it and asks again at once queues behind whoever was already waiting"""
+    import threading
+    import time
+    lock = engine.FairLock()
+    order = []
+    lock.acquire()
+    def waiter():
+        with lock:
+            order.append("waiter")
+    th = threading.Thread(target=waiter)
+    th.start()
+    while lock.waiting() < 1:
+        time.sleep(0.001)
+    lock.release()
+    with lock:                      # asked for after the waiter: served after it
+        order.append("holder again")
+    th.join()
+    assert order == ["waiter", "holder again"] and lock.waiting() == -1
