@@ -203,7 +203,7 @@ def main():
     score_ms = fam["score"]["ms"]
     launches = max(fam["score"]["launches"], 1)
     achieved = (flop_per_frame * n_score_frames / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
-    roofline = {"kernel": "score_mfma_rows_ml_k<4> (HOG filter scoring of every pyramid level of a %d-frame batch, 5 filters x 3100 MAC per position)" % args.detect_batch, "bound": "mfma",
+    roofline = {"kernel": "score_roll_k (HOG filter scoring of every pyramid level of a %d-frame batch, 5 filters x 3100 MAC per position)" % args.detect_batch, "bound": "mfma",
                 "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_ms": round(score_ms / launches, 4),
@@ -479,7 +479,7 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
                                   "per-clip clustering, no collective" % (args.clips, args.frames, args.width, args.height, args.fps, args.shots, args.faces, world),
                       "parallelism": "farm: clip i on rank i %% %d; one engine run per rank (detector of clip i + 1 beside the state machine of clip i)" % world,
                       "detect_batch": args.detect_batch, "collective": "none"},
-           "roofline": {"kernel": "score_mfma_rows_ml_k<4>", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "roofline": {"kernel": "score_roll_k", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(score_ms / launches, 4)},
            "cpu_baseline": cpu, "parity": parity,
            "kernel_families_ms": fam,
@@ -600,7 +600,7 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
                                   "into HBM buffers of the library (device-to-device from the resident clip), released shot by shot" % (n, n / args.fps / 60.0, world, per_shot, args.faces),
                       "parallelism": "frame ranges cut at shot boundaries x%d + all-gather of track embeddings + one global clustering" % world if world > 1 else "single GPU (one range)",
                       "detect_batch": args.detect_batch, "collective": pdist.collective_name()},
-           "roofline": {"kernel": "score_mfma_rows_ml_k<4>", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "roofline": {"kernel": "score_roll_k", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(score_ms / launches, 4)},
            "cpu_baseline": cpu, "parity": parity,
            "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},

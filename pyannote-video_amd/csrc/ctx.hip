@@ -89,7 +89,7 @@ static void load_detector(Ctx* c, const char* path)
     if (d.d_w) (void)hipFree(d.d_w);
     d.d_w = upload<float>(w.f32(), w.numel());
     {
-        // B fragments of score_mfma_rows_ml_k.  K of one filter row = the 12 cells x 31 planes a tile of three column shifts spans, taken
+        // B fragments of score_roll_k.  K of one filter row = the 12 cells x 31 planes a tile of three column shifts spans, taken
         // as ONE run of 372 values (index kk = 31 * cell + plane; no pad plane) = 93 k-steps of 4: lane (column j = lane & 15 = 5 * shift +
         // filter, kq = lane >> 4) holds kk = 4 * step + kq.  Packed four steps per lane: [m][group of 8 steps: 12][half: 2][lane: 64][4];
         // steps 93..95 stay zero and are never issued.

@@ -252,8 +252,9 @@ struct LvDesc {
     int h, w, rb;                               // level image, row pitch in bytes (multiple of 64)
     int cells_nr, cells_nc, visible_nr, visible_nc;
     int fh, fw, hog_nr, hog_nc;                 // feature map (with its zero border) and the cells that carry features
-    int feat_bx, score_bx, score_by;
+    int feat_bx, score_bx;
     int valid_score;
+    int roll_nseg, roll_rows;                   // K3 v5: a column strip is walked in roll_nseg pieces of roll_rows output rows
     int strips, chunks, chunk_rows, fused_tasks;  // fused FHOG: 64-lane strips of 61 feature columns x chunks of chunk_rows feature rows
     long long img_off, img_stride;              // bytes
     long long feat_off, feat_stride;            // floats
@@ -484,67 +485,69 @@ __global__ void __launch_bounds__(256) feat_ring_zero_k(MlStarts st, const LvDes
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K3 v3: one wave owns R consecutive output rows x 96 columns and walks the R + 9 feature rows it needs ONCE.
-// Staged feature row t feeds output row j through filter row m = t - j, so every A fragment read from the slab is used for
-// up to R MFMAs and the slab is filled (R+9)/R times per output row instead of 10 times.  K of a filter row is the run of 12 cells x 31
-// planes (cells packed in the slab, no pad plane) = 93 k-steps, walked in 12 groups of 8 (the last of 5).  B fragments (packed four
-// k-steps per lane: [m][group][2][64 lanes][4]) and A fragments are fetched one group ahead of the MFMAs that consume them; the
-// next feature row is loaded into registers while the current one is multiplied.  Each accumulator still receives its
-// terms in (m, n, p) order  =>  bit-identical to the oracle's chain.
-template <int R>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base,
-                     const float4* __restrict__ Bg4, ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
+// K3: a block of TWO waves owns one column strip (96 output columns) of one level of one frame and walks it top to bottom,
+// one feature row per step, staged ONCE into a double-buffered slab both waves read (each fetches half of row s + 1 while row s is
+// multiplied; one barrier per step).  At step s the ten output rows s - 9 .. s are alive (row r takes filter row m = s - r); wave w owns
+// the rows r = w (mod 2), i.e. five of them at every step -- the two waves always have the same work, whatever the phase.  A wave's
+// slot q holds the row with m = p + 2 q (p = parity of s - w): on odd steps slot 4 completes (m = 9), is written out, and the slots
+// move up by one (40 register moves per 1860 MFMAs).  A feature row leaves HBM / L2 once per strip (round 2's form, one wave per 4 output rows x 96 columns with a slab of its own, staged every row
+// 3.25 times -- 3.8 x the feature maps from beyond L2, now 1.09 x) and feeds five MFMAs per fragment read instead of at most four.  Same B fragments, same (m, n, p) order per accumulator => bit-identical to the oracle.
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+score_roll_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base,
+             const float4* __restrict__ Bg4, ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
 {
-    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 31, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11, NT = FR + R - 1;
-    constexpr int LAST_STEPS = 93 - 8 * (NK - 1);   // k-steps of the last group of a filter row (5): 12 cells x 31 planes = 93 steps of 4
-    constexpr int NST = (SEG * 8 + 63) / 64;
-    constexpr int RSRC_FLAGS = 0x00020000;          // raw buffer, 32-bit data format (out-of-range lanes read 0)
+    constexpr int FR = 10, FC = 10, NK = 12, PITCH = 31, MT = 2, WCOLS = MT * 48, SEG = WCOLS + 11, R = 5;
+    constexpr int LAST_STEPS = 93 - 8 * (NK - 1);
+    constexpr int NSTW = (SEG * 8 + 127) / 128;     // 16-byte pieces of a row segment per thread (7)
+    constexpr int SLAB = (SEG * PITCH + 3) / 4 * 4; // floats per slab buffer
+    constexpr int RSRC_FLAGS = 0x00020000;
     extern __shared__ __attribute__((aligned(16))) float s_seg[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = ml_block(st);
+    const int g = (int)blockIdx.x;
     if (g >= st.b0[st.nl]) return;
     const int l = ml_level(st, g);
     const LvDesc d = lv[l];
     const int local = g - st.b0[l];
     const int bx = local % d.score_bx;
-    const int by = (local / d.score_bx) % d.score_by;
-    const int b = __builtin_amdgcn_readfirstlane(local / (d.score_bx * d.score_by));
-    const int fh = d.fh, fw = d.fw;
-    // A block = four waves on four vertically adjacent row groups of one column strip.  They share no data on chip, but they start
-    // together and walk in step, and their re-reads of each other's feature rows partly hit in L2: measured 6.0 GB per launch from
-    // beyond L2 against 7.4 GB when every wave is a workgroup of its own (same kernel time either way).
-    const int r_top = (by * 4 + wave) * R, c_base = bx * WCOLS;
-    const int r1 = fh - (FR - FR / 2 - 1), c1 = fw - (FC - FC / 2 - 1);
-    if (r_top + FR / 2 >= r1) return;               // wave-uniform: row group past the level's last output row
-    float* seg = s_seg + (size_t)wave * SEG * PITCH;
-    const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride + (size_t)c_base * PVF_FHOG_STRIDE;
+    const int sg = (local / d.score_bx) % d.roll_nseg;
+    const int b = __builtin_amdgcn_readfirstlane(local / (d.score_bx * d.roll_nseg));
+    const int fw = d.fw;
+    const int c_base = bx * WCOLS;
+    const int c1 = fw - (FC - FC / 2 - 1);
+    // this block's piece of the strip: output rows r_base .. r_base + out_rows - 1 (by their top feature row), i.e. the feature rows
+    // r_base .. r_base + fh - 1; below, rows and steps are counted from r_base
+    const int r_base = sg * d.roll_rows;
+    const int out_rows = min(d.roll_rows, d.fh - (FR - 1) - r_base);
+    const int fh = out_rows + FR - 1;
+    const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)r_base * fw + c_base) * PVF_FHOG_STRIDE;
     const int seg_cells = (fw - c_base < SEG) ? fw - c_base : SEG;
     const int i = lane & 15, kq = lane >> 4;
     const int lane16 = lane * 16;
-    f32x4 acc[R][MT];
-#pragma unroll
-    for (int j = 0; j < R; ++j)
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool two_tiles = (c_base + 48 + FC / 2 < c1);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)Bg4, 0, FR * NK * 2 * 64 * 16, RSRC_FLAGS);
-    u32x4 sv[NST];
-    // the segment of one feature row is one linear run of seg_cells * 128 bytes: lane + 64 u -> 16 bytes at 16 * (lane + 64 u)
-    auto load_row = [&](int fr) {
+    f32x4 acc[R][MT];
+#pragma unroll
+    for (int q = 0; q < R; ++q)
+#pragma unroll
+        for (int tt = 0; tt < MT; ++tt) acc[q][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // this thread's share of a feature row: the 16-byte pieces tid + 128 u of the segment's seg_cells * 128 bytes (beyond: zeros), fetched
+    // and parked in two halves (u < NH, then the rest) so that only NH pieces are held in registers at a time
+    constexpr int NH = (NSTW + 1) / 2;
+    u32x4 sv[NH];
+    const int tid16 = (int)threadIdx.x * 16;
+    auto load_part = [&](int fr, int half) {
         const int bytes = (fr < fh) ? seg_cells * PVF_FHOG_STRIDE * 4 : 0;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + (size_t)fr * fw * PVF_FHOG_STRIDE), 0, bytes, RSRC_FLAGS);
 #pragma unroll
-        for (int u = 0; u < NST; ++u) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, u * 1024, 0);
+        for (int u = 0; u < NH; ++u)
+            if (half * NH + u < NSTW) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid16, (half * NH + u) * 2048, 0);
     };
-    auto fill_slab = [&]() {
-        // cells are packed (31 floats each, the feature map's pad plane is dropped): the 12 x 31 values a tile row spans form ONE run,
-        // 93 k-steps of 4 instead of 12 x 8
+    auto fill_part = [&](float* seg, int half) {
 #pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int idx = lane + 64 * u;
-            if (idx < SEG * 8) {
+        for (int u = 0; u < NH; ++u) {
+            const int idx = (int)threadIdx.x + 128 * (half * NH + u);
+            if (half * NH + u < NSTW && idx < SEG * 8) {
                 const int cell = idx >> 3, q = idx & 7;
                 uint32_t* dd = reinterpret_cast<uint32_t*>(seg + cell * PITCH + 4 * q);
                 dd[0] = sv[u].x; dd[1] = sv[u].y; dd[2] = sv[u].z;
@@ -552,126 +555,20 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
             }
         }
     };
-    load_row(r_top);
-    fill_slab();
-    load_row(r_top + 1);
-    const float* a0 = seg + (3 * i) * PITCH + kq;
-    // B fragments of output row j at step t: filter row m = t - j, clamped: the fragments of a row that is not active at that step (m
-    // outside the filter, or an output row past the level's last one) are loaded but never used.  (Sending those loads out of range
-    // instead -- a per-row lane offset beyond the table, so that they return zeros without touching memory -- was measured 5 % slower:
-    // the extra offset registers push spills into the loop.)
-    auto row_on = [&](int t, int j) { const int m = t - j; return (m >= 0 && m < FR) && (r_top + j + FR / 2 < r1); };
-    auto b_off = [&](int t, int j) { const int m = t - j; return (m < 0 ? 0 : (m >= FR ? FR - 1 : m)) * NK * 2048; };
-    u32x4 bn[R][2];
-    float an[8 * MT];
-    // the (t, n) walk is ONE software pipeline: fragments of (t, n + 1) -- or of (t + 1, 0), after the slab has been refilled -- are
-    // requested before the MFMAs of (t, n) are issued, so a wave never reaches a step boundary with nothing in flight
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-        bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, b_off(0, j), 0);
-        bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, b_off(0, j) + 1024, 0);
-    }
-#pragma unroll
-    for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-        for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 4 * pq];
-    for (int t = 0; t < NT; ++t) {
-        int bo[R];
-        bool on[R];
-        bool all_on = two_tiles;
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            on[j] = row_on(t, j);
-            all_on = all_on && on[j];
-            bo[j] = b_off(t, j);
-        }
-#pragma unroll
-        for (int n = 0; n < NK; ++n) {
-            float ac[8 * MT];
-            float bc[R][8];
-#pragma unroll
-            for (int q = 0; q < 8 * MT; ++q) ac[q] = an[q];
-#pragma unroll
-            for (int j = 0; j < R; ++j)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const uint32_t b0 = bn[j][h].x, b1 = bn[j][h].y, b2 = bn[j][h].z, b3 = bn[j][h].w;   // scalars first: bit_cast of a vector element lvalue reads element 0
-                    bc[j][4 * h] = __uint_as_float(b0); bc[j][4 * h + 1] = __uint_as_float(b1);
-                    bc[j][4 * h + 2] = __uint_as_float(b2); bc[j][4 * h + 3] = __uint_as_float(b3);
-                }
-            if (n + 1 < NK) {
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + (n + 1) * 2048, 0);
-                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bo[j] + (n + 1) * 2048 + 1024, 0);
-                }
-#pragma unroll
-                for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-                    for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 32 * (n + 1) + 4 * pq];
-            } else {
-                // last cell column of this feature row: its A fragments are in registers, so the slab takes the next row now
-                // (LDS serves a wave's requests in order), and the first fragments of step t + 1 follow it
-                fill_slab();
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    const int o = b_off(t + 1, j);
-                    bn[j][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, o, 0);
-                    bn[j][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, o + 1024, 0);
-                }
-#pragma unroll
-                for (int pq = 0; pq < 8; ++pq)
-#pragma unroll
-                    for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 4 * pq];
-                load_row(r_top + t + 2);                    // (past the last step: fetched, never used)
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const int steps = (n == NK - 1) ? LAST_STEPS : 8;      // (n is an unrolled constant)
-            if (all_on) {
-                // steady state: 2R independent accumulator chains interleaved
-#pragma unroll
-                for (int pq = 0; pq < steps; ++pq)
-#pragma unroll
-                    for (int j = 0; j < R; ++j)
-#pragma unroll
-                        for (int tt = 0; tt < MT; ++tt)
-                            acc[j][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + tt], bc[j][pq], acc[j][tt], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < R; ++j) {
-                    if (!on[j]) continue;
-                    if (two_tiles) {
-#pragma unroll
-                        for (int pq = 0; pq < steps; ++pq)
-#pragma unroll
-                            for (int tt = 0; tt < MT; ++tt)
-                                acc[j][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + tt], bc[j][pq], acc[j][tt], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int pq = 0; pq < steps; ++pq)
-                            acc[j][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT], bc[j][pq], acc[j][0], 0, 0, 0);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    const int jc = lane & 15;
-    if (jc < 15) {
-        const int s = jc / 5, f = jc % 5;
-        const float th = sp.thresh[f];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int r = r_top + j + FR / 2;
-            if (r >= r1) continue;
+    auto emit = [&](int r_out, const f32x4 (&a)[MT]) {
+        const int jc = lane & 15;
+        if (jc < 15) {
+            const int sft = jc / 5, f = jc % 5;
+            const float th = sp.thresh[f];
+            const int r = r_base + r_out + FR / 2;
 #pragma unroll
             for (int tt = 0; tt < MT; ++tt)
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int pos = 4 * (lane >> 4) + reg;
-                    const int cc = c_base + tt * 48 + 3 * pos + s + FC / 2;
-                    const float v = acc[j][tt][reg];
-                    if (cc < c1 && v >= th) {
+                    const int cc = c_base + tt * 48 + 3 * pos + sft + FC / 2;
+                    const float v = a[tt][reg];
+                    if (cc < c1 && v >= th && (tt == 0 || two_tiles)) {
                         const int idx = atomicAdd(&counts[b], 1);
                         if (idx < sp.cap) {
                             CandRec rec;
@@ -681,6 +578,108 @@ score_mfma_rows_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const fl
                     }
                 }
         }
+    };
+    load_part(0, 0); fill_part(s_seg, 0);
+    load_part(0, 1); fill_part(s_seg, 1);
+    __syncthreads();
+    for (int s = 0; s < fh; ++s) {
+        const float* seg = s_seg + (s & 1) * SLAB;
+        float* nxt = s_seg + ((s + 1) & 1) * SLAB;
+        load_part(s + 1, 0);                        // (past the last row: zeros, never used)
+        const int p = (s - wave) & 1;
+        const int r0 = s - p;                       // slot q holds output row r0 - 2 q, which takes filter row p + 2 q at this step
+        bool on[R];
+        bool all_on = two_tiles, any_on = false;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int r = r0 - 2 * q;
+            on[q] = (r >= 0 && r < out_rows);
+            all_on = all_on && on[q];
+            any_on = any_on || on[q];
+        }
+        if (any_on) {
+            const int bop = p * NK * 2048;
+            const float* a0 = seg + (3 * i) * PITCH + kq;
+            u32x4 bn[R][2];
+            float an[8 * MT];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                bn[q][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bop + 2 * q * NK * 2048, 0);
+                bn[q][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bop + 2 * q * NK * 2048 + 1024, 0);
+            }
+#pragma unroll
+            for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 4 * pq];
+#pragma unroll
+            for (int n = 0; n < NK; ++n) {
+                float ac[8 * MT];
+                float bc[R][8];
+#pragma unroll
+                for (int x = 0; x < 8 * MT; ++x) ac[x] = an[x];
+#pragma unroll
+                for (int q = 0; q < R; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t b0 = bn[q][h].x, b1 = bn[q][h].y, b2 = bn[q][h].z, b3 = bn[q][h].w;
+                        bc[q][4 * h] = __uint_as_float(b0); bc[q][4 * h + 1] = __uint_as_float(b1);
+                        bc[q][4 * h + 2] = __uint_as_float(b2); bc[q][4 * h + 3] = __uint_as_float(b3);
+                    }
+                if (n + 1 < NK) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {
+                        bn[q][0] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bop + (2 * q * NK + n + 1) * 2048, 0);
+                        bn[q][1] = __builtin_amdgcn_raw_buffer_load_b128(brs, lane16, bop + (2 * q * NK + n + 1) * 2048 + 1024, 0);
+                    }
+#pragma unroll
+                    for (int pq = 0; pq < 8; ++pq)
+#pragma unroll
+                        for (int tt = 0; tt < MT; ++tt) an[pq * MT + tt] = a0[(tt * 48) * PITCH + 32 * (n + 1) + 4 * pq];
+                }
+                if (n == NK / 2) { fill_part(nxt, 0); load_part(s + 1, 1); }     // (the slab being filled is not the one being read)
+                __builtin_amdgcn_sched_barrier(0);
+                const int steps = (n == NK - 1) ? LAST_STEPS : 8;      // (n is an unrolled constant)
+                if (all_on) {
+#pragma unroll
+                    for (int pq = 0; pq < steps; ++pq)
+#pragma unroll
+                        for (int q = 0; q < R; ++q)
+#pragma unroll
+                            for (int tt = 0; tt < MT; ++tt)
+                                acc[q][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + tt], bc[q][pq], acc[q][tt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) {
+                        if (!on[q]) continue;
+                        if (two_tiles) {
+#pragma unroll
+                            for (int pq = 0; pq < steps; ++pq)
+#pragma unroll
+                                for (int tt = 0; tt < MT; ++tt)
+                                    acc[q][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT + tt], bc[q][pq], acc[q][tt], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int pq = 0; pq < steps; ++pq)
+                                acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[pq * MT], bc[q][pq], acc[q][0], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        else { fill_part(nxt, 0); load_part(s + 1, 1); }
+        if (p == 1) {
+            // slot 4 has taken its last filter row (m = 9): write it out, move the slots up, slot 0 starts the row s + 1
+            if (on[R - 1]) emit(r0 - 2 * (R - 1), acc[R - 1]);
+#pragma unroll
+            for (int q = R - 1; q > 0; --q)
+#pragma unroll
+                for (int tt = 0; tt < MT; ++tt) acc[q][tt] = acc[q - 1][tt];
+#pragma unroll
+            for (int tt = 0; tt < MT; ++tt) acc[0][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        fill_part(nxt, 1);
+        __syncthreads();
     }
 }
 
@@ -688,8 +687,8 @@ struct MlPlan {
     int h = 0, w = 0, upsample = -1, B = 0;
     std::vector<LvDesc> lv;
     std::vector<LevelDims> ups;
-    MlStarts feat, score, fused;
-    int feat_blocks = 0, score_blocks = 0, fused_blocks = 0;
+    MlStarts feat, fused, walk;
+    int feat_blocks = 0, fused_blocks = 0, walk_blocks = 0;
     size_t img_bytes = 0, feat_floats = 0, up_bytes = 0;
     LvDesc* d_lv = nullptr;
     RowTab* d_rowtab = nullptr;                // row tables of every resize stage: upsampling stages first, then level l from level l - 1
@@ -726,7 +725,7 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
     PVF_REQUIRE((int)dims.size() <= ML_MAX, "too many pyramid levels");
     auto al = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
     for (size_t u = 0; u + 1 < p.ups.size(); ++u) p.up_bytes = std::max(p.up_bytes, (size_t)p.ups[u].h * al((size_t)p.ups[u].w * 3, 64) * B);
-    p.feat.nl = p.score.nl = p.fused.nl = (int)dims.size();
+    p.feat.nl = p.fused.nl = p.walk.nl = (int)dims.size();
     const int chunk_big = 32;                  // feature rows per fused-FHOG task on the large levels
     for (size_t l = 0; l < dims.size(); ++l) {
         LvDesc d;
@@ -744,20 +743,37 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         d.feat_off = (long long)p.feat_floats; d.feat_stride = (long long)d.fh * d.fw * PVF_FHOG_STRIDE;
         p.feat_floats += (size_t)d.feat_stride * B;
         d.feat_bx = std::max((d.fw + 255) / 256, 0);
-        const int out_r = d.fh - 9, out_c = d.fw - 9;
-        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0; d.score_by = d.valid_score ? (out_r + 15) / 16 : 0;    // a block = 4 waves x 4 rows x 96 columns
+        const int out_c = d.fw - 9;
+        d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0;        // column strips of 96 output columns (K3)
         // fused FHOG tasks: strips of 61 feature columns x chunks of feature rows (smaller chunks for the small levels: more tasks)
         d.strips = feat_ok ? (d.hog_nc + FUSED_OUT - 1) / FUSED_OUT : 0;
         d.chunk_rows = (d.hog_nr >= 2 * chunk_big) ? chunk_big : std::max((d.hog_nr + 1) / 2, 1);
         d.chunks = feat_ok ? (d.hog_nr + d.chunk_rows - 1) / d.chunk_rows : 0;
         d.fused_tasks = d.strips * d.chunks * B;
         p.feat.b0[l] = p.feat_blocks; p.feat_blocks += d.feat_bx * d.fh * B;
-        p.score.b0[l] = p.score_blocks; p.score_blocks += d.score_bx * d.score_by * B;
         p.fused.b0[l] = p.fused_blocks; p.fused_blocks += (d.fused_tasks + 3) / 4;
         p.lv.push_back(d);
     }
     const int nl = (int)dims.size();
-    p.feat.b0[nl] = p.feat_blocks; p.score.b0[nl] = p.score_blocks;
+    {
+        // K3 v5: a block per column strip and piece of <= roll_max output rows.  A piece re-reads the 9 feature rows above it and starts
+        // with 9 steps of partial work, so pieces are as tall as the launch allows: no block longer than about half of what a block slot
+        // (4 per CU) works through in the whole launch -- 1080p x 128 frames: whole strips (270 rows); 4K x 32 frames: two pieces per strip
+        // on the largest level (measured: 64-row pieces cost 3 % at 1080p, whole 540-row strips 4 % at 4K)
+        long long total = 0;
+        for (const LvDesc& d : p.lv) if (d.valid_score) total += (long long)d.score_bx * (d.fh - 9 + 9) * B;
+        const int slots = 4 * 256;
+        int roll_max = (int)std::max<long long>(64, total / slots / 2);
+        if (getenv("PVF_SCORE_SEG")) roll_max = std::max(2, atoi(getenv("PVF_SCORE_SEG")));
+        for (int l = 0; l < nl; ++l) {
+            LvDesc& d = p.lv[l];
+            const int out_r = d.fh - 9;
+            d.roll_nseg = d.valid_score ? (out_r + roll_max - 1) / roll_max : 0;
+            d.roll_rows = d.valid_score ? ((out_r + d.roll_nseg - 1) / d.roll_nseg + 1) / 2 * 2 : 0;
+            p.walk.b0[l] = p.walk_blocks; p.walk_blocks += d.score_bx * d.roll_nseg * B;
+        }
+    }
+    p.feat.b0[nl] = p.feat_blocks; p.walk.b0[nl] = p.walk_blocks;
     p.fused.b0[nl] = p.fused_blocks;
     HIP_CHECK(hipMalloc((void**)&p.d_lv, sizeof(LvDesc) * nl));
     HIP_CHECK(hipMemcpy(p.d_lv, p.lv.data(), sizeof(LvDesc) * nl, hipMemcpyHostToDevice));
@@ -866,12 +882,11 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
     const DetectorModel& m = c->det;
     const int B = (int)frames.size();
     MlPlan* p = ml_features(c, frames, upsample);
-    if (p->score_blocks == 0) return;
+    if (p->walk_blocks == 0) return;
     ProfScope ps(c, "score");
-    const size_t lds = (size_t)4 * (2 * 48 + 11) * 31 * sizeof(float);          // four waves x 107 packed cells of 31 planes
+    const size_t lds = (size_t)2 * (((2 * 48 + 11) * 31 + 3) / 4 * 4) * sizeof(float);      // one slab of 107 packed cells of 31 planes, double-buffered
     const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
-    hipLaunchKernelGGL(score_mfma_rows_ml_k<4>, dim3(ml_grid(p->score_blocks)), dim3(256), lds, c->stream, p->score, p->d_lv, B, c->s_feat.as<float>(), b4,
-                       sp0, d_counts, d_cands);
+    hipLaunchKernelGGL(score_roll_k, dim3(p->walk_blocks), dim3(128), lds, c->stream, p->walk, p->d_lv, B, c->s_feat.as<float>(), b4, sp0, d_counts, d_cands);
 }
 
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* oh, int* ow)

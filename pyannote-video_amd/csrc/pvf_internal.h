@@ -132,7 +132,7 @@ struct DetectorModel {
     double nms_iou = 0, nms_covered = 0;
     std::vector<float> thresh;
     float* d_w = nullptr;    // [nf][frows][fcols][32]
-    float* d_bmfma4 = nullptr; // B fragments of score_mfma_rows_ml_k: [10][12][2][64 lanes][4 k-steps] (3 shifts x 5 filters per 16-column MFMA tile)
+    float* d_bmfma4 = nullptr; // B fragments of score_roll_k: [10][12][2][64 lanes][4 k-steps] (3 shifts x 5 filters per 16-column MFMA tile)
 };
 
 struct ShapeModel {

@@ -199,6 +199,9 @@ class ExtractStream(object):
         return pts, emb
 
 
+EXTRACT_CALL_MAX = 4096          # faces per landmark / embedding call (the network's largest forward)
+
+
 def compute_many(ctx, items):
     """landmarks + embeddings of several batches -- [(ExtractStream, work)], possibly of different videos -- in ONE library call (a call
     costs 2-4 ms of idle GPU around its kernels whatever its size, and the deep layers of the network fill the chip only from a
@@ -595,14 +598,30 @@ class Engine(object):
                 while pending:
                     w = faces_of(pending[0])
                     m = len(w[1]) if w is not None else 0
-                    if take and faces + m > 4096:
+                    if take and faces + m > EXTRACT_CALL_MAX:
                         break
                     take.append(pending.pop(0))
                     faces += m
                 note("extract begin", counters["extracted"])
                 if faces:
-                    with lock:
-                        compute_many(self.ctx, [(msg[1].ex, faces_of(msg)) for msg in take if msg[1].ex is not None])
+                    # one library call per <= 4096 faces, the context given up in between (a crowded shot has 10 000: the tracking
+                    # thread's bulk tracker calls for the next shot are served between the pieces instead of after 80 ms)
+                    items = [(msg[1].ex, faces_of(msg)) for msg in take if msg[1].ex is not None and faces_of(msg) is not None]
+                    piece, m = [], 0
+                    for ex, w in items:
+                        a, n_w = 0, len(w[1])
+                        while a < n_w:
+                            b = min(n_w, a + EXTRACT_CALL_MAX - m)
+                            piece.append((ex, (w[0][a:b], w[1][a:b])))
+                            m += b - a
+                            a = b
+                            if m >= EXTRACT_CALL_MAX:
+                                with lock:
+                                    compute_many(self.ctx, piece)
+                                piece, m = [], 0
+                    if piece:
+                        with lock:
+                            compute_many(self.ctx, piece)
                 for kind, job, work in take:
                     if kind == "work":
                         if work is not None:

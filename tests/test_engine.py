@@ -207,12 +207,15 @@ def test_shots_grouped_into_one_set_of_lanes_equal_shot_by_shot():
     assert calls[0] > calls[1] > calls[2]
 
 
-@pytest.mark.parametrize("extract_min", [0, 40, 100000])
-def test_many_jobs_through_one_engine_run_equal_one_run_each(extract_min):
+@pytest.mark.parametrize("extract_min", [0, 40, 100000, -16])
+def test_many_jobs_through_one_engine_run_equal_one_run_each(extract_min, monkeypatch):
     """several videos as jobs of ONE engine run (run_many / the clip farm); extract_min > 0: their faces wait for each other and go through
     the landmark / embedding calls together, across shots and videos (engine.compute_many) -- same rows per video, fewer calls"""
     clips = [make_video(20 + k, n_shots=2, n=18, faces=3) for k in range(4)]
     singles = [run_engine(*c, mode="resident") for c in clips]
+    if extract_min < 0:                               # -16: at most 16 faces per call -- batches are cut into pieces, across videos too
+        monkeypatch.setattr(engine, "EXTRACT_CALL_MAX", -extract_min)
+        extract_min = 100000
     ctx = FakeContext([], [])
     for k, c in enumerate(clips):                     # frame indices restart per clip: key the scripted detections by object
         for f, d in zip(c[0], c[1]):
@@ -247,7 +250,9 @@ def test_many_jobs_through_one_engine_run_equal_one_run_each(extract_min):
         assert np.array_equal(pts, single[2][0]) and np.array_equal(emb, single[2][1])
         n_faces += len(pts)
     assert sum(landmark_calls) == n_faces
-    if extract_min == 100000:
+    if engine.EXTRACT_CALL_MAX == 16:
+        assert max(landmark_calls) <= 16 and len(landmark_calls) >= n_faces // 16
+    elif extract_min == 100000:
         assert len(landmark_calls) < 12               # everything waited until the GPU thread had no shot left to detect (12 batches exist)
     if extract_min == 40:
         assert len(landmark_calls) < 12               # (12 batches exist: two shots and the end of each of the four videos)

@@ -19,10 +19,10 @@ python - $O/pmc_fetch_size.txt $TAG <<'PY'
 import hashlib, json, re, sys
 kb = None
 for line in open(sys.argv[1]):
-    if "score_mfma_rows_ml_k" in line:
+    if "score_roll_k" in line:
         kb = float(re.search(r"FETCH_SIZE=([0-9.e+]+)", line).group(1)); n = int(re.search(r"n=(\d+)", line).group(1))
 if kb is not None:
-    d = {"kernel": "score_mfma_rows_ml_k<4>", "detect_batch": 128, "frame": "1920x1080", "launches_in_pass": n, "fetch_size_kb_per_launch": kb,
+    d = {"kernel": "score_roll_k", "detect_batch": 128, "frame": "1920x1080", "launches_in_pass": n, "fetch_size_kb_per_launch": kb,
          "traffic_bytes_per_launch": kb * 1024 * 2,
          "detect_hip_sha256_16": hashlib.sha256(open("pyannote-video_amd/csrc/detect.hip", "rb").read()).hexdigest()[:16],
          "source": "profiles/%s_pmc_fetch_size.txt (rocprofv3 --kernel-trace --pmc FETCH_SIZE over `bench.py --steps 1`, a pass of its own; average over the "
