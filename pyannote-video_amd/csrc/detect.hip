@@ -485,13 +485,20 @@ __global__ void __launch_bounds__(256) feat_ring_zero_k(MlStarts st, const LvDes
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K3: a block of TWO waves owns one column strip (96 output columns) of one level of one frame and walks it top to bottom,
-// one feature row per step, staged ONCE into a double-buffered slab both waves read (each fetches half of row s + 1 while row s is
-// multiplied; one barrier per step).  At step s the ten output rows s - 9 .. s are alive (row r takes filter row m = s - r); wave w owns
-// the rows r = w (mod 2), i.e. five of them at every step -- the two waves always have the same work, whatever the phase.  A wave's
-// slot q holds the row with m = p + 2 q (p = parity of s - w): on odd steps slot 4 completes (m = 9), is written out, and the slots
-// move up by one (40 register moves per 1860 MFMAs).  A feature row leaves HBM / L2 once per strip (round 2's form, one wave per 4 output rows x 96 columns with a slab of its own, staged every row
-// 3.25 times -- 3.8 x the feature maps from beyond L2, now 1.09 x) and feeds five MFMAs per fragment read instead of at most four.  Same B fragments, same (m, n, p) order per accumulator => bit-identical to the oracle.
+// K3: the five filters on every window position of every level, on the fp32 matrix cores.  N = 5 filters would fill 5 of 16 MFMA columns,
+// so three neighbouring output columns share one 16-column tile (column = 5 * shift + filter; K grows from 10 to 12 cells per filter row;
+// the zero entries of B are exact no-ops in the fmaf chain); K of a filter row is the packed run of 12 cells x 31 planes (the feature map's
+// pad plane is dropped in the slab) = 93 k-steps of 4; B fragments come packed four k-steps per lane ([m][cell column][2][64 lanes][4]) and
+// are fetched one cell column ahead; every accumulator receives its terms in (m, n, p) order  =>  bit-identical to the oracle's chain.
+// A block of TWO waves owns one column strip (96 output columns) of one level of one frame and walks it top to bottom, one feature row
+// per step, staged ONCE into a double-buffered slab both waves read (each fetches half of row s + 1 while row s is multiplied; one
+// barrier per step).  At step s the ten output rows s - 9 .. s are alive (row r takes filter row m = s - r); wave w owns the rows
+// r = w (mod 2), i.e. five of them at every step -- the two waves always have the same work, whatever the phase.  A wave's slot q holds
+// the row with m = p + 2 q (p = parity of s - w): on odd steps slot 4 completes (m = 9), is written out, and the slots move up by one
+// (40 register moves per 1860 MFMAs).  A feature row leaves HBM / L2 once per strip and feeds five MFMAs per fragment read.  (Round 2's
+// form -- one wave per 4 output rows x 96 columns with a slab of its own -- staged every row 3.25 times: 3.8 x the feature maps from
+// beyond L2, now 1.09 x; a four-wave form with three rows per wave and one shared slab was 12 % slower: its waves hold 1 to 3 rows' worth
+// of work per step and the barrier waits for the longest.  DESIGN.md section 3.)
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 score_roll_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __restrict__ feat_base,
              const float4* __restrict__ Bg4, ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
@@ -770,6 +777,7 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
             const int out_r = d.fh - 9;
             d.roll_nseg = d.valid_score ? (out_r + roll_max - 1) / roll_max : 0;
             d.roll_rows = d.valid_score ? ((out_r + d.roll_nseg - 1) / d.roll_nseg + 1) / 2 * 2 : 0;
+            if (d.valid_score) d.roll_nseg = (out_r + d.roll_rows - 1) / d.roll_rows;      // (rounding the height up may have emptied the last piece)
             p.walk.b0[l] = p.walk_blocks; p.walk_blocks += d.score_bx * d.roll_nseg * B;
         }
     }
