@@ -107,6 +107,21 @@ __global__ void __launch_bounds__(256) row_norms_k(const double* __restrict__ X,
     nrm[a] = s;
 }
 
+// sqrt of a squared distance: 0 or a number far from the ends of the exponent range.  The steps are the device library's own (v_rsq_f64,
+// one coupled Newton step on g ~ sqrt x and h ~ 1 / (2 sqrt x), two corrections by the exact residual x - g g), i.e. the same bits, without
+// the rescaling and class checks it wraps around them for subnormal / huge / infinite arguments (7 of its 17 instructions).
+__device__ __forceinline__ double sqrt_nonneg(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return x == 0.0 ? 0.0 : g;                       // (rsq(0) is infinite)
+}
+
 __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
 {
     constexpr int DIM = 128, KS = DIM / 4;
@@ -131,7 +146,7 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
 #pragma unroll
         for (int s = 0; s < KS; ++s) af[s] = ok ? xa[4 * s] : 0.0;
     }
-    double na4[4], rb[4], rcnt[4];
+    double na4[4], rb[4];
     int rt[4], rpart[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -145,7 +160,6 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
         if (t >= 0 && !(t >= a.t0 && t < a.t1)) t = -1;                       // rows of another rank's share
         rt[r] = t;
         rpart[r] = t >= 0 ? a.seg_part[ab * 16 + seg] : -1;
-        rcnt[r] = t >= 0 ? (double)(a.row_start[t + 1] - a.row_start[t]) : 1.0;
     }
     // staging: a wave moves rows wave, wave + 4, ... of the column block straight from HBM into LDS (buffer_load_dwordx4 ... lds: 64 lanes x
     // 16 bytes = one row of 128 doubles, no registers in between), asynchronously: the block for step cb + 1 is requested before the
@@ -219,7 +233,7 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) d[r] = sqrt(d2[r] > 0.0 ? d2[r] : 0.0);
+                for (int r = 0; r < 4; ++r) d[r] = sqrt_nonneg(d2[r] > 0.0 ? d2[r] : 0.0);
             }
             // rows of every row track: R'[column][row segment] = sum_row d[row][column] Rind[segment][row]; this lane's d[s] is
             // element (column i16, row 4 s + k4) of d^T, i.e. the A operand of step s
@@ -238,13 +252,14 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
             const int cont = colCont[buf];                 // (uniform)
             const int j = colSegTrack[buf][i16];
             if (j >= 0 && i16 != cont) {
-                const double ccnt = (double)(a.row_start[j + 1] - a.row_start[j]);
+                // sums, not means: the division by the two track lengths (35 instructions per entry, in a branch few lanes take) is left
+                // to pair_norm_k / pair_chunks_k, one pass over the finished rows
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = rt[q];
                     if (i < 0) continue;
                     if (rpart[q] >= 0) a.P[(size_t)rpart[q] * a.T + j] = t2[q];
-                    else a.D[(size_t)i * a.T + j] = (i == j) ? 0.0 : t2[q] / (rcnt[q] * ccnt);
+                    else a.D[(size_t)i * a.T + j] = t2[q];
                 }
             }
             f64x4 carry = (f64x4){0.0, 0.0, 0.0, 0.0};
@@ -279,6 +294,18 @@ __global__ void __launch_bounds__(256) pair_chunks_k(const double* __restrict__ 
     D[(size_t)i * T + j] = (i == j) ? 0.0 : s / cnt;
 }
 
+// rows of D that pair_tiles_k wrote as sums (tracks that lie inside one 16-row block): sum / (rows of i x rows of j), the diagonal zero
+__global__ void __launch_bounds__(256) pair_norm_k(double* __restrict__ D, const int32_t* __restrict__ row_start, const int* __restrict__ is_big, int T, int t0)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = t0 + blockIdx.y;
+    if (j >= T || is_big[i]) return;
+    const int ni = row_start[i + 1] - row_start[i], nj = row_start[j + 1] - row_start[j];
+    if (ni <= 0 || nj <= 0) return;
+    const double v = D[(size_t)i * T + j];
+    D[(size_t)i * T + j] = (i == j) ? 0.0 : v / ((double)ni * (double)nj);
+}
+
 static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* row_start, int T, double* h_D, double** d_D_keep, int t0, int t1,
                                 int metric)
 {
@@ -286,7 +313,7 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
     // ---- blocking (host, O(N)): blocks of 16 consecutive rows; segments = runs of one track inside a block
     const int nb = (N + 15) / 16;
     std::vector<int> row_track(N), row_segidx(N, 0), blk_cont(nb, -1), blk_clean(nb, 1), seg_track((size_t)nb * 16, -1), seg_part((size_t)nb * 16, -1);
-    std::vector<int> big_track, big_c0, big_nc;
+    std::vector<int> big_track, big_c0, big_nc, is_big(T, 0);
     for (int t = 0; t < T; ++t) for (int r = row_start[t]; r < row_start[t + 1]; ++r) row_track[r] = t;
     for (int b = 0; b < nb; ++b) {
         const int r0 = b * 16, nr = std::min(16, N - r0);
@@ -306,6 +333,7 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
         const int b_first = row_start[t] / 16, b_last = (row_start[t + 1] - 1) / 16;
         if (b_last == b_first) continue;
         big_track.push_back(t); big_c0.push_back(n_chunks); big_nc.push_back(b_last - b_first + 1);
+        is_big[t] = 1;
         for (int b = b_first; b <= b_last; ++b)
             seg_part[(size_t)b * 16 + (b == b_first ? row_segidx[row_start[t]] : 0)] = n_chunks++;
     }
@@ -327,7 +355,7 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t xb = al((size_t)N * DIM * 8), nbz = al((size_t)N * 8), ib = al((size_t)N * 4), bb = al((size_t)nb * 4), pb = al((size_t)std::max(n_chunks, 1) * T * 8);
     const size_t rsb = al((size_t)(T + 1) * 4), rgb = al((size_t)(n_ranges + 1) * 4), bigb = al((size_t)std::max<size_t>(big_track.size(), 1) * 4);
-    c->s_clu0.ensure(xb + nbz + 2 * ib + bb + 2 * al((size_t)nb * 16 * 4) + pb + rsb + rgb + 3 * bigb + 4096);
+    c->s_clu0.ensure(xb + nbz + 2 * ib + bb + 2 * al((size_t)nb * 16 * 4) + pb + 2 * rsb + rgb + 3 * bigb + 4096);
     c->s_clu1.ensure((size_t)T * T * sizeof(double) + (size_t)T * 64 + 4096);
     uint8_t* p = c->s_clu0.as<uint8_t>();
     auto take = [&](size_t bytes) { uint8_t* q = p; p += bytes; return q; };
@@ -338,6 +366,7 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
     double* dP = (double*)take(pb);
     int* dRow = (int*)take(rsb); int* dRange = (int*)take(rgb);
     int* dBigT = (int*)take(bigb); int* dBigC0 = (int*)take(bigb); int* dBigNc = (int*)take(bigb);
+    int* dIsBig = (int*)take(rsb);
     double* dD = c->s_clu1.as<double>();
     auto up = [&](void* d, const void* h, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream)); };
     up(dX, X, (size_t)N * DIM * 8);
@@ -345,6 +374,7 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
     up(dBC, blk_cont.data(), (size_t)nb * 4);
     up(dST, seg_track.data(), (size_t)nb * 16 * 4); up(dSP, seg_part.data(), (size_t)nb * 16 * 4);
     up(dRow, row_start, (size_t)(T + 1) * 4); up(dRange, range_b0.data(), (size_t)(n_ranges + 1) * 4);
+    up(dIsBig, is_big.data(), (size_t)T * 4);
     up(dBigT, big_track.data(), big_track.size() * 4); up(dBigC0, big_c0.data(), big_c0.size() * 4); up(dBigNc, big_nc.data(), big_nc.size() * 4);
     // the staging buffers above are std::vectors: the copies must have run before they go out of scope
     HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -356,6 +386,7 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
         a.blk_cont = dBC; a.seg_track = dST; a.seg_part = dSP; a.range_b0 = dRange; a.row_start = dRow; a.D = dD; a.P = dP;
         a.n_blocks = nb; a.n_ranges = n_ranges; a.t0 = t0; a.t1 = t1; a.metric = metric;
         hipLaunchKernelGGL(pair_tiles_k, dim3(row_groups, n_ranges), dim3(256), 0, c->stream, a);
+        if (t1 > t0) hipLaunchKernelGGL(pair_norm_k, dim3((T + 255) / 256, t1 - t0), dim3(256), 0, c->stream, dD, dRow, dIsBig, T, t0);
         // tracks of the requested range that span several blocks
         std::vector<int> sel;
         for (size_t k = 0; k < big_track.size(); ++k) if (big_track[k] >= t0 && big_track[k] < t1) sel.push_back((int)k);
