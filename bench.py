@@ -406,10 +406,10 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
     clustered on its own; no collective anywhere.  One step = this rank's clips through ONE engine run (FacePipeline.run_many)."""
     import numpy as np
     import torch
-    from pyannote_video_amd import synth, pipeline
+    from pyannote_video_amd import synth, pipeline, dist as pdist
     from pyannote_video_amd.runtime import Context
     ctx = Context(device=local_rank)
-    mine = list(range(rank, args.clips, world))
+    mine = pdist.shard_clips(args.clips, world)[rank]
     t_gen = time.time()
     clips, videos, tensors = [], [], []
     for i in mine:

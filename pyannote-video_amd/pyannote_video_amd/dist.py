@@ -149,6 +149,25 @@ def shard_shots(shot_ranges, world_size):
     return out
 
 
+def shard_clips(n_clips, world_size, frames=None):
+    """The clip farm (BASELINE.json configs[3]: independent videos, one result each, no exchange step): which clips every rank takes.
+    Without `frames`: round robin (clips of one length).  With `frames` = frame count per clip: longest first onto the rank with the least
+    work so far (ties: lowest rank), each rank's clips then in input order.  -> [[clip indices] per rank]; every clip exactly once."""
+    out = [[] for _ in range(world_size)]
+    if frames is None:
+        for i in range(n_clips):
+            out[i % world_size].append(i)
+        return out
+    if len(frames) != n_clips:
+        raise ValueError("shard_clips: one frame count per clip")
+    load = [0] * world_size
+    for i in sorted(range(n_clips), key=lambda k: (-int(frames[k]), k)):
+        r = min(range(world_size), key=lambda q: (load[q], q))
+        out[r].append(i)
+        load[r] += int(frames[i])
+    return [sorted(c) for c in out]
+
+
 def _gather_padded(loc, dev):
     """all-gather of float64 [n_r, k] blocks of different n_r: one count exchange + one padded payload exchange"""
     import torch

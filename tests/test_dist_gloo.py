@@ -142,3 +142,24 @@ def test_distance_shard_bounds_cover_and_balance():
         assert [DistanceShard(r, world).track_range(rs) for r in range(world)] == list(zip(cuts, cuts[1:]))
         rows = [int(rs[b] - rs[a]) for a, b in zip(cuts, cuts[1:])]
         assert max(rows) <= rs[-1] / world + sizes.max()          # no share exceeds the even split by more than one track
+
+
+def test_clip_farm_assignment_covers_every_clip_once_and_balances():
+    """dist.shard_clips (configs[3]: independent clips over the ranks, no exchange step): every clip on exactly one rank; equal clips go
+    round robin, clips of different lengths longest-first onto the least loaded rank"""
+    from pyannote_video_amd import dist as pdist
+    for n, world in ((64, 8), (64, 1), (5, 8), (0, 4), (13, 3)):
+        parts = pdist.shard_clips(n, world)
+        assert len(parts) == world and sorted(i for p in parts for i in p) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        assert all(p == sorted(p) for p in parts)
+    assert pdist.shard_clips(64, 8)[3] == list(range(3, 64, 8))
+    rng = np.random.default_rng(7)
+    frames = rng.integers(50, 5000, 41).tolist()
+    parts = pdist.shard_clips(41, 4, frames=frames)
+    assert sorted(i for p in parts for i in p) == list(range(41)) and all(p == sorted(p) for p in parts)
+    loads = [sum(frames[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= max(frames)                  # longest-processing-time-first: within one clip of each other
+    assert pdist.shard_clips(41, 4, frames=frames) == parts        # deterministic: every rank computes the same table
+    with pytest.raises(ValueError):
+        pdist.shard_clips(3, 2, frames=[1, 2])
