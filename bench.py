@@ -34,8 +34,8 @@ FP32_PEAK_TFLOPS = 157.3   # dense fp32 (vector == f32 MFMA) peak, MI355X_MICROA
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=("c2", "c3", "c4", "c5"), default="c2", help="BASELINE.json configuration (default c2 = configs[1], the one the metric is quoted on)")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU (c2: 1000, c3: 22500, c4: 250 per clip, c5: 500)")
     ap.add_argument("--width", type=int, default=None)
