@@ -5,7 +5,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpvface.so")
+# PVF_LIBRARY: another build of the SAME library (the address-sanitizer build of `make asan`, tests/README); never a different implementation
+LIB_PATH = os.environ.get("PVF_LIBRARY") or os.path.join(_HERE, "libpvface.so")
 
 _lib = None
 
