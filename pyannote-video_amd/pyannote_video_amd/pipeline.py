@@ -9,11 +9,9 @@ with the inter-stage text formats applied in memory (3-decimal boxes + int() tru
 results equal what the file-based flow produces.  The video is staged once; the reference decodes it twice.
 """
 import time as _time
-import os
 import numpy as np
 from . import formats
 from . import _lib
-from . import runtime as _runtime
 from .face_tracking import FaceTracking
 from .tracking_by_detection import HipTrackers
 from .clustering import FaceClustering

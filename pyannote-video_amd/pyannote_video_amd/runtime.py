@@ -3,7 +3,7 @@ import contextlib
 import ctypes as C
 import numpy as np
 from . import _lib
-from ._lib import check, ptr, handles, Rect
+from ._lib import check, ptr, handles
 from . import models as _models
 
 
