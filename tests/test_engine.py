@@ -104,10 +104,10 @@ def make_video(seed, n_shots=4, n=30, **kw):
     return frames, dets, times, shots
 
 
-def run_engine(frames, dets, times, shots, mode, overlap=True, limit=8192, window=4096, extract=True, group=1):
+def run_engine(frames, dets, times, shots, mode, overlap=True, limit=8192, window=4096, extract=True, group=1, batch=7):
     ctx = FakeContext(frames, dets)
     tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0, trackers=HipTrackers(ctx))
-    eng = engine.Engine(ctx, tbd, detect_batch_size=7, overlap=overlap, speculate_limit=limit, speculate_window=window, group=group)
+    eng = engine.Engine(ctx, tbd, detect_batch_size=batch, overlap=overlap, speculate_limit=limit, speculate_window=window, group=group)
     if mode == "resident":
         job = engine.VideoJob(ctx, 640, 360, frames=frames, times=times, extract=extract)
         src = engine.resident_source(job, frames, times, shots, 1)
@@ -306,3 +306,14 @@ def test_fair_lock_serves_in_order_of_arrival():
         order.append("holder again")
     th.join()
     assert order == ["waiter", "holder again"] and lock.waiting() == -1
+
+
+def test_long_shots_detected_batch_by_batch_equal_whole_shot_calls():
+    """a shot of four or more detector batches is detected in one library call per batch, the context lock given up in between (engine._detect);
+    the detections, tracks and faces are those of the whole-shot call, the detector is called more often"""
+    frames, dets, times, shots = make_video(11, n_shots=3, n=33)
+    whole = run_engine(frames, dets, times, shots, "resident", batch=1000)
+    pieces = run_engine(frames, dets, times, shots, "resident", batch=7)          # 33+ frames >= 4 x 7: batch by batch
+    assert pieces[0] == whole[0] and pieces[1] == whole[1]
+    assert np.array_equal(pieces[2][0], whole[2][0]) and np.array_equal(pieces[2][1], whole[2][1])
+    assert whole[3].detect_calls == 3 and pieces[3].detect_calls >= 3 * 5
