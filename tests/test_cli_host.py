@@ -1,0 +1,143 @@
+"""CPU: the `extract` verb's own work (cli.extract: a reader thread feeding frames that carry faces, batches through ONE landmark +
+descriptor call, a writer thread formatting and writing batch i while batch i + 1 is computed) on a scripted context: the two files must
+hold, line for line, what a plain loop over getFaceGenerator's pairing (pipeline.faces_per_frame, pyannote-face.py:121-175, 287-311)
+writes, whatever the batch size; an error on any of the three threads reaches the caller."""
+import numpy as np
+import pytest
+
+from pyannote_video_amd import cli, formats, pipeline
+
+
+class ScriptVideo(object):
+    def __init__(self, n, w=64, h=48, fps=25.0):
+        self.n, self.frame_size, self.size, self.frame_rate = n, (w, h), (w, h), fps
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        w, h = self.frame_size
+        for i in range(self.n):
+            a = np.zeros((h, w, 3), np.uint8)
+            a[0, 0, 0], a[0, 0, 1] = i // 256, i % 256
+            yield i / self.frame_rate, a
+
+
+class Dev(object):
+    def __init__(self, i, shape):
+        self.i, self.shape, self.released = i, shape, False
+
+    def release(self):
+        assert not self.released
+        self.released = True
+
+
+class Ring(object):
+    def __init__(self, log):
+        self.log = log
+
+    def push(self, rgb):
+        d = Dev(int(rgb[0, 0, 0]) * 256 + int(rgb[0, 0, 1]), rgb.shape)
+        self.log.append(d)
+        return d
+
+    def close(self):
+        pass
+
+
+class ScriptContext(object):
+    def __init__(self, fail_at=None):
+        self.calls, self.frames, self.fail_at = [], [], fail_at
+
+    def load_shape_predictor(self, path):
+        pass
+
+    def load_embedder(self, path):
+        pass
+
+    def ingest_ring(self, h, w, depth=16):
+        return Ring(self.frames)
+
+    def landmarks_embed(self, frames, boxes):
+        self.calls.append(len(boxes))
+        if self.fail_at is not None and len(self.calls) > self.fail_at:
+            raise RuntimeError("scripted device error")
+        pts = np.zeros((len(boxes), 68, 2), np.int32)
+        emb = np.zeros((len(boxes), 128), np.float32)
+        for k, (f, b) in enumerate(zip(frames, boxes)):
+            assert not f.released, "face computed on a released frame"
+            pts[k, :, 0] = b[0] + np.arange(68) + f.i
+            pts[k, :, 1] = b[1] + 2 * np.arange(68)
+            emb[k] = np.sin(0.01 * (f.i + b[0] + b[1]) + 0.1 * np.arange(128)) * 0.1
+        return pts, emb
+
+
+def make_tracks(n_frames, fps=25.0, seed=0):
+    rng = np.random.default_rng(seed)
+    tracks = []
+    for k in range(5):
+        a = int(rng.integers(0, n_frames // 2))
+        b = int(rng.integers(a + 3, n_frames))
+        x, y = rng.uniform(0.1, 0.5, 2)
+        tracks.append([(i / fps, (x + 0.001 * i, y, x + 0.3, y + 0.3), "forward" if i > a else "detection") for i in range(a, b)])
+    return tracks
+
+
+def expected_files(video, track_path):
+    rows = formats.read_tracks(track_path)
+    w, h = video.frame_size
+    times = [i / video.frame_rate for i in range(len(video))]
+    ctx = ScriptContext()
+    lm, em = [], []
+    for fi, T, g in pipeline.faces_per_frame(rows, times, w, h):
+        f = Dev(fi, (h, w, 3))
+        for ident, box in g:
+            pts, emb = ctx.landmarks_embed([f], [box])
+            lm.append(formats.landmark_rows([T], [ident], pts, w, h))
+            em.append(formats.embedding_rows([T], [ident], emb))
+    return b"".join(lm), b"".join(em)
+
+
+@pytest.mark.parametrize("batch", [1, 7, 2048])
+def test_extract_verb_files_equal_the_plain_loop(tmp_path, batch):
+    video = ScriptVideo(60)
+    tp = str(tmp_path / "track.txt")
+    formats.write_tracks(tp, make_tracks(60))
+    want_lm, want_em = expected_files(video, tp)
+    assert want_lm.count(b"\n") > 50
+    ctx = ScriptContext()
+    lp, ep = str(tmp_path / "landmarks.txt"), str(tmp_path / "embedding.txt")
+    cli.extract(video, "unused", "unused", tp, lp, ep, ctx=ctx, batch=batch, ahead=4)
+    assert open(lp, "rb").read() == want_lm and open(ep, "rb").read() == want_em
+    assert all(d.released for d in ctx.frames) and len(ctx.frames) > 0          # frames the verb staged itself went back
+    if batch == 2048:
+        assert len(ctx.calls) == 1
+    if batch == 1:
+        assert len(ctx.calls) >= want_lm.count(b"\n") // 5                      # (a frame's faces stay together)
+
+
+def test_extract_verb_hands_on_errors_of_its_threads(tmp_path):
+    video = ScriptVideo(60)
+    tp = str(tmp_path / "track.txt")
+    formats.write_tracks(tp, make_tracks(60))
+    lp, ep = str(tmp_path / "landmarks.txt"), str(tmp_path / "embedding.txt")
+    with pytest.raises(RuntimeError, match="scripted device error"):               # the computing thread
+        cli.extract(video, "unused", "unused", tp, lp, ep, ctx=ScriptContext(fail_at=1), batch=7, ahead=4)
+
+    class BadVideo(ScriptVideo):                                                    # the reader thread
+        def __iter__(self):
+            for k, item in enumerate(ScriptVideo.__iter__(self)):
+                if k == 20:
+                    raise IOError("scripted decode error")
+                yield item
+    with pytest.raises(IOError, match="scripted decode error"):
+        cli.extract(BadVideo(60), "unused", "unused", tp, lp, ep, ctx=ScriptContext(), batch=7, ahead=4)
+    orig = formats.embedding_rows                                                   # the writer thread
+    try:
+        def boom(*a, **k):
+            raise ValueError("scripted formatter error")
+        formats.embedding_rows = boom
+        with pytest.raises(ValueError, match="scripted formatter error"):
+            cli.extract(video, "unused", "unused", tp, lp, ep, ctx=ScriptContext(), batch=7, ahead=4)
+    finally:
+        formats.embedding_rows = orig
