@@ -141,3 +141,58 @@ def test_extract_verb_hands_on_errors_of_its_threads(tmp_path):
             cli.extract(video, "unused", "unused", tp, lp, ep, ctx=ScriptContext(), batch=7, ahead=4)
     finally:
         formats.embedding_rows = orig
+
+
+# ---- `track` and `process` on the streaming engine, scripted context (detections, trackers, landmark / descriptor stand-ins of test_engine) ----
+def _engine_fixture(seed=5):
+    from tests.test_engine import FakeContext, make_video, numpy_frame, run_engine
+    frames, dets, times, shots = make_video(seed, n_shots=3, n=20)
+
+    class Ctx(FakeContext):
+        def load_shape_predictor(self, path):
+            pass
+
+        def load_embedder(self, path):
+            pass
+
+        def landmarks_embed(self, fr, boxes):             # (the `extract` verb's one call; the engine may use either form)
+            pts = self.landmarks(fr, boxes)
+            return pts, self.embed(fr, pts)
+
+    class Video(object):
+        frame_rate, size, frame_size = 25.0, (640, 360), (640, 360)
+
+        def __len__(self):
+            return len(frames)
+
+        def __iter__(self):
+            for t, f in zip(times, frames):
+                yield t, numpy_frame(f)
+
+    want = run_engine(frames, dets, times, shots, "resident")
+    return Ctx(frames, dets), Video(), shots, want
+
+
+def test_track_verb_writes_the_engine_s_tracks(tmp_path):
+    ctx, video, shots, want = _engine_fixture()
+    out = str(tmp_path / "track.txt")
+    cli.track(video, shots, out, ctx=ctx)
+    lines = [l for i, trk in enumerate(want[0]) for l in formats.track_lines(i, trk)]
+    assert len(lines) > 100 and open(out).readlines() == lines
+    assert not ctx.trk
+
+
+def test_process_verb_writes_what_track_then_extract_write(tmp_path):
+    """one pass (cli.process) == the two verbs one after the other, file for file; and == the engine's own arrays"""
+    ctx, video, shots, want = _engine_fixture()
+    p = {k: str(tmp_path / (k + ".txt")) for k in ("t1", "l1", "e1", "t2", "l2", "e2")}
+    cli.process(video, shots, "unused", "unused", p["t1"], p["l1"], p["e1"], ctx=ctx)
+    ctx2, video2, shots2, _ = _engine_fixture()
+    cli.track(video2, shots2, p["t2"], ctx=ctx2)
+    cli.extract(video2, "unused", "unused", p["t2"], p["l2"], p["e2"], ctx=ctx2, batch=16)
+    for a, b in (("t1", "t2"), ("l1", "l2"), ("e1", "e2")):
+        assert open(p[a], "rb").read() == open(p[b], "rb").read(), a
+    face_T, face_id, _ = want[1]
+    pts, emb = want[2]
+    assert open(p["l1"], "rb").read() == formats.landmark_rows(face_T, face_id, pts, 640, 360)
+    assert open(p["e1"], "rb").read() == formats.embedding_rows(face_T, face_id, emb)
