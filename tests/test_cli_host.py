@@ -196,3 +196,52 @@ def test_process_verb_writes_what_track_then_extract_write(tmp_path):
     pts, emb = want[2]
     assert open(p["l1"], "rb").read() == formats.landmark_rows(face_T, face_id, pts, 640, 360)
     assert open(p["e1"], "rb").read() == formats.embedding_rows(face_T, face_id, emb)
+
+
+def test_pipeline_run_many_equals_run_per_clip():
+    """FacePipeline.run_many (the clip farm, configs[3]): every clip's result dictionary == FacePipeline.run on that clip alone, although the
+    farm extracts the faces of several clips in one call (Engine.extract_min)"""
+    from tests.test_engine import FakeContext, make_video
+    clips = [make_video(40 + k, n_shots=2, n=16, faces=3) for k in range(3)]
+
+    class Ctx(FakeContext):
+        def __init__(self):
+            FakeContext.__init__(self, [], [])
+            self.embed_calls = []
+
+        def load_shape_predictor(self, path):
+            pass
+
+        def load_embedder(self, path):
+            pass
+
+        def detect_many(self, frs, batch, upsample=1, adjust_threshold=0.0, cap=64, arrays=False):
+            class W(object):
+                def __init__(s, f):
+                    s.i = id(f)
+            return FakeContext.detect_many(self, [W(f) for f in frs], batch, upsample, adjust_threshold, cap, arrays)
+
+        def embed(self, frames, pts):
+            self.embed_calls.append(len(pts))
+            return FakeContext.embed(self, frames, pts)
+
+    def fresh():
+        ctx = Ctx()
+        for c in clips:
+            for f, d in zip(c[0], c[1]):
+                ctx.dets_of[id(f)] = d
+        return ctx, pipeline.FacePipeline(ctx, "unused", "unused", detect_batch_size=7)
+
+    ctx, pipe = fresh()
+    singles = [pipe.run(c[0], c[2], 25.0, c[3], cluster=False) for c in clips]
+    n_single_calls = len(ctx.embed_calls)
+    ctx, pipe = fresh()
+    seen = []
+    farm = pipe.run_many([dict(frames=c[0], times=c[2], frame_rate=25.0, shots=c[3]) for c in clips], cluster=False,
+                         on_result=lambda k, r: seen.append(k))
+    assert seen == [0, 1, 2] and len(ctx.embed_calls) < n_single_calls
+    for a, b in zip(farm, singles):
+        assert a["tracks"] == b["tracks"] and a["track_rows"] == b["track_rows"]
+        assert np.array_equal(a["face_T"], b["face_T"]) and np.array_equal(a["face_id"], b["face_id"]) and a["face_boxes"] == b["face_boxes"]
+        assert np.array_equal(a["landmarks"], b["landmarks"]) and np.array_equal(a["embeddings"], b["embeddings"]) and np.array_equal(a["X"], b["X"])
+        assert len(a["face_T"]) > 20
