@@ -245,3 +245,39 @@ def test_pipeline_run_many_equals_run_per_clip():
         assert np.array_equal(a["face_T"], b["face_T"]) and np.array_equal(a["face_id"], b["face_id"]) and a["face_boxes"] == b["face_boxes"]
         assert np.array_equal(a["landmarks"], b["landmarks"]) and np.array_equal(a["embeddings"], b["embeddings"]) and np.array_equal(a["X"], b["X"])
         assert len(a["face_T"]) > 20
+
+
+def test_tracking_call_streams_through_the_engine():
+    """TrackingByDetection.__call__(video, segmentation) -- the reference's entry point (tracking.py:374-434) -- with the GPU tracker backend:
+    the video goes through the streaming engine in a worker thread, the tracks come out shot after shot, equal to the engine's own"""
+    from tests.test_engine import FakeContext, make_video, numpy_frame, run_engine
+    from pyannote_video_amd.tracking_by_detection import TrackingByDetection, HipTrackers
+    from pyannote_video_amd._core import Segment
+    frames, dets, times, shots = make_video(6, n_shots=3, n=20)
+    ctx = FakeContext(frames, dets)
+
+    class Video(object):
+        frame_rate, size, frame_size = 25.0, (640, 360), (640, 360)
+
+        def __len__(self):
+            return len(frames)
+
+        def __iter__(self):
+            for t, f in zip(times, frames):
+                yield t, numpy_frame(f)
+
+    tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0, trackers=HipTrackers(ctx))
+    got = list(tbd(Video(), [Segment(a, b) for a, b in shots]))
+    want = run_engine(frames, dets, times, shots, "resident", extract=False)[0]
+    assert len(got) > 5 and got == want
+    assert not ctx.trk
+
+    class BadVideo(Video):                      # an error in the reader thread reaches the caller of the generator
+        def __iter__(self):
+            for k, item in enumerate(Video.__iter__(self)):
+                if k == 30:
+                    raise IOError("scripted decode error")
+                yield item
+    tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0, trackers=HipTrackers(FakeContext(frames, dets)))
+    with pytest.raises(IOError, match="scripted decode error"):
+        list(tbd(BadVideo(), [Segment(a, b) for a, b in shots]))
