@@ -29,6 +29,24 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "pyannote-video_amd"))
 
 FP32_PEAK_TFLOPS = 157.3   # dense fp32 (vector == f32 MFMA) peak, MI355X_MICROARCH.md chip table
+PMC_SCORE_FILE = "r04_pmc_score.json"      # rocprofv3 --pmc FETCH_SIZE pass of the scoring kernel, keyed on the hash of csrc/detect.hip
+EMBED_GFLOP_PER_FACE = 0.542               # the 29-conv ResNet on a 150 x 150 chip
+TRACKER_GFLOP_PER_FRAME = 0.3              # DSST starts + updates of ~8 faces, both passes
+
+
+def e2e_object(flop_score_per_frame, faces, frames, seconds):
+    """whole-step arithmetic against the fp32 peak: scoring + embedding + tracker FLOPs of the frames processed / the step's wall time"""
+    g = (flop_score_per_frame * frames + EMBED_GFLOP_PER_FACE * 1e9 * faces + TRACKER_GFLOP_PER_FRAME * 1e9 * frames) / max(frames, 1) / 1e9
+    tf = g * 1e9 * frames / seconds / 1e12 if seconds > 0 else 0.0
+    return {"gflop_per_frame": round(g, 3), "tflops": round(tf, 2), "frac_of_fp32_peak": round(tf / FP32_PEAK_TFLOPS, 4),
+            "note": "scoring (positions x 3100 MAC x 5 filters) + %.3f GFLOP per embedded face + %.1f GFLOP/frame of tracker FFTs, over the timed steps' "
+                    "wall time of the slowest rank; pyramid / FHOG / landmark work is byte-bound and not counted" % (EMBED_GFLOP_PER_FACE, TRACKER_GFLOP_PER_FRAME)}
+
+
+def labels_digest(labels):
+    """sha256[:16] of the sorted (track, label) pairs: two runs that print the same digest assigned every track to the same cluster"""
+    import hashlib
+    return hashlib.sha256(json.dumps(sorted((int(k), int(v)) for k, v in labels.items())).encode()).hexdigest()[:16]
 
 
 def main():
@@ -51,12 +69,26 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): every rank owns --frames frames of an N x --frames video; strong: ONE video of --frames frames "
                          "(BASELINE.json configs[2]'s shape: a fixed video cut into N frame ranges at shot boundaries)")
-    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the all-core CPU-oracle sample, centred on the first shot cut (0 = skip)")
-    ap.add_argument("--cpu-frames-1t", type=int, default=4, help="frames of the single-thread CPU-oracle sample (same centre)")
+    ap.add_argument("--cpu-frames", type=int, default=100, help="frames of the all-core CPU-oracle sample, centred on the first shot cut (0 = skip)")
+    ap.add_argument("--cpu-frames-1t", type=int, default=16, help="frames of the single-thread CPU-oracle sample (same centre)")
     ap.add_argument("--no-host-ingest", action="store_true", help="skip the extra pass whose frames start in pinned host memory")
     ap.add_argument("--no-overlap", action="store_true", help="no GPU-feeding thread: every stage runs in the caller's thread, shot after shot")
     ap.add_argument("--small-models", action="store_true", help="debug only: reduced landmark model")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST SWITCH: with --gpus N on a box with fewer than N devices, run the N ranks anyway, all on device 0 (gloo rendezvous, "
+                         "torch.distributed collectives: two ranks of one RCCL communicator cannot share a device).  Exercises the launcher, the "
+                         "shot-range sharding, the gather and the global clustering; the line says `oversubscribed`: its value is NOT a scaling figure")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks this process launches (0: a free one)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)             # this process becomes the launcher: N ranks of this script, one per GPU
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node %d "
+                         "bench.py --gpus %d ...), or run `python bench.py --gpus %d` and let it launch them\n"
+                         % (args.gpus, os.environ["WORLD_SIZE"], args.gpus, args.gpus, args.gpus))
+        sys.exit(2)
     defaults = {"c2": dict(frames=1000, width=1920, height=1080, fps=25.0, faces=8, shots=4, detect_batch=128),
                 "c3": dict(frames=22500, width=1920, height=1080, fps=25.0, faces=8, shots=4, detect_batch=128),
                 "c4": dict(frames=250, width=1280, height=720, fps=25.0, faces=8, shots=2, detect_batch=128),
@@ -64,7 +96,7 @@ def main():
     for k, v in defaults.items():
         if getattr(args, k) is None:
             setattr(args, k, v)
-    if args.config == "c5" and args.cpu_frames == 32:
+    if args.config == "c5" and args.cpu_frames == 100:
         args.cpu_frames, args.cpu_frames_1t = 8, 0          # a 4K frame costs the CPU oracle four 1080p frames
 
     import numpy as np
@@ -72,6 +104,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_dev = torch.cuda.device_count()
+    if args.oversubscribe and world > n_dev:
+        local_rank = local_rank % max(n_dev, 1)          # several ranks per device (test switch)
+    elif local_rank >= n_dev:
+        sys.stderr.write("bench.py: rank %d needs device %d but this box shows %d GPU(s); --gpus N wants N devices "
+                         "(--oversubscribe is the 1-GPU test switch)\n" % (rank, local_rank, n_dev))
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -159,8 +198,10 @@ def main():
         import cProfile
         pr = cProfile.Profile()
         pr.enable()
+    frames_scored_timed = 0
     for _ in range(args.steps):
         last = step()
+        frames_scored_timed += int(pipe.last_engine.stats.get("frames_detected", 0))
     if prof_path:
         pr.disable()
         import pstats
@@ -172,10 +213,7 @@ def main():
     timed_engine = pipe.last_engine
     for c in ctxs:
         c.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, world, device)
     res, labels, tm = last
     if os.environ.get("PVF_DUMP") and rank == 0:
         ident_of_track = {}
@@ -199,7 +237,9 @@ def main():
     geo = pipeline.detector_geometry(args.height, args.width)
     positions = sum(g[4] for g in geo)
     flop_per_frame = positions * 3100 * 5 * 2.0          # 10x10 cells x 31 planes, 5 filters, FMA = 2 flop
-    n_score_frames = n_local * args.steps
+    # frames the detector actually scored inside the timed steps (with --detect-every only every k-th frame is: counting all frames
+    # would print a `frac` above 1); the engine counts them, summed over the ranks' steps on rank 0 only (every rank does the same work)
+    n_score_frames = frames_scored_timed if frames_scored_timed is not None else n_local * args.steps
     score_ms = fam["score"]["ms"]
     launches = max(fam["score"]["launches"], 1)
     achieved = (flop_per_frame * n_score_frames / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
@@ -215,10 +255,10 @@ def main():
     try:
         import hashlib
         src_hash = hashlib.sha256(open(os.path.join(ROOT, "pyannote-video_amd", "csrc", "detect.hip"), "rb").read()).hexdigest()[:16]
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_score.json")))
+        pm = json.load(open(os.path.join(ROOT, "profiles", PMC_SCORE_FILE)))
         if pm["detect_batch"] == args.detect_batch and pm["frame"] == "%dx%d" % (args.width, args.height) and pm.get("detect_hip_sha256_16") == src_hash:
             roofline["traffic"] = pm["traffic_bytes_per_launch"]
-            roofline["traffic_source"] = pm["source"]
+            roofline["traffic_attached_from_profiles_not_measured_in_this_run"] = pm["source"]
             roofline["algorithmic_bytes_per_launch"] = sum(g[2] * g[3] for g in geo) * 128.0 * n_score_frames / launches   # features read once
     except Exception:
         pass
@@ -246,8 +286,11 @@ def main():
                                   "in total, one video cut into shot ranges" if (args.scaling == "strong" and world > 1) else "per GPU"),
                    "detect_every": args.detect_every, "upsample": 1, "tracking": "forward+backward DSST, CLI defaults (overlap 0.5, conf 10, gap 1.0)",
                    "parallelism": "shot-range sharding x%d + all-gather of track embeddings" % world if world > 1 else "single GPU",
-                   "detect_batch": args.detect_batch, "collective": pdist.collective_name()},
+                   "detect_batch": args.detect_batch, "collective": pdist.collective_name(),
+                   "devices": min(world, n_dev), "oversubscribed": bool(world > n_dev)},
         "roofline": roofline,
+        "e2e": e2e_object(flop_per_frame if args.detect_every == 0.0 else flop_per_frame * n_score_frames / max(n_local * args.steps, 1),
+                          int(len(res["face_T"])) * args.steps, n_local * args.steps, elapsed),
         "cpu_baseline": cpu,
         "parity": parity,
         "host_ingest": host,
@@ -256,10 +299,48 @@ def main():
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
         "kernel_families_ms": fam,
         "results": {"tracks": len(res["tracks"]), "faces_embedded": int(len(res["face_T"])), "clusters": n_clusters,
+                    "tracks_clustered_globally": len(labels), "labels_sha256_16": labels_digest(labels),
                     "identities_in_video": len(set(tr["ident"] for shot in video.tracks for tr in shot))},
         "setup_seconds": {"generate_frames_in_hbm": round(t_gen, 1)},
     }
     print(json.dumps(out))
+
+
+def max_over_ranks(seconds, world, device):
+    """the slowest rank's time (the all-reduce runs where the job's backend lives: the device for nccl, host memory for gloo)"""
+    if world <= 1:
+        return seconds
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks (one process per GPU, torch.distributed.run on
+    127.0.0.1) with this command line and hand their output through; rank 0 prints the JSON line.  Fewer than N visible devices is an
+    error unless --oversubscribe (the 1-GPU test switch) was given."""
+    import socket
+    import subprocess
+    import torch
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if n_dev < args.gpus:
+        if not args.oversubscribe:
+            sys.stderr.write("bench.py: --gpus %d but this box shows %d GPU(s)\n" % (args.gpus, n_dev))
+            sys.exit(2)
+        env["PVF_DIST_BACKEND"] = "gloo"             # ranks that share a device cannot form an RCCL communicator
+        env["PVF_DIST_COLLECTIVE"] = "torch"
+    port = args.master_port
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 class HbmSampler(object):
@@ -440,10 +521,7 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
     elapsed = time.perf_counter() - t0
     hbm.stop()
     ctx.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, world, device)
     fam = {}
     for name in ("pyramid", "fhog", "score", "chip", "ert", "conv", "dsst", "pdist", "hac"):
         ms, n = ctx.prof_get(name)
@@ -561,10 +639,7 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
     elapsed = time.perf_counter() - t0
     hbm.stop()
     ctx.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, world, device)
     res, labels, tm = last
     fam = {}
     for name in ("pyramid", "fhog", "score", "chip", "ert", "conv", "dsst", "pdist", "hac"):

@@ -58,7 +58,8 @@ int32_t pvf_set_tracker_tables(pvf_handle ctx, const double* mask64, const doubl
 int32_t pvf_frame_upload(pvf_handle ctx, const uint8_t* rgb, int32_t h, int32_t w, int64_t row_stride_bytes, pvf_handle* frame);
 /* `rgb` may also be a device address (a decoder that delivers into HBM): the frame is copied into a buffer of the library's own, so
  * the source may be overwritten as soon as the call returns */
-/* wrap a frame that already lives in HBM (no copy; the caller keeps it alive until pvf_frame_release) */
+/* wrap a frame that already lives in HBM (no copy; the caller keeps it alive until pvf_frame_release RETURNS: compute calls queue their
+ * kernels without waiting for them, so releasing a wrapped frame waits for the compute stream -- only then may the memory be reused) */
 int32_t pvf_frame_wrap_device(pvf_handle ctx, const void* dev_rgb, int32_t h, int32_t w, pvf_handle* frame);
 /* Releasing never waits for the GPU: the buffer of a frame the library allocated itself (upload, ingest ring, device resize) goes back
  * to a pool together with an event on the compute stream, and whoever takes it next orders its first write behind that event.

@@ -705,6 +705,14 @@ extern "C" int32_t pvf_format_rows(const double* t, const int64_t* identifier, c
     for (int d = 0; d < decimals; ++d) scale *= 10.0;
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(8, n_rows / 256));
     std::vector<int64_t> len(n_rows, 0);
+    // a row's slot holds 42 bytes per value: finite values of 1e25 and more (27+ digits before the point) do not fit and are refused
+    // BEFORE anything is written (NaN and +-inf print as 3-4 characters) -- descriptors and timestamps are many orders below that
+    auto fits = [](double v) { return !(std::fabs(v) >= 1e25) || std::isinf(v); };
+    for (int64_t r = 0; r < n_rows; ++r) {
+        PVF_REQUIRE(fits(t[r]), "pvf_format_rows: a timestamp of 1e25 or more does not fit the fixed row layout");
+        const double* v = values + (size_t)r * n_cols;
+        for (int c = 0; c < n_cols; ++c) PVF_REQUIRE(fits(v[c]), "pvf_format_rows: a value of magnitude 1e25 or more does not fit the fixed row layout");
+    }
     auto work = [&](int64_t r0, int64_t r1) {
         for (int64_t r = r0; r < r1; ++r) {
             char* o = out + r * per_row;

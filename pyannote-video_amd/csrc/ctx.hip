@@ -432,6 +432,10 @@ static void release_frame_locked(Ctx* c, pvf_handle frame)
     c->frames.erase(it);
     if (f.ready) { (void)hipEventSynchronize(f.ready); (void)hipEventDestroy(f.ready); }     // released before any kernel read it: let the upload finish
     if (f.owned) c->pool_give((uint8_t*)f.d, (size_t)f.h * f.w * 3);
+    // memory the caller owns (pvf_frame_wrap_device): compute calls no longer end with a stream synchronisation, so kernels that read this
+    // frame may still be queued -- the caller is free to reuse the memory as soon as this returns, hence the wait (pooled buffers go back
+    // behind an event instead and never wait)
+    else (void)hipStreamSynchronize(c->stream);
 }
 
 extern "C" int32_t pvf_frame_release(pvf_handle h, pvf_handle frame)

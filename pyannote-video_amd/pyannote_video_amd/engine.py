@@ -249,6 +249,27 @@ class ShotInput(object):
         self.resize = resize            # (width, height) of the detection frames still to be made on the device (--min-size)
 
 
+def release_shot_frames(si):
+    """error / shutdown paths: a shot that will not be processed gives back the frames the engine staged for it (frames the caller
+    owns are left alone; a frame released twice is reported by the library and ignored here)"""
+    if not isinstance(si, ShotInput):
+        return
+    frames = []
+    if si.natives is not None:
+        frames.extend(f for _, f in si.cache)                 # down-scaled copies the engine made
+        if si.owned:
+            frames.extend(si.natives)
+    elif si.owned:
+        frames.extend(f for _, f in si.cache)
+    else:
+        frames.extend(f for _, f in si.cache if getattr(f, "transient", False))
+    for f in frames:
+        try:
+            f.release()
+        except Exception:       # noqa: BLE001 -- already released (the store got there first)
+            pass
+
+
 class JobEnd(object):
     """marks the end of a job's shots in the source"""
     __slots__ = ("job",)
@@ -315,18 +336,33 @@ class FairLock(object):
     def __init__(self):
         self._c = threading.Condition(threading.Lock())
         self._next = self._serving = 0
+        self._gone = set()          # tickets whose holder gave up while waiting (an exception, e.g. KeyboardInterrupt): skipped when served
 
     def acquire(self):
         with self._c:
             me = self._next
             self._next += 1
-            while self._serving != me:
-                self._c.wait()
+            try:
+                while self._serving != me:
+                    self._c.wait()
+            except BaseException:
+                # the ticket must not block everybody behind it: served already -> pass it on, otherwise mark it to be skipped
+                if self._serving == me:
+                    self._advance()
+                else:
+                    self._gone.add(me)
+                raise
+
+    def _advance(self):
+        self._serving += 1
+        while self._serving in self._gone:
+            self._gone.discard(self._serving)
+            self._serving += 1
+        self._c.notify_all()
 
     def release(self):
         with self._c:
-            self._serving += 1
-            self._c.notify_all()
+            self._advance()
 
     def waiting(self):
         return self._next - self._serving - 1
@@ -337,6 +373,52 @@ class FairLock(object):
 
     def __exit__(self, *exc):
         self.release()
+
+
+class _InterpreterTuning(object):
+    """Process-wide interpreter settings a pipelined run wants, reference-counted over the engines that are running (two engines at
+    once used to restore each other's values in the wrong order and could leave the 0.1 ms switch interval behind for good):
+      * no cyclic garbage collection -- a full collection in the middle of a shot stalls both threads for tens of milliseconds;
+      * a 0.1 ms thread switch interval -- the GPU thread re-takes the interpreter lock after every library call, and with the default
+        5 ms each of those hand-overs can stall the GPU queue for milliseconds while the caller's thread runs the tracking state machine.
+    The first engine in sets them, the last one out restores what it found.  They are in effect in the caller's code too while a
+    generator-backed run (TrackingByDetection.__call__) is suspended between two yields; PVF_NO_INTERPRETER_TUNING=1 leaves both alone."""
+
+    def __init__(self):
+        self._mu = threading.Lock()
+        self._users = 0
+        self._saved = None
+
+    def __enter__(self):
+        if os.environ.get("PVF_NO_INTERPRETER_TUNING") == "1":
+            return self
+        import gc
+        import sys
+        with self._mu:
+            if self._users == 0:
+                self._saved = (gc.isenabled(), sys.getswitchinterval())
+                gc.disable()
+                sys.setswitchinterval(1e-4)
+            self._users += 1
+        return self
+
+    def __exit__(self, *exc):
+        if os.environ.get("PVF_NO_INTERPRETER_TUNING") == "1":
+            return False
+        import gc
+        import sys
+        with self._mu:
+            self._users -= 1
+            if self._users == 0 and self._saved is not None:
+                was_enabled, interval = self._saved
+                self._saved = None
+                sys.setswitchinterval(interval)
+                if was_enabled:
+                    gc.enable()
+        return False
+
+
+_interpreter_tuning = _InterpreterTuning()
 
 
 class WindowedPlan(object):
@@ -451,12 +533,16 @@ class Engine(object):
             lock = _NoLock()
         with lock:
             if si.resize is not None:
+                # decided from the frames themselves: a source that honours `frame_size` (the reference's Video resizes on the host,
+                # video.py:402-403) already delivers detection-size frames and gets no second copy; native frames are resized here
                 tw, th = si.resize
-                si.natives = [f for _, f in si.cache]
-                si.cache = [(t, ctx.resize(f, tw, th)) for t, f in si.cache]
+                if any((int(f.shape[1]), int(f.shape[0])) != (tw, th) for _, f in si.cache):
+                    si.natives = [f for _, f in si.cache]
+                    si.cache = [(t, ctx.resize(f, tw, th)) for t, f in si.cache]
                 si.resize = None
         cache, flags = si.cache, si.flags
         idx = [i for i, f in enumerate(flags) if f]
+        self.stats["frames_detected"] = self.stats.get("frames_detected", 0) + len(idx)      # frames that go through the detector kernels
         counts = np.zeros(len(cache), np.int64)
         boxes = np.zeros((0, 4), np.float64)
         raw = None
@@ -546,20 +632,8 @@ class Engine(object):
                 for job in jobs:
                     on_job_final(job)
             return jobs
-        import gc
-        import sys
-        was_enabled = gc.isenabled()
-        gc.disable()      # a full collection in the middle of a shot stalls both threads for tens of milliseconds
-        old_interval = sys.getswitchinterval()
-        # the GPU thread re-takes the interpreter lock after every library call; with the default 5 ms switch interval each of
-        # those hand-overs can stall the GPU queue for milliseconds while this thread runs the tracking state machine
-        sys.setswitchinterval(1e-4)
-        try:
+        with _interpreter_tuning:
             return self._run_pipelined(source, backend, n_shots, on_job_final)
-        finally:
-            sys.setswitchinterval(old_interval)
-            if was_enabled:
-                gc.enable()
 
     def _run_pipelined(self, source, backend, n, on_job_final):
         """GPU thread: detect(k), speculate(k), extract(k-1) ...; this thread: lanes + merging of shot k as soon as its detections
@@ -720,6 +794,7 @@ class Engine(object):
         th = threading.Thread(target=gpu_thread, name="pvface-gpu")
         th.start()
         finished, ok = [], False
+        seen_jobs = []
         k = 0
         try:
             while True:
@@ -748,6 +823,8 @@ class Engine(object):
                 note("host begin", k)
                 jbs = []
                 for si, raw, plans in members:
+                    if si.job not in seen_jobs:
+                        seen_jobs.append(si.job)
                     si.job.accept(si)
                     jbs.append(self.tracking.begin_shot(si.cache, si.flags, detections_as_lists(len(si.cache), raw), lane_backend, plans))
                 self.tracking._run_lanes([lane for jb in jbs for lane in jb["lanes"]], lane_backend)
@@ -764,6 +841,26 @@ class Engine(object):
             if not ok:
                 done.put(None)
             th.join()
+            if not ok:
+                # an error on either side: the frames the engine staged go back to the pool now, not whenever the garbage collector (which
+                # a run switches off) finds their handles: shots still queued for this thread, then everything the jobs' stores hold
+                while True:
+                    try:
+                        item = ready.get_nowait()
+                    except queue.Empty:
+                        break
+                    if isinstance(item, tuple) and item and item[0] == "shots":
+                        for si, _, _ in item[1]:
+                            release_shot_frames(si)
+                for job in seen_jobs:
+                    try:
+                        job.store.release_all()
+                    except Exception:       # noqa: BLE001 -- the original error is the one to report
+                        pass
+                try:
+                    self.ctx.pool_trim(0)
+                except Exception:           # noqa: BLE001 -- (scripted test contexts have no pool)
+                    pass
         while not ready.empty():
             item = ready.get()
             if isinstance(item, BaseException):
@@ -867,7 +964,12 @@ class StreamSource(object):
         self._stop = True
         while self.th.is_alive():
             try:
-                self.q.get(timeout=0.05)
+                release_shot_frames(self.q.get(timeout=0.05))      # a shot nobody will process: its staged frames go back to the pool
             except queue.Empty:
                 pass
         self.th.join()
+        while True:
+            try:
+                release_shot_frames(self.q.get_nowait())
+            except queue.Empty:
+                break

@@ -662,7 +662,10 @@ class TrackingByDetection(object):
         w, h = native_size
         batch = int(max(8, min(128, 128 * (1920 * 1080) // max(w * h, 1))))
         eng = engine.Engine(ctx, self, detect_batch_size=max(batch, int(self.detect_batch_size)))
-        src = engine.StreamSource(ctx, [(job, video, segmentation, every, detection_size if detection_size != native_size else None)])
+        # the engine resizes on the device whatever does not have the detection size yet (checked per shot on the frames themselves:
+        # `video.frame_size` was set above, so a reference-style Video already delivers that size; min_size = 0 frames of another size
+        # than the announced one are brought to it as the non-streaming path does)
+        src = engine.StreamSource(ctx, [(job, video, segmentation, every, detection_size)])
         state = {}
 
         def work():

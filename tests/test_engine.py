@@ -317,3 +317,49 @@ def test_long_shots_detected_batch_by_batch_equal_whole_shot_calls():
     assert pieces[0] == whole[0] and pieces[1] == whole[1]
     assert np.array_equal(pieces[2][0], whole[2][0]) and np.array_equal(pieces[2][1], whole[2][1])
     assert whole[3].detect_calls == 3 and pieces[3].detect_calls >= 3 * 5
+
+
+def test_fair_lock_survives_a_waiter_that_gives_up():
+    """an exception while waiting for the lock (KeyboardInterrupt) used to leave a ticket nobody serves -- every later acquire
+    deadlocked.  A waiter that gives up is skipped; one that gives up at the moment it is served passes the lock on."""
+    import threading
+    from pyannote_video_amd.engine import FairLock
+    lock = FairLock()
+    lock.acquire()                                   # ticket 0 holds the lock
+    hit = []
+
+    def impatient():
+        real_wait = lock._c.wait
+
+        def wait(*a, **k):
+            lock._c.wait = real_wait
+            raise KeyboardInterrupt()
+        lock._c.wait = wait
+        try:
+            lock.acquire()                           # ticket 1: gives up while waiting
+        except KeyboardInterrupt:
+            hit.append("interrupted")
+    t = threading.Thread(target=impatient); t.start(); t.join()
+    assert hit == ["interrupted"]
+    got = []
+    t2 = threading.Thread(target=lambda: (lock.acquire(), got.append(1), lock.release()))
+    t2.start()                                       # ticket 2 waits behind the abandoned ticket 1
+    lock.release()
+    t2.join(5)
+    assert got == [1] and not t2.is_alive()
+    with lock:                                       # and the lock is still usable
+        assert lock.waiting() == 0
+
+
+def test_interpreter_tuning_is_reference_counted():
+    """two engines at once restored each other's gc / switch-interval settings in the wrong order"""
+    import gc
+    import sys
+    from pyannote_video_amd.engine import _interpreter_tuning as tune
+    before = (gc.isenabled(), sys.getswitchinterval())
+    with tune:
+        assert not gc.isenabled() and sys.getswitchinterval() == pytest.approx(1e-4)
+        with tune:
+            assert not gc.isenabled()
+        assert not gc.isenabled() and sys.getswitchinterval() == pytest.approx(1e-4)     # the inner exit restored nothing
+    assert (gc.isenabled(), sys.getswitchinterval()) == (before[0], pytest.approx(before[1]))

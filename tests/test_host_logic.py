@@ -375,6 +375,15 @@ def test_text_rows_formatted_by_the_library_equal_python_formatting():
     x = np.concatenate([(rng.integers(-10**7, 10**7, 20000) + 0.5) / 1e5, rng.normal(0, 1, 20000), rng.normal(0, 1e3, 10000), [1e12, -3e15]])
     assert _lib.format_rows(np.zeros(1), np.zeros(1, np.int64), x.reshape(1, -1)) == ("0.000 0" + "".join(" %.5f" % v for v in x.tolist()) + "\n").encode()
     assert formats.embedding_rows([], [], np.zeros((0, 128))) == b""
+    # values that would not fit a row's fixed slot (27+ digits before the point) are refused before anything is written (they
+    # used to run past the row slot and, on the last row, past the buffer); NaN / inf print like Python's format
+    for big in (1e25, -3e38, 1e300):
+        with pytest.raises(Exception, match="does not fit"):
+            _lib.format_rows(np.zeros(2), np.zeros(2, np.int64), np.array([[0.5, 1.0], [big, 2.0]]))
+    with pytest.raises(Exception, match="does not fit"):
+        _lib.format_rows(np.array([1e30]), np.zeros(1, np.int64), np.zeros((1, 2)))
+    assert _lib.format_rows(np.zeros(1), np.zeros(1, np.int64), np.array([[np.nan, np.inf, -np.inf, 9.9e24]])) == \
+        ("0.000 0" + "".join(" %.5f" % v for v in [float("nan"), float("inf"), float("-inf"), 9.9e24]) + "\n").encode()
 
 
 @pytest.mark.parametrize("seed", range(6))
