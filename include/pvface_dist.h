@@ -3,8 +3,8 @@
  *
  * The reference has no distributed code at all; BASELINE.json's north_star asks for videos / frame ranges
  * partitioned over the 8 GPUs of a node "with an RCCL all-gather over xGMI of per-shard 128-D track embeddings before a single global
- * clustering".  That all-gather is this library: one process per GPU, ranks exchange their (time, track id, 128 values) rows -- and, for
- * the split distance matrix, their rows of the T x T matrix -- with ncclAllGather on a stream of their own.  It is a separate shared object
+ * clustering".  That all-gather is this library: one process per GPU, ranks exchange their (128 float32 values, time, track id) rows --
+ * and, for the split distance matrix, their rows of the T x T matrix -- over RCCL on a stream of their own, HBM to HBM.  It is a separate shared object
  * so that single-GPU users of libpvface.so do not need RCCL.  The 128-byte communicator id travels out of band (torch.distributed, MPI, a file).
  *
  * Conventions as in pvface.h: 0 on success, < 0 on error with pvfd_last_error(); caller owns host buffers.
@@ -25,13 +25,14 @@ int32_t pvfd_unique_id(uint8_t id[PVFD_ID_BYTES]);
 /* every rank: join the communicator (ncclCommInitRank) on GPU `device`; collective call */
 int32_t pvfd_comm_create(int32_t device, int32_t rank, int32_t world, const uint8_t id[PVFD_ID_BYTES], pvfd_handle* comm);
 int32_t pvfd_comm_destroy(pvfd_handle comm);
-/* All-gather of a different number of float64 rows per rank (collective): rank r contributes n_rows x row_doubles values; `counts`
- * receives every rank's row count, `out` (room for out_cap_rows rows) all rows in rank order, *total_rows their number.
- * Two ncclAllGather calls (counts, then the payload padded to the largest share) over xGMI; payloads here are <= 32 MB per rank. */
-int32_t pvfd_allgather_rows(pvfd_handle comm, const double* rows, int64_t n_rows, int32_t row_doubles, int64_t* counts,
-                            double* out, int64_t out_cap_rows, int64_t* total_rows);
-/* the largest row count over the ranks for a contribution of n_rows (collective; sizes the buffers of the call above) */
-int32_t pvfd_max_rows(pvfd_handle comm, int64_t n_rows, int64_t* counts, int64_t* total_rows);
+/* every rank's value of n (collective; one ncclAllGather of int64): the row counts that size the payload exchange */
+int32_t pvfd_allgather_counts(pvfd_handle comm, int64_t n, int64_t* counts /* [world] */);
+/* All-gather of a different number of BYTES per rank, device memory to device memory (collective): rank r contributes nbytes[r]
+ * bytes from d_send; d_recv (sum of nbytes) receives all contributions in rank order.  One ncclGroup of ncclBroadcast calls, exact
+ * sizes; the call returns when the data is in place.  The caller orders its own streams around the call (the producer of d_send
+ * must have finished; consumers of d_recv may start afterwards).  What travels in a run: 528 bytes per face (float32[128], float64
+ * time, int32 track id) -- 95 MB per rank at configs[2]'s 180 000 faces -- and each rank's rows of the T x T track-pair matrix. */
+int32_t pvfd_allgatherv_dev(pvfd_handle comm, const void* d_send, const int64_t* nbytes /* [world] */, void* d_recv);
 
 #ifdef __cplusplus
 }

@@ -10,12 +10,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* clustering.py:104-112: the pairs i < j only (itertools.combinations), matrix[i, j] = matrix[j, i] = similarity; the diagonal stays 0
+ * like squareform's.  (Up to round 3 this restatement summed both triangles independently -- D[j][i] could differ from D[i][j] in the
+ * last bits, which the reference's mirrored matrix never does.) */
 void pvo_pair_mean_dist(const double* X, int N, int dim, const int32_t* row_start, int T, double* D)
 {
     (void)N;
-    for (int i = 0; i < T; ++i)
-        for (int j = 0; j < T; ++j) {
-            if (i == j) { D[(size_t)i * T + j] = 0; continue; }
+    for (int i = 0; i < T; ++i) {
+        D[(size_t)i * T + i] = 0;
+        for (int j = i + 1; j < T; ++j) {
             double sum = 0;
             for (int a = row_start[i]; a < row_start[i + 1]; ++a)
                 for (int b = row_start[j]; b < row_start[j + 1]; ++b) {
@@ -25,7 +28,9 @@ void pvo_pair_mean_dist(const double* X, int N, int dim, const int32_t* row_star
                 }
             const double cnt = (double)(row_start[i + 1] - row_start[i]) * (double)(row_start[j + 1] - row_start[j]);
             D[(size_t)i * T + j] = sum / cnt;
+            D[(size_t)j * T + i] = sum / cnt;
         }
+    }
 }
 
 /* mean over the union block == size-weighted mean of the two block means (clustering.py:116-119 recomputes it from

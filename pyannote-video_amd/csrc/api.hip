@@ -616,11 +616,15 @@ extern "C" int32_t pvf_debug_extract_chip(pvf_handle h, pvf_handle frame, const 
 }
 
 // ---- S5 -------------------------------------------------------------------------------------------
+static PairInput table_f64(const double* X) { PairInput in; in.X = X; return in; }
+static PairOutput host_full(double* D) { PairOutput o; o.out = D; return o; }
+
 extern "C" int32_t pvf_pair_mean_dist(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T, double* D)
 {
     API_BEGIN
     ENTER(c, h);
-    pair_mean_dist_dev(c, X, N, dim, row_start, T, D, nullptr);
+    PVF_REQUIRE(X && row_start && D, "pvf_pair_mean_dist: bad arguments");
+    pair_mean_dist_dev(c, table_f64(X), N, dim, row_start, T, host_full(D), nullptr, 0, T, 0, true);
     API_END
 }
 
@@ -629,7 +633,8 @@ extern "C" int32_t pvf_pair_mean_dist_metric(pvf_handle h, const double* X, int3
 {
     API_BEGIN
     ENTER(c, h);
-    pair_mean_dist_dev(c, X, N, dim, row_start, T, D, nullptr, 0, -1, metric);
+    PVF_REQUIRE(X && row_start && D, "pvf_pair_mean_dist_metric: bad arguments");
+    pair_mean_dist_dev(c, table_f64(X), N, dim, row_start, T, host_full(D), nullptr, 0, T, metric, true);
     API_END
 }
 
@@ -638,7 +643,27 @@ extern "C" int32_t pvf_pair_mean_dist_rows(pvf_handle h, const double* X, int32_
 {
     API_BEGIN
     ENTER(c, h);
-    pair_mean_dist_dev(c, X, N, dim, row_start, T, D, nullptr, track0, track1);
+    PVF_REQUIRE(X && row_start && D, "pvf_pair_mean_dist_rows: bad arguments");
+    pair_mean_dist_dev(c, table_f64(X), N, dim, row_start, T, host_full(D), nullptr, track0, track1, 0, false);
+    API_END
+}
+
+static PairInput table_f32(const float* emb, int64_t stride, int32_t n_src, int32_t on_device, const int32_t* order, int32_t decimals)
+{
+    PairInput in;
+    in.emb = emb; in.emb_stride = stride; in.n_src = n_src; in.emb_on_device = on_device != 0; in.order = order; in.decimals = decimals;
+    return in;
+}
+
+extern "C" int32_t pvf_pair_upper_rows_f32(pvf_handle h, const float* emb, int64_t row_stride_bytes, int32_t n_src, int32_t emb_on_device,
+                                           const int32_t* order, int32_t N, int32_t decimals, const int32_t* row_start, int32_t T,
+                                           int32_t track0, int32_t track1, double* rows_out, int32_t out_on_device)
+{
+    API_BEGIN
+    ENTER(c, h);
+    PVF_REQUIRE(emb && row_start && (rows_out || track1 <= track0), "pvf_pair_upper_rows_f32: bad arguments");
+    PairOutput o; o.out = rows_out; o.on_device = out_on_device != 0; o.compact = true;
+    pair_mean_dist_dev(c, table_f32(emb, row_stride_bytes, n_src, emb_on_device, order, decimals), N, 128, row_start, T, o, nullptr, track0, track1, 0, false);
     API_END
 }
 
@@ -656,13 +681,43 @@ extern "C" int32_t pvf_cluster_dist(pvf_handle h, const double* D, const int32_t
     API_END
 }
 
+extern "C" int32_t pvf_cluster_upper(pvf_handle h, const double* U, int32_t on_device, const int32_t* row_start, int32_t T, double threshold,
+                                     int32_t* labels, double* merge_log, int32_t* n_merges)
+{
+    API_BEGIN
+    ENTER(c, h);
+    PVF_REQUIRE(T > 0 && U && row_start && labels, "pvf_cluster_upper: bad arguments");
+    c->s_clu1.ensure((size_t)T * T * sizeof(double) + (size_t)T * 64 + 4096);
+    double* dD = c->s_clu1.as<double>();
+    HIP_CHECK(hipMemcpyAsync(dD, U, (size_t)T * T * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    mirror_upper_dev(c, dD, T);
+    const int n = hac_dev(c, dD, row_start, T, threshold, labels, merge_log);
+    if (n_merges) *n_merges = n;
+    API_END
+}
+
 extern "C" int32_t pvf_cluster_tracks(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
                                       double threshold, int32_t* labels, double* merge_log, int32_t* n_merges)
 {
     API_BEGIN
     ENTER(c, h);
+    PVF_REQUIRE(X && row_start && labels, "pvf_cluster_tracks: bad arguments");
     double* dD = nullptr;
-    pair_mean_dist_dev(c, X, N, dim, row_start, T, nullptr, &dD);
+    pair_mean_dist_dev(c, table_f64(X), N, dim, row_start, T, PairOutput(), &dD, 0, T, 0, true);
+    const int n = hac_dev(c, dD, row_start, T, threshold, labels, merge_log);
+    if (n_merges) *n_merges = n;
+    API_END
+}
+
+extern "C" int32_t pvf_cluster_tracks_f32(pvf_handle h, const float* emb, int64_t row_stride_bytes, int32_t n_src, int32_t emb_on_device,
+                                          const int32_t* order, int32_t N, int32_t decimals, const int32_t* row_start, int32_t T, int32_t metric,
+                                          double threshold, int32_t* labels, double* merge_log, int32_t* n_merges)
+{
+    API_BEGIN
+    ENTER(c, h);
+    PVF_REQUIRE(emb && row_start && labels, "pvf_cluster_tracks_f32: bad arguments");
+    double* dD = nullptr;
+    pair_mean_dist_dev(c, table_f32(emb, row_stride_bytes, n_src, emb_on_device, order, decimals), N, 128, row_start, T, PairOutput(), &dD, 0, T, metric, true);
     const int n = hac_dev(c, dD, row_start, T, threshold, labels, merge_log);
     if (n_merges) *n_merges = n;
     API_END

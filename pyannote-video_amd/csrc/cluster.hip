@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) track_pair_mean_k(const double* __restric
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = t0 + blockIdx.y;
     if (j >= T) return;
-    if (i == j) { D[(size_t)i * T + j] = 0.0; return; }
+    if (j <= i) { D[(size_t)i * T + j] = 0.0; return; }      // upper triangle only (mirror_upper_k fills the rest)
     double sum = 0;
     for (int a = row_start[i]; a < row_start[i + 1]; ++a) sum += S[(size_t)a * T + j];
     const double cnt = (double)(row_start[i + 1] - row_start[i]) * (double)(row_start[j + 1] - row_start[j]);
@@ -83,6 +83,11 @@ __global__ void __launch_bounds__(256) track_pair_mean_k(const double* __restric
 //   shape).  A column segment whose track goes on in the next block hands its column of T2 on to segment 0 of the next tile (a lane
 //   shuffle); complete ones are written: row segments that are a whole track -> D[i][j] = sum / (n_i n_j); row segments of a track
 //   that spans several blocks -> P[part][j], summed in part order by pair_chunks_k.
+// ONLY THE UPPER TRIANGLE IS COMPUTED (round 4), like the reference: clustering.py:104-112 walks itertools.combinations(range(n), 2) and
+// stores matrix[i, j] = matrix[j, i] = similarity.  Rows are sorted by track, so every (row, column) pair of a track pair i < j lies in
+// a tile whose column block is not before its row block: a wave visits the column blocks cb >= its row block only, entries with
+// track(row) >= track(column) are never written, and mirror_upper_k copies D[i][j] to D[j][i] afterwards (round 3 swept every column
+// block for every row block: twice the algorithm's FLOPs).  The additions that form an entry i < j are the same as before, in the same order.
 // D[i][i] = 0 like scipy's squareform diagonal.  Round 2 reduced the tile with LDS round trips and lane-serial running sums (16
 // dependent steps per tile on 16 lanes): 10-16 TFLOP/s; the matrix-core reduction removes every serial step from the tile.
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -133,7 +138,12 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ab = blockIdx.x * 4 + wave;             // row block of this wave
     const bool have = ab < a.n_blocks;
-    const int cb0 = a.range_b0[blockIdx.y], cb1 = a.range_b0[blockIdx.y + 1];
+    // upper triangle: this workgroup's four row blocks need the column blocks from its first row block on; a range that ends before it
+    // has nothing for them.  (Starting inside a range leaves the sums of a column track that began earlier incomplete: that track is
+    // the one the first row of the row block belongs to, i.e. not AFTER any row track of this workgroup -- never written.)
+    const int cb1 = a.range_b0[blockIdx.y + 1];
+    const int cb0 = max(a.range_b0[blockIdx.y], (int)blockIdx.x * 4);
+    if (cb0 >= cb1) return;
     const int ar0 = have ? ab * 16 : 0, anr = have ? min(16, a.N - ab * 16) : 0;
     // a wave whose rows all lie outside [t0, t1) has nothing to write (row tracks are contiguous in a block)
     bool wanted = false;
@@ -192,7 +202,7 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
     for (int cb = cb0; cb < cb1; ++cb) {
         const int buf = (cb - cb0) & 1;
         if (cb + 1 < cb1) stage(cb + 1, buf ^ 1);
-        if (wanted) {
+        if (wanted && cb >= ab) {
             const int br0 = cb * 16;
             f64x4 acc = (f64x4){0.0, 0.0, 0.0, 0.0};
             const double* bp = &Bs[buf][i16 * PT_PITCH + k4];
@@ -257,7 +267,7 @@ __device__ __forceinline__ void pair_tiles_body(const PtArgs& a)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = rt[q];
-                    if (i < 0) continue;
+                    if (i < 0 || i >= j) continue;             // track pairs i < j only
                     if (rpart[q] >= 0) a.P[(size_t)rpart[q] * a.T + j] = t2[q];
                     else a.D[(size_t)i * a.T + j] = t2[q];
                 }
@@ -288,10 +298,11 @@ __global__ void __launch_bounds__(256) pair_chunks_k(const double* __restrict__ 
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = big_track[blockIdx.y];
     if (j >= T) return;
+    if (j <= i) { D[(size_t)i * T + j] = 0.0; return; }      // (P holds nothing for j <= i)
     double s = 0.0;
     for (int c = 0; c < big_nc[blockIdx.y]; ++c) s += P[(size_t)(big_c0[blockIdx.y] + c) * T + j];
     const double cnt = (double)(row_start[i + 1] - row_start[i]) * (double)(row_start[j + 1] - row_start[j]);
-    D[(size_t)i * T + j] = (i == j) ? 0.0 : s / cnt;
+    D[(size_t)i * T + j] = s / cnt;
 }
 
 // rows of D that pair_tiles_k wrote as sums (tracks that lie inside one 16-row block): sum / (rows of i x rows of j), the diagonal zero
@@ -301,13 +312,83 @@ __global__ void __launch_bounds__(256) pair_norm_k(double* __restrict__ D, const
     const int i = t0 + blockIdx.y;
     if (j >= T || is_big[i]) return;
     const int ni = row_start[i + 1] - row_start[i], nj = row_start[j + 1] - row_start[j];
-    if (ni <= 0 || nj <= 0) return;
+    if (j <= i || ni <= 0 || nj <= 0) { D[(size_t)i * T + j] = 0.0; return; }
     const double v = D[(size_t)i * T + j];
-    D[(size_t)i * T + j] = (i == j) ? 0.0 : v / ((double)ni * (double)nj);
+    D[(size_t)i * T + j] = v / ((double)ni * (double)nj);
 }
 
-static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* row_start, int T, double* h_D, double** d_D_keep, int t0, int t1,
-                                int metric)
+// D[j][i] = D[i][j] for i < j (clustering.py:111-112): 32 x 32 tiles turned through LDS so that reads and writes are both row-wise
+__global__ void __launch_bounds__(256) mirror_upper_k(double* __restrict__ D, int T)
+{
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int i = bi * 32 + r, j = bj * 32 + tx;
+        tile[r][tx] = (i < T && j < T) ? D[(size_t)i * T + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int j = bj * 32 + r, i = bi * 32 + tx;          // writes D[j][i], i runs along the row
+        if (i < T && j < T && i < j) D[(size_t)j * T + i] = tile[tx][r];
+    }
+}
+
+void mirror_upper_dev(Ctx* c, double* dD, int T)
+{
+    const int nb = (T + 31) / 32;
+    hipLaunchKernelGGL(mirror_upper_k, dim3(nb, nb), dim3(256), 0, c->stream, dD, T);
+}
+
+// the table the clustering works on, made on the device: row k = np.round(float64(emb[order[k]]), decimals) (pipeline's X: the float64
+// value of the 5-decimal text the reference writes and reads back, pyannote-face.py:307-311 + clustering.py:70-75; numpy evaluates the
+// rounding as rint(x * 10^d) / 10^d -- three correctly rounded operations, the same three here and in pvf_round_rows)
+__global__ void __launch_bounds__(256) gather_round_rows_k(const uint8_t* __restrict__ emb, long long stride_bytes, const int32_t* __restrict__ order,
+                                                           int N, int dim, double scale, int do_round, double* __restrict__ X)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)N * dim) return;
+    const int k = (int)(i / dim), d = (int)(i % dim);
+    const int src = order ? order[k] : k;
+    double v = (double)reinterpret_cast<const float*>(emb + (size_t)src * stride_bytes)[d];
+    if (do_round) v = rint(v * scale) / scale;
+    X[i] = v;
+}
+
+// the input table on the device: dX[N][dim] float64, from the float64 host table or from float32 rows (host or device) gathered + rounded
+static void stage_table(Ctx* c, const PairInput& in, int N, int dim, double* dX, uint8_t* d_tmp, int32_t* d_order)
+{
+    if (in.X) { HIP_CHECK(hipMemcpyAsync(dX, in.X, (size_t)N * dim * 8, hipMemcpyHostToDevice, c->stream)); return; }
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(in.emb);
+    long long stride = in.emb_stride;
+    if (!in.emb_on_device) {
+        // host rows: one strided copy into scratch (4 bytes per value: half of what the float64 table would move)
+        HIP_CHECK(hipMemcpy2DAsync(d_tmp, (size_t)dim * 4, in.emb, (size_t)in.emb_stride, (size_t)dim * 4, (size_t)in.n_src, hipMemcpyHostToDevice, c->stream));
+        src = d_tmp; stride = (long long)dim * 4;
+    }
+    if (in.order) HIP_CHECK(hipMemcpyAsync(d_order, in.order, (size_t)N * 4, hipMemcpyHostToDevice, c->stream));
+    double scale = 1.0;
+    for (int d = 0; d < in.decimals; ++d) scale *= 10.0;
+    hipLaunchKernelGGL(gather_round_rows_k, dim3((unsigned)(((size_t)N * dim + 255) / 256)), dim3(256), 0, c->stream, src, stride,
+                       in.order ? d_order : nullptr, N, dim, scale, in.decimals >= 0 ? 1 : 0, dX);
+}
+
+static inline size_t stage_tmp_bytes(const PairInput& in, int dim) { return (in.X || in.emb_on_device) ? 0 : (size_t)in.n_src * dim * 4; }
+
+// rows [t0, t1) of D leave the device: into the full matrix `out` addresses (rows outside the range untouched) or, compact, into
+// (t1 - t0) x T doubles; host or device memory
+static void copy_rows_out(Ctx* c, const double* dD, int T, int t0, int t1, const PairOutput& o)
+{
+    if (!o.out || t1 <= t0) return;
+    double* dst = o.compact ? o.out : o.out + (size_t)t0 * T;
+    HIP_CHECK(hipMemcpyAsync(dst, dD + (size_t)t0 * T, (size_t)(t1 - t0) * T * sizeof(double), o.on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+}
+
+static void pair_mean_dist_mfma(Ctx* c, const PairInput& in, int N, const int32_t* row_start, int T, const PairOutput& out, double** d_D_keep, int t0, int t1,
+                                int metric, bool mirror)
 {
     constexpr int DIM = 128;
     // ---- blocking (host, O(N)): blocks of 16 consecutive rows; segments = runs of one track inside a block
@@ -337,10 +418,13 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
         for (int b = b_first; b <= b_last; ++b)
             seg_part[(size_t)b * 16 + (b == b_first ? row_segidx[row_start[t]] : 0)] = n_chunks++;
     }
-    // column ranges: about six rounds of workgroups over the chip (4 resident per CU), cut only at blocks that do not take a segment over
-    // from their predecessor (the sums of a track that spans blocks are carried from tile to tile inside a range)
+    // column ranges, cut only at blocks that do not take a segment over from their predecessor (the sums of a track that spans blocks
+    // are carried from tile to tile inside a range).  With the upper triangle about half of the (row group, range) workgroups have work
+    // (the ones on the diagonal part of a range); ~24 pieces per workgroup slot (3 resident per CU) keep the tail of the launch -- the
+    // last pieces running alone -- near 2 % of it; a piece is at least 16 column blocks (its row blocks are loaded once per piece)
     const int row_groups = (nb + 3) / 4;
-    int want_ranges = std::max(1, std::min(nb, (6 * 4 * c->n_cu + row_groups - 1) / row_groups));
+    int want_ranges = (2 * 24 * 3 * c->n_cu + row_groups - 1) / row_groups;
+    want_ranges = std::max(1, std::min(want_ranges, std::max(1, nb / 16)));
     want_ranges = std::max(want_ranges, (nb >> 16) + 1);            // a range is addressed with 32-bit byte offsets: at most 2^20 rows
     std::vector<int> range_b0{0};
     for (int k = 1; k < want_ranges; ++k) {
@@ -355,7 +439,8 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
     auto al = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t xb = al((size_t)N * DIM * 8), nbz = al((size_t)N * 8), ib = al((size_t)N * 4), bb = al((size_t)nb * 4), pb = al((size_t)std::max(n_chunks, 1) * T * 8);
     const size_t rsb = al((size_t)(T + 1) * 4), rgb = al((size_t)(n_ranges + 1) * 4), bigb = al((size_t)std::max<size_t>(big_track.size(), 1) * 4);
-    c->s_clu0.ensure(xb + nbz + 2 * ib + bb + 2 * al((size_t)nb * 16 * 4) + pb + 2 * rsb + rgb + 3 * bigb + 4096);
+    const size_t tmpb = al(stage_tmp_bytes(in, DIM)), ordb = al(in.order ? (size_t)N * 4 : 0);
+    c->s_clu0.ensure(xb + nbz + 2 * ib + bb + 2 * al((size_t)nb * 16 * 4) + pb + 2 * rsb + rgb + 3 * bigb + tmpb + ordb + 4096);
     c->s_clu1.ensure((size_t)T * T * sizeof(double) + (size_t)T * 64 + 4096);
     uint8_t* p = c->s_clu0.as<uint8_t>();
     auto take = [&](size_t bytes) { uint8_t* q = p; p += bytes; return q; };
@@ -367,9 +452,10 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
     int* dRow = (int*)take(rsb); int* dRange = (int*)take(rgb);
     int* dBigT = (int*)take(bigb); int* dBigC0 = (int*)take(bigb); int* dBigNc = (int*)take(bigb);
     int* dIsBig = (int*)take(rsb);
+    uint8_t* dTmp = take(tmpb); int32_t* dOrder = (int32_t*)take(ordb);
     double* dD = c->s_clu1.as<double>();
     auto up = [&](void* d, const void* h, size_t bytes) { if (bytes) HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream)); };
-    up(dX, X, (size_t)N * DIM * 8);
+    stage_table(c, in, N, DIM, dX, dTmp, dOrder);
     up(dRT, row_track.data(), (size_t)N * 4); up(dRS, row_segidx.data(), (size_t)N * 4);
     up(dBC, blk_cont.data(), (size_t)nb * 4);
     up(dST, seg_track.data(), (size_t)nb * 16 * 4); up(dSP, seg_part.data(), (size_t)nb * 16 * 4);
@@ -394,39 +480,51 @@ static void pair_mean_dist_mfma(Ctx* c, const double* X, int N, const int32_t* r
             const int k0 = sel.front(), nsel = (int)sel.size();     // (big_track is sorted: those inside [t0, t1) are consecutive entries)
             hipLaunchKernelGGL(pair_chunks_k, dim3((T + 255) / 256, nsel), dim3(256), 0, c->stream, dP, dBigT + k0, dBigC0 + k0, dBigNc + k0, dRow, T, dD);
         }
+        if (mirror) mirror_upper_dev(c, dD, T);
     }
     HIP_CHECK(hipGetLastError());
-    if (h_D && t1 > t0)
-        HIP_CHECK(hipMemcpyAsync(h_D + (size_t)t0 * T, dD + (size_t)t0 * T, (size_t)(t1 - t0) * T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    copy_rows_out(c, dD, T, t0, t1, out);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (d_D_keep) *d_D_keep = dD;
 }
 
-// D rows of the tracks [t0, t1) only (all columns): the unit of work when several GPUs split the pairwise distances of one
-// global clustering -- a track's rows all live in one contiguous block, so every entry of D is still produced by one sequential
-// chain, the same one the single-GPU call runs.  h_D / d_D_keep address the full T x T matrix (rows outside the range untouched).
-void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* row_start, int T, double* h_D, double** d_D_keep,
-                        int t0, int t1, int metric)
+// Upper-triangle entries D[i][j], i < j, of the tracks i in [t0, t1) (all columns j > i): the unit of work when several GPUs split the
+// pairwise distances of one global clustering -- a track's rows all live in one contiguous block, so every entry is produced by the
+// same chain of additions the single-GPU call runs.  mirror: also D[j][i] = D[i][j] (whole matrix only: t0 = 0, t1 = T), as the
+// reference stores it.  Entries j <= i of the computed rows are zero without mirror.
+void pair_mean_dist_dev(Ctx* c, const PairInput& in, int N, int dim, const int32_t* row_start, int T, const PairOutput& out, double** d_D_keep,
+                        int t0, int t1, int metric, bool mirror)
 {
     if (t1 < 0) t1 = T;
     PVF_REQUIRE(0 <= t0 && t0 <= t1 && t1 <= T, "pair_mean_dist: bad track range");
     PVF_REQUIRE(N > 0 && T > 0 && dim > 0 && dim <= 4096, "pair_mean_dist: bad sizes");
     PVF_REQUIRE(row_start[0] == 0 && row_start[T] == N, "pair_mean_dist: row_start must cover [0, N)");
     PVF_REQUIRE(metric == 0 || metric == 1, "pair_mean_dist: metric 0 (euclidean) or 1 (cosine)");
-    if (dim == 128) { pair_mean_dist_mfma(c, X, N, row_start, T, h_D, d_D_keep, t0, t1, metric); return; }
+    PVF_REQUIRE(!mirror || (t0 == 0 && t1 == T), "pair_mean_dist: only a whole matrix can be mirrored");
+    PVF_REQUIRE((in.X != nullptr) != (in.emb != nullptr), "pair_mean_dist: one input table");
+    if (in.emb) {
+        PVF_REQUIRE(in.emb_stride >= (int64_t)dim * 4 && in.emb_stride % 4 == 0 && in.n_src >= 1 && in.decimals <= 15, "pair_mean_dist: bad float32 rows");
+        if (in.order) for (int k = 0; k < N; ++k) PVF_REQUIRE(in.order[k] >= 0 && in.order[k] < in.n_src, "pair_mean_dist: row order out of range");
+        else PVF_REQUIRE(in.n_src >= N, "pair_mean_dist: fewer float32 rows than N");
+    }
+    if (dim == 128) { pair_mean_dist_mfma(c, in, N, row_start, T, out, d_D_keep, t0, t1, metric, mirror); return; }
     PVF_REQUIRE(metric == 0, "pair_mean_dist: cosine is implemented for 128-D rows");
-    const size_t xb = (size_t)N * dim * sizeof(double);
-    const size_t sb = (size_t)N * T * sizeof(double), db = (size_t)T * T * sizeof(double), rb = (size_t)(T + 1) * sizeof(int32_t);
-    c->s_clu0.ensure(2 * xb + sb + rb + 512);
+    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t xb = al((size_t)N * dim * sizeof(double));
+    const size_t sb = al((size_t)N * T * sizeof(double)), db = (size_t)T * T * sizeof(double), rb = al((size_t)(T + 1) * sizeof(int32_t));
+    const size_t tmpb = al(stage_tmp_bytes(in, dim)), ordb = al(in.order ? (size_t)N * 4 : 0);
+    c->s_clu0.ensure(2 * xb + sb + rb + tmpb + ordb + 512);
     c->s_clu1.ensure(db + (size_t)T * 64 + 4096);
     uint8_t* p = c->s_clu0.as<uint8_t>();
     double* dX = reinterpret_cast<double*>(p); p += xb;
     double* dXt = reinterpret_cast<double*>(p); p += xb;
     double* dS = reinterpret_cast<double*>(p); p += sb;
-    int32_t* dR = reinterpret_cast<int32_t*>(p);
+    int32_t* dR = reinterpret_cast<int32_t*>(p); p += rb;
+    uint8_t* dTmp = p; p += tmpb;
+    int32_t* dOrder = reinterpret_cast<int32_t*>(p);
     double* dD = c->s_clu1.as<double>();
-    HIP_CHECK(hipMemcpyAsync(dX, X, xb, hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipMemcpyAsync(dR, row_start, rb, hipMemcpyHostToDevice, c->stream));
+    stage_table(c, in, N, dim, dX, dTmp, dOrder);
+    HIP_CHECK(hipMemcpyAsync(dR, row_start, (size_t)(T + 1) * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     {
         ProfScope ps(c, "pdist");
         hipLaunchKernelGGL(transpose_k, dim3((unsigned)(((size_t)N * dim + 255) / 256)), dim3(256), 0, c->stream, dX, N, dim, dXt);
@@ -435,10 +533,10 @@ void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* 
             hipLaunchKernelGGL(row_track_sums_k, dim3(a1 - a0), dim3(256), (dim + PD_CHUNK) * sizeof(double), c->stream, dX, dXt, N, dim, dR, T, dS, a0);
         if (t1 > t0)
             hipLaunchKernelGGL(track_pair_mean_k, dim3((T + 255) / 256, t1 - t0), dim3(256), 0, c->stream, dS, dR, T, dD, t0);
+        if (mirror) mirror_upper_dev(c, dD, T);
     }
     HIP_CHECK(hipGetLastError());
-    if (h_D && t1 > t0)
-        HIP_CHECK(hipMemcpyAsync(h_D + (size_t)t0 * T, dD + (size_t)t0 * T, (size_t)(t1 - t0) * T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    copy_rows_out(c, dD, T, t0, t1, out);
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (d_D_keep) *d_D_keep = dD;
 }

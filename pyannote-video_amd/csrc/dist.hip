@@ -1,6 +1,6 @@
 // dist.hip -- libpvface_dist.so: the RCCL all-gather of the multi-GPU path behind a C ABI (include/pvface_dist.h).
-// One process per GPU; each communicator owns a HIP stream and grow-only device buffers.  xGMI is point to point, the payload is small
-// (a few MB per rank), so the exchange is latency bound: two collectives per gather (row counts, then one padded payload), never per-row sends.
+// One process per GPU; each communicator owns a HIP stream.  Payloads live in device memory on both sides (the caller's buffers: the
+// gathered rows feed the clustering kernels where they land); two collectives per gather: the counts, then the payload in exact sizes.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <cstdint>
@@ -106,43 +106,37 @@ extern "C" int32_t pvfd_comm_destroy(pvfd_handle h)
     API_END
 }
 
-extern "C" int32_t pvfd_max_rows(pvfd_handle h, int64_t n_rows, int64_t* counts, int64_t* total_rows)
+extern "C" int32_t pvfd_allgather_counts(pvfd_handle h, int64_t n, int64_t* counts)
 {
     API_BEGIN
     Comm* c = get(h);
     HIPC(hipSetDevice(c->device));
-    if (!counts || n_rows < 0) throw Err("pvfd_max_rows: bad arguments");
-    gather_counts(c, n_rows, counts);
-    int64_t tot = 0;
-    for (int r = 0; r < c->world; ++r) tot += counts[r];
-    if (total_rows) *total_rows = tot;
+    if (!counts) throw Err("pvfd_allgather_counts: bad arguments");
+    gather_counts(c, n, counts);
     API_END
 }
 
-extern "C" int32_t pvfd_allgather_rows(pvfd_handle h, const double* rows, int64_t n_rows, int32_t row_doubles, int64_t* counts, double* out,
-                                       int64_t out_cap_rows, int64_t* total_rows)
+// All-gather of a different number of bytes per rank, device memory to device memory: one group of ncclBroadcast calls, rank r the root of
+// the r-th one, each receiving straight into its place in d_recv -- exact sizes (a padded ncclAllGather would move world x the largest
+// share: with the triangle split of the distance matrix the last rank's share is 5x the first one's), no staging copy, no host bounce.
+// xGMI is point to point: every rank sends its share to world - 1 peers, so the step costs about (total bytes) / (per-link rate).
+extern "C" int32_t pvfd_allgatherv_dev(pvfd_handle h, const void* d_send, const int64_t* nbytes, void* d_recv)
 {
     API_BEGIN
     Comm* c = get(h);
     HIPC(hipSetDevice(c->device));
-    if (!counts || !out || n_rows < 0 || row_doubles <= 0 || (n_rows > 0 && !rows)) throw Err("pvfd_allgather_rows: bad arguments");
-    gather_counts(c, n_rows, counts);
-    int64_t tot = 0, cap = 1;
-    for (int r = 0; r < c->world; ++r) { tot += counts[r]; if (counts[r] > cap) cap = counts[r]; }
-    if (total_rows) *total_rows = tot;
-    if (tot > out_cap_rows) throw Err("pvfd_allgather_rows: output buffer too small for the gathered rows");
-    const size_t slot = (size_t)cap * row_doubles;          // doubles per rank in the padded payload
-    c->grow(&c->d_send, &c->send_cap, slot * sizeof(double));
-    c->grow(&c->d_recv, &c->recv_cap, slot * sizeof(double) * c->world);
-    HIPC(hipMemsetAsync(c->d_send, 0, slot * sizeof(double), c->stream));
-    if (n_rows) HIPC(hipMemcpyAsync(c->d_send, rows, (size_t)n_rows * row_doubles * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    NCCLC(ncclAllGather(c->d_send, c->d_recv, slot, ncclDouble, c->comm, c->stream));
-    size_t o = 0;
+    if (!nbytes || !d_recv) throw Err("pvfd_allgatherv_dev: bad arguments");
+    for (int r = 0; r < c->world; ++r) if (nbytes[r] < 0) throw Err("pvfd_allgatherv_dev: negative count");
+    if (nbytes[c->rank] > 0 && !d_send) throw Err("pvfd_allgatherv_dev: no send buffer");
+    NCCLC(ncclGroupStart());
+    size_t off = 0;
     for (int r = 0; r < c->world; ++r) {
-        const size_t n = (size_t)counts[r] * row_doubles;
-        if (n) HIPC(hipMemcpyAsync(out + o, (const double*)c->d_recv + (size_t)r * slot, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        o += n;
+        char* dst = (char*)d_recv + off;
+        if (nbytes[r] > 0)          // (every rank knows every count: empty shares are skipped by all of them alike)
+            NCCLC(ncclBroadcast(r == c->rank ? d_send : (const void*)dst, dst, (size_t)nbytes[r], ncclInt8, r, c->comm, c->stream));
+        off += (size_t)nbytes[r];
     }
+    NCCLC(ncclGroupEnd());
     HIPC(hipStreamSynchronize(c->stream));
     API_END
 }

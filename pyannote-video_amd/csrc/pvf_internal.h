@@ -351,6 +351,15 @@ void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<
 void overlap_matrix_host(const double* a, int na, const double* b, int nb, double ratio, double* out);
 void munkres_host(const double* cost, int n, int32_t* row_to_col);
 // clustering (cluster.hip)
-void pair_mean_dist_dev(Ctx* c, const double* X, int N, int dim, const int32_t* row_start, int T, double* h_D, double** d_D_keep,
-                        int t0 = 0, int t1 = -1, int metric = 0);
+// the table of a clustering: float64 host rows (the reference's, read from embedding.txt), or float32 rows in host or device memory of
+// which row k of the table is np.round(float64(emb[order[k]]), decimals) -- gathered and rounded on the device (decimals < 0: no rounding)
+struct PairInput {
+    const double* X = nullptr;
+    const float* emb = nullptr; int64_t emb_stride = 0; int n_src = 0; const int32_t* order = nullptr; int decimals = -1; bool emb_on_device = false;
+};
+// where the rows [t0, t1) of D go: nowhere (out == nullptr), into the full T x T matrix `out` addresses, or (compact) into (t1 - t0) x T values
+struct PairOutput { double* out = nullptr; bool on_device = false; bool compact = false; };
+void pair_mean_dist_dev(Ctx* c, const PairInput& in, int N, int dim, const int32_t* row_start, int T, const PairOutput& out, double** d_D_keep,
+                        int t0, int t1, int metric, bool mirror);
+void mirror_upper_dev(Ctx* c, double* dD, int T);
 int hac_dev(Ctx* c, double* d_D, const int32_t* row_start, int T, double threshold, int32_t* labels, double* merge_log);

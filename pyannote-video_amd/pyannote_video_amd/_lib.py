@@ -75,6 +75,9 @@ _SIGS = {
     "pvf_pair_mean_dist_rows": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P]),
     "pvf_cluster_dist": (C.c_int32, [H, P, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_cluster_tracks": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
+    "pvf_cluster_upper": (C.c_int32, [H, P, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
+    "pvf_cluster_tracks_f32": (C.c_int32, [H, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, C.c_double, P, P, P]),
+    "pvf_pair_upper_rows_f32": (C.c_int32, [H, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P, C.c_int32]),
     "pvf_format_rows": (C.c_int32, [P, P, P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int64, P]),
     "pvf_round_rows": (C.c_int32, [P, C.c_int64, C.c_int32, P]),
     "pvf_parse_rows": (C.c_int32, [C.c_char_p, C.c_int64, P, C.c_int64, P, P]),

@@ -96,10 +96,9 @@ class FaceClustering(object):
         else:
             # several GPUs, every one holding all rows: each computes the distance-matrix rows of its share of the tracks
             # (balanced by row count), the rows are exchanged, and every rank agglomerates the same complete matrix
-            T = len(track_ids)
             t0, t1 = self.shard.track_range(row_start)
-            D = self.shard.assemble(ctx.pair_mean_dist_rows(Xs, row_start, t0, t1), row_start)
-            labels, log = ctx.cluster_dist(D, row_start, cut)
+            U = self.shard.assemble(ctx.pair_mean_dist_rows(Xs, row_start, t0, t1)[t0:t1], row_start)
+            labels, log = ctx.cluster_upper(U, row_start, cut)
         self.history = [(int(track_ids[int(a)]), int(track_ids[int(b)]), float(d)) for a, b, d, _ in log]
         if self.force:
             # complete dendrogram in `history`; the partition returned is the one before the first merge above the threshold
@@ -110,6 +109,54 @@ class FaceClustering(object):
                     break
                 labels[labels == int(b)] = int(a)
         return [int(track_ids[int(l)]) for l in labels]
+
+    # ---- the in-memory path: float32 descriptors straight from the embedder, no float64 table on the host ---------------------------
+    @staticmethod
+    def plan_rows(time, track):
+        """Index work of `preprocess` + `cluster_arrays` for rows given as (time, track) columns: -> (track ids that take part, sorted;
+        order = the rows of those tracks in (track, time) order -- clustering.py:72 sort_values(by=['track', 'time']); row_start).
+        Tracks whose extent is an empty segment (one timestamp) are left out like the reference leaves them out (clustering.py:76-79)."""
+        time = np.asarray(time, np.float64)
+        track = np.asarray(track, np.int64)
+        order = np.lexsort((time, track))
+        tr, tm = track[order], time[order]
+        ids, first, count = np.unique(tr, return_index=True, return_counts=True)
+        # Segment(t_min, t_max) is empty when its duration is not above pyannote.core's precision (1e-6): _core.Segment.__bool__
+        keep = (tm[first + count - 1] - tm[first]) > 1e-6
+        if not keep.all():
+            order = order[np.repeat(keep, count)]
+            ids, count = ids[keep], count[keep]
+        row_start = np.concatenate([[0], np.cumsum(count)]).astype(np.int32)
+        return ids, order.astype(np.int32), row_start
+
+    def cluster_rows(self, time, track, emb, decimals=5, src_index=None):
+        """{track: label} for float32 descriptor rows `emb` (numpy [n, 128] or runtime.DeviceRows) with their (time, track) columns (of
+        row src_index[k] of `emb` when given): what
+        preprocess((time, track, round(emb, 5))) followed by __call__ returns, with the rounding, the (track, time) gather, the pair
+        means and the agglomeration on the device (pvf_cluster_tracks_f32; the split form over the ranks of a job when `shard` is set)."""
+        ctx = self.ctx or runtime.default_context()
+        ids, order, row_start = self.plan_rows(time, track)
+        if len(ids) == 0:
+            self.history = []
+            return {}
+        if src_index is not None:          # row k of (time, track) is emb[src_index[k]] (rows that were reordered without being moved)
+            order = np.asarray(src_index)[order].astype(np.int32)
+        cut = float("inf") if self.force else self.threshold
+        if self.shard is None or self.metric == "cosine":
+            labels, log = ctx.cluster_tracks_f32(emb, order, row_start, cut, decimals=decimals, metric=1 if self.metric == "cosine" else 0)
+        else:
+            labels, log = self.shard.cluster(ctx, emb, order, row_start, cut, decimals)
+        return self._labels_of(ids, labels, log)
+
+    def _labels_of(self, ids, labels, log):
+        self.history = [(int(ids[int(a)]), int(ids[int(b)]), float(d)) for a, b, d, _ in log]
+        if self.force:
+            labels = np.arange(len(ids))
+            for a, b, d, _ in log:
+                if not (d <= self.threshold):
+                    break
+                labels[labels == int(b)] = int(a)
+        return {int(t): int(ids[int(l)]) for t, l in zip(ids.tolist(), labels)}
 
     def __call__(self, starting_point, features=None):
         tracks = sorted(set(label for _, _, label in starting_point.itertracks(yield_label=True)))

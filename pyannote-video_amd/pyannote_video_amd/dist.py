@@ -1,9 +1,19 @@
 """Multi-GPU: one process per GPU; a long video is cut into contiguous frame ranges at shot boundaries, every rank runs
 detect -> track -> extract on its range with no data-path collective, then ONE exchange step: an all-gather of the
-per-rank (time, track id, 128-D embedding) rows over RCCL/xGMI, followed by a single global clustering.
+per-rank (128-D float32 embedding, time, track id) rows over RCCL/xGMI, followed by a single global clustering.
 
 Track ids: the reference numbers tracks in yield order over the whole video (pyannote-face.py:261) and tracks never span
-shots (tracking.py:359-362,410-417), so global id = local id + exclusive prefix sum of the per-rank track counts."""
+shots (tracking.py:359-362,410-417), so global id = local id + exclusive prefix sum of the per-rank track counts.
+
+What travels (round 4): 528 bytes per face -- the 128 float32 values the embedder produced, the float64 time, the int32 track id --
+instead of 130 float64 columns; the gathered rows STAY IN HBM: the clustering's float64 table (np.round(x, 5) of every row, in (track,
+time) order) is made from them on the device (pvf_pair_upper_rows_f32), every rank computes the upper-triangle rows of the track-pair
+matrix for a share of the tracks of equal triangle AREA, those rows are all-gathered device to device, mirrored and agglomerated
+(pvf_cluster_upper).  Only the (time, track id) columns come back to the host, where the row order is decided.
+
+ONE collective path: `libpvface_dist.so` (include/pvface_dist.h: RCCL behind a C ABI) whenever the job runs on GPUs over nccl; a
+communicator that cannot be set up is an ERROR.  The torch.distributed collectives are used only when PVF_DIST_COLLECTIVE=torch asks
+for them (CPU tests over gloo; `bench.py --oversubscribe`, where several ranks share one device and cannot form an RCCL communicator)."""
 import ctypes as C
 import os
 import numpy as np
@@ -15,11 +25,13 @@ _DIST_SIGS = {
     "pvfd_unique_id": (C.c_int32, [C.c_void_p]),
     "pvfd_comm_create": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pvfd_comm_destroy": (C.c_int32, [C.c_uint64]),
-    "pvfd_allgather_rows": (C.c_int32, [C.c_uint64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    "pvfd_max_rows": (C.c_int32, [C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pvfd_allgather_counts": (C.c_int32, [C.c_uint64, C.c_int64, C.c_void_p]),
+    "pvfd_allgatherv_dev": (C.c_int32, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 DIST_EXPORTS = sorted(_DIST_SIGS)
 _dist_lib = None
+
+ROW_BYTES = 528           # one face on the wire: float32[128] | float64 time | int32 local track id | int32 zero
 
 
 def dist_lib():
@@ -35,11 +47,12 @@ def dist_lib():
 
 
 class RcclRows(object):
-    """one communicator of libpvface_dist.so per process: all-gather of float64 rows with a different count per rank"""
+    """one communicator of libpvface_dist.so per process: all-gather of byte rows in device memory, a different count per rank"""
+    name = "libpvface_dist"
 
     def __init__(self, device, rank, world, unique_id):
         self.l = dist_lib()
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.device = rank, world, int(device)
         h = C.c_uint64(0)
         idb = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self._check(self.l.pvfd_comm_create(int(device), int(rank), int(world), idb, C.byref(h)))
@@ -57,17 +70,24 @@ class RcclRows(object):
             raise RuntimeError("libpvface_dist: " + l.pvfd_last_error().decode("utf-8", "replace"))
         return bytes(buf)
 
-    def allgather_rows(self, rows):
-        """rows float64 [n, k] (n may differ per rank, k must not) -> (all rows in rank order [N, k], counts per rank)"""
-        rows = np.ascontiguousarray(rows, np.float64)
-        n, k = rows.shape
-        counts = np.zeros(self.world, np.int64)
-        total = C.c_int64(0)
-        self._check(self.l.pvfd_max_rows(self.h, n, counts.ctypes.data_as(C.c_void_p), C.byref(total)))
-        out = np.zeros((max(total.value, 1), k), np.float64)
-        self._check(self.l.pvfd_allgather_rows(self.h, rows.ctypes.data_as(C.c_void_p), n, k, counts.ctypes.data_as(C.c_void_p),
-                                               out.ctypes.data_as(C.c_void_p), len(out), C.byref(total)))
-        return out[:total.value], [int(c) for c in counts]
+    def counts(self, n):
+        out = np.zeros(self.world, np.int64)
+        self._check(self.l.pvfd_allgather_counts(self.h, int(n), out.ctypes.data_as(C.c_void_p)))
+        return [int(c) for c in out]
+
+    def allgather(self, t):
+        """t: torch uint8 [n, k] on this communicator's device (n may differ per rank, k must not) -> (all rows in rank order, a uint8
+        [N, k] tensor on the device; the row count of every rank).  Device to device: nothing passes through host memory."""
+        import torch
+        assert t.is_cuda and t.dtype == torch.uint8 and t.dim() == 2
+        t = t.contiguous()
+        n, k = int(t.shape[0]), int(t.shape[1])
+        counts = self.counts(n)
+        out = torch.empty((max(sum(counts), 1), k), dtype=torch.uint8, device=t.device)
+        nbytes = np.asarray([c * k for c in counts], np.int64)
+        torch.cuda.synchronize(t.device)                  # whoever produced t (another library's stream, torch's) is done
+        self._check(self.l.pvfd_allgatherv_dev(self.h, C.c_void_p(t.data_ptr() if n else 0), nbytes.ctypes.data_as(C.c_void_p), C.c_void_p(out.data_ptr())))
+        return out[:sum(counts)], counts
 
     def close(self):
         if getattr(self, "h", None):
@@ -75,58 +95,96 @@ class RcclRows(object):
             self.h = None
 
 
-_rccl = {"tried": False, "comm": None}
+class TorchRows(object):
+    """the same exchange over torch.distributed (PVF_DIST_COLLECTIVE=torch only): gloo on CPU tensors (tensors on a device travel through
+    host memory), nccl on device tensors"""
+    name = "torch"
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.on_host = dist.get_backend() != "nccl"
+
+    def counts(self, n):
+        import torch
+        import torch.distributed as dist
+        dev = "cpu" if self.on_host else "cuda"
+        c = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+        allc = [torch.zeros_like(c) for _ in range(self.world)]
+        dist.all_gather(allc, c)
+        return [int(x[0]) for x in allc]
+
+    def allgather(self, t):
+        import torch
+        import torch.distributed as dist
+        home = t.device
+        n, k = int(t.shape[0]), int(t.shape[1])
+        counts = self.counts(n)
+        cap = max(max(counts), 1)
+        work = "cpu" if self.on_host else home
+        pay = torch.zeros((cap, k), dtype=torch.uint8, device=work)
+        if n:
+            pay[:n] = t.to(work)
+        parts = [torch.zeros_like(pay) for _ in range(self.world)]
+        dist.all_gather(parts, pay)
+        out = torch.cat([parts[r][:counts[r]] for r in range(self.world)]) if sum(counts) else torch.zeros((0, k), dtype=torch.uint8, device=work)
+        return out.to(home), counts
+
+    def close(self):
+        pass
 
 
-def rccl_rows():
-    """The process's RCCL communicator of libpvface_dist.so, or None when the job does not run on GPUs over nccl (CPU tests over gloo),
-    when PVF_DIST_COLLECTIVE=torch asks for the torch.distributed collectives, or when any rank failed to set it up (all ranks then
-    agree to use torch.distributed instead -- decided with one all-reduce, so no rank is left waiting in a collective)."""
-    import torch
+_exchange = {"tried": False, "comm": None}
+
+
+def exchange():
+    """The process's exchange step, or None for a single process.  Over nccl: the RCCL communicator of libpvface_dist.so -- if it
+    cannot be set up on every rank the job FAILS (no silent change of collective).  PVF_DIST_COLLECTIVE=torch selects the
+    torch.distributed collectives explicitly; a job on another backend than nccl (gloo) must say so."""
     import torch.distributed as dist
-    if _rccl["tried"]:
-        return _rccl["comm"]
-    _rccl["tried"] = True
+    if _exchange["tried"]:
+        return _exchange["comm"]
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return None
-    if dist.get_backend() != "nccl" or os.environ.get("PVF_DIST_COLLECTIVE", "rccl") == "torch":
-        return None
+    _exchange["tried"] = True
+    want = os.environ.get("PVF_DIST_COLLECTIVE", "rccl")
+    if want == "torch":
+        _exchange["comm"] = TorchRows()
+        return _exchange["comm"]
+    if dist.get_backend() != "nccl":
+        raise RuntimeError("pyannote_video_amd.dist: the job runs over the %r backend, where libpvface_dist.so's RCCL communicator cannot be used; "
+                           "set PVF_DIST_COLLECTIVE=torch to ask for the torch.distributed collectives explicitly" % dist.get_backend())
+    import torch
     rank, world = dist.get_rank(), dist.get_world_size()
-    comm, ok = None, 1
+    err = None
     try:
         box = [RcclRows.unique_id() if rank == 0 else None]
-    except Exception:
-        box, ok = [None], 0
+    except Exception as e:      # noqa: BLE001 -- reported below, on every rank
+        box, err = [None], e
     dist.broadcast_object_list(box, src=0)
+    comm = None
     try:
         if box[0] is None:
-            raise RuntimeError("no communicator id")
+            raise RuntimeError("rank 0 could not create a communicator id")
         comm = RcclRows(torch.cuda.current_device(), rank, world, box[0])
-    except Exception as e:                      # noqa: BLE001 -- any failure means: use the torch path, together
-        import sys
-        sys.stderr.write("[pvface] libpvface_dist unavailable on rank %d (%s); using torch.distributed collectives\n" % (rank, e))
-        ok, err = 0, e
-    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    except Exception as e:      # noqa: BLE001
+        err = err or e
+    flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)           # every rank learns whether all of them have the communicator
     if int(flag.item()) != 1:
         if comm is not None:
             comm.close()
-        comm = None
-        if os.environ.get("PVF_DIST_STRICT", "0") == "1":
-            # a job that asked for the C-ABI collective (bench.py --gpus N > 1 does) must not measure something else in its place
-            raise RuntimeError("libpvface_dist.so: the RCCL communicator could not be set up on every rank and PVF_DIST_STRICT=1 forbids "
-                               "the torch.distributed fallback (set PVF_DIST_COLLECTIVE=torch to ask for it explicitly)")
-    _rccl["comm"] = comm
+        raise RuntimeError("libpvface_dist.so: the RCCL communicator could not be set up on every rank (%s); "
+                           "PVF_DIST_COLLECTIVE=torch selects the torch.distributed collectives explicitly" % (err if err is not None else "another rank failed"))
+    _exchange["comm"] = comm
     return comm
 
 
 def collective_name():
-    """which exchange step a multi-GPU run uses: 'libpvface_dist' (RCCL behind the C ABI), 'torch' (torch.distributed collectives) or
-    'none' (a single process)"""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return "none"
-    return "libpvface_dist" if rccl_rows() is not None else "torch"
+    """which exchange step a multi-GPU run uses: 'libpvface_dist' (RCCL behind the C ABI), 'torch' (asked for with
+    PVF_DIST_COLLECTIVE=torch) or 'none' (a single process)"""
+    ex = exchange()
+    return "none" if ex is None else ex.name
 
 
 def shard_shots(shot_ranges, world_size):
@@ -168,126 +226,120 @@ def shard_clips(n_clips, world_size, frames=None):
     return [sorted(c) for c in out]
 
 
-def _gather_padded(loc, dev):
-    """all-gather of float64 [n_r, k] blocks of different n_r: one count exchange + one padded payload exchange"""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size()
-    cnt = torch.tensor([len(loc)], dtype=torch.int64, device=dev)
-    allc = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(allc, cnt)
-    rows = [int(c[0]) for c in allc]
-    pay = torch.zeros((max(max(rows), 1), loc.shape[1]), dtype=torch.float64, device=dev)
-    if len(loc):
-        pay[:len(loc)] = torch.from_numpy(np.ascontiguousarray(loc, np.float64)).to(dev)
-    allp = [torch.zeros_like(pay) for _ in range(world)]
-    dist.all_gather(allp, pay)
-    return [allp[r][:rows[r]].cpu().numpy() for r in range(world)]
+class GatheredEmb(object):
+    """the float32 descriptor rows of all ranks after the exchange: `rows` (numpy float32 [n, 128] on a CPU job, runtime.DeviceRows in HBM
+    otherwise) and `index`: row k of the result is rows[index[k]] (the rows themselves are never moved: the clustering gathers on the
+    device)"""
+
+    def __init__(self, rows, index=None):
+        self.rows, self.index = rows, index
+
+    def __len__(self):
+        return len(self.index) if self.index is not None else (self.rows.n if hasattr(self.rows, "n") else len(self.rows))
+
+    def numpy(self):
+        """float32 [N, 128] in result order (tests, debugging: downloads the rows)"""
+        rows = self.rows
+        if hasattr(rows, "keep") and rows.keep is not None:
+            a = rows.keep[:, :512].contiguous().cpu().numpy().view(np.float32).reshape(-1, 128)
+        else:
+            a = np.asarray(rows, np.float32).reshape(-1, 128)
+        return a if self.index is None else a[self.index]
 
 
-def gather_rows(face_T, face_id, X, n_tracks, device=None, file_T=None, file_id=None):
-    """All-gather variable-length rows from every rank.  Returns (T, id_global, X) concatenated in rank order and the
-    per-rank track offsets.  Uses torch.distributed (backend nccl == RCCL on ROCm, gloo on CPU).
+def _wire_rows(face_T, face_id, emb):
+    n = len(face_T)
+    buf = np.zeros((n, ROW_BYTES), np.uint8)
+    if n:
+        buf[:, :512] = np.ascontiguousarray(emb, np.float32).reshape(n, 128).view(np.uint8)
+        buf[:, 512:520] = np.ascontiguousarray(face_T, np.float64).reshape(n, 1).view(np.uint8)
+        buf[:, 520:524] = np.ascontiguousarray(face_id, np.int32).reshape(n, 1).view(np.uint8)
+    return buf
 
-    file_T / file_id: this rank's share of the track table in file order (FacePipeline.run(..., reorder=False)["file_T"/"file_id"]).
-    When given, the shares are gathered too (a few bytes per row) and the rows are put into the order the reference's `extract`
-    writes them for the WHOLE video (formats.file_order: pandas' unstable sort of the complete table decides the order of the
-    faces of one frame), so a sharded run returns exactly the rows of a single-process run."""
-    import torch
-    import torch.distributed as dist
+
+def gather_rows(face_T, face_id, emb, n_tracks, device=None, file_T=None, file_id=None):
+    """All-gather variable-length rows from every rank.  emb: this rank's float32 descriptors [n, 128] (FacePipeline.run's
+    "embeddings").  Returns (T, global track id, GatheredEmb) in rank order -- or in the reference's file order, below -- and the
+    per-rank track offsets.
+
+    device: where the gathered rows live (a torch device; None: the current CUDA device when the job runs on GPUs, host memory on a CPU
+    job).  file_T / file_id: this rank's share of the track table in file order (FacePipeline.run(..., reorder=False)["file_T"/"file_id"]).
+    When given, the shares are gathered too (16 bytes per row) and the rows are put into the order the reference's `extract` writes
+    them for the WHOLE video (formats.file_order: pandas' unstable sort of the complete table decides the order of the faces of one
+    frame), so a sharded run returns exactly the rows of a single-process run."""
     from . import formats
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
-        T, ids, Xa = np.asarray(face_T, np.float64), np.asarray(face_id, np.int64), np.asarray(X, np.float64)
+    ex = exchange()
+    if ex is None:
+        T, ids = np.asarray(face_T, np.float64), np.asarray(face_id, np.int64)
+        X = GatheredEmb(np.ascontiguousarray(emb, np.float32).reshape(-1, 128))
         if file_T is not None and len(T):
             perm = formats.file_order(T, ids, file_T, file_id)
-            T, ids, Xa = T[perm], ids[perm], Xa[perm]
-        return T, ids, Xa, [0]
-    world = dist.get_world_size()
-    rc = rccl_rows()
-    if rc is not None:
-        # the C-ABI collective (libpvface_dist.so): one row of (T, local id, 128 values, this rank's track count) per face; a rank
-        # without faces still announces its track count with a marker row
-        nT = len(face_T)
-        loc = np.zeros((max(nT, 1), 131), np.float64)
-        loc[:, 130] = float(n_tracks)
-        if nT:
-            loc[:, 0] = np.asarray(face_T, np.float64); loc[:, 1] = np.asarray(face_id, np.float64); loc[:, 2:130] = np.asarray(X, np.float64)
-        else:
-            loc[0, 1] = -1.0
-        allrows, counts = rc.allgather_rows(loc)
-        tracks, o = [], 0
-        for cnt in counts:
-            tracks.append(int(allrows[o, 130])); o += cnt
-        offsets = [0]
-        for k in tracks[:-1]:
-            offsets.append(offsets[-1] + k)
-        Ts, ids, Xs, o = [], [], [], 0
-        for r, cnt in enumerate(counts):
-            a = allrows[o:o + cnt]; o += cnt
-            a = a[a[:, 1] >= 0]
-            Ts.append(a[:, 0]); ids.append(a[:, 1].astype(np.int64) + offsets[r]); Xs.append(a[:, 2:130])
-        T, gid, Xa = np.concatenate(Ts), np.concatenate(ids), np.ascontiguousarray(np.concatenate(Xs))
-        if file_T is not None:
-            ft = np.stack([np.asarray(file_T, np.float64), np.asarray(file_id, np.float64)], 1).reshape(-1, 2)
-            marker = len(ft) == 0
-            fall, fcounts = rc.allgather_rows(ft if not marker else np.array([[0.0, -1.0]]))
-            fT, fid, o = [], [], 0
-            for r, cnt in enumerate(fcounts):
-                a = fall[o:o + cnt]; o += cnt
-                a = a[a[:, 1] >= 0]
-                fT.append(a[:, 0]); fid.append(a[:, 1].astype(np.int64) + offsets[r])
-            if len(T):
-                perm = formats.file_order(T, gid, np.concatenate(fT), np.concatenate(fid))
-                T, gid, Xa = T[perm], gid[perm], np.ascontiguousarray(Xa[perm])
-        return T, gid, Xa, offsets
-    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    counts = torch.tensor([len(face_T), int(n_tracks)], dtype=torch.int64, device=dev)
-    allc = [torch.zeros_like(counts) for _ in range(world)]
-    dist.all_gather(allc, counts)
-    rows = [int(c[0]) for c in allc]
-    tracks = [int(c[1]) for c in allc]
+            T, ids, X.index = T[perm], ids[perm], np.asarray(perm, np.int64)
+        return T, ids, X, [0]
+    import torch
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    device = torch.device(device)
+    # ---- who has how many tracks (global id = local id + the tracks of the ranks before)
+    tracks = ex.counts(int(n_tracks))
     offsets = [0]
     for k in tracks[:-1]:
         offsets.append(offsets[-1] + k)
-    cap = max(max(rows), 1)
-    # one padded payload per rank: [cap, 130] float64 = (T, local id, 128 values); <= 32 MB/rank even at 3e4 rows
-    pay = torch.zeros((cap, 130), dtype=torch.float64, device=dev)
-    if len(face_T):
-        loc = np.concatenate([np.asarray(face_T, np.float64)[:, None], np.asarray(face_id, np.float64)[:, None],
-                              np.asarray(X, np.float64)], axis=1)
-        pay[:len(face_T)] = torch.from_numpy(loc).to(dev)
-    allp = [torch.zeros_like(pay) for _ in range(world)]
-    dist.all_gather(allp, pay)
-    Ts, ids, Xs = [], [], []
-    for r in range(world):
-        a = allp[r][:rows[r]].cpu().numpy()
-        Ts.append(a[:, 0]); ids.append(a[:, 1].astype(np.int64) + offsets[r]); Xs.append(a[:, 2:])
-    T, gid, Xa = np.concatenate(Ts), np.concatenate(ids), np.ascontiguousarray(np.concatenate(Xs))
+    # ---- the faces: one 528-byte row each, gathered into device memory, where the descriptors stay
+    mine = torch.from_numpy(_wire_rows(face_T, face_id, emb)).to(device)
+    G, counts = ex.allgather(mine)
+    N = int(G.shape[0])
+    meta = G[:, 512:ROW_BYTES].contiguous().cpu().numpy() if N else np.zeros((0, 16), np.uint8)
+    T = meta[:, :8].copy().view(np.float64).reshape(-1)
+    gid = meta[:, 8:12].copy().view(np.int32).reshape(-1).astype(np.int64)
+    o = 0
+    for r, c in enumerate(counts):
+        gid[o:o + c] += offsets[r]
+        o += c
+    if G.is_cuda:
+        from .runtime import DeviceRows
+        X = GatheredEmb(DeviceRows(G.data_ptr(), N, ROW_BYTES, keep=G))
+    else:
+        X = GatheredEmb(G[:, :512].contiguous().numpy().view(np.float32).reshape(-1, 128))
     if file_T is not None:
-        parts = _gather_padded(np.stack([np.asarray(file_T, np.float64), np.asarray(file_id, np.float64)], 1).reshape(-1, 2), dev)
-        fT = np.concatenate([p[:, 0] for p in parts])
-        fid = np.concatenate([p[:, 1].astype(np.int64) + offsets[r] for r, p in enumerate(parts)])
-        if len(T):
-            perm = formats.file_order(T, gid, fT, fid)
-            T, gid, Xa = T[perm], gid[perm], np.ascontiguousarray(Xa[perm])
-    return T, gid, Xa, offsets
+        m = len(file_T)
+        ft = np.zeros((m, 16), np.uint8)
+        if m:
+            ft[:, :8] = np.ascontiguousarray(file_T, np.float64).reshape(m, 1).view(np.uint8)
+            ft[:, 8:12] = np.ascontiguousarray(file_id, np.int32).reshape(m, 1).view(np.uint8)
+        F, fcounts = ex.allgather(torch.from_numpy(ft).to(device))
+        F = F.cpu().numpy()
+        fT = F[:, :8].copy().view(np.float64).reshape(-1)
+        fid = F[:, 8:12].copy().view(np.int32).reshape(-1).astype(np.int64)
+        o = 0
+        for r, c in enumerate(fcounts):
+            fid[o:o + c] += offsets[r]
+            o += c
+        if N:
+            perm = np.asarray(formats.file_order(T, gid, fT, fid), np.int64)
+            T, gid, X.index = T[perm], gid[perm], perm
+    return T, gid, X, offsets
 
 
 class DistanceShard(object):
-    """Splits the N x N pairwise distances of the global clustering over the ranks: every rank already holds all gathered rows,
-    computes the rows of the T x T track-pair matrix for a contiguous share of the tracks (balanced by row count, so by work),
-    and one all-gather of those rows (T x T doubles in total) gives every rank the complete matrix.  Without it each rank would
-    repeat the whole O(N^2) step, which grows with the square of the number of GPUs under weak scaling."""
+    """Splits the pairwise distances of the global clustering over the ranks: every rank already holds all gathered rows and computes
+    the upper-triangle entries D[i][j], j > i, of a contiguous share of the tracks i; one all-gather of those rows (T x T doubles in
+    total, device to device) gives every rank the complete upper triangle, which is mirrored (clustering.py:111-112) and agglomerated
+    identically everywhere.  Shares are cut by equal triangle AREA -- the pairs (row a, row b > a) a rank computes -- not by equal
+    rows: the first rows have all the others to their right, the last ones almost nothing.  Without the split each rank would repeat
+    the whole O(N^2) step, which grows with the square of the number of GPUs under weak scaling."""
 
     def __init__(self, rank, world, device=None):
         self.rank, self.world, self.device = rank, world, device
 
     def bounds(self, row_start):
+        """track cuts [world + 1]: rank r takes the tracks [cuts[r], cuts[r + 1]).  The pairs above row a number a N - a^2 / 2 of the
+        N^2 / 2 in total, so rank r's share ends at the row a = N (1 - sqrt(1 - r / world)), moved down to a track boundary."""
         n = int(row_start[-1])
         T = len(row_start) - 1
         cuts = [0]
         for r in range(1, self.world):
-            target = n * r / float(self.world)
+            target = n * (1.0 - np.sqrt(1.0 - r / float(self.world)))
             t = cuts[-1]
             while t < T and row_start[t + 1] <= target:
                 t += 1
@@ -299,36 +351,48 @@ class DistanceShard(object):
         cuts = self.bounds(row_start)
         return cuts[self.rank], cuts[self.rank + 1]
 
-    def assemble(self, D_mine, row_start):
+    def assemble(self, U_mine, row_start):
+        """U_mine: this rank's rows [(t1 - t0), T] (numpy) -> the assembled T x T upper triangle (numpy); the host form of cluster()"""
         import torch
-        import torch.distributed as dist
-        T = D_mine.shape[0]
+        T = len(row_start) - 1
+        ex = exchange()
+        dev = self.device if self.device is not None else ("cpu" if (isinstance(ex, TorchRows) and ex.on_host) else "cuda")
+        t = torch.from_numpy(np.ascontiguousarray(U_mine, np.float64).reshape(-1, T).view(np.uint8).reshape(-1, T * 8)).to(dev)
+        G, counts = ex.allgather(t)
         cuts = self.bounds(row_start)
-        rc = rccl_rows()
-        if rc is not None:
-            a, b = cuts[self.rank], cuts[self.rank + 1]
-            allrows, counts = rc.allgather_rows(np.ascontiguousarray(D_mine[a:b]).reshape(b - a, T))
-            assert counts == [cuts[r + 1] - cuts[r] for r in range(self.world)] and len(allrows) == T
-            return np.ascontiguousarray(allrows)
-        dev = self.device if self.device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-        t = torch.from_numpy(np.ascontiguousarray(D_mine)).to(dev)
-        parts = [torch.zeros_like(t) for _ in range(self.world)]
-        dist.all_gather(parts, t)
-        D = np.zeros((T, T), np.float64)
-        for r in range(self.world):
-            a, b = cuts[r], cuts[r + 1]
-            if b > a:
-                D[a:b] = parts[r][a:b].cpu().numpy()
-        return D
+        assert counts == [cuts[r + 1] - cuts[r] for r in range(self.world)] and int(G.shape[0]) == T
+        return G.cpu().numpy().view(np.float64).reshape(T, T)
+
+    def cluster(self, ctx, emb, order, row_start, cut, decimals=5):
+        """the split clustering with everything in HBM: this rank's rows of the upper triangle from the float32 rows (table made on the
+        device), all-gather device to device, mirror + agglomeration -> (labels, merge log)"""
+        import torch
+        from .runtime import DeviceRows
+        T = len(row_start) - 1
+        t0, t1 = self.track_range(row_start)
+        ex = exchange()
+        if not isinstance(emb, DeviceRows):
+            # rows in host memory (a CPU-resident gather): the host form
+            U = self.assemble(ctx.pair_upper_rows_f32(emb, order, row_start, t0, t1, decimals=decimals), row_start)
+            return ctx.cluster_upper(U, row_start, cut)
+        dev = emb.keep.device if emb.keep is not None else torch.device("cuda", torch.cuda.current_device())
+        mine = torch.empty((max(t1 - t0, 0), T), dtype=torch.float64, device=dev)
+        if t1 > t0:
+            ctx.pair_upper_rows_f32(emb, order, row_start, t0, t1, decimals=decimals, out=DeviceRows.of_tensor(mine))
+        G, counts = ex.allgather(mine.view(torch.uint8).reshape(-1, T * 8))
+        cuts = self.bounds(row_start)
+        assert counts == [cuts[r + 1] - cuts[r] for r in range(self.world)] and int(G.shape[0]) == T
+        return ctx.cluster_upper(DeviceRows(G.data_ptr(), T, T * 8, keep=G), row_start, cut)
 
 
 def global_cluster(clustering, face_T, face_id, X):
-    """single global clustering on the gathered rows (computed identically on every rank)"""
+    """single global clustering on the gathered rows (computed identically on every rank); X: what gather_rows returned (or float32
+    rows [N, 128])"""
     if len(face_T) == 0:
         return {}
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and clustering.shard is None:
         clustering.shard = DistanceShard(dist.get_rank(), dist.get_world_size())
-    sp, data = clustering.model.preprocess((face_T, face_id, X))
-    res = clustering(sp, features=data)
-    return {int(track): int(label) for _, track, label in res.itertracks(yield_label=True)}
+    if isinstance(X, GatheredEmb):
+        return clustering.cluster_rows(face_T, face_id, X.rows, src_index=X.index)
+    return clustering.cluster_rows(face_T, face_id, X)

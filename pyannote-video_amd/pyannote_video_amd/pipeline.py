@@ -78,6 +78,7 @@ class FacePipeline(object):
                                      track_max_gap=track_max_gap, ctx=ctx, detect_batch_size=detect_batch_size)
         self.clustering = FaceClustering(threshold=threshold, ctx=ctx)
         self.detect_every = detect_every
+        self.return_table = True       # results carry "X", the float64 table of the clustering (a host pass over all descriptors)
         self.detect_min_size = detect_min_size
         # trackers a shot may hold at once before its bulk starts are windowed (2.39 MB of filters each): engine.WindowedPlan
         self.speculate_limit, self.speculate_window = speculate_limit, speculate_window
@@ -116,14 +117,15 @@ class FacePipeline(object):
         t2 = _time.perf_counter()
         face_T = np.asarray(ex.face_T, np.float64)
         face_id = np.asarray(ex.face_id, np.int64)
-        # np.round(x, 5) of the float64 value (== parsing the '%.5f' text for these magnitudes; formats.quantise_embedding is the literal
-        # form), computed by the library: numpy's own np.round spends 10-28 ms on 8000 x 128 values at the very end of the run
-        Xq = _lib.round_rows(emb, 5) if len(emb) else np.zeros((0, 128))
         labels = {}
         if len(face_T) and cluster:
-            starting_point, data = self.clustering.model.preprocess((face_T, face_id, Xq))
-            result = self.clustering(starting_point, features=data)
-            labels = {int(track): int(label) for _, track, label in result.itertracks(yield_label=True)}
+            # FaceClustering()(*model.preprocess(embedding.txt)) of the reference (clustering.py:130-134) on the rows in memory: the
+            # float32 descriptors go up once (4 bytes per value); the table the reference reads back from the '%.5f' text --
+            # np.round(float64(x), 5), rows in (track, time) order -- is made on the device, followed by the pair means and the agglomeration
+            labels = self.clustering.cluster_rows(face_T, face_id, emb)
+        # "X": that table on the host (np.round(x, 5) of the float64 value == parsing the '%.5f' text for these magnitudes;
+        # formats.quantise_embedding is the literal form), for callers that want it; the clustering above does not need it
+        Xq = (_lib.round_rows(emb, 5) if len(emb) else np.zeros((0, 128))) if self.return_table else None
         if tm is not None:
             tm["cluster_s"] = _time.perf_counter() - t2
             t1 = job.t_tracked if job.t_tracked is not None else t2

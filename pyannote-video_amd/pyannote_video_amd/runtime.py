@@ -84,6 +84,20 @@ def _boxes_and_scores(out, scores, counts):
     return [([tuple(b) for b in rows[i][:cnt[i]]], scores[i, :cnt[i]].copy()) for i in range(len(cnt))]
 
 
+class DeviceRows(object):
+    """rows in device memory handed to the library by address: n rows, `stride` bytes apart; `keep` = whatever owns the memory
+    (a torch tensor, a buffer of another library), kept alive as long as this object"""
+
+    def __init__(self, ptr, n, stride, keep=None):
+        self.ptr, self.n, self.stride, self.keep = int(ptr), int(n), int(stride), keep
+
+    @classmethod
+    def of_tensor(cls, t):
+        """a 2-D contiguous torch tensor on the device"""
+        assert t.dim() == 2 and t.is_contiguous()
+        return cls(t.data_ptr(), t.shape[0], t.shape[1] * t.element_size(), keep=t)
+
+
 class Context(object):
     def __init__(self, device=0, detector=_models.DEFAULT_DETECTOR, landmarks=None, embedding=None, priority=0):
         self._h = None
@@ -494,8 +508,69 @@ class Context(object):
         check(self._l.pvf_cluster_tracks(self._h, ptr(X), X.shape[0], X.shape[1], ptr(rs), T, float(threshold), ptr(labels), ptr(log), C.byref(n)))
         return labels, log[:n.value]
 
+    @staticmethod
+    def _f32_rows(emb):
+        """(address, row stride in bytes, rows, on device?, keep-alive) of float32 descriptor rows: a numpy array or a DeviceRows"""
+        if isinstance(emb, DeviceRows):
+            return C.c_void_p(emb.ptr), emb.stride, emb.n, 1, emb
+        a = np.asarray(emb)
+        if a.dtype != np.float32 or a.ndim != 2 or a.shape[1] != 128 or a.strides[1] != 4 or a.strides[0] < 512:
+            a = np.ascontiguousarray(a, np.float32).reshape(-1, 128)
+        return ptr(a), int(a.strides[0]) if len(a) else 512, len(a), 0, a
+
+    def cluster_tracks_f32(self, emb, order, row_start, threshold, decimals=5, metric=0):
+        """the in-memory clustering (pvf_cluster_tracks_f32): float32 descriptors (numpy [n, 128] or DeviceRows), rows of the table =
+        round(emb[order], decimals) made on the device, upper-triangle pair means, mirror, agglomeration -> (labels, merge log)"""
+        p, stride, n_src, on_dev, keep = self._f32_rows(emb)
+        rs = np.ascontiguousarray(row_start, np.int32)
+        T = len(rs) - 1
+        order = None if order is None else np.ascontiguousarray(order, np.int32)
+        N = int(rs[-1])
+        labels = np.zeros(T, np.int32)
+        log = np.zeros((max(T - 1, 1), 4), np.float64)
+        n = C.c_int32(0)
+        check(self._l.pvf_cluster_tracks_f32(self._h, p, stride, n_src, on_dev, None if order is None else ptr(order), N, int(decimals), ptr(rs), T,
+                                             int(metric), float(threshold), ptr(labels), ptr(log), C.byref(n)))
+        return labels, log[:n.value]
+
+    def pair_upper_rows_f32(self, emb, order, row_start, track0, track1, decimals=5, out=None):
+        """the upper-triangle entries of rows [track0, track1) of the track-pair matrix, compact [(track1 - track0), T]: into `out`
+        (a DeviceRows of T * 8-byte rows: stays in HBM for the all-gather) or returned as a numpy array"""
+        p, stride, n_src, on_dev, keep = self._f32_rows(emb)
+        rs = np.ascontiguousarray(row_start, np.int32)
+        T = len(rs) - 1
+        order = None if order is None else np.ascontiguousarray(order, np.int32)
+        m = int(track1) - int(track0)
+        if out is None:
+            res = np.zeros((max(m, 0), T), np.float64)
+            op, odev = ptr(res), 0
+        else:
+            if out.n < m or out.stride != T * 8:
+                raise ValueError("pair_upper_rows_f32: `out` must hold (track1 - track0) rows of T float64 values")
+            res, op, odev = out, C.c_void_p(out.ptr), 1
+        check(self._l.pvf_pair_upper_rows_f32(self._h, p, stride, n_src, on_dev, None if order is None else ptr(order), int(rs[-1]), int(decimals),
+                                              ptr(rs), T, int(track0), int(track1), op, odev))
+        return res
+
+    def cluster_upper(self, U, row_start, threshold):
+        """mirror + agglomeration of an assembled upper triangle: U numpy [T, T] or a DeviceRows of T rows of T float64"""
+        rs = np.ascontiguousarray(row_start, np.int32)
+        T = len(rs) - 1
+        if isinstance(U, DeviceRows):
+            if U.n != T or U.stride != T * 8:
+                raise ValueError("cluster_upper: a T x T matrix is expected")
+            p, on_dev = C.c_void_p(U.ptr), 1
+        else:
+            U = np.ascontiguousarray(U, np.float64)
+            p, on_dev = ptr(U), 0
+        labels = np.zeros(T, np.int32)
+        log = np.zeros((max(T - 1, 1), 4), np.float64)
+        n = C.c_int32(0)
+        check(self._l.pvf_cluster_upper(self._h, p, on_dev, ptr(rs), T, float(threshold), ptr(labels), ptr(log), C.byref(n)))
+        return labels, log[:n.value]
+
     def pair_mean_dist_rows(self, X, row_start, track0, track1):
-        """rows [track0, track1) of the T x T track-pair mean-distance matrix (the other rows are zero)"""
+        """upper-triangle entries (j > i) of rows [track0, track1) of the T x T track-pair mean-distance matrix (everything else zero)"""
         X = np.ascontiguousarray(X, np.float64)
         rs = np.ascontiguousarray(row_start, np.int32)
         T = len(rs) - 1

@@ -15,21 +15,25 @@ import torch.distributed as dist
 from pyannote_video_amd import dist as pd
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-if os.environ.get("PVF_TEST_ROWS_OVER_GLOO"):
-    # drive the code path of the C-ABI collective (libpvface_dist.so: RcclRows.allgather_rows) with a gloo stand-in of the same interface
-    class GlooRows(object):
-        def allgather_rows(self, rows):
-            parts = pd._gather_padded(np.ascontiguousarray(rows, np.float64), "cpu")
-            return np.concatenate(parts), [len(p) for p in parts]
-    pd._rccl["tried"] = True; pd._rccl["comm"] = GlooRows()
+if os.environ.get("PVF_TEST_EXPECT_REFUSAL"):
+    # a job over gloo that did not ask for the torch.distributed collectives: the exchange must refuse, not pick one silently
+    try:
+        pd.exchange()
+        out = {"rank": rank, "refused": False}
+    except RuntimeError as e:
+        out = {"rank": rank, "refused": "PVF_DIST_COLLECTIVE=torch" in str(e)}
+    open(sys.argv[2] + ".%d" % rank, "w").write(json.dumps(out))
+    dist.barrier(); dist.destroy_process_group(); sys.exit(0)
 rng = np.random.default_rng(100 + rank)
 n_tracks = 3 + rank
 rows = 5 + 2 * rank
 T = rng.random(rows) + 10 * rank
 ids = rng.integers(0, n_tracks, rows)
-X = np.round(rng.normal(size=(rows, 128)), 5)
+X = rng.normal(size=(rows, 128)).astype(np.float32)
 gT, gid, gX, offsets = pd.gather_rows(T, ids, X, n_tracks)
-out = {"rank": rank, "n": int(len(gT)), "offsets": offsets, "ids": gid.tolist(), "sumX": float(gX.sum()), "T0": float(gT[0]), "Tlast": float(gT[-1])}
+gX = gX.numpy()
+out = {"rank": rank, "n": int(len(gT)), "offsets": offsets, "ids": gid.tolist(), "sumX": float(gX.astype(np.float64).sum()), "T0": float(gT[0]), "Tlast": float(gT[-1]),
+       "collective": pd.collective_name(), "mine_back": bool(np.array_equal(gX[sum(5 + 2 * r for r in range(rank)):][:rows], X))}
 open(sys.argv[2] + ".%d" % rank, "w").write(json.dumps(out))
 dist.barrier(); dist.destroy_process_group()
 '''
@@ -38,27 +42,42 @@ dist.barrier(); dist.destroy_process_group()
 import pytest
 
 
-@pytest.mark.parametrize("rows_lib_path", [False, True])
-def test_gather_rows_world2(tmp_path, rows_lib_path):
-    """rows_lib_path: the branch of gather_rows that goes through the C-ABI collective's interface (driven over gloo here)"""
+def _run2(script, args, port, **env):
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), str(script)] + args, env=dict(os.environ, MASTER_ADDR="127.0.0.1", **env), timeout=240)
+
+
+def test_gather_rows_world2(tmp_path):
+    """528-byte rows (float32[128], float64 time, int32 local id) gathered over gloo (PVF_DIST_COLLECTIVE=torch, the explicit opt-in)"""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "out")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    if rows_lib_path:
-        env["PVF_TEST_ROWS_OVER_GLOO"] = "1"
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                           "--master-port", "29613", str(script), ROOT, out], env=env, timeout=240)
+    _run2(script, [ROOT, out], 29613, PVF_DIST_COLLECTIVE="torch")
     import json
     r0, r1 = (json.loads(open(out + ".%d" % r).read()) for r in (0, 1))
     assert r0["n"] == r1["n"] == 5 + 7
+    assert r0["collective"] == r1["collective"] == "torch"
     assert r0["offsets"] == r1["offsets"] == [0, 3]
     assert r0["ids"] == r1["ids"]                       # every rank sees the same global rows, rank order
     assert max(r0["ids"][:5]) < 3 and min(r0["ids"][5:]) >= 3
     assert abs(r0["sumX"] - r1["sumX"]) < 1e-9
+    assert r0["mine_back"] and r1["mine_back"]          # the float32 values travel unchanged
     rng0, rng1 = np.random.default_rng(100), np.random.default_rng(101)
     t0 = rng0.random(5); t1 = rng1.random(7) + 10
     assert r0["T0"] == t0[0] and r0["Tlast"] == t1[-1]
+
+
+def test_exchange_refuses_to_pick_a_collective_silently(tmp_path):
+    """ONE collective path: over a backend where libpvface_dist.so's RCCL communicator cannot exist (gloo) the exchange raises unless
+    PVF_DIST_COLLECTIVE=torch asked for the torch.distributed collectives (no silent dual back-end)"""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = str(tmp_path / "out")
+    env = {k: v for k, v in os.environ.items() if k != "PVF_DIST_COLLECTIVE"}
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29615", str(script), ROOT, out], env=dict(env, MASTER_ADDR="127.0.0.1", PVF_TEST_EXPECT_REFUSAL="1"), timeout=240)
+    import json
+    assert all(json.loads(open(out + ".%d" % r).read())["refused"] is True for r in (0, 1))
 
 
 ORDER_WORKER = r'''
@@ -69,25 +88,17 @@ import torch.distributed as dist
 from pyannote_video_amd import dist as pd
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-if os.environ.get("PVF_TEST_ROWS_OVER_GLOO"):
-    # drive the code path of the C-ABI collective (libpvface_dist.so: RcclRows.allgather_rows) with a gloo stand-in of the same interface
-    class GlooRows(object):
-        def allgather_rows(self, rows):
-            parts = pd._gather_padded(np.ascontiguousarray(rows, np.float64), "cpu")
-            return np.concatenate(parts), [len(p) for p in parts]
-    pd._rccl["tried"] = True; pd._rccl["comm"] = GlooRows()
 table = json.loads(open(sys.argv[3]).read())[rank]                     # this rank's share of the track table, file order
 fT, fid = np.array(table["T"]), np.array(table["id"])
 order = np.random.default_rng(rank).permutation(len(fT))               # faces arrive in any order within the shard
-X = np.zeros((len(fT), 128)); X[:, 0] = fT[order]; X[:, 1] = fid[order]
+X = np.zeros((len(fT), 128), np.float32); X[:, 0] = (fT[order] * 1000).round(); X[:, 1] = fid[order]      # (float32-exact keys)
 gT, gid, gX, offsets = pd.gather_rows(fT[order], fid[order], X, table["n_tracks"], file_T=fT, file_id=fid)
-open(sys.argv[2] + ".%d" % rank, "w").write(json.dumps({"T": gT.tolist(), "ids": gid.tolist(), "x0": gX[:, 0].tolist()}))
+open(sys.argv[2] + ".%d" % rank, "w").write(json.dumps({"T": gT.tolist(), "ids": gid.tolist(), "x0": gX.numpy()[:, 0].tolist()}))
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
-@pytest.mark.parametrize("rows_lib_path", [False, True])
-def test_gather_rows_restores_reference_row_order_world2(tmp_path, rows_lib_path):
+def test_gather_rows_restores_reference_row_order_world2(tmp_path):
     """faces of one timestamp come out in the order pandas' (unstable) sort of the WHOLE track table gives (formats.file_order),
     however the table was split over the ranks"""
     import json
@@ -106,14 +117,12 @@ def test_gather_rows_restores_reference_row_order_world2(tmp_path, rows_lib_path
     script = tmp_path / "worker.py"
     script.write_text(ORDER_WORKER)
     out = str(tmp_path / "out")
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                           "--master-port", "29617", str(script), ROOT, out, str(tmp_path / "table.json")],
-                          env=dict(os.environ, MASTER_ADDR="127.0.0.1", **({"PVF_TEST_ROWS_OVER_GLOO": "1"} if rows_lib_path else {})), timeout=240)
+    _run2(script, [ROOT, out, str(tmp_path / "table.json")], 29617, PVF_DIST_COLLECTIVE="torch")
     r0, r1 = (json.loads(open(out + ".%d" % r).read()) for r in (0, 1))
     want = formats.pandas_sort_order(fT)
     assert r0 == r1
     assert r0["T"] == [fT[i] for i in want] and r0["ids"] == [fid[i] for i in want]
-    assert r0["x0"] == r0["T"]                                          # the payload rows moved with their keys
+    assert r0["x0"] == [round(t * 1000) for t in r0["T"]]               # the payload rows moved with their keys
 
 
 def test_shard_planner_contiguous_and_balanced():
@@ -130,6 +139,7 @@ def test_shard_planner_contiguous_and_balanced():
 
 
 def test_distance_shard_bounds_cover_and_balance():
+    """shares of the upper triangle: contiguous, complete, and equal in AREA (pairs (a, b > a) computed) to within one track's strip"""
     from pyannote_video_amd.dist import DistanceShard
     rng = np.random.default_rng(2)
     for trial in range(50):
@@ -140,8 +150,16 @@ def test_distance_shard_bounds_cover_and_balance():
         assert cuts[0] == 0 and cuts[-1] == T and len(cuts) == world + 1
         assert all(a <= b for a, b in zip(cuts, cuts[1:]))
         assert [DistanceShard(r, world).track_range(rs) for r in range(world)] == list(zip(cuts, cuts[1:]))
-        rows = [int(rs[b] - rs[a]) for a, b in zip(cuts, cuts[1:])]
-        assert max(rows) <= rs[-1] / world + sizes.max()          # no share exceeds the even split by more than one track
+        n = float(rs[-1])
+        above = lambda a: a * n - a * a / 2.0                    # pairs (row < a, any later row)
+        area = [above(float(rs[b])) - above(float(rs[a])) for a, b in zip(cuts, cuts[1:])]
+        assert abs(sum(area) - n * n / 2.0) < 1e-6
+        assert max(area) <= n * n / 2.0 / world + sizes.max() * n     # no share exceeds the even split by more than one track's strip
+    # many equal tracks: the first rank takes few tracks (long rows of the triangle), the last one many
+    rs = (np.arange(4001) * 10).astype(np.int32)
+    cuts = DistanceShard(0, 8).bounds(rs)
+    n_tracks = [b - a for a, b in zip(cuts, cuts[1:])]
+    assert n_tracks[0] < 300 and n_tracks[-1] > 1300 and all(a <= b for a, b in zip(n_tracks, n_tracks[1:]))
 
 
 def test_clip_farm_assignment_covers_every_clip_once_and_balances():

@@ -46,7 +46,7 @@ X = np.concatenate([p["X"] for p in parts]); E = np.concatenate([p["embeddings"]
 fT = np.concatenate([p["file_T"] for p in parts]); fid = np.concatenate([p["file_id"] + o for p, o in zip(parts, off)])
 perm = formats.file_order(T, ids, fT, fid)
 T, ids, X, E, L = T[perm], ids[perm], X[perm], E[perm], L[perm]
-labels = pd.global_cluster(pipe.clustering, T, ids, X)
+labels = pd.global_cluster(pipe.clustering, T, ids, E)
 out = {
     "tracks_whole": len(whole["tracks"]), "tracks_parts": [len(p["tracks"]) for p in parts], "faces": int(len(whole["face_T"])),
     "rows_equal": bool(np.array_equal(T, whole["face_T"]) and np.array_equal(ids, whole["face_id"])),

@@ -284,19 +284,32 @@ def test_pair_mean_dist_and_hac(ctx, oracle):
     assert len(set(labels.tolist())) == len(set(ident.tolist()))
     # the split form used by several GPUs: row ranges of D stitched together == the whole D, bit for bit; HAC from that D
     from pyannote_video_amd.dist import DistanceShard
+    assert np.array_equal(D, D.T)                         # the reference stores matrix[i, j] = matrix[j, i] (clustering.py:111-112)
     for world in (2, 3):
-        Dsum = np.zeros_like(D)
+        U = np.zeros_like(D)
         covered = []
         for r in range(world):
             t0, t1 = DistanceShard(r, world).track_range(rs)
             covered.append((t0, t1))
-            part = ctx.pair_mean_dist_rows(X, rs, t0, t1)
-            assert not part[:t0].any() and not part[t1:].any()
-            Dsum[t0:t1] = part[t0:t1]
+            part = ctx.pair_mean_dist_rows(X, rs, t0, t1)      # the entries j > i of the rows [t0, t1), zeros elsewhere
+            assert not part[:t0].any() and not part[t1:].any() and not np.tril(part).any()
+            U[t0:t1] = part[t0:t1]
         assert covered[0][0] == 0 and covered[-1][1] == T and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
-        assert np.array_equal(Dsum, D)
-        l2, log2 = ctx.cluster_dist(Dsum, rs, 0.6)
+        assert np.array_equal(U, np.triu(D, 1))
+        l2, log2 = ctx.cluster_upper(U, rs, 0.6)               # mirror + agglomeration
         assert np.array_equal(l2, labels) and np.array_equal(log2, log)
+        l3, log3 = ctx.cluster_dist(U + U.T, rs, 0.6)
+        assert np.array_equal(l3, labels) and np.array_equal(log3, log)
+    # the in-memory path: float32 descriptors, table = round(x, 5) in (track, time) order made on the device
+    E = X.astype(np.float32)
+    perm = rng.permutation(len(E))                               # rows arrive in any order; `order` puts them back
+    inv = np.argsort(perm).astype(np.int32)
+    Xr = np.round(E.astype(np.float64), 5)
+    lf, logf = ctx.cluster_tracks_f32(E[perm], inv, rs, 0.6)
+    lw, logw = ctx.cluster_tracks(Xr, rs, 0.6)
+    assert np.array_equal(lf, lw) and np.array_equal(logf, logw)  # bit for bit: the same table, the same kernels
+    Uf = ctx.pair_upper_rows_f32(E[perm], inv, rs, 3, 41)
+    assert Uf.shape == (38, T) and np.array_equal(Uf, np.triu(ctx.pair_mean_dist(Xr, rs), 1)[3:41])
 
 
 def _tracks(rng, sizes, K=40, noise=0.05):
@@ -323,11 +336,13 @@ def test_pair_mean_dist_matrix_core_kernel_all_block_shapes(ctx, oracle):
     assert np.allclose(D, Dr, rtol=1e-12, atol=1e-13), np.abs(D - Dr).max()
     assert not D.diagonal().any()
     # row ranges stitched == whole, bit for bit, wherever the cuts fall
+    assert np.array_equal(D, D.T)
     for cuts in ([0, 4, 9, 22], [0, 1, 20, 22], [0, 10, 22]):
         Ds = np.zeros_like(D)
         for t0, t1 in zip(cuts, cuts[1:]):
             Ds[t0:t1] = ctx.pair_mean_dist_rows(X, rs, t0, t1)[t0:t1]
-        assert np.array_equal(Ds, D)
+        assert np.array_equal(Ds, np.triu(D, 1))           # upper-triangle shares; mirrored == the whole matrix
+        assert np.array_equal(Ds + Ds.T, D)
     # cosine distance (north_star's metric): mean of 1 - cos over the block
     Dc = ctx.pair_mean_dist(X, rs, metric=1)
     Xn = X / np.linalg.norm(X, axis=1, keepdims=True)

@@ -32,10 +32,10 @@ s0, s1 = pd.shard_shots(ranges, world)[rank]
 i0, i1 = ranges[s0][0], ranges[s1 - 1][1]
 frames = [ctx.upload(v.frame(i)) for i in range(i0, i1)]
 res = pipe.run(frames, times[i0:i1], v.frame_rate, v.shots()[s0:s1], cluster=False, last_shard=(rank == world - 1), reorder=False)
-T, ids, X, offsets = pd.gather_rows(res["face_T"], res["face_id"], res["X"], len(res["tracks"]), file_T=res["file_T"], file_id=res["file_id"])
-labels = pd.global_cluster(pipe.clustering, T, ids, X)
-out = {"rank": rank, "n_tracks": len(res["tracks"]), "offsets": offsets, "T": T.tolist(), "ids": ids.tolist(),
-       "Xsum": float(np.abs(X).sum()), "labels": sorted(labels.items())}
+T, ids, X, offsets = pd.gather_rows(res["face_T"], res["face_id"], res["embeddings"], len(res["tracks"]), file_T=res["file_T"], file_id=res["file_id"])
+labels = pd.global_cluster(pipe.clustering, T, ids, X)          # split over the two ranks: upper-triangle shares, gathered, mirrored
+out = {"rank": rank, "n_tracks": len(res["tracks"]), "offsets": offsets, "T": T.tolist(), "ids": ids.tolist(), "in_hbm": hasattr(X.rows, "ptr"),
+       "Xsum": float(np.abs(X.numpy().astype(np.float64)).sum()), "labels": sorted(labels.items()), "history": pipe.clustering.history}
 open(sys.argv[2] + ".%d" % rank, "w").write(json.dumps(out))
 dist.barrier(); dist.destroy_process_group(); ctx.close()
 '''
@@ -48,7 +48,8 @@ def test_two_shards_equal_single_process(tmp_path, model_dir):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     out = str(tmp_path / "out")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # two ranks on ONE device cannot form an RCCL communicator: gloo rendezvous + the torch.distributed collectives, asked for explicitly
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PVF_DIST_COLLECTIVE="torch")
     subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                            "--master-port", "29633", str(script), ROOT, out, model_dir], env=env, timeout=600)
     r0, r1 = (json.loads(open(out + ".%d" % r).read()) for r in (0, 1))
@@ -64,25 +65,59 @@ def test_two_shards_equal_single_process(tmp_path, model_dir):
     assert r0["ids"] == r1["ids"] and r0["labels"] == r1["labels"]
     # only the shard that ends the video applies getFaceGenerator's dropped-last-group habit => identical rows, ids, labels
     assert r0["T"] == res["face_T"].tolist() and r0["ids"] == res["face_id"].tolist()
-    assert abs(r0["Xsum"] - float(np.abs(res["X"]).sum())) < 1e-9
+    assert r0["in_hbm"] and r1["in_hbm"]                 # the gathered descriptors stay in device memory
+    assert abs(r0["Xsum"] - float(np.abs(res["embeddings"].astype(np.float64)).sum())) < 1e-9
     assert dict(map(tuple, r0["labels"])) == res["labels"]
+    assert [tuple(h) for h in r0["history"]] == [tuple(h) for h in r1["history"]] == pipe.clustering.history     # same merges, same distances
     ctx.close()
 
 
-def test_rccl_allgather_rows_single_rank():
-    """libpvface_dist.so on the one GPU of this box: communicator of size 1 -- id, ncclCommInitRank, both collectives of a gather, teardown
-    (a box with one GPU cannot host two ranks of one RCCL communicator; the N > 1 exchange logic is covered over gloo on CPU)"""
+def test_rccl_allgatherv_single_rank():
+    """libpvface_dist.so on the one GPU of this box: communicator of size 1 -- id, ncclCommInitRank, the count exchange and the grouped
+    ncclBroadcast all-gather between DEVICE buffers, teardown (a box with one GPU cannot host two ranks of one RCCL communicator; the
+    N > 1 exchange logic is covered over gloo on CPU and with two processes on this GPU above)"""
+    import torch
     from pyannote_video_amd import dist
-    rng = np.random.default_rng(3)
     comm = dist.RcclRows(0, 0, 1, dist.RcclRows.unique_id())
-    for n in (0, 1, 37, 5000):
-        rows = rng.normal(size=(n, 131))
-        out, counts = comm.allgather_rows(rows)
-        assert counts == [n] and out.shape == (n, 131) and np.array_equal(out, rows)
-    D = rng.normal(size=(40, 40))
-    out, counts = comm.allgather_rows(D)
-    assert np.array_equal(out, D)
+    assert comm.counts(37) == [37]
+    g = torch.Generator().manual_seed(3)
+    for n, k in ((0, 528), (1, 528), (37, 528), (5000, 528), (40, 320)):
+        rows = torch.randint(0, 256, (n, k), dtype=torch.uint8, generator=g).cuda()
+        out, counts = comm.allgather(rows)
+        assert counts == [n] and tuple(out.shape) == (n, k) and out.is_cuda and torch.equal(out, rows)
+        assert n == 0 or out.data_ptr() != rows.data_ptr()
     comm.close()
+
+
+def test_bench_launches_ranks_itself_and_two_ranks_equal_one(tmp_path):
+    """`python bench.py --gpus 2` starts two ranks by itself (the flag used to be parsed and ignored).  On a 1-GPU box
+    --oversubscribe puts both on device 0 (gloo rendezvous, torch.distributed collectives): launcher, shot-range sharding, the 528-byte
+    row exchange, the split upper-triangle distances and the global clustering all run; the labels equal the 1-rank run on the same 128
+    frames.  Without --oversubscribe the same command is an error here, not a silent 1-GPU measurement."""
+    common = ["--frames", "128", "--steps", "1", "--warmup", "0", "--cpu-frames", "0", "--no-dropin", "--no-host-ingest", "--scaling", "strong",
+              "--detect-batch", "32"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PVF_DIST_COLLECTIVE", None)
+
+    def run(extra):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, env=env, timeout=900, capture_output=True, text=True)
+        return p
+    p2 = run(["--gpus", "2", "--oversubscribe"])
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    l2 = json.loads([l for l in p2.stdout.splitlines() if l.startswith("{")][-1])
+    p1 = run(["--gpus", "1"])
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    l1 = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][-1])
+    assert l2["n_gpus"] == 2 and l1["n_gpus"] == 1
+    assert l2["config"]["oversubscribed"] is True and l2["config"]["devices"] == 1 and l2["config"]["collective"] == "torch"
+    assert l1["config"]["collective"] == "none" and l2["scaling"] == "strong"
+    assert l2["results"]["tracks_clustered_globally"] == l1["results"]["tracks_clustered_globally"] > 0
+    assert l2["results"]["labels_sha256_16"] == l1["results"]["labels_sha256_16"]
+    assert l2["results"]["clusters"] == l1["results"]["clusters"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        p = run(["--gpus", "2"])
+        assert p.returncode != 0 and "GPU" in p.stderr
 
 
 def test_cluster_stress_reduced_config5(ctx, oracle):

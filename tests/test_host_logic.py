@@ -547,3 +547,51 @@ def test_read_embeddings_round_trip(tmp_path):
     (tmp_path / "empty.txt").write_bytes(b"")
     tt, ii, xx = formats.read_embeddings(str(tmp_path / "empty.txt"))
     assert len(tt) == 0 and xx.shape == (0, 128)
+
+
+def test_in_memory_clustering_plan_equals_preprocess_and_call():
+    """FaceClustering.cluster_rows (float32 rows in memory, table made on the device) hands the kernels exactly the rows, in exactly the
+    order, that preprocess() + __call__ hand them for the float64 table (clustering.py:59-83: (track, time) order, single-timestamp
+    tracks left out), with and without a source index; the labels are mapped back the same way"""
+    from pyannote_video_amd.clustering import FaceClustering
+    rng = np.random.default_rng(8)
+
+    class Rec(object):
+        def cluster_tracks(self, X, row_start, cut):
+            self.f64 = (np.array(X), np.array(row_start), cut)
+            T = len(row_start) - 1
+            return np.arange(T) // 2 * 2, np.array([[2 * k, 2 * k + 1, 0.25, 2.0] for k in range(T // 2)])
+
+        def cluster_tracks_f32(self, emb, order, row_start, cut, decimals=5, metric=0):
+            self.f32 = (np.round(np.asarray(emb)[order].astype(np.float64), decimals), np.array(row_start), cut, metric)
+            T = len(row_start) - 1
+            return np.arange(T) // 2 * 2, np.array([[2 * k, 2 * k + 1, 0.25, 2.0] for k in range(T // 2)])
+
+    for trial in range(20):
+        n_tracks = int(rng.integers(1, 12))
+        time, track = [], []
+        for t in range(n_tracks):
+            n = int(rng.integers(1, 6))
+            t0 = float(rng.integers(0, 100)) / 25.0
+            single = rng.random() < 0.25
+            for k in range(1 if single else n):
+                time.append(t0 + k / 25.0); track.append(3 * t + 1)        # (ids with gaps)
+        perm = rng.permutation(len(time))
+        time, track = np.array(time)[perm], np.array(track)[perm]
+        emb = rng.normal(0, 0.1, (len(time), 128)).astype(np.float32)
+        rec = Rec()
+        fc = FaceClustering(ctx=rec)
+        sp, feats = fc.model.preprocess((time, track, np.round(emb.astype(np.float64), 5)))
+        want = fc(sp, features=feats)
+        want_labels = {int(t): int(l) for _, t, l in want.itertracks(yield_label=True)}
+        hist = fc.history
+        got = fc.cluster_rows(time, track, emb)
+        if not want_labels:
+            assert got == {} and not hasattr(rec, "f32")
+            continue
+        assert got == want_labels and fc.history == hist
+        assert np.array_equal(rec.f32[0], rec.f64[0]) and np.array_equal(rec.f32[1], rec.f64[1]) and rec.f32[2] == rec.f64[2]
+        # rows that were reordered without being moved (a gathered table): row k of (time, track) is emb2[src[k]]
+        src = rng.permutation(len(time))
+        emb2 = np.zeros_like(emb); emb2[src] = emb
+        assert fc.cluster_rows(time, track, emb2, src_index=src) == want_labels and np.array_equal(rec.f32[0], rec.f64[0])

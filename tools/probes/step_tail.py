@@ -20,7 +20,7 @@ pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=128)
 def step(tm):
     res = pipe.run(frames, times, video.frame_rate, shots, timings=tm, cluster=False)
     t0 = time.perf_counter()
-    T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["X"], len(res["tracks"]), device=dev)
+    T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["embeddings"], len(res["tracks"]), device=dev)
     t1 = time.perf_counter()
     labels = pdist.global_cluster(pipe.clustering, T, ids, X)
     tm["gather_s"] = t1 - t0; tm["cluster_s2"] = time.perf_counter() - t1
