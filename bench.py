@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--no-host-ingest", action="store_true", help="skip the extra pass whose frames start in pinned host memory")
     ap.add_argument("--no-overlap", action="store_true", help="no GPU-feeding thread: every stage runs in the caller's thread, shot after shot")
     ap.add_argument("--small-models", action="store_true", help="debug only: reduced landmark model")
+    ap.add_argument("--parity-seed", type=int, default=None, help="seed of the extra 8-frame parity window placed at random in the clip (default: from the clock; printed in the line)")
+    ap.add_argument("--distinct-clips", type=int, default=6, help="c3: how many differently seeded 1000-frame clips (identities drawn from a pool of 250) the long video "
+                    "cycles through; 23 makes every loop of the default 22 500 frames its own clip (143 GB resident source)")
+    ap.add_argument("--cluster-check-frames", type=int, default=3000, help="c3: the tracks of the first that many frames are clustered again by the CPU oracle (0: skip)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST SWITCH: with --gpus N on a box with fewer than N devices, run the N ranks anyway, all on device 0 (gloo rendezvous, "
                          "torch.distributed collectives: two ranks of one RCCL communicator cannot share a device).  Exercises the launcher, the "
@@ -569,44 +573,56 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
     print(json.dumps(out))
 
 
-class LoopedVideo(object):
-    """A long video = a resident clip played in a loop, delivered the way a decoder that writes into HBM would deliver it: every frame
-    is copied into a fresh buffer of the library's (pvf_frame_upload from a device address) that the engine releases when it is done with
-    it.  Timestamps continue (frame i of the long video at i / frame_rate); the shot cuts repeat with the clip."""
+class LoopedClips(object):
+    """A long video = K differently seeded resident clips played one after the other, again and again (loop j plays clip j % K), delivered
+    the way a decoder that writes into HBM would deliver it: every frame is copied into a fresh buffer of the library's (pvf_frame_upload
+    from a device address) that the engine releases when it is done with it.  Timestamps continue; the shot cuts repeat with the clips."""
 
-    def __init__(self, ctx, frames_t, n_frames, frame_rate, first_index=0):
-        self.ctx, self.ft, self.n, self.frame_rate, self.first = ctx, frames_t, int(n_frames), float(frame_rate), int(first_index)
-        self.size = self.frame_size = (int(frames_t.shape[2]), int(frames_t.shape[1]))
+    def __init__(self, ctx, clips_t, n_frames, frame_rate, first_index=0):
+        self.ctx, self.clips, self.n, self.frame_rate, self.first = ctx, clips_t, int(n_frames), float(frame_rate), int(first_index)
+        self.size = self.frame_size = (int(clips_t[0].shape[2]), int(clips_t[0].shape[1]))
 
     def __len__(self):
         return self.n
 
+    def source_of(self, i):
+        """(clip, frame in the clip) that plays at frame i of the long video"""
+        m = int(self.clips[0].shape[0])
+        return (i // m) % len(self.clips), i % m
+
     def __iter__(self):
-        m, h, w = int(self.ft.shape[0]), int(self.ft.shape[1]), int(self.ft.shape[2])
-        base, stride = self.ft.data_ptr(), h * w * 3
+        h, w = int(self.clips[0].shape[1]), int(self.clips[0].shape[2])
+        stride = h * w * 3
+        bases = [c.data_ptr() for c in self.clips]
         for i in range(self.n):
-            yield (self.first + i) / self.frame_rate, self.ctx.upload_device(base + ((self.first + i) % m) * stride, h, w, transient=True)
+            k, j = self.source_of(self.first + i)
+            yield (self.first + i) / self.frame_rate, self.ctx.upload_device(bases[k] + j * stride, h, w, transient=True)
 
 
 def bench_stream(args, rank, local_rank, world, device, lp, ep):
     """BASELINE.json configs[2]: one long 1080p video cut into frame ranges at shot boundaries, one range per GPU, streamed through the
     bounded-memory engine (FacePipeline.run_stream): frames arrive one by one, shots are detected / tracked / extracted in flight and
-    their frames released, then ONE all-gather of the (time, track, 128-D) rows and one global clustering."""
+    their frames released, then ONE all-gather of the (128 float32, time, track) rows and one global clustering."""
     import numpy as np
     import torch
     from pyannote_video_amd import synth, pipeline, dist as pdist
     from pyannote_video_amd.runtime import Context
     clip_n = 1000
-    video = synth.SyntheticVideo(width=args.width, height=args.height, n_frames=clip_n, n_shots=args.shots, faces=args.faces, seed=20260925, frame_rate=args.fps)
+    n = args.frames
+    first = rank * n                                        # this rank's frame range of the world * n frame video
+    loops = range(first // clip_n, (first + n - 1) // clip_n + 1)
+    K = max(1, min(int(args.distinct_clips), len(loops)))
+    # the video plays K differently seeded clips (identities from a pool of 250) one after the other: loop j plays clip j % K.  Round 3
+    # looped ONE clip, so the 720 tracks of a 22 500-frame range were 22.5 copies of the same 32.
+    videos = [synth.SyntheticVideo(width=args.width, height=args.height, n_frames=clip_n, n_shots=args.shots, faces=args.faces, identities=250,
+                                   seed=20260925 + k, frame_rate=args.fps) for k in range(K)]
     t_gen = time.time()
-    frames_t = video.frames_torch(device)
+    clips_t = [v.frames_torch(device) for v in videos]
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     ctx = Context(device=local_rank)
     pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap)
     pipe.return_table = False       # (the float64 host copy of the clustering's table: nobody reads it here)
-    n = args.frames
-    first = rank * n                                        # this rank's frame range of the world * n frame video
     per_shot = clip_n // args.shots
     assert n % per_shot == 0, "--frames must be a multiple of the shot length (%d) so that the ranges are cut at shot boundaries" % per_shot
     shots = [((first + k * per_shot) / args.fps, (first + (k + 1) * per_shot) / args.fps) for k in range(n // per_shot)]
@@ -614,7 +630,7 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
     def step(frames=n):
         tm = {}
         t_step = time.perf_counter()
-        src = LoopedVideo(ctx, frames_t, frames, args.fps, first_index=first)
+        src = LoopedClips(ctx, clips_t, frames, args.fps, first_index=first)
         res = pipe.run_stream(src, shots[:frames // per_shot], timings=tm, cluster=False, last_shard=(rank == world - 1), reorder=(world == 1))
         T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["embeddings"], len(res["tracks"]), device=device,
                                                file_T=res["file_T"] if world > 1 else None, file_id=res["file_id"] if world > 1 else None)
@@ -654,40 +670,84 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
     flop_per_frame = sum(g[4] for g in geo) * 3100 * 5 * 2.0
     score_ms, launches = fam["score"]["ms"], max(fam["score"]["launches"], 1)
     achieved = (flop_per_frame * n * args.steps / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
-    parity, cpu = None, None
+    parity, cpu, cluster_check = None, None, None
     if world == 1 and args.cpu_frames > 0:
-        # parity gate through the STREAMING path: a window across the seam of the loop (last frames of the clip's last shot, first
-        # frames of its first shot: a cut), product (run_stream, frames delivered one by one) vs the CPU oracle flow
+        # parity gate through the STREAMING path: a window across the seam between two loops (last frames of one clip's last shot, first
+        # frames of the next clip's first shot: a cut), product (run_stream, frames delivered one by one) vs the CPU oracle flow
         m = min(8, args.cpu_frames)
         i0 = clip_n - m // 2
         idx = list(range(i0, i0 + m))
         times = [i / args.fps for i in idx]
         wshots = [(a, b) for a, b in shots if b > times[0] and a <= times[-1]]
-        r = pipe.run_stream(LoopedVideo(ctx, frames_t, m, args.fps, first_index=i0), wshots)
-        parity, dt, threads = oracle_window_parity([np.ascontiguousarray(frames_t[i % clip_n].cpu().numpy()) for i in idx], times, wshots, args.fps, video.frame_size, r, lp, ep,
-                                                   label="frames %d..%d of the long video (across the seam of the loop: a cut), streamed product vs CPU oracle flow" % (idx[0], idx[-1]))
+        win = LoopedClips(ctx, clips_t, m, args.fps, first_index=i0)
+        r = pipe.run_stream(win, wshots)
+        frames_np = [np.ascontiguousarray(clips_t[k][j].cpu().numpy()) for k, j in (win.source_of(i) for i in idx)]
+        parity, dt, threads = oracle_window_parity(frames_np, times, wshots, args.fps, videos[0].frame_size, r, lp, ep,
+                                                   label="frames %d..%d of the long video (across the seam between two clips: a cut), streamed product vs CPU oracle flow" % (idx[0], idx[-1]))
         cpu = {"value": round(m / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port", "sample": "the same %d-frame window, whole flow" % m}
+    if world == 1 and args.cluster_check_frames > 0 and len(res["face_T"]):
+        cluster_check = oracle_cluster_check(pipe, res, args.cluster_check_frames / args.fps)
     peak_frames = res.get("peak_frames_resident")
+    idents = set(tr["ident"] for v in videos for shot in v.tracks for tr in shot)       # identity k looks the same in every clip
     out = {"metric": "frames/sec end-to-end detect->embed->cluster, one long 1080p@25fps video in frame ranges (BASELINE.json configs[2])",
            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32 (detector, embedder) / f64 (tracker, clustering) / u8 frames",
-           "data": "synthetic: the 1000-frame configs[1] clip played in a loop (timestamps and track numbers continue; every loop adds its tracks to the global clustering)",
+           "data": "synthetic: %d differently seeded 1000-frame clips (identities from a pool of 250) played one after the other, loop j = clip j %% %d; timestamps and "
+                   "track numbers continue; every loop adds its tracks to the global clustering" % (K, K),
            "config": {"workload": "configs[2]: %d frames per GPU (%.1f min of 1080p 25 fps video; %d GPUs x that = the whole video), %d-frame shots, %d faces/frame; frames delivered one by one "
-                                  "into HBM buffers of the library (device-to-device from the resident clip), released shot by shot" % (n, n / args.fps / 60.0, world, per_shot, args.faces),
+                                  "into HBM buffers of the library (device-to-device from the resident clips), released shot by shot" % (n, n / args.fps / 60.0, world, per_shot, args.faces),
                       "parallelism": "frame ranges cut at shot boundaries x%d + all-gather of track embeddings + one global clustering" % world if world > 1 else "single GPU (one range)",
-                      "detect_batch": args.detect_batch, "collective": pdist.collective_name()},
+                      "detect_batch": args.detect_batch, "collective": pdist.collective_name(), "distinct_clips": K},
            "roofline": {"kernel": "score_roll_k", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(score_ms / launches, 4)},
-           "cpu_baseline": cpu, "parity": parity,
+                        "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "traffic_note": "not measured for this configuration (a --pmc pass of its own)",
+                        "avg_launch_ms": round(score_ms / launches, 4)},
+           "e2e": e2e_object(flop_per_frame, int(len(res["face_T"])) * args.steps, n * args.steps, elapsed),
+           "cpu_baseline": cpu, "parity": parity, "cluster_check": cluster_check,
            "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
            "kernel_families_ms": fam,
-           "hbm": dict(hbm.report(frames_bytes=int(frames_t.numel())), peak_frames_resident=peak_frames,
+           "hbm": dict(hbm.report(frames_bytes=sum(int(c.numel()) for c in clips_t)), peak_frames_resident=peak_frames,
                        whole_range_resident_would_be_bytes=int(n) * args.width * args.height * 3),
            "results": {"tracks": len(res["tracks"]), "faces_embedded": int(len(res["face_T"])), "clusters": len(set(labels.values())),
-                       "identities_in_video": len(set(tr["ident"] for shot in video.tracks for tr in shot))},
-           "setup_seconds": {"generate_clip_in_hbm": round(t_gen, 1)}}
+                       "tracks_clustered_globally": len(labels), "labels_sha256_16": labels_digest(labels),
+                       "identities_in_video": len(idents)},
+           "setup_seconds": {"generate_clips_in_hbm": round(t_gen, 1)}}
     print(json.dumps(out))
+
+
+def oracle_cluster_check(pipe, res, t_end):
+    """The clustering kernels against the CPU oracle on the pipeline's own descriptors: the tracks that END before t_end seconds (long
+    tracks of ~250 rows each, real embeddings) -- pair means + agglomeration by the oracle (C, all cores) and by the product on the same
+    rows; labels and merge order must agree, D to 1e-12."""
+    import numpy as np
+    from oracle import oracle
+    from pyannote_video_amd import _lib
+    T_, ids_, emb = np.asarray(res["face_T"]), np.asarray(res["face_id"]), res["embeddings"]
+    last = {}
+    for t, i in zip(T_.tolist(), ids_.tolist()):
+        last[i] = max(last.get(i, t), t)
+    keep_ids = sorted(i for i, t in last.items() if t < t_end)
+    sel = np.isin(ids_, keep_ids)
+    if sel.sum() < 2:
+        return None
+    tids, order, row_start = pipe.clustering.plan_rows(T_[sel], ids_[sel])
+    if len(tids) < 2:
+        return None
+    E = np.ascontiguousarray(emb[sel])
+    X = _lib.round_rows(E, 5)[order]
+    oracle.lib().pvo_set_threads(oracle.usable_cpus(cap=1024))
+    t0 = time.perf_counter()
+    Dr = oracle.pair_mean_dist(X, row_start)
+    lr, logr = oracle.hac(Dr, np.diff(row_start), pipe.clustering.threshold)
+    dt = time.perf_counter() - t0
+    ctx = pipe.ctx
+    D = ctx.pair_mean_dist(X, row_start)
+    lg, logg = ctx.cluster_tracks_f32(E, order, row_start, pipe.clustering.threshold)
+    rel = float(np.max(np.abs(D - Dr) / np.maximum(Dr, 1e-300))) if len(tids) > 1 else 0.0
+    return {"tracks": int(len(tids)), "rows": int(row_start[-1]), "oracle_seconds": round(dt, 2),
+            "labels": "exact" if np.array_equal(lg, lr) else "MISMATCH",
+            "merge_order": "exact" if len(logg) == len(logr) and np.array_equal(logg[:, :2], logr[:, :2]) else "MISMATCH",
+            "D_max_rel_err": rel, "clusters": int(len(set(lr.tolist())))}
 
 
 def host_ingest_pass(ctx, pipe, frames_t, times, video, shots, args):
@@ -805,6 +865,19 @@ def cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args):
         "labels": "exact" if res["labels"] == labels else "MISMATCH",
         "tracks": len(tracks), "faces": int(len(ref_e)),
     }
+    if args.detect_every == 0.0 and video.n_frames >= 64:
+        # a window nobody chose: 8 frames at a position drawn from a seed that changes with every run and is printed (the
+        # other windows always sit on a cut)
+        seed = args.parity_seed if args.parity_seed is not None else int(time.time())
+        i0 = int(np.random.default_rng(seed).integers(0, video.n_frames - 8))
+        idx3 = list(range(i0, i0 + 8))
+        times3 = [video.timestamp(i) for i in idx3]
+        shots3 = [(a, b) for a, b in video.shots() if b > times3[0] and a <= times3[-1]]
+        res3 = pipe.run([ctx.wrap_torch(frames_t[i]) for i in idx3], times3, video.frame_rate, shots3)
+        p3, _, _ = oracle_window_parity([np.ascontiguousarray(frames_t[i].cpu().numpy()) for i in idx3], times3, shots3, video.frame_rate, video.frame_size, res3, lp, ep,
+                                        label="frames %d..%d (drawn from --parity-seed %d)" % (idx3[0], idx3[-1], seed))
+        p3["seed"] = seed
+        parity["random_window"] = p3
     if video.n_shots >= 4 and args.config == "c2" and args.detect_every == 0.0:
         # a second, smaller window at the LAST cut of the clip (shots 3 | 4): other faces, other backgrounds, other tracker histories
         cut2 = video.shot_bounds[video.n_shots - 1]

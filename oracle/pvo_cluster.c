@@ -16,6 +16,8 @@
 void pvo_pair_mean_dist(const double* X, int N, int dim, const int32_t* row_start, int T, double* D)
 {
     (void)N;
+    /* rows of the triangle are independent (each entry is one sequential chain whatever the thread count) */
+    #pragma omp parallel for schedule(dynamic, 1) if (T > 8)
     for (int i = 0; i < T; ++i) {
         D[(size_t)i * T + i] = 0;
         for (int j = i + 1; j < T; ++j) {

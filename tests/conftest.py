@@ -43,6 +43,21 @@ def ctx(model_paths):
 
 
 @pytest.fixture(scope="session")
+def full_model_paths(tmp_path_factory):
+    """the FULL landmark model (15 cascades x 500 trees x 500 pixels, what bench.py runs) + the embedder"""
+    from pyannote_video_amd import models
+    return models.ensure_synthetic_models(str(tmp_path_factory.mktemp("models_full")), small=False)
+
+
+@pytest.fixture(scope="session")
+def ctx_full(full_model_paths):
+    from pyannote_video_amd.runtime import Context
+    c = Context(device=0, landmarks=full_model_paths[0], embedding=full_model_paths[1])
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
 def small_video():
     from pyannote_video_amd import synth
     return synth.SyntheticVideo(width=640, height=360, n_frames=12, n_shots=2, faces=3, min_face=50, max_face=110, seed=7)

@@ -384,3 +384,36 @@ def test_hac_tie_order_equals_oracle(ctx, oracle, T):
     assert np.array_equal(log[:, :2], logr[:, :2])
     assert np.array_equal(log[:, 2:], logr[:, 2:])           # distances and sizes: the same operations in the same order
     assert np.array_equal(labels, lr)
+
+
+def test_detector_with_hundreds_of_candidates_at_the_threshold(ctx, oracle, small_video):
+    """the synthetic detector is fit to the renderer, so at the shipped threshold few window scores sit near it.
+    Here `adjust_threshold` is lowered until ~20 000 windows of one frame pass (bisection on the CPU oracle) -- the threshold then lies in
+    the dense part of the score distribution -- and the raw candidates (score bits, filter, level, position, box) and the final boxes
+    must still equal the oracle's at that threshold and 1e-3 to either side of it; the counts differ by >= 100 between the two outer
+    thresholds, i.e. at least that many windows score within 1e-3 of the middle one: every one of them decided the same way on both sides."""
+    det = _detector(oracle)
+    f = small_video.frame(5)
+    lo, hi = -6.0, 0.0                                   # adjust: candidates(lo) > target > candidates(hi)
+    n_lo = len(det.detect_raw(f, 1, lo))
+    assert n_lo > 20000, n_lo
+    for _ in range(12):
+        mid = 0.5 * (lo + hi)
+        if len(det.detect_raw(f, 1, mid)) > 20000:
+            lo = mid
+        else:
+            hi = mid
+    A = float(np.float32(lo))
+    counts = []
+    for adj in (A - 1e-3, A, A + 1e-3):
+        raw_c = det.detect_raw(f, 1, adj)
+        raw_g = ctx.detect_raw(f, 1, adj)
+        assert 1000 < len(raw_c) < 65000
+        assert len(raw_g) == len(raw_c), (adj, len(raw_g), len(raw_c))
+        assert raw_g == raw_c
+        counts.append(len(raw_c))
+        boxes_g, scores_g = ctx.detect(f, 1, adj)
+        fin_c = det.detect(f, 1, adj)
+        assert boxes_g == [d[5] for d in fin_c]
+        assert np.array_equal(scores_g, np.array([d[0] for d in fin_c], np.float32))
+    assert counts[0] - counts[2] >= 100, counts          # windows within 1e-3 of the middle threshold

@@ -9,17 +9,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def full_models(tmp_path_factory):
-    from pyannote_video_amd import models
-    return models.ensure_synthetic_models(str(tmp_path_factory.mktemp("models_full")), small=False)
-
-
-@pytest.fixture(scope="module")
-def ctx_full(full_models):
-    from pyannote_video_amd.runtime import Context
-    c = Context(device=0, landmarks=full_models[0], embedding=full_models[1])
-    yield c
-    c.close()
+def full_models(full_model_paths):
+    return full_model_paths
 
 
 @pytest.fixture(scope="module")

@@ -72,21 +72,58 @@ def test_two_shards_equal_single_process(tmp_path, model_dir):
     ctx.close()
 
 
-def test_rccl_allgatherv_single_rank():
-    """libpvface_dist.so on the one GPU of this box: communicator of size 1 -- id, ncclCommInitRank, the count exchange and the grouped
-    ncclBroadcast all-gather between DEVICE buffers, teardown (a box with one GPU cannot host two ranks of one RCCL communicator; the
-    N > 1 exchange logic is covered over gloo on CPU and with two processes on this GPU above)"""
-    import torch
-    from pyannote_video_amd import dist
-    comm = dist.RcclRows(0, 0, 1, dist.RcclRows.unique_id())
-    assert comm.counts(37) == [37]
-    g = torch.Generator().manual_seed(3)
-    for n, k in ((0, 528), (1, 528), (37, 528), (5000, 528), (40, 320)):
-        rows = torch.randint(0, 256, (n, k), dtype=torch.uint8, generator=g).cuda()
-        out, counts = comm.allgather(rows)
-        assert counts == [n] and tuple(out.shape) == (n, k) and out.is_cuda and torch.equal(out, rows)
-        assert n == 0 or out.data_ptr() != rows.data_ptr()
-    comm.close()
+RCCL_WORKER = r'''
+import os, sys
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "pyannote-video_amd"))
+import torch                                   # FIRST, as in bench.py: the process then runs on the HIP runtime and the RCCL torch ships
+import torch.distributed as td
+torch.cuda.set_device(0)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[2])
+td.init_process_group("nccl", rank=0, world_size=1)
+x = torch.ones(4, device="cuda"); td.all_reduce(x)               # torch's own RCCL communicator is live beside ours
+from pyannote_video_amd import dist
+from pyannote_video_amd.runtime import Context, DeviceRows
+import numpy as np
+comm = dist.RcclRows(0, 0, 1, dist.RcclRows.unique_id())
+assert comm.counts(37) == [37]
+g = torch.Generator().manual_seed(3)
+for n, k in ((0, 528), (1, 528), (37, 528), (5000, 528), (40, 320)):
+    rows = torch.randint(0, 256, (n, k), dtype=torch.uint8, generator=g).cuda()
+    out, counts = comm.allgather(rows)
+    assert counts == [n] and tuple(out.shape) == (n, k) and out.is_cuda and torch.equal(out, rows)
+    assert n == 0 or out.data_ptr() != rows.data_ptr()
+# the whole device-resident exchange + split clustering with this communicator as the job's exchange step (world 1: one share)
+dist._exchange["tried"] = True; dist._exchange["comm"] = comm
+rng = np.random.default_rng(5)
+T, ids = np.repeat(np.arange(12) * 1.0, 5) + np.tile(np.arange(5) * 0.04, 12), np.repeat(np.arange(12), 5)
+cent = rng.normal(size=(3, 128)); cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+E = (0.55 * cent[ids % 3] + 0.01 * rng.normal(size=(60, 128))).astype(np.float32)
+gT, gid, X, off = dist.gather_rows(T, ids, E, 12, file_T=T, file_id=ids)
+assert off == [0] and isinstance(X.rows, DeviceRows) and np.array_equal(X.numpy(), E[X.index]) and np.array_equal(gT, T[X.index])
+from pyannote_video_amd.clustering import FaceClustering
+ctx = Context(device=0, detector=None)
+fc = FaceClustering(ctx=ctx); fc.shard = dist.DistanceShard(0, 1)
+lab_split = fc.cluster_rows(gT, gid, X.rows, src_index=X.index)      # rows in HBM -> upper rows -> all-gather (RCCL) -> mirror + HAC
+lab_one = FaceClustering(ctx=ctx).cluster_rows(T, ids, E)
+assert lab_split == lab_one and len(set(lab_one.values())) == 3
+comm.close(); ctx.close(); td.destroy_process_group()
+print("RCCL-OK")
+'''
+
+
+def test_rccl_allgatherv_single_rank(tmp_path):
+    """libpvface_dist.so on the one GPU of this box, in a process set up like bench.py's ranks (torch imported first, the job's nccl
+    process group alive): communicator of size 1 -- id, ncclCommInitRank, the count exchange, the grouped ncclBroadcast all-gather
+    between DEVICE buffers -- then gather_rows + the split clustering through it with every payload in HBM, and teardown.  (A box with
+    one GPU cannot host two ranks of one RCCL communicator; the N > 1 exchange logic is covered over gloo on CPU and with two processes
+    on this GPU above.)"""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    env.pop("PVF_DIST_COLLECTIVE", None)
+    p = subprocess.run([sys.executable, str(script), ROOT, "29655"], env=env, timeout=600, capture_output=True, text=True)
+    assert p.returncode == 0 and "RCCL-OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
 
 
 def test_bench_launches_ranks_itself_and_two_ranks_equal_one(tmp_path):
@@ -114,8 +151,8 @@ def test_bench_launches_ranks_itself_and_two_ranks_equal_one(tmp_path):
     assert l2["results"]["tracks_clustered_globally"] == l1["results"]["tracks_clustered_globally"] > 0
     assert l2["results"]["labels_sha256_16"] == l1["results"]["labels_sha256_16"]
     assert l2["results"]["clusters"] == l1["results"]["clusters"]
-    import torch
-    if torch.cuda.device_count() < 2:
+    from pyannote_video_amd import _lib
+    if _lib.device_count() < 2:
         p = run(["--gpus", "2"])
         assert p.returncode != 0 and "GPU" in p.stderr
 

@@ -136,20 +136,21 @@ def _check_against_oracle(res, ref):
     assert res["labels"] == labels
 
 
-def test_gpu_parity_c4_clip(ctx, oracle, model_paths):
-    """configs[3] shape: a 720p clip, 8 faces, a window around its shot cut, the whole flow against the CPU oracle"""
+def test_gpu_parity_c4_clip(ctx_full, oracle, full_model_paths):
+    """configs[3] shape: a 720p clip, 8 faces, a window around its shot cut, the whole flow against the CPU oracle (FULL landmark model,
+    like every oracle-checked end-to-end window since round 4)"""
     from pyannote_video_amd import synth, pipeline
     v = synth.SyntheticVideo(width=1280, height=720, n_frames=250, n_shots=2, faces=8, seed=20260925)
     idx = list(range(121, 131))
     frames_np = [v.frame(i) for i in idx]
     times = [v.timestamp(i) for i in idx]
-    pipe = pipeline.FacePipeline(ctx, model_paths[0], model_paths[1], detect_batch_size=8)
-    res = pipe.run_many([dict(frames=[ctx.upload(f) for f in frames_np], times=times, frame_rate=v.frame_rate, shots=v.shots())])[0]
+    pipe = pipeline.FacePipeline(ctx_full, full_model_paths[0], full_model_paths[1], detect_batch_size=8)
+    res = pipe.run_many([dict(frames=[ctx_full.upload(f) for f in frames_np], times=times, frame_rate=v.frame_rate, shots=v.shots())])[0]
     assert len(res["tracks"]) >= 12
-    _check_against_oracle(res, _oracle_flow(oracle, frames_np, times, v.shots(), v.frame_rate, model_paths))
+    _check_against_oracle(res, _oracle_flow(oracle, frames_np, times, v.shots(), v.frame_rate, full_model_paths))
 
 
-def test_gpu_parity_c5_e2e(ctx, oracle, model_paths):
+def test_gpu_parity_c5_e2e(ctx_full, oracle, full_model_paths):
     """configs[4] shape: 3840 x 2160, 50 fps, 40 faces per frame, six frames across a cut, bulk tracker starts in windows of 64 (every shot is
     over the limit), streamed through the ingest ring: tracks, landmarks, embeddings and labels against the CPU oracle"""
     from pyannote_video_amd import synth, pipeline
@@ -157,13 +158,13 @@ def test_gpu_parity_c5_e2e(ctx, oracle, model_paths):
     idx = list(range(247, 253))
     frames_np = [v.frame(i) for i in idx]
     times = [v.timestamp(i) for i in idx]
-    pipe = pipeline.FacePipeline(ctx, model_paths[0], model_paths[1], detect_batch_size=4, speculate_limit=100, speculate_window=64)
+    pipe = pipeline.FacePipeline(ctx_full, full_model_paths[0], full_model_paths[1], detect_batch_size=4, speculate_limit=100, speculate_window=64)
     res = pipe.run_stream(list(zip(times, frames_np)), v.shots(), frame_rate=v.frame_rate, size=v.size)
     assert pipe.last_engine.stats["windowed_shots"] == 2 and len(res["tracks"]) >= 60
-    _check_against_oracle(res, _oracle_flow(oracle, frames_np, times, v.shots(), v.frame_rate, model_paths))
+    _check_against_oracle(res, _oracle_flow(oracle, frames_np, times, v.shots(), v.frame_rate, full_model_paths))
 
 
-def test_gpu_parity_1080p_every_half_second(ctx, oracle, model_paths):
+def test_gpu_parity_1080p_every_half_second(ctx_full, oracle, full_model_paths):
     """`--every 0.5` at the benched size (reference tracking.py:383-386,425): detection on every 12th frame, trackers carry the faces in
     between (committed deferred updates, on-demand updates frame after frame, both passes)"""
     from pyannote_video_amd import synth, pipeline
@@ -173,8 +174,8 @@ def test_gpu_parity_1080p_every_half_second(ctx, oracle, model_paths):
     times = [v.timestamp(i) for i in idx]
     # frame indices count from the start of the video: hand the window over with its own numbering (i % every on 236..263 differs from
     # 0..27), i.e. run the reference flow and the product on a clip that STARTS at frame 236: both count from 0
-    pipe = pipeline.FacePipeline(ctx, model_paths[0], model_paths[1], detect_every=0.5, detect_batch_size=8)
-    res = pipe.run([ctx.upload(f) for f in frames_np], times, v.frame_rate, v.shots())
-    ref = _oracle_flow(oracle, frames_np, times, v.shots(), v.frame_rate, model_paths, every=0.5)
+    pipe = pipeline.FacePipeline(ctx_full, full_model_paths[0], full_model_paths[1], detect_every=0.5, detect_batch_size=8)
+    res = pipe.run([ctx_full.upload(f) for f in frames_np], times, v.frame_rate, v.shots())
+    ref = _oracle_flow(oracle, frames_np, times, v.shots(), v.frame_rate, full_model_paths, every=0.5)
     assert any("forward" in st and "backward" in st for tr in ref[0] for _, _, st in tr)
     _check_against_oracle(res, ref)
