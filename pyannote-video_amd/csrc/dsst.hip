@@ -786,8 +786,13 @@ static DsstBuffers prepare(Ctx* c, const std::vector<Tracker*>& t, const std::ve
     c->s_trk0.ensure(chips64 + chips_sc + 256);
     b.chips64 = c->s_trk0.as<uint8_t>();
     b.chips_sc = b.chips64 + (chips64 + 63) / 64 * 64;
-    c->s_feat.ensure((size_t)n * FS * FS * PVF_FHOG_STRIDE * sizeof(float));
-    b.feat = c->s_feat.as<float>();
+    // a buffer of the tracker's own (round 4).  Up to round 3 this was the detector's s_feat: the chips' features overwrote the ZERO BORDER
+    // of the detector's level-0 feature maps without telling it (feat_ring_owner), so the next detector batch of the same plan scored
+    // the windows that reach into the border -- the top rows of the first frames -- on tracker features.  Invisible at the shipped
+    // threshold on faces away from the frame's edge; found by tests/test_gpu_parity.py::test_detector_with_hundreds_of_candidates_at_
+    // the_threshold after a tracker test.  512 KB per tracker of a call.
+    c->s_trkfeat.ensure((size_t)n * FS * FS * PVF_FHOG_STRIDE * sizeof(float));
+    b.feat = c->s_trkfeat.as<float>();
     b.F = nullptr;
     if (need_F) {                                  // plane spectra in HBM: the full update only (2 MB per tracker)
         c->s_trk1.ensure((size_t)n * NPL * FS * FS * sizeof(double2));

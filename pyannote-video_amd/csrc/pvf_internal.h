@@ -222,7 +222,7 @@ struct Ctx {
     std::map<std::string, ProfFamily> prof;
     std::vector<hipEvent_t> event_pool;
     // scratch (grow only)
-    DevBuf s_grad, s_pyr, s_hist, s_norm, s_feat, s_cand, s_misc, s_chip, s_chip_pyr, s_act0, s_act1, s_act2, s_trk0, s_trk1, s_trk2, s_clu0, s_clu1;
+    DevBuf s_grad, s_pyr, s_hist, s_norm, s_feat, s_cand, s_misc, s_chip, s_chip_pyr, s_act0, s_act1, s_act2, s_trk0, s_trk1, s_trk2, s_trkfeat, s_clu0, s_clu1;
     HostBuf h_cand, h_misc;
     StageRing stage;
     // det_run_many: alternating candidate buffers / frame-pointer tables / completion events of the two batches in flight

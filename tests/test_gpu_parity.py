@@ -417,3 +417,24 @@ def test_detector_with_hundreds_of_candidates_at_the_threshold(ctx, oracle, smal
         assert boxes_g == [d[5] for d in fin_c]
         assert np.array_equal(scores_g, np.array([d[0] for d in fin_c], np.float32))
     assert counts[0] - counts[2] >= 100, counts          # windows within 1e-3 of the middle threshold
+
+
+def test_detector_border_windows_after_tracker_work(ctx, oracle, small_video):
+    """Round-4 finding of the test above: the tracker used the detector's feature scratch for its chip features and overwrote the ZERO
+    BORDER of the level-0 feature maps, so a detector call that followed tracker work (every batch of a pipeline run but the first)
+    scored the windows reaching into the border on stale tracker features -- invisible at the shipped threshold unless a face touches
+    the frame's edge.  Detector -> tracker starts + updates -> detector with the threshold in the dense part of the score distribution:
+    every raw candidate (20 000 of them, the border rows included) must still equal the oracle's."""
+    det = _detector(oracle)
+    f0, f1, f = small_video.frame(0), small_video.frame(1), small_video.frame(5)
+    boxes = ctx.detect(f0, 1)[0]
+    dbox = [tuple(float(v) for v in b) for b in boxes]
+    trk = ctx.tracker_create_many(len(dbox))
+    ctx.tracker_start_many(trk, [f0] * len(dbox), dbox)
+    ctx.tracker_update_many(trk, [f1] * len(dbox))
+    adj = -0.80712890625
+    raw_c = det.detect_raw(f, 1, adj)
+    raw_g = ctx.detect_raw(f, 1, adj)
+    assert len(raw_c) > 15000 and min(r[3] for r in raw_c) == 5           # windows of the first scanned row are among them
+    assert raw_g == raw_c
+    ctx.tracker_destroy_many(trk)
