@@ -18,6 +18,17 @@
     Ctx* c = pvf_ctx(h);                                           \
     std::lock_guard<std::recursive_mutex> _api_lock(c->api_mu);    \
     HIP_CHECK(hipSetDevice(c->device))
+// the detector side (its own stream, scratch and lock: runs beside the calls above)
+#define ENTER_DET(c, h)                                            \
+    Ctx* c = pvf_ctx(h);                                           \
+    std::lock_guard<std::recursive_mutex> _det_lock(c->det_mu);    \
+    HIP_CHECK(hipSetDevice(c->device))
+// debug entries that use scratch of both sides
+#define ENTER_BOTH(c, h)                                           \
+    Ctx* c = pvf_ctx(h);                                           \
+    std::lock_guard<std::recursive_mutex> _det_lock(c->det_mu);    \
+    std::lock_guard<std::recursive_mutex> _api_lock(c->api_mu);    \
+    HIP_CHECK(hipSetDevice(c->device))
 
 // ---- S1 -------------------------------------------------------------------------------------------
 // a frame with more raw candidates than the candidate slots hold (a threshold lowered far below the operating point, a pathological
@@ -41,7 +52,7 @@ extern "C" int32_t pvf_detect_batch(pvf_handle h, const pvf_handle* frames, int3
                                     pvf_rect_i32* out, float* scores, int32_t* counts, int32_t cap)
 {
     API_BEGIN
-    ENTER(c, h);
+    ENTER_DET(c, h);
     PVF_REQUIRE(n_frames > 0 && frames && out && counts && cap > 0, "pvf_detect_batch: bad arguments");
     PVF_REQUIRE(upsample >= 0 && upsample <= 2, "pvf_detect_batch: upsample must be 0..2");
     std::vector<Frame> fr(n_frames);
@@ -65,7 +76,7 @@ extern "C" int32_t pvf_detect_many(pvf_handle h, const pvf_handle* frames, int32
                                    pvf_rect_i32* out, float* scores, int32_t* counts, int32_t cap)
 {
     API_BEGIN
-    ENTER(c, h);
+    ENTER_DET(c, h);
     PVF_REQUIRE(n_frames > 0 && batch > 0 && frames && out && counts && cap > 0, "pvf_detect_many: bad arguments");
     PVF_REQUIRE(upsample >= 0 && upsample <= 2, "pvf_detect_many: upsample must be 0..2");
     std::vector<Frame> fr(n_frames);
@@ -97,7 +108,7 @@ extern "C" int32_t pvf_debug_detect_raw(pvf_handle h, pvf_handle frame, int32_t 
                                         int32_t cap, int32_t* n)
 {
     API_BEGIN
-    ENTER(c, h);
+    ENTER_DET(c, h);
     std::vector<Frame> fr{c->frame(frame)};
     std::vector<std::vector<RawDet>> raw;
     with_candidate_room(c, [&]() { det_run_batch(c, fr, upsample, adjust, raw); });
@@ -116,7 +127,7 @@ extern "C" int32_t pvf_debug_pyramid_level(pvf_handle h, pvf_handle frame, int32
                                            int32_t* ow)
 {
     API_BEGIN
-    ENTER(c, h);
+    ENTER_DET(c, h);
     std::vector<uint8_t> buf;
     int hh = 0, ww = 0;
     det_pyramid_level(c, c->frame(frame), upsample, level, out ? &buf : nullptr, &hh, &ww);
@@ -128,7 +139,7 @@ extern "C" int32_t pvf_debug_pyramid_level(pvf_handle h, pvf_handle frame, int32
 extern "C" int32_t pvf_debug_level_features(pvf_handle h, pvf_handle frame, int32_t upsample, int32_t level, float* out, int32_t* fh, int32_t* fw)
 {
     API_BEGIN
-    ENTER(c, h);
+    ENTER_DET(c, h);
     std::vector<float> buf;
     int a = 0, b = 0;
     det_level_features(c, c->frame(frame), upsample, level, out ? &buf : nullptr, &a, &b);
@@ -141,7 +152,7 @@ extern "C" int32_t pvf_debug_fhog(pvf_handle h, const uint8_t* img, int32_t ih, 
                                   float* out, int32_t* fh, int32_t* fw)
 {
     API_BEGIN
-    ENTER(c, h);
+    ENTER_BOTH(c, h);
     int a = 0, b = 0;
     if (!out) { fhog_dims(ih, iw, cell, pad_r, pad_c, &a, &b); *fh = a; *fw = b; return 0; }
     std::vector<float> buf;

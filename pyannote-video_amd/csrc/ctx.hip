@@ -201,23 +201,27 @@ static void load_embedder(Ctx* c, const char* path)
 }
 
 // ---------------------------------------------------------------------------------------------------
-ProfScope::ProfScope(Ctx* ctx, const char* family) : c(ctx)
+ProfScope::ProfScope(Ctx* ctx, const char* family, hipStream_t on) : c(ctx), s(on ? on : ctx->stream)
 {
     if (!c->prof_on) return;
-    f = &c->prof[family];
-    auto get = [&]() {
-        hipEvent_t e;
-        if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
-        else HIP_CHECK(hipEventCreate(&e));
-        return e;
-    };
-    a = get(); b = get();
-    HIP_CHECK(hipEventRecord(a, c->stream));
+    {
+        std::lock_guard<std::mutex> lk(c->prof_mu);
+        f = &c->prof[family];                          // (std::map: the address survives later insertions)
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->event_pool.empty()) { e = c->event_pool.back(); c->event_pool.pop_back(); }
+            else HIP_CHECK(hipEventCreate(&e));
+            return e;
+        };
+        a = get(); b = get();
+    }
+    HIP_CHECK(hipEventRecord(a, s));
 }
 ProfScope::~ProfScope()
 {
     if (!f) return;
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, s);
+    std::lock_guard<std::mutex> lk(c->prof_mu);
     f->pending.emplace_back(a, b);
     f->launches += 1;
 }
@@ -225,6 +229,8 @@ ProfScope::~ProfScope()
 static void prof_drain(Ctx* c)
 {
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->det_stream));
+    std::lock_guard<std::mutex> lk(c->prof_mu);
     for (auto& kv : c->prof) {
         for (auto& pr : kv.second.pending) {
             float ms = 0;
@@ -273,8 +279,10 @@ extern "C" int32_t pvf_ctx_create_prio(int32_t device, int32_t priority_class, p
     {
         int lo = 0, hi = 0;   // numerically lower = higher priority
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const int prio = priority_class > 0 ? hi : (priority_class < 0 ? lo : (lo + hi) / 2);
+        // the detector's stream at the lowest priority, the latency-bound side above it (class < 0: both at the lowest)
+        const int prio = priority_class < 0 ? lo : hi;
         HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio));
+        HIP_CHECK(hipStreamCreateWithPriority(&c->det_stream, hipStreamNonBlocking, lo));
     }
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     uint64_t id = g_next_ctx++;
@@ -291,6 +299,7 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
     Ctx* c = pvf_ctx(h);
     HIP_CHECK(hipSetDevice(c->device));
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->det_stream);
     for (auto& kv : c->frames) if (kv.second.owned) (void)hipFree((void*)kv.second.d);
     for (auto& kv : c->trackers) {
         Tracker& t = *kv.second;
@@ -301,10 +310,15 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
     for (int k = 0; k < 2; ++k) if (c->det_ev[k]) (void)hipEventDestroy(c->det_ev[k]);
     ml_plans_free(c);
     ingest_free_all(c);
-    for (auto& kv : c->frame_pool) for (auto q : kv.second) { if (q.free_after) (void)hipEventDestroy(q.free_after); (void)hipFree(q.p); }
+    for (auto& kv : c->frame_pool) for (auto q : kv.second) {
+        if (q.free_after) (void)hipEventDestroy(q.free_after);
+        if (q.free_after_det) (void)hipEventDestroy(q.free_after_det);
+        (void)hipFree(q.p);
+    }
     if (c->d_orient_lut) (void)hipFree(c->d_orient_lut);
     if (c->d_grad_lut) (void)hipFree(c->d_grad_lut);
     (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->det_stream);
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     g_ctxs.erase(h);
     API_END
@@ -314,7 +328,9 @@ extern "C" int32_t pvf_sync(pvf_handle h)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> det_lock(c->det_mu);
     std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
+    HIP_CHECK(hipStreamSynchronize(c->det_stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
     API_END
 }
@@ -323,6 +339,7 @@ extern "C" int32_t pvf_load_detector(pvf_handle h, const char* path)
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
+    std::lock_guard<std::recursive_mutex> det_lock(c->det_mu);
     std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
     HIP_CHECK(hipSetDevice(c->device));
     PVF_REQUIRE(path != nullptr, "pvf_load_detector: path is NULL (the Python layer passes the packaged default)");
@@ -435,7 +452,7 @@ static void release_frame_locked(Ctx* c, pvf_handle frame)
     // memory the caller owns (pvf_frame_wrap_device): compute calls no longer end with a stream synchronisation, so kernels that read this
     // frame may still be queued -- the caller is free to reuse the memory as soon as this returns, hence the wait (pooled buffers go back
     // behind an event instead and never wait)
-    else (void)hipStreamSynchronize(c->stream);
+    else { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->det_stream); }
 }
 
 extern "C" int32_t pvf_frame_release(pvf_handle h, pvf_handle frame)
@@ -472,6 +489,7 @@ extern "C" int32_t pvf_frame_pool_trim(pvf_handle h, int64_t keep_bytes, int64_t
             v.pop_back();
             c->frame_pool_bytes -= kv.first;
             if (b.free_after) { (void)hipEventSynchronize(b.free_after); (void)hipEventDestroy(b.free_after); }
+            if (b.free_after_det) { (void)hipEventSynchronize(b.free_after_det); (void)hipEventDestroy(b.free_after_det); }
             HIP_CHECK(hipFree(b.p));
         }
     }

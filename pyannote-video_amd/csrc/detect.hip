@@ -165,7 +165,7 @@ static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint
     // one strip of RS rows per wave: walking 2 / 4 strips with the next strip's source rows in flight behind the current one's arithmetic was
     // measured no faster (65 / 66 / 78 us per 1080p frame for 1 / 2 / 4 strips): the kernel is not waiting for its loads
     dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
-    hipLaunchKernelGGL((resize_rows_k<RS, 1>), grid, dim3(256), 0, c->stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
+    hipLaunchKernelGGL((resize_rows_k<RS, 1>), grid, dim3(256), 0, c->det_stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
 }
 
 static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
@@ -236,7 +236,7 @@ static void upload_frame_ptrs(Ctx* c, const std::vector<Frame>& frames, const ui
     h.ensure(frames.size() * sizeof(void*));
     const uint8_t** hp = h.as<const uint8_t*>();
     for (size_t i = 0; i < frames.size(); ++i) hp[i] = frames[i].d;
-    HIP_CHECK(hipMemcpyAsync(d.p, hp, frames.size() * sizeof(void*), hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(d.p, hp, frames.size() * sizeof(void*), hipMemcpyHostToDevice, c->det_stream));
     *d_ptrs = d.as<const uint8_t*>();
 }
 
@@ -811,7 +811,7 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
     uint8_t* up_tmp = base + ((p->img_bytes + 63) / 64) * 64;
     const uint8_t** d_ptrs = nullptr;
     upload_frame_ptrs(c, frames, &d_ptrs);
-    ProfScope ps(c, "pyramid");
+    ProfScope ps(c, "pyramid", c->det_stream);
     auto al = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
     const uint8_t* cur = nullptr;
     int ch = h, cw = w, crb = w * 3;
@@ -827,7 +827,7 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
     if (!cur) {
         for (int b = 0; b < B; ++b)
             HIP_CHECK(hipMemcpy2DAsync(base + p->lv[0].img_off + (size_t)b * p->lv[0].img_stride, (size_t)p->lv[0].rb, frames[b].d, (size_t)w * 3,
-                                       (size_t)w * 3, (size_t)h, hipMemcpyDeviceToDevice, c->stream));
+                                       (size_t)w * 3, (size_t)h, hipMemcpyDeviceToDevice, c->det_stream));
     }
     for (size_t l = 1; l < p->lv.size(); ++l)
         launch_resize_rows(c, nullptr, base + p->lv[l - 1].img_off, (size_t)p->lv[l - 1].img_stride, p->lv[l - 1].rb, p->lv[l - 1].h, p->lv[l - 1].w,
@@ -846,11 +846,11 @@ static void check_dpp_direction(Ctx* c)
 {
     MlPlanCache* pc = c->ml_plans;
     if (pc->dpp_probe < 0) {
-        c->s_misc.ensure(128 * sizeof(int));
-        hipLaunchKernelGGL(dpp_probe_k, dim3(1), dim3(64), 0, c->stream, c->s_misc.as<int>());
+        c->s_cand.ensure(128 * sizeof(int));            // (a detector-side buffer: s_misc belongs to the other stream's entry points)
+        hipLaunchKernelGGL(dpp_probe_k, dim3(1), dim3(64), 0, c->det_stream, c->s_cand.as<int>());
         int h[128];
-        HIP_CHECK(hipMemcpyAsync(h, c->s_misc.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipStreamSynchronize(c->stream));
+        HIP_CHECK(hipMemcpyAsync(h, c->s_cand.p, sizeof h, hipMemcpyDeviceToHost, c->det_stream));
+        HIP_CHECK(hipStreamSynchronize(c->det_stream));
         bool ok = true;
         for (int i = 0; i < 64; ++i) {
             ok = ok && h[i] == (i < 63 ? i + 101 : 0);
@@ -873,14 +873,14 @@ static MlPlan* ml_features(Ctx* c, const std::vector<Frame>& frames, int upsampl
     c->s_feat.ensure(p->feat_floats * sizeof(float) + 64);
     if (p->fused_blocks == 0) return p;
     check_dpp_direction(c);
-    ProfScope ps(c, "fhog");
+    ProfScope ps(c, "fhog", c->det_stream);
     // the fused kernel writes hog cells only: the zero padding ring is written when this plan first meets this buffer (other plans
     // and the stage-access entries share s_feat, so the owner is tracked)
     if (c->s_feat.p != feat_before || c->feat_ring_owner != (const void*)p) {
-        hipLaunchKernelGGL(feat_ring_zero_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->stream, p->feat, p->d_lv, B, c->s_feat.as<float>(), oy, ox);
+        hipLaunchKernelGGL(feat_ring_zero_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->det_stream, p->feat, p->d_lv, B, c->s_feat.as<float>(), oy, ox);
         c->feat_ring_owner = (const void*)p;
     }
-    hipLaunchKernelGGL(fhog_fused_ml_k, dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
+    hipLaunchKernelGGL(fhog_fused_ml_k, dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->det_stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
                        c->s_feat.as<float>(), lut2, oy, ox);
     return p;
 }
@@ -891,10 +891,10 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
     const int B = (int)frames.size();
     MlPlan* p = ml_features(c, frames, upsample);
     if (p->walk_blocks == 0) return;
-    ProfScope ps(c, "score");
+    ProfScope ps(c, "score", c->det_stream);
     const size_t lds = (size_t)2 * (((2 * 48 + 11) * 31 + 3) / 4 * 4) * sizeof(float);      // one slab of 107 packed cells of 31 planes, double-buffered
     const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
-    hipLaunchKernelGGL(score_roll_k, dim3(p->walk_blocks), dim3(128), lds, c->stream, p->walk, p->d_lv, B, c->s_feat.as<float>(), b4, sp0, d_counts, d_cands);
+    hipLaunchKernelGGL(score_roll_k, dim3(p->walk_blocks), dim3(128), lds, c->det_stream, p->walk, p->d_lv, B, c->s_feat.as<float>(), b4, sp0, d_counts, d_cands);
 }
 
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* oh, int* ow)
@@ -907,9 +907,9 @@ void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vec
     if (out) {
         out->resize((size_t)(*oh) * (*ow) * 3);
         HIP_CHECK(hipMemcpy2DAsync(out->data(), (size_t)(*ow) * 3, c->s_pyr.as<uint8_t>() + p->lv[level].img_off, (size_t)p->lv[level].rb,
-                                   (size_t)(*ow) * 3, (size_t)(*oh), hipMemcpyDeviceToHost, c->stream));
+                                   (size_t)(*ow) * 3, (size_t)(*oh), hipMemcpyDeviceToHost, c->det_stream));
     }
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->det_stream));
 }
 
 // features of one pyramid level as the batched detector computes them (parity tests of the multi-level FHOG kernels)
@@ -924,9 +924,9 @@ void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::ve
     if (out) {
         out->resize((size_t)d.fh * d.fw * PVF_FHOG_STRIDE);
         if (!out->empty())
-            HIP_CHECK(hipMemcpyAsync(out->data(), c->s_feat.as<float>() + d.feat_off, out->size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipMemcpyAsync(out->data(), c->s_feat.as<float>() + d.feat_off, out->size() * sizeof(float), hipMemcpyDeviceToHost, c->det_stream));
     }
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->det_stream));
 }
 
 static bool raw_less(const RawDet& x, const RawDet& y)
@@ -950,7 +950,7 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     c->s_cand.ensure((size_t)B * cap * sizeof(CandRec) + (size_t)B * sizeof(int) + 64);
     int* d_counts = c->s_cand.as<int>();
     CandRec* d_cands = reinterpret_cast<CandRec*>(c->s_cand.as<uint8_t>() + (((size_t)B * sizeof(int) + 63) / 64) * 64);
-    HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), c->stream));
+    HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), c->det_stream));
     ScoreParams sp;
     for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
     sp.n_filters = m.n_filters; sp.cap = cap;
@@ -959,17 +959,17 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     c->h_cand.ensure((size_t)B * cap * sizeof(CandRec) + (size_t)B * sizeof(int) + 64);
     int* h_counts = c->h_cand.as<int>();
     CandRec* h_cands = reinterpret_cast<CandRec*>(c->h_cand.as<uint8_t>() + (((size_t)B * sizeof(int) + 63) / 64) * 64);
-    HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->det_stream));
+    HIP_CHECK(hipStreamSynchronize(c->det_stream));
     raw_sorted.assign(B, {});
     for (int b = 0; b < B; ++b) {
         const int n = h_counts[b];
         if (n > cap) throw CandOverflow(n);
         if (n == 0) continue;
         HIP_CHECK(hipMemcpyAsync(h_cands + (size_t)b * cap, d_cands + (size_t)b * cap, (size_t)n * sizeof(CandRec), hipMemcpyDeviceToHost,
-                                 c->stream));
+                                 c->det_stream));
     }
-    HIP_CHECK(hipStreamSynchronize(c->stream));
+    HIP_CHECK(hipStreamSynchronize(c->det_stream));
     for (int b = 0; b < B; ++b) decode_candidates(m, upsample, h_cands + (size_t)b * cap, h_counts[b], raw_sorted[b]);
 }
 
@@ -1019,15 +1019,15 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
         const int B = (int)fr.size();
         int* d_counts = c->s_cand2[slot].as<int>();
         CandRec* d_cands = reinterpret_cast<CandRec*>(c->s_cand2[slot].as<uint8_t>() + cnt_bytes);
-        HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), c->stream));
+        HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), c->det_stream));
         c->det_slot = slot;
         det_run_batch_ml(c, fr, upsample, sp, d_counts, d_cands);
         HIP_CHECK(hipGetLastError());
         uint8_t* hb = c->h_cand2[slot].as<uint8_t>();
-        HIP_CHECK(hipMemcpyAsync(hb, d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpyAsync(hb, d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->det_stream));
         HIP_CHECK(hipMemcpy2DAsync(hb + cnt_bytes, (size_t)PF * sizeof(CandRec), d_cands, (size_t)cap * sizeof(CandRec),
-                                   (size_t)PF * sizeof(CandRec), (size_t)B, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipEventRecord(c->det_ev[slot], c->stream));
+                                   (size_t)PF * sizeof(CandRec), (size_t)B, hipMemcpyDeviceToHost, c->det_stream));
+        HIP_CHECK(hipEventRecord(c->det_ev[slot], c->det_stream));
     };
     auto collect = [&](int o, int slot) {
         const int B = std::min(N, o + batch) - o;
@@ -1038,7 +1038,7 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
         const CandRec* d_cands = reinterpret_cast<const CandRec*>(c->s_cand2[slot].as<uint8_t>() + cnt_bytes);
         for (int b = 0; b < B; ++b)
             if (h_counts[b] > cap) {
-                HIP_CHECK(hipStreamSynchronize(c->stream));         // the next batch is in flight on the shared scratch: let it finish before the call is repeated
+                HIP_CHECK(hipStreamSynchronize(c->det_stream));         // the next batch is in flight on the shared scratch: let it finish before the call is repeated
                 throw CandOverflow(h_counts[b]);
             }
         // rare: frames with more candidates than were copied back ahead are fetched whole, one after the other
@@ -1047,10 +1047,10 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
         for (int b = 0; b < B; ++b)
             if (h_counts[b] > PF) {
                 big[b].resize(h_counts[b]);
-                HIP_CHECK(hipMemcpyAsync(big[b].data(), d_cands + (size_t)b * cap, (size_t)h_counts[b] * sizeof(CandRec), hipMemcpyDeviceToHost, c->stream));
+                HIP_CHECK(hipMemcpyAsync(big[b].data(), d_cands + (size_t)b * cap, (size_t)h_counts[b] * sizeof(CandRec), hipMemcpyDeviceToHost, c->det_stream));
                 any_big = true;
             }
-        if (any_big) HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (any_big) HIP_CHECK(hipStreamSynchronize(c->det_stream));
         // rectangles, order and suppression per frame: independent, so the frames of a batch are shared out over a few threads.  For every
         // batch but a call's last this runs while the next batch's kernels are queued; the last one's is what the GPU waits for
         auto frames_of = [&](int b0, int b1) {

@@ -13,8 +13,11 @@
 static const float h_dirx[9] = {1.0000f, 0.9397f, 0.7660f, 0.500f, 0.1736f, -0.1736f, -0.5000f, -0.7660f, -0.9397f};
 static const float h_diry[9] = {0.0000f, 0.3420f, 0.6428f, 0.8660f, 0.9848f, 0.9848f, 0.8660f, 0.6428f, 0.3420f};
 
+static std::recursive_mutex g_lut_mu;      // the two tables are built on first use, by whichever side (detector / tracker) gets there first
+
 const uint8_t* orientation_lut(Ctx* c)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_lut_mu);
     if (c->d_orient_lut) return c->d_orient_lut;
     std::vector<uint8_t> lut((size_t)511 * 511);
     for (int by = -255; by <= 255; ++by)
@@ -42,6 +45,7 @@ const uint8_t* orientation_lut(Ctx* c)
 // per gather and made the gradient pass texture-addresser bound).
 const uint8_t* orientation_lut_tiled(Ctx* c)
 {
+    std::lock_guard<std::recursive_mutex> lk(g_lut_mu);
     if (c->d_grad_lut) return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
     orientation_lut(c);
     std::vector<uint8_t> ol((size_t)511 * 511);

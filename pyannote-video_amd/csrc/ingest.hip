@@ -197,7 +197,7 @@ extern "C" int32_t pvf_frame_resize(pvf_handle h, pvf_handle frame, int32_t out_
 {
     API_BEGIN
     Ctx* c = pvf_ctx(h);
-    std::lock_guard<std::recursive_mutex> api_lock(c->api_mu);
+    std::lock_guard<std::recursive_mutex> det_lock(c->det_mu);       // the --min-size copies are made where the detector runs
     HIP_CHECK(hipSetDevice(c->device));
     PVF_REQUIRE(out && out_w > 0 && out_h > 0, "pvf_frame_resize: bad arguments");
     const Frame f = c->frame(frame);
@@ -220,8 +220,8 @@ extern "C" int32_t pvf_frame_resize(pvf_handle h, pvf_handle frame, int32_t out_
     const int32_t* dxi = (const int32_t*)p; const int32_t* dyi = dxi + out_w;
     const int16_t* dxc = (const int16_t*)(dyi + out_h); const int16_t* dyc = dxc + 2 * out_w;
     const size_t bytes = (size_t)out_h * out_w * 3;
-    uint8_t* d = c->take_frame_buffer(bytes, c->stream);
-    hipLaunchKernelGGL(cv_resize_linear_k, dim3((out_w + 255) / 256, out_h), dim3(256), 0, c->stream, f.d, f.h, f.w, d, out_h, out_w, dxi, dxc, dyi, dyc);
+    uint8_t* d = c->take_frame_buffer(bytes, c->det_stream);
+    hipLaunchKernelGGL(cv_resize_linear_k, dim3((out_w + 255) / 256, out_h), dim3(256), 0, c->det_stream, f.d, f.h, f.w, d, out_h, out_w, dxi, dxc, dyi, dyc);
     HIP_CHECK(hipGetLastError());
     Frame g; g.d = d; g.h = out_h; g.w = out_w; g.owned = true; g.pooled = true;
     *out = c->add_frame(g);

@@ -204,7 +204,13 @@ struct ChipDetails { double l, t, r, b, cs, sn; int rows, cols; };
 
 struct Ctx {
     int device = 0;
+    // TWO streams (round 4).  `det_stream` runs the detector (pyramid, FHOG, scoring: VALU- and MFMA-bound kernels whose grids fill the
+    // chip) and the device resize of --min-size; `stream` runs everything else -- tracker, chips, landmarks, embedding, clustering, shot
+    // detection: latency-bound chains the host waits on -- at a higher priority.  The two sides have their own scratch buffers and their
+    // own entry-point locks (det_mu / api_mu), so a thread that detects shot k + 1 and a thread that tracks / extracts shot k really
+    // run side by side on the device (tools/probes/overlap_probe.py measured what that hides).  Frames are read by both.
     hipStream_t stream = nullptr;
+    hipStream_t det_stream = nullptr;
     DetectorModel det;
     ShapeModel shape;
     EmbedModel emb;
@@ -217,7 +223,9 @@ struct Ctx {
     // guards the frame table, the buffer pool and the ingest rings, which a decoder thread fills (pvf_ingest_*, pvf_frame_upload /
     // _release) while another thread runs kernels.  Order: api_mu before frames_mu, never the other way round.
     std::recursive_mutex api_mu;
+    std::recursive_mutex det_mu;       // the detector-side entry points (pvf_detect*, pvf_frame_resize); order: det_mu, api_mu, frames_mu
     std::mutex frames_mu;
+    std::mutex prof_mu;                // the profiling families and the event pool (ProfScope runs on both sides)
     bool prof_on = false;
     std::map<std::string, ProfFamily> prof;
     std::vector<hipEvent_t> event_pool;
@@ -234,7 +242,7 @@ struct Ctx {
     int n_cu = 256;
     // released frame buffers by size.  A buffer comes back with the event recorded on the compute stream at its release: whoever takes it
     // next orders its first write behind that event (pool_take), so releasing a frame never waits for the kernels that still read it.
-    struct PoolBuf { uint8_t* p; hipEvent_t free_after; };
+    struct PoolBuf { uint8_t* p; hipEvent_t free_after; hipEvent_t free_after_det; };      // (one event per stream that may still read it)
     std::map<size_t, std::deque<PoolBuf>> frame_pool;      // oldest release first: its event is the most likely to have passed
     size_t frame_pool_bytes = 0;
     void* ingest_rings = nullptr;                          // pinned staging rings of this context (ingest.hip)
@@ -251,8 +259,9 @@ struct Ctx {
         auto it = frames.find(id);
         if (it == frames.end()) throw PvfError("unknown frame handle");
         Frame& f = it->second;
-        if (f.ready) {          // queued by pvf_ingest_submit on the copy stream: order this context's kernels behind the copy
+        if (f.ready) {          // queued by pvf_ingest_submit on the copy stream: order this context's kernels (both streams) behind the copy
             HIP_CHECK(hipStreamWaitEvent(stream, f.ready, 0));
+            HIP_CHECK(hipStreamWaitEvent(det_stream, f.ready, 0));
             (void)hipEventDestroy(f.ready);
             f.ready = nullptr;
         }
@@ -263,7 +272,7 @@ struct Ctx {
     // outside frames_mu).
     uint8_t* take_frame_buffer(size_t bytes, hipStream_t writer)
     {
-        PoolBuf b{nullptr, nullptr};
+        PoolBuf b{nullptr, nullptr, nullptr};
         {
             std::lock_guard<std::mutex> lk(frames_mu);
             auto& v = frame_pool[bytes];
@@ -273,20 +282,23 @@ struct Ctx {
             HIP_CHECK(hipMalloc((void**)&b.p, bytes));
             return b.p;
         }
-        if (b.free_after) {
-            if (writer) HIP_CHECK(hipStreamWaitEvent(writer, b.free_after, 0));
-            else HIP_CHECK(hipEventSynchronize(b.free_after));
-            (void)hipEventDestroy(b.free_after);
+        for (hipEvent_t e : {b.free_after, b.free_after_det}) {
+            if (!e) continue;
+            if (writer) HIP_CHECK(hipStreamWaitEvent(writer, e, 0));
+            else HIP_CHECK(hipEventSynchronize(e));
+            (void)hipEventDestroy(e);
         }
         return b.p;
     }
     // frames_mu held by the caller
     void pool_give(uint8_t* p, size_t bytes)
     {
-        hipEvent_t e = nullptr;
+        hipEvent_t e = nullptr, e2 = nullptr;
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(e, stream));
-        frame_pool[bytes].push_back(PoolBuf{p, e});
+        HIP_CHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(e2, det_stream));
+        frame_pool[bytes].push_back(PoolBuf{p, e, e2});
         frame_pool_bytes += bytes;
     }
     uint64_t add_frame(const Frame& f)
@@ -305,8 +317,8 @@ struct Ctx {
 };
 
 struct ProfScope {
-    Ctx* c; ProfFamily* f = nullptr; hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(Ctx* ctx, const char* family);
+    Ctx* c; ProfFamily* f = nullptr; hipEvent_t a = nullptr, b = nullptr; hipStream_t s = nullptr;
+    ProfScope(Ctx* ctx, const char* family, hipStream_t on = nullptr);       // on: the stream the family's kernels run on (default: c->stream)
     ~ProfScope();
 };
 

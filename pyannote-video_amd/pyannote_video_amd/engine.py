@@ -661,6 +661,7 @@ class Engine(object):
             pending.append(msg)
             if msg[0] == "work":
                 counters["received"] += 1
+                ahead.release()                      # the shot's tracks exist: the detector may take another one on
 
         def run_pending(counters, force):
             """the faces that are waiting go through the landmark / embedding kernels, <= 4096 per library call (the network's largest
@@ -708,89 +709,127 @@ class Engine(object):
                         ready.put(("final done", job))
                 note("extracted", counters["extracted"] - 1)
 
+        # ---- two GPU-feeding threads (round 4), one per stream of the context:
+        #   detector thread   detect(k + 1): pyramids, FHOG, scoring, NMS on the detector's stream and lock -- needs nothing but frames
+        #   tracker thread    speculate(k): the bulk tracker starts + first updates; landmarks + descriptors of finished shots; on the
+        #                     context's main stream, whose entry points it shares (FairLock) with the on-demand tracker calls of the
+        #                     tracking thread.
+        # The detector of shot k + 1 (VALU- / MFMA-bound, fills the chip) runs BESIDE the latency-bound tracker and extraction work of
+        # shot k instead of after it (reference tracking.py:199-259 vs :426: independent across shots).
+        # shots that are detected (or being detected) and whose tracks do not exist yet -- their frames are resident: one in the detector,
+        # one in the bulk tracker work, one in the state machine (groups of shots: two groups)
+        limit = max(3, 2 * self.group)
+        ahead = threading.Semaphore(limit)
+        stop = threading.Event()
+
+        def detector_thread():
+            k = 0
+            try:
+                for item in source:
+                    if stop.is_set():
+                        return
+                    if isinstance(item, JobEnd):
+                        done.put(("jobend", item.job))
+                        continue
+                    while not ahead.acquire(timeout=0.05):
+                        if stop.is_set():
+                            release_shot_frames(item)
+                            return
+                    note("detect begin", k)
+                    raw, counts, boxes = self._detect(item, None)
+                    note("detected", k)
+                    done.put(("det", item, raw, counts, boxes))
+                    k += 1
+                done.put(("eof",))
+            except BaseException as e:      # noqa: BLE001 -- handed on to the caller's thread through the tracker thread
+                done.put(("error", e))
+
         def gpu_thread():
             counters = {"received": 0, "extracted": 0, "finals": 0}
             shots = ends = 0
             eager = self.extract_min <= 0
+            waiting = []                             # detections that arrived while the tracking thread is too far behind
+            group = []
+            eof = False
+
+            def flush():
+                if group:
+                    ready.put(("shots", list(group)))
+                    del group[:]
+
+            def speculate(msg):
+                nonlocal shots
+                _, si, raw, counts, boxes = msg
+                k = shots
+                if group and group[-1][0].job is not si.job:
+                    flush()
+                note("speculate begin", k)
+                with lock:
+                    lane_backend.release_dead()
+                    plans = self._speculate(si, backend, lane_backend, raw, counts, boxes)
+                note("speculated", k)
+                shots += 1
+                group.append((si, raw, plans))
+                if len(group) >= self.group or (n is not None and k == n - 1):
+                    flush()
+
+            def faces_waiting():
+                return sum(len(w[1]) for w in map(faces_of, pending) if w is not None)
+
             try:
-                def drain():
-                    """everything the tracking thread has handed back so far"""
-                    while True:
-                        try:
-                            msg = done.get_nowait()
-                        except queue.Empty:
+                while True:
+                    # what this thread could do now.  Bulk tracker work first (the tracking thread waits for it), but never more than
+                    # `limit` shots ahead of that thread (a slow state machine -- a crowded shot -- must not let detected shots pile up).
+                    can_spec = bool(waiting) and (waiting[0][0] == "jobend" or shots - counters["received"] < limit)
+                    last_call = eof and not waiting                  # nothing will be detected any more: whatever waits goes, whatever its size
+                    # Towards the end of a run of known length the faces of the last finished shots are held back until the LAST shot's
+                    # bulk tracker work is queued: its state machine (17-21 ms on the host, plus its on-demand tracker calls) then runs
+                    # beside ~25 ms of landmark / embedding kernels instead of leaving the GPU idle at the very end.
+                    hold = n is not None and shots < n and counters["extracted"] >= n - 3 and not last_call
+                    can_extract = bool(pending) and not hold and (last_call or eager or faces_waiting() >= self.extract_min)
+                    if last_call:
+                        flush()
+                        if not pending and counters["extracted"] >= shots and counters["finals"] >= ends:
                             break
-                        if msg is None:
-                            return False
-                        receive(msg, counters)
-                    run_pending(counters, eager)
-                    return True
-
-                group = []
-
-                def flush():
-                    if group:
-                        ready.put(("shots", list(group)))
-                        del group[:]
-
-                for item in source:
-                    if isinstance(item, JobEnd):
-                        flush()
-                        ends += 1
-                        ready.put(("end", item.job))
-                        continue
-                    si, k = item, shots
-                    if group and group[-1][0].job is not si.job:
-                        flush()
-                    # never more than three shots (or two groups) ahead of the tracking thread (a slow state machine -- a crowded shot --
-                    # must not let detected shots, i.e. their frames, pile up)
-                    while shots - counters["received"] >= max(3, 2 * self.group):
-                        msg = done.get()
-                        if msg is None:
-                            return
-                        receive(msg, counters)
-                        run_pending(counters, eager)
-                    note("detect begin", k)
-                    raw, counts, boxes = self._detect(si, lock)
-                    note("detected", k)
-                    # faces of the shots the tracking thread has finished meanwhile (it is idle now, so the host side of these
-                    # calls does not compete with its state machine for the interpreter; measured better than after speculate).
-                    # Towards the end of a run of known length the order changes: the faces of the last TWO finished shots are held
-                    # back until the last shot's bulk tracker work is queued, so that its state machine (17-21 ms on the host, plus
-                    # its on-demand tracker calls) runs beside ~34 ms of embedding instead of leaving the GPU idle at the very end.
-                    if n is None or k < n - 2:
-                        if not drain():
-                            return
-                    note("speculate begin", k)
-                    with lock:
-                        lane_backend.release_dead()
-                        plans = self._speculate(si, backend, lane_backend, raw, counts, boxes)
-                    note("speculated", k)
-                    shots += 1
-                    group.append((si, raw, plans))
-                    if len(group) >= self.group or (n is not None and k == n - 1):
-                        flush()
-                    if n is not None and k == n - 1:
-                        if not drain():
-                            return
-                flush()
-                ready.put(("stop",))
-                while counters["extracted"] < shots or counters["finals"] < ends:
-                    if pending and done.empty():
-                        run_pending(counters, True)          # nothing else to do: what waits goes now, whatever its size
-                        continue
-                    msg = done.get()
+                    try:
+                        msg = done.get_nowait() if (can_spec or can_extract) else done.get()
+                    except queue.Empty:
+                        msg = False
                     if msg is None:
                         return
-                    receive(msg, counters)
-                    if not drain():
-                        return
+                    if msg is not False:
+                        kind = msg[0]
+                        if kind == "error":
+                            raise msg[1]
+                        if kind in ("det", "jobend"):
+                            waiting.append(msg)                      # (a job's end keeps its place behind the job's last shot)
+                        elif kind == "eof":
+                            eof = True
+                        else:
+                            receive(msg, counters)
+                        continue                                     # look again: the state has changed
+                    if can_spec:
+                        w = waiting.pop(0)
+                        if w[0] == "jobend":
+                            flush()
+                            ends += 1
+                            ready.put(("end", w[1]))
+                        else:
+                            speculate(w)
+                        continue
+                    if can_extract:
+                        run_pending(counters, True)                  # (the decision was taken above)
+                flush()
+                ready.put(("stop",))
                 with lock:
                     lane_backend.release_dead()
                 ready.put(("idle",))
             except BaseException as e:      # noqa: BLE001 -- handed to the caller's thread
+                stop.set()
                 ready.put(e)
 
+        det_th = threading.Thread(target=detector_thread, name="pvface-detector")
+        det_th.start()
         th = threading.Thread(target=gpu_thread, name="pvface-gpu")
         th.start()
         finished, ok = [], False
@@ -839,8 +878,10 @@ class Engine(object):
             ok = True
         finally:
             if not ok:
+                stop.set()
                 done.put(None)
             th.join()
+            det_th.join()
             if not ok:
                 # an error on either side: the frames the engine staged go back to the pool now, not whenever the garbage collector (which
                 # a run switches off) finds their handles: shots still queued for this thread, then everything the jobs' stores hold

@@ -1,6 +1,7 @@
 """`Context`: one GPU, one HIP stream, the loaded models and the frames staged in HBM.  Thin Python over the C ABI."""
 import contextlib
 import ctypes as C
+import threading
 import numpy as np
 from . import _lib
 from ._lib import check, ptr, handles
@@ -99,6 +100,8 @@ class DeviceRows(object):
 
 
 class Context(object):
+    _stage_mu = threading.RLock()      # (instances make their own in __init__; this one serves objects built without it, e.g. test doubles)
+
     def __init__(self, device=0, detector=_models.DEFAULT_DETECTOR, landmarks=None, embedding=None, priority=0):
         self._h = None
         l = _lib.lib()
@@ -111,6 +114,7 @@ class Context(object):
         self._staged_order = []
         self.stage_capacity = 1024
         self._hold = 0         # > 0 while a call is collecting frame handles: nothing staged may be evicted until it has run
+        self._stage_mu = threading.RLock()   # the staging cache is used from the detector thread and the tracker / extraction threads
         self._tables = False
         self._models = {}
         if detector:
@@ -233,35 +237,39 @@ class Context(object):
         if isinstance(rgb, DeviceFrame):
             return rgb
         key = (id(rgb), rgb.__array_interface__["data"][0] if hasattr(rgb, "__array_interface__") else 0)
-        f = self._staged.get(key)
-        if f is None or f.keep is not rgb:
-            f = self.upload(rgb)
-            f.keep = rgb   # keeps the id stable while cached
-            self._staged[key] = f
-            self._staged_order.append(key)
-            if not self._hold:
-                self._trim()
-        return f
+        with self._stage_mu:
+            f = self._staged.get(key)
+            if f is None or f.keep is not rgb:
+                f = self.upload(rgb)
+                f.keep = rgb   # keeps the id stable while cached
+                self._staged[key] = f
+                self._staged_order.append(key)
+                if not self._hold:
+                    self._trim()
+            return f
 
     def _trim(self):
-        while len(self._staged_order) > self.stage_capacity:
-            old = self._staged_order.pop(0)
-            g = self._staged.pop(old, None)
-            if g is not None:
-                g.release()
+        with self._stage_mu:
+            while len(self._staged_order) > self.stage_capacity:
+                old = self._staged_order.pop(0)
+                g = self._staged.pop(old, None)
+                if g is not None:
+                    g.release()
 
     @contextlib.contextmanager
     def _staging(self):
         """Frames staged inside the block stay resident until the block ends: one call may reference more distinct numpy
         frames than the cache holds (a 4096-tracker batch of a long shot), and a handle released before the C call runs is
         an 'unknown frame handle'.  The cache is trimmed back to its capacity afterwards."""
-        self._hold += 1
+        with self._stage_mu:
+            self._hold += 1
         try:
             yield
         finally:
-            self._hold -= 1
-            if not self._hold:
-                self._trim()
+            with self._stage_mu:
+                self._hold -= 1
+                if not self._hold:
+                    self._trim()
 
     def _handles(self, frames):
         if isinstance(frames, np.ndarray) and frames.dtype == np.uint64:     # handles the caller looked up before (frame_handles)
