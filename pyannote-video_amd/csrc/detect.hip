@@ -846,11 +846,13 @@ static void check_dpp_direction(Ctx* c)
 {
     MlPlanCache* pc = c->ml_plans;
     if (pc->dpp_probe < 0) {
-        c->s_cand.ensure(128 * sizeof(int));            // (a detector-side buffer: s_misc belongs to the other stream's entry points)
-        hipLaunchKernelGGL(dpp_probe_k, dim3(1), dim3(64), 0, c->det_stream, c->s_cand.as<int>());
+        int* d = nullptr;                                // (a buffer of its own, once per context: every scratch buffer is somebody's state)
+        HIP_CHECK(hipMalloc((void**)&d, 128 * sizeof(int)));
+        hipLaunchKernelGGL(dpp_probe_k, dim3(1), dim3(64), 0, c->det_stream, d);
         int h[128];
-        HIP_CHECK(hipMemcpyAsync(h, c->s_cand.p, sizeof h, hipMemcpyDeviceToHost, c->det_stream));
+        HIP_CHECK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->det_stream));
         HIP_CHECK(hipStreamSynchronize(c->det_stream));
+        (void)hipFree(d);
         bool ok = true;
         for (int i = 0; i < 64; ++i) {
             ok = ok && h[i] == (i < 63 ? i + 101 : 0);
