@@ -9,8 +9,14 @@
  *   - every function returns 0 on success, <0 on error; pvf_last_error() gives the thread-local message;
  *     nothing throws or aborts across the boundary;
  *   - handles are opaque uint64_t; the caller owns every host buffer, the library owns device memory;
- *   - one HIP stream per context; a context serialises its own compute calls (they may come from any thread), different
- *     contexts (= different GPUs / ranks) run side by side in different threads or processes;
+ *   - TWO HIP streams per context, each with the entry points, the scratch buffers and the lock of its side: the DETECTOR side
+ *     (pvf_detect, pvf_detect_batch, pvf_detect_many, pvf_frame_resize: pyramid, FHOG and scoring kernels whose grids fill the chip)
+ *     and the rest (trackers, chips, landmarks, embedding, clustering, shot detection: latency-bound chains the host waits on,
+ *     on a stream of higher priority).  Calls of one side are serialised by the library (they may come from any thread); a call
+ *     of the detector side and a call of the other side run side by side, on the host and on the device -- the streaming engine
+ *     detects shot k + 1 in one thread while another tracks and extracts shot k.  Frames are read by both sides; a result the
+ *     other side consumes (detections -> tracker starts) passes through the host, which is the ordering between the two streams.
+ *     Different contexts (= different GPUs / ranks) run side by side in different threads or processes;
  *   - frames are uint8 RGB, HWC, C-contiguous (ref: pyannote/video/video.py:148-149,400-401);
  *   - there is NO CPU fallback: without a gfx950 device pvf_ctx_create fails.
  */
@@ -31,7 +37,7 @@ const char* pvf_last_error(void);
 int32_t pvf_version(void);
 int32_t pvf_device_count(int32_t* n);
 int32_t pvf_ctx_create(int32_t device, pvf_handle* ctx);
-/* same, choosing the HIP stream priority class: -1 low, 0 default, +1 high (latency-bound work such as trackers) */
+/* same, choosing the priority class of the context's main (non-detector) stream: -1 as low as the detector's stream, 0 / +1 above it */
 int32_t pvf_ctx_create_prio(int32_t device, int32_t priority_class, pvf_handle* ctx);
 int32_t pvf_ctx_destroy(pvf_handle ctx);
 int32_t pvf_sync(pvf_handle ctx);

@@ -250,7 +250,7 @@ static void prof_drain(Ctx* c)
     catch (const std::exception& e) { pvf_set_error(e.what()); return -1; } \
     catch (...) { pvf_set_error("unknown error"); return -2; }
 
-extern "C" int32_t pvf_version(void) { return 300; }      // round 3: streaming frame pool, thread-safe frame table, pvf_landmarks_embed, text rows
+extern "C" int32_t pvf_version(void) { return 400; }      // round 4: two streams per context, upper-triangle pair means, float32 in-memory clustering entries
 
 extern "C" int32_t pvf_device_count(int32_t* n)
 {
