@@ -302,6 +302,9 @@ def main():
         "hbm": hbm.report(frames_bytes=int(frames_t.numel()), engine=timed_engine),
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
         "kernel_families_ms": fam,
+        "kernel_families_note": "HIP-event time per family on the stream it runs on: the detector families (pyramid, fhog, score) on one stream, the rest on the "
+                                "other; the two streams run side by side, so the sum may exceed the steps' wall time, and a family's time includes "
+                                "what it lost to the other stream's kernels",
         "results": {"tracks": len(res["tracks"]), "faces_embedded": int(len(res["face_T"])), "clusters": n_clusters,
                     "tracks_clustered_globally": len(labels), "labels_sha256_16": labels_digest(labels),
                     "identities_in_video": len(set(tr["ident"] for shot in video.tracks for tr in shot))},
@@ -563,7 +566,9 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
                       "parallelism": "farm: clip i on rank i %% %d; one engine run per rank (detector of clip i + 1 beside the state machine of clip i)" % world,
                       "detect_batch": args.detect_batch, "collective": "none"},
            "roofline": {"kernel": "score_roll_k", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "avg_launch_ms": round(score_ms / launches, 4)},
+                        "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "traffic_note": "not measured for this configuration (a --pmc pass of its own)",
+                        "avg_launch_ms": round(score_ms / launches, 4)},
+           "e2e": e2e_object(flop_per_frame, sum(int(len(r["face_T"])) for r in results) * args.steps, len(mine) * args.frames * args.steps, elapsed),
            "cpu_baseline": cpu, "parity": parity,
            "kernel_families_ms": fam,
            "hbm": hbm.report(frames_bytes=sum(int(t.numel()) for t in tensors)),
