@@ -1006,6 +1006,13 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
     PVF_REQUIRE(!frames.empty() && batch > 0, "no frames");
     const int N = (int)frames.size();
     raw_sorted.assign(N, {});
+    // equal batches: a 250-frame shot at batch 128 runs as 125 + 125, not 128 + 122.  Launch plans (and the layout of the feature
+    // maps, zero border included) are per batch size: two sizes per shot meant two plans taking turns on the feature buffer and a
+    // pass re-zeroing the border before EVERY batch (2.6 ms per 1000 frames, profiles/r03_rocprof_kernel_stats.txt: feat_ring_zero_k)
+    {
+        const int nb = (N + batch - 1) / batch;
+        batch = (N + nb - 1) / nb;
+    }
     const int cap = c->det_cand_cap, PF = DET_PREFETCH;
     ScoreParams sp;
     for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
