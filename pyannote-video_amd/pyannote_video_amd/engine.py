@@ -102,10 +102,14 @@ class ExtractStream(object):
         self.face_boxes, self.face_T, self.face_id = [], [], []
         self.pts, self.emb = [], []
         self.emitted = []     # (frame index, T) of every group handed on, in order
+        # landmarks + descriptors computed AHEAD, right after a shot's detections exist (Engine._speculate_faces): {(frame index, box):
+        # (points, descriptor)}.  Both are functions of the frame and the box alone, so a face whose final box turns out to be the one
+        # predicted from its detection takes its result from here; any other face is computed when its track exists, as before.
+        self.spec = {}
 
     def _emit(self, available):
         """faces of the groups that may be handed on now: (frames, boxes, frame index below which every face has been handed on)"""
-        face_frames, boxes = [], []
+        face_frames, boxes, keys = [], [], []
         times = self.times
         while self.fi < len(times) and self.gi < available:
             T, g = self.groups[self.gi]
@@ -114,12 +118,13 @@ class ExtractStream(object):
                 continue
             for ident, box in g:
                 face_frames.append(self.frames[self.fi]); boxes.append(box)
+                keys.append((self.fi, box))
                 self.face_T.append(T); self.face_id.append(ident)
             self.emitted.append((self.fi, T))
             self.gi += 1
             self.fi += 1
         self.face_boxes.extend(boxes)
-        return face_frames, boxes, self.fi
+        return face_frames, boxes, self.fi, keys
 
     def compute(self, work):
         """GPU part: landmarks + embeddings of one batch of faces returned by prepare(); batches must arrive in order"""
@@ -202,29 +207,51 @@ class ExtractStream(object):
 EXTRACT_CALL_MAX = 4096          # faces per landmark / embedding call (the network's largest forward)
 
 
+def landmarks_embed(ctx, frames, boxes):
+    if hasattr(ctx, "landmarks_embed"):
+        return ctx.landmarks_embed(frames, boxes)          # one library call: no interpreter between the two stages
+    pts = ctx.landmarks(frames, boxes)
+    return pts, ctx.embed(frames, pts)
+
+
 def compute_many(ctx, items):
     """landmarks + embeddings of several batches -- [(ExtractStream, work)], possibly of different videos -- in ONE library call (a call
     costs 2-4 ms of idle GPU around its kernels whatever its size, and the deep layers of the network fill the chip only from a
-    few thousand faces on); every stream receives its own rows, in order"""
-    frames, boxes, cuts = [], [], []
+    few thousand faces on); every stream receives its own rows, in order.  Faces whose result was computed ahead (ExtractStream.spec)
+    take it from there; only the others go to the GPU."""
+    frames, boxes, cuts, found = [], [], [], []
     for ex, work in items:
-        if work is not None and work[1]:
+        if work is None or not work[1]:
+            continue
+        keys = work[3] if len(work) > 3 else None
+        got = [ex.spec.pop(k, None) for k in keys] if (keys and ex.spec) else [None] * len(work[1])
+        miss = [i for i, g in enumerate(got) if g is None]
+        if len(miss) == len(got):
             frames.extend(work[0]); boxes.extend(work[1])
-            cuts.append((ex, len(work[1])))
-    if not boxes:
+        else:
+            frames.extend(work[0][i] for i in miss); boxes.extend(work[1][i] for i in miss)
+        cuts.append((ex, len(got), miss))
+        found.append(got)
+    if not cuts:
         return
-    if hasattr(ctx, "landmarks_embed"):
-        pts, emb = ctx.landmarks_embed(frames, boxes)      # one library call: no interpreter between the two stages
-    else:
-        pts = ctx.landmarks(frames, boxes)
-        emb = ctx.embed(frames, pts)
-    if len(cuts) == 1:
-        cuts[0][0].pts.append(pts); cuts[0][0].emb.append(emb)
-        return
+    pts = emb = None
+    if boxes:
+        pts, emb = landmarks_embed(ctx, frames, boxes)
     a = 0
-    for ex, m in cuts:
-        ex.pts.append(pts[a:a + m]); ex.emb.append(emb[a:a + m])
-        a += m
+    for (ex, m, miss), got in zip(cuts, found):
+        if len(miss) == m:                                   # nothing was computed ahead: the rows as they came
+            ex.pts.append(pts[a:a + m]); ex.emb.append(emb[a:a + m])
+            a += m
+            continue
+        p = np.empty((m, 68, 2), np.int32)
+        e = np.empty((m, 128), np.float32)
+        hit = [i for i in range(m) if got[i] is not None]
+        if hit:
+            p[hit] = np.stack([got[i][0] for i in hit]); e[hit] = np.stack([got[i][1] for i in hit])
+        if miss:
+            p[miss] = pts[a:a + len(miss)]; e[miss] = emb[a:a + len(miss)]
+            a += len(miss)
+        ex.pts.append(p); ex.emb.append(e)
 
 
 def detections_as_lists(n_frames, raw):
@@ -520,6 +547,9 @@ class Engine(object):
         # is there).  A run over many short videos sets it: their per-shot and end-of-video batches are small, and a call's fixed
         # cost is paid per call (compute_many)
         self.extract_min = int(extract_min)
+        # landmarks + descriptors of a shot's DETECTIONS are computed as soon as the detections exist, beside the shot's state machine,
+        # instead of after it (pipelined runs; shots whose bulk tracker work is windowed keep the GPU for that).  See _speculate_faces.
+        self.speculate_faces = os.environ.get("PVF_SPECULATE_FACES", "1") != "0"
         self.stats = {}
 
     # ---- the GPU-side work of one shot ---------------------------------------------------------------------------------------
@@ -584,6 +614,37 @@ class Engine(object):
                     WindowedPlan(lane_backend, fh[::-1].copy(), times[::-1], cnt[::-1].copy(), rev, self.speculate_window))
         det_at = {t: d for (t, _), d in zip(cache, detections_as_lists(len(cache), raw))}
         return backend.speculate(cache, det_at), backend.speculate(list(reversed(cache)), det_at)
+
+    def _speculate_faces(self, si, counts, boxes, lock):
+        """`extract` computes landmarks and a descriptor for every row of the track file: frame, box (pyannote-face.py:287-311).  Both are
+        functions of the frame and the box alone, and with a detection on the frame the row's box IS the detection (tracking.py:261-296
+        averages the boxes of one timestamp: the detection node both passes share) after its trip through the file: normalised
+        (tracking.py:432), written with 3 decimals, parsed as float32, multiplied back and truncated (pyannote-face.py:125-145).  So the
+        faces of a shot can be computed from its detections alone, while the tracking thread is still deciding which track each belongs
+        to -- for the LAST shot of a video that takes the extraction off the end of the run.  Results wait in ExtractStream.spec under
+        (frame index, box); a face whose final box differs (merged with tracker boxes, a frame served late) misses and is computed as
+        before; what is never asked for (the reference's dropped last group) is discarded with the job."""
+        job = si.job
+        n = int(len(boxes))
+        if job.ex is None or n == 0 or n > self.speculate_limit:
+            return
+        natives = si.natives if si.natives is not None else [f for _, f in si.cache]
+        owner = np.repeat(np.arange(len(si.cache)), np.asarray(counts, np.int64)).tolist()
+        dims_det = np.array([job.tw, job.th, job.tw, job.th], np.float64)
+        dims_nat = np.array([job.w, job.h, job.w, job.h], np.float64)
+        norm = (np.asarray(boxes, np.float64) / dims_det).ravel().tolist()                      # TrackingByDetection._normalize_track
+        q = np.asarray([round(v, 3) for v in norm], np.float64).astype(np.float32).astype(np.float64).reshape(-1, 4)   # ExtractStream.prepare
+        ints = np.trunc(q * dims_nat).astype(np.int64).tolist()                                 # formats.denormalise
+        rects = [tuple(r) for r in ints]
+        frames = [natives[i] for i in owner]
+        spec = job.ex.spec
+        for a in range(0, n, EXTRACT_CALL_MAX):
+            b = min(n, a + EXTRACT_CALL_MAX)
+            with lock:
+                pts, emb = landmarks_embed(self.ctx, frames[a:b], rects[a:b])
+            for k in range(a, b):
+                spec[(si.base + owner[k], rects[k])] = (pts[k - a], emb[k - a])
+        self.stats["faces_speculated"] = self.stats.get("faces_speculated", 0) + n
 
     # ---- sequential form (no GPU-feeding thread): every stage in the caller's thread, shot after shot --------------------------
     def _run_sequential(self, source, backend):
@@ -687,7 +748,7 @@ class Engine(object):
                         a, n_w = 0, len(w[1])
                         while a < n_w:
                             b = min(n_w, a + EXTRACT_CALL_MAX - m)
-                            piece.append((ex, (w[0][a:b], w[1][a:b])))
+                            piece.append((ex, (w[0][a:b], w[1][a:b], None, w[3][a:b] if len(w) > 3 else None)))
                             m += b - a
                             a = b
                             if m >= EXTRACT_CALL_MAX:
@@ -772,6 +833,10 @@ class Engine(object):
                 group.append((si, raw, plans))
                 if len(group) >= self.group or (n is not None and k == n - 1):
                     flush()
+                if self.speculate_faces:
+                    note("faces ahead begin", k)
+                    self._speculate_faces(si, counts, boxes, lock)
+                    note("faces ahead done", k)
 
             def faces_waiting():
                 return sum(len(w[1]) for w in map(faces_of, pending) if w is not None)

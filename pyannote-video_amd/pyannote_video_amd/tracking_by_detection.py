@@ -49,6 +49,16 @@ def get_min_max_t(track):
     return (min(t for t, _, _ in track), max(t for t, _, _ in track))
 
 
+def _floats(a):
+    """confidences of a batch as Python floats (the values float(a[k]) gives, in one conversion)"""
+    return a.tolist() if hasattr(a, "tolist") else [float(v) for v in a]
+
+
+def _rows(a):
+    """positions of a batch as tuples of Python floats (tuple(float(v) for v in a[k]) for every row, in one conversion)"""
+    return [tuple(r) for r in a.tolist()] if hasattr(a, "tolist") else [tuple(float(v) for v in r) for r in a]
+
+
 class HipTrackers(object):
     """Batched tracker backend on one Context (default)."""
 
@@ -390,8 +400,9 @@ class TrackingByDetection(object):
                     yield ('commit', [trackers[i] for i in late], [uncommitted.pop(i) for i in late])
                 if need:
                     psr, boxes = yield ('update', [trackers[i] for i in need], [frame] * len(need))
+                    psr, boxes = _floats(psr), _rows(boxes)          # Python floats, one conversion per batch
                     for k, identifier in enumerate(need):
-                        fresh[identifier] = (float(psr[k]), tuple(float(v) for v in boxes[k]))
+                        fresh[identifier] = (psr[k], boxes[k])
                 for identifier in ids:
                     if deferring and identifier in cached:
                         uncommitted[identifier] = frame
@@ -420,11 +431,13 @@ class TrackingByDetection(object):
                 else:
                     handles = yield ('start', [frame] * len(detections), [tuple(float(v) for v in d) for d in detections])
                     ppsr = ppos = None
+                if ppsr is not None:
+                    ppsr, ppos = _floats(ppsr), _rows(ppos)
                 for d, detection in enumerate(detections):
                     trackers[new_identifier] = handles[d]
                     previous[new_identifier] = (t, detection, DETECTION)
                     if ppsr is not None:
-                        cached[new_identifier] = (float(ppsr[d]), tuple(float(v) for v in ppos[d]))
+                        cached[new_identifier] = (ppsr[d], ppos[d])
                     new_identifier += 1
         for identifier in list(trackers):
             h = kill(identifier)
