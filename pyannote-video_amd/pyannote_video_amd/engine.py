@@ -102,10 +102,12 @@ class ExtractStream(object):
         self.face_boxes, self.face_T, self.face_id = [], [], []
         self.pts, self.emb = [], []
         self.emitted = []     # (frame index, T) of every group handed on, in order
-        # landmarks + descriptors computed AHEAD, right after a shot's detections exist (Engine._speculate_faces): {(frame index, box):
-        # (points, descriptor)}.  Both are functions of the frame and the box alone, so a face whose final box turns out to be the one
-        # predicted from its detection takes its result from here; any other face is computed when its track exists, as before.
-        self.spec = {}
+        # landmarks + descriptors computed AHEAD, right after a shot's detections exist (Engine.plan_faces / run_faces).  Both are
+        # functions of the frame and the box alone, so a face whose final box turns out to be the one predicted from its detection takes
+        # its result from here; any other face is computed when its track exists, as before.
+        self.spec_index = {}      # (frame index, box) -> row in the results computed ahead
+        self.spec_blocks = []     # [(first row, points [m, 68, 2], descriptors [m, 128])] one block per shot, in order
+        self.spec_rows = 0
 
     def _emit(self, available):
         """faces of the groups that may be handed on now: (frames, boxes, frame index below which every face has been handed on)"""
@@ -217,38 +219,47 @@ def landmarks_embed(ctx, frames, boxes):
 def compute_many(ctx, items):
     """landmarks + embeddings of several batches -- [(ExtractStream, work)], possibly of different videos -- in ONE library call (a call
     costs 2-4 ms of idle GPU around its kernels whatever its size, and the deep layers of the network fill the chip only from a
-    few thousand faces on); every stream receives its own rows, in order.  Faces whose result was computed ahead (ExtractStream.spec)
+    few thousand faces on); every stream receives its own rows, in order.  Faces whose result was computed ahead (ExtractStream.spec_*)
     take it from there; only the others go to the GPU."""
-    frames, boxes, cuts, found = [], [], [], []
+    frames, boxes, cuts = [], [], []
     for ex, work in items:
         if work is None or not work[1]:
             continue
+        m = len(work[1])
         keys = work[3] if len(work) > 3 else None
-        got = [ex.spec.pop(k, None) for k in keys] if (keys and ex.spec) else [None] * len(work[1])
-        miss = [i for i, g in enumerate(got) if g is None]
-        if len(miss) == len(got):
+        rows = None
+        if keys and ex.spec_index:
+            pop = ex.spec_index.pop
+            rows = np.fromiter((pop(k, -1) for k in keys), np.int64, m)
+            if (rows < 0).all():
+                rows = None
+        if rows is None:
             frames.extend(work[0]); boxes.extend(work[1])
+            cuts.append((ex, m, None, None))
         else:
-            frames.extend(work[0][i] for i in miss); boxes.extend(work[1][i] for i in miss)
-        cuts.append((ex, len(got), miss))
-        found.append(got)
+            miss = np.nonzero(rows < 0)[0]
+            if len(miss):
+                ml = miss.tolist()
+                frames.extend(work[0][i] for i in ml); boxes.extend(work[1][i] for i in ml)
+            cuts.append((ex, m, rows, miss))
     if not cuts:
         return
     pts = emb = None
     if boxes:
         pts, emb = landmarks_embed(ctx, frames, boxes)
     a = 0
-    for (ex, m, miss), got in zip(cuts, found):
-        if len(miss) == m:                                   # nothing was computed ahead: the rows as they came
+    for ex, m, rows, miss in cuts:
+        if rows is None:                                     # nothing was computed ahead: the rows as they came
             ex.pts.append(pts[a:a + m]); ex.emb.append(emb[a:a + m])
             a += m
             continue
         p = np.empty((m, 68, 2), np.int32)
         e = np.empty((m, 128), np.float32)
-        hit = [i for i in range(m) if got[i] is not None]
-        if hit:
-            p[hit] = np.stack([got[i][0] for i in hit]); e[hit] = np.stack([got[i][1] for i in hit])
-        if miss:
+        for first, bp, be in ex.spec_blocks:                 # (a batch's faces come from one or two shots: one or two gathers)
+            sel = np.nonzero((rows >= first) & (rows < first + len(bp)))[0]
+            if len(sel):
+                p[sel] = bp[rows[sel] - first]; e[sel] = be[rows[sel] - first]
+        if len(miss):
             p[miss] = pts[a:a + len(miss)]; e[miss] = emb[a:a + len(miss)]
             a += len(miss)
         ex.pts.append(p); ex.emb.append(e)
@@ -615,35 +626,46 @@ class Engine(object):
         det_at = {t: d for (t, _), d in zip(cache, detections_as_lists(len(cache), raw))}
         return backend.speculate(cache, det_at), backend.speculate(list(reversed(cache)), det_at)
 
-    def _speculate_faces(self, si, counts, boxes, lock):
+    def plan_faces(self, si, counts, boxes):
         """`extract` computes landmarks and a descriptor for every row of the track file: frame, box (pyannote-face.py:287-311).  Both are
         functions of the frame and the box alone, and with a detection on the frame the row's box IS the detection (tracking.py:261-296
         averages the boxes of one timestamp: the detection node both passes share) after its trip through the file: normalised
         (tracking.py:432), written with 3 decimals, parsed as float32, multiplied back and truncated (pyannote-face.py:125-145).  So the
         faces of a shot can be computed from its detections alone, while the tracking thread is still deciding which track each belongs
-        to -- for the LAST shot of a video that takes the extraction off the end of the run.  Results wait in ExtractStream.spec under
-        (frame index, box); a face whose final box differs (merged with tracker boxes, a frame served late) misses and is computed as
+        to -- for the LAST shot of a video that takes the extraction off the end of the run.  This is the host part: (frames, boxes,
+        keys) of the shot's detections, made in the detector thread while the tracker thread's bulk tracker call runs (the interpreter
+        is free then).  A face whose final box differs (merged with tracker boxes, a frame served late) misses and is computed as
         before; what is never asked for (the reference's dropped last group) is discarded with the job."""
         job = si.job
         n = int(len(boxes))
-        if job.ex is None or n == 0 or n > self.speculate_limit:
-            return
+        if not self.speculate_faces or job.ex is None or n == 0 or n > self.speculate_limit:
+            return None
         natives = si.natives if si.natives is not None else [f for _, f in si.cache]
         owner = np.repeat(np.arange(len(si.cache)), np.asarray(counts, np.int64)).tolist()
         dims_det = np.array([job.tw, job.th, job.tw, job.th], np.float64)
         dims_nat = np.array([job.w, job.h, job.w, job.h], np.float64)
         norm = (np.asarray(boxes, np.float64) / dims_det).ravel().tolist()                      # TrackingByDetection._normalize_track
         q = np.asarray([round(v, 3) for v in norm], np.float64).astype(np.float32).astype(np.float64).reshape(-1, 4)   # ExtractStream.prepare
-        ints = np.trunc(q * dims_nat).astype(np.int64).tolist()                                 # formats.denormalise
-        rects = [tuple(r) for r in ints]
-        frames = [natives[i] for i in owner]
-        spec = job.ex.spec
+        rects = [tuple(r) for r in np.trunc(q * dims_nat).astype(np.int64).tolist()]            # formats.denormalise
+        base = si.base
+        return [natives[i] for i in owner], rects, [(base + i, r) for i, r in zip(owner, rects)]
+
+    def run_faces(self, ex, plan, lock):
+        """the GPU part, in the tracker thread right after the shot's bulk tracker work: one landmark + descriptor call per <= 4096 faces;
+        the rows stay as arrays, a dictionary maps (frame index, box) to its row"""
+        frames, rects, keys = plan
+        n = len(rects)
+        parts = []
         for a in range(0, n, EXTRACT_CALL_MAX):
             b = min(n, a + EXTRACT_CALL_MAX)
             with lock:
-                pts, emb = landmarks_embed(self.ctx, frames[a:b], rects[a:b])
-            for k in range(a, b):
-                spec[(si.base + owner[k], rects[k])] = (pts[k - a], emb[k - a])
+                parts.append(landmarks_embed(self.ctx, frames[a:b], rects[a:b]))
+        pts = parts[0][0] if len(parts) == 1 else np.concatenate([p for p, _ in parts])
+        emb = parts[0][1] if len(parts) == 1 else np.concatenate([e for _, e in parts])
+        first = ex.spec_rows
+        ex.spec_blocks.append((first, pts, emb))
+        ex.spec_rows += n
+        ex.spec_index.update(zip(keys, range(first, first + n)))      # (two detections with one box on one frame: the later row wins, same values)
         self.stats["faces_speculated"] = self.stats.get("faces_speculated", 0) + n
 
     # ---- sequential form (no GPU-feeding thread): every stage in the caller's thread, shot after shot --------------------------
@@ -800,6 +822,9 @@ class Engine(object):
                     raw, counts, boxes = self._detect(item, None)
                     note("detected", k)
                     done.put(("det", item, raw, counts, boxes))
+                    plan = self.plan_faces(item, counts, boxes)          # (beside the tracker thread's bulk tracker call for this shot)
+                    if plan is not None:
+                        done.put(("faces", item.job.ex, plan))
                     k += 1
                 done.put(("eof",))
             except BaseException as e:      # noqa: BLE001 -- handed on to the caller's thread through the tracker thread
@@ -833,10 +858,6 @@ class Engine(object):
                 group.append((si, raw, plans))
                 if len(group) >= self.group or (n is not None and k == n - 1):
                     flush()
-                if self.speculate_faces:
-                    note("faces ahead begin", k)
-                    self._speculate_faces(si, counts, boxes, lock)
-                    note("faces ahead done", k)
 
             def faces_waiting():
                 return sum(len(w[1]) for w in map(faces_of, pending) if w is not None)
@@ -845,7 +866,7 @@ class Engine(object):
                 while True:
                     # what this thread could do now.  Bulk tracker work first (the tracking thread waits for it), but never more than
                     # `limit` shots ahead of that thread (a slow state machine -- a crowded shot -- must not let detected shots pile up).
-                    can_spec = bool(waiting) and (waiting[0][0] == "jobend" or shots - counters["received"] < limit)
+                    can_spec = bool(waiting) and (waiting[0][0] in ("jobend", "faces") or shots - counters["received"] < limit)
                     last_call = eof and not waiting                  # nothing will be detected any more: whatever waits goes, whatever its size
                     # Towards the end of a run of known length the faces of the last finished shots are held back until the LAST shot's
                     # bulk tracker work is queued: its state machine (17-21 ms on the host, plus its on-demand tracker calls) then runs
@@ -866,7 +887,7 @@ class Engine(object):
                         kind = msg[0]
                         if kind == "error":
                             raise msg[1]
-                        if kind in ("det", "jobend"):
+                        if kind in ("det", "jobend", "faces"):
                             waiting.append(msg)                      # (a job's end keeps its place behind the job's last shot)
                         elif kind == "eof":
                             eof = True
@@ -879,6 +900,10 @@ class Engine(object):
                             flush()
                             ends += 1
                             ready.put(("end", w[1]))
+                        elif w[0] == "faces":
+                            note("faces ahead begin")
+                            self.run_faces(w[1], w[2], lock)
+                            note("faces ahead done")
                         else:
                             speculate(w)
                         continue
