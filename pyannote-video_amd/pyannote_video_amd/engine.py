@@ -656,8 +656,9 @@ class Engine(object):
         frames, rects, keys = plan
         n = len(rects)
         parts = []
-        for a in range(0, n, EXTRACT_CALL_MAX):
-            b = min(n, a + EXTRACT_CALL_MAX)
+        step = min(EXTRACT_CALL_MAX, 512)           # short calls: the tracking thread's on-demand tracker calls get the context in between
+        for a in range(0, n, step):
+            b = min(n, a + step)
             with lock:
                 parts.append(landmarks_embed(self.ctx, frames[a:b], rects[a:b]))
         pts = parts[0][0] if len(parts) == 1 else np.concatenate([p for p, _ in parts])
@@ -822,9 +823,13 @@ class Engine(object):
                     raw, counts, boxes = self._detect(item, None)
                     note("detected", k)
                     done.put(("det", item, raw, counts, boxes))
-                    plan = self.plan_faces(item, counts, boxes)          # (beside the tracker thread's bulk tracker call for this shot)
-                    if plan is not None:
-                        done.put(("faces", item.job.ex, plan))
+                    # the LAST shot of a run of known length: its faces are computed ahead, beside its state machine (for the other
+                    # shots extraction is off the critical path anyway, and computing ahead there only competes with the detector);
+                    # planned here while the tracker thread's bulk tracker call for the shot runs
+                    if n is not None and k == n - 1:
+                        plan = self.plan_faces(item, counts, boxes)
+                        if plan is not None:
+                            done.put(("faces", item.job.ex, plan))
                     k += 1
                 done.put(("eof",))
             except BaseException as e:      # noqa: BLE001 -- handed on to the caller's thread through the tracker thread
