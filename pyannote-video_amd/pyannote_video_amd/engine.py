@@ -656,7 +656,7 @@ class Engine(object):
         frames, rects, keys = plan
         n = len(rects)
         parts = []
-        step = min(EXTRACT_CALL_MAX, 512)           # short calls: the tracking thread's on-demand tracker calls get the context in between
+        step = min(EXTRACT_CALL_MAX, 1024)          # short calls: the tracking thread's on-demand tracker calls get the context in between
         for a in range(0, n, step):
             b = min(n, a + step)
             with lock:
@@ -876,7 +876,8 @@ class Engine(object):
                     # Towards the end of a run of known length the faces of the last finished shots are held back until the LAST shot's
                     # bulk tracker work is queued: its state machine (17-21 ms on the host, plus its on-demand tracker calls) then runs
                     # beside ~25 ms of landmark / embedding kernels instead of leaving the GPU idle at the very end.
-                    hold = n is not None and shots < n and counters["extracted"] >= n - 3 and not last_call
+                    # (with the last shot's own faces computed ahead in that window too, only ONE finished shot is held back for it)
+                    hold = n is not None and shots < n and counters["extracted"] >= n - (2 if self.speculate_faces else 3) and not last_call
                     can_extract = bool(pending) and not hold and (last_call or eager or faces_waiting() >= self.extract_min)
                     if last_call:
                         flush()
