@@ -102,16 +102,10 @@ class ExtractStream(object):
         self.face_boxes, self.face_T, self.face_id = [], [], []
         self.pts, self.emb = [], []
         self.emitted = []     # (frame index, T) of every group handed on, in order
-        # landmarks + descriptors computed AHEAD, right after a shot's detections exist (Engine.plan_faces / run_faces).  Both are
-        # functions of the frame and the box alone, so a face whose final box turns out to be the one predicted from its detection takes
-        # its result from here; any other face is computed when its track exists, as before.
-        self.spec_index = {}      # (frame index, box) -> row in the results computed ahead
-        self.spec_blocks = []     # [(first row, points [m, 68, 2], descriptors [m, 128])] one block per shot, in order
-        self.spec_rows = 0
 
     def _emit(self, available):
         """faces of the groups that may be handed on now: (frames, boxes, frame index below which every face has been handed on)"""
-        face_frames, boxes, keys = [], [], []
+        face_frames, boxes = [], []
         times = self.times
         while self.fi < len(times) and self.gi < available:
             T, g = self.groups[self.gi]
@@ -120,13 +114,12 @@ class ExtractStream(object):
                 continue
             for ident, box in g:
                 face_frames.append(self.frames[self.fi]); boxes.append(box)
-                keys.append((self.fi, box))
                 self.face_T.append(T); self.face_id.append(ident)
             self.emitted.append((self.fi, T))
             self.gi += 1
             self.fi += 1
         self.face_boxes.extend(boxes)
-        return face_frames, boxes, self.fi, keys
+        return face_frames, boxes, self.fi
 
     def compute(self, work):
         """GPU part: landmarks + embeddings of one batch of faces returned by prepare(); batches must arrive in order"""
@@ -209,60 +202,29 @@ class ExtractStream(object):
 EXTRACT_CALL_MAX = 4096          # faces per landmark / embedding call (the network's largest forward)
 
 
-def landmarks_embed(ctx, frames, boxes):
-    if hasattr(ctx, "landmarks_embed"):
-        return ctx.landmarks_embed(frames, boxes)          # one library call: no interpreter between the two stages
-    pts = ctx.landmarks(frames, boxes)
-    return pts, ctx.embed(frames, pts)
-
-
 def compute_many(ctx, items):
     """landmarks + embeddings of several batches -- [(ExtractStream, work)], possibly of different videos -- in ONE library call (a call
     costs 2-4 ms of idle GPU around its kernels whatever its size, and the deep layers of the network fill the chip only from a
-    few thousand faces on); every stream receives its own rows, in order.  Faces whose result was computed ahead (ExtractStream.spec_*)
-    take it from there; only the others go to the GPU."""
+    few thousand faces on); every stream receives its own rows, in order"""
     frames, boxes, cuts = [], [], []
     for ex, work in items:
-        if work is None or not work[1]:
-            continue
-        m = len(work[1])
-        keys = work[3] if len(work) > 3 else None
-        rows = None
-        if keys and ex.spec_index:
-            pop = ex.spec_index.pop
-            rows = np.fromiter((pop(k, -1) for k in keys), np.int64, m)
-            if (rows < 0).all():
-                rows = None
-        if rows is None:
+        if work is not None and work[1]:
             frames.extend(work[0]); boxes.extend(work[1])
-            cuts.append((ex, m, None, None))
-        else:
-            miss = np.nonzero(rows < 0)[0]
-            if len(miss):
-                ml = miss.tolist()
-                frames.extend(work[0][i] for i in ml); boxes.extend(work[1][i] for i in ml)
-            cuts.append((ex, m, rows, miss))
-    if not cuts:
+            cuts.append((ex, len(work[1])))
+    if not boxes:
         return
-    pts = emb = None
-    if boxes:
-        pts, emb = landmarks_embed(ctx, frames, boxes)
+    if hasattr(ctx, "landmarks_embed"):
+        pts, emb = ctx.landmarks_embed(frames, boxes)      # one library call: no interpreter between the two stages
+    else:
+        pts = ctx.landmarks(frames, boxes)
+        emb = ctx.embed(frames, pts)
+    if len(cuts) == 1:
+        cuts[0][0].pts.append(pts); cuts[0][0].emb.append(emb)
+        return
     a = 0
-    for ex, m, rows, miss in cuts:
-        if rows is None:                                     # nothing was computed ahead: the rows as they came
-            ex.pts.append(pts[a:a + m]); ex.emb.append(emb[a:a + m])
-            a += m
-            continue
-        p = np.empty((m, 68, 2), np.int32)
-        e = np.empty((m, 128), np.float32)
-        for first, bp, be in ex.spec_blocks:                 # (a batch's faces come from one or two shots: one or two gathers)
-            sel = np.nonzero((rows >= first) & (rows < first + len(bp)))[0]
-            if len(sel):
-                p[sel] = bp[rows[sel] - first]; e[sel] = be[rows[sel] - first]
-        if len(miss):
-            p[miss] = pts[a:a + len(miss)]; e[miss] = emb[a:a + len(miss)]
-            a += len(miss)
-        ex.pts.append(p); ex.emb.append(e)
+    for ex, m in cuts:
+        ex.pts.append(pts[a:a + m]); ex.emb.append(emb[a:a + m])
+        a += m
 
 
 def detections_as_lists(n_frames, raw):
@@ -558,9 +520,6 @@ class Engine(object):
         # is there).  A run over many short videos sets it: their per-shot and end-of-video batches are small, and a call's fixed
         # cost is paid per call (compute_many)
         self.extract_min = int(extract_min)
-        # landmarks + descriptors of a shot's DETECTIONS are computed as soon as the detections exist, beside the shot's state machine,
-        # instead of after it (pipelined runs; shots whose bulk tracker work is windowed keep the GPU for that).  See _speculate_faces.
-        self.speculate_faces = os.environ.get("PVF_SPECULATE_FACES", "1") != "0"
         self.stats = {}
 
     # ---- the GPU-side work of one shot ---------------------------------------------------------------------------------------
@@ -625,49 +584,6 @@ class Engine(object):
                     WindowedPlan(lane_backend, fh[::-1].copy(), times[::-1], cnt[::-1].copy(), rev, self.speculate_window))
         det_at = {t: d for (t, _), d in zip(cache, detections_as_lists(len(cache), raw))}
         return backend.speculate(cache, det_at), backend.speculate(list(reversed(cache)), det_at)
-
-    def plan_faces(self, si, counts, boxes):
-        """`extract` computes landmarks and a descriptor for every row of the track file: frame, box (pyannote-face.py:287-311).  Both are
-        functions of the frame and the box alone, and with a detection on the frame the row's box IS the detection (tracking.py:261-296
-        averages the boxes of one timestamp: the detection node both passes share) after its trip through the file: normalised
-        (tracking.py:432), written with 3 decimals, parsed as float32, multiplied back and truncated (pyannote-face.py:125-145).  So the
-        faces of a shot can be computed from its detections alone, while the tracking thread is still deciding which track each belongs
-        to -- for the LAST shot of a video that takes the extraction off the end of the run.  This is the host part: (frames, boxes,
-        keys) of the shot's detections, made in the detector thread while the tracker thread's bulk tracker call runs (the interpreter
-        is free then).  A face whose final box differs (merged with tracker boxes, a frame served late) misses and is computed as
-        before; what is never asked for (the reference's dropped last group) is discarded with the job."""
-        job = si.job
-        n = int(len(boxes))
-        if not self.speculate_faces or job.ex is None or n == 0 or n > self.speculate_limit:
-            return None
-        natives = si.natives if si.natives is not None else [f for _, f in si.cache]
-        owner = np.repeat(np.arange(len(si.cache)), np.asarray(counts, np.int64)).tolist()
-        dims_det = np.array([job.tw, job.th, job.tw, job.th], np.float64)
-        dims_nat = np.array([job.w, job.h, job.w, job.h], np.float64)
-        norm = (np.asarray(boxes, np.float64) / dims_det).ravel().tolist()                      # TrackingByDetection._normalize_track
-        q = np.asarray([round(v, 3) for v in norm], np.float64).astype(np.float32).astype(np.float64).reshape(-1, 4)   # ExtractStream.prepare
-        rects = [tuple(r) for r in np.trunc(q * dims_nat).astype(np.int64).tolist()]            # formats.denormalise
-        base = si.base
-        return [natives[i] for i in owner], rects, [(base + i, r) for i, r in zip(owner, rects)]
-
-    def run_faces(self, ex, plan, lock):
-        """the GPU part, in the tracker thread right after the shot's bulk tracker work: one landmark + descriptor call per <= 4096 faces;
-        the rows stay as arrays, a dictionary maps (frame index, box) to its row"""
-        frames, rects, keys = plan
-        n = len(rects)
-        parts = []
-        step = min(EXTRACT_CALL_MAX, 1024)          # short calls: the tracking thread's on-demand tracker calls get the context in between
-        for a in range(0, n, step):
-            b = min(n, a + step)
-            with lock:
-                parts.append(landmarks_embed(self.ctx, frames[a:b], rects[a:b]))
-        pts = parts[0][0] if len(parts) == 1 else np.concatenate([p for p, _ in parts])
-        emb = parts[0][1] if len(parts) == 1 else np.concatenate([e for _, e in parts])
-        first = ex.spec_rows
-        ex.spec_blocks.append((first, pts, emb))
-        ex.spec_rows += n
-        ex.spec_index.update(zip(keys, range(first, first + n)))      # (two detections with one box on one frame: the later row wins, same values)
-        self.stats["faces_speculated"] = self.stats.get("faces_speculated", 0) + n
 
     # ---- sequential form (no GPU-feeding thread): every stage in the caller's thread, shot after shot --------------------------
     def _run_sequential(self, source, backend):
@@ -771,7 +687,7 @@ class Engine(object):
                         a, n_w = 0, len(w[1])
                         while a < n_w:
                             b = min(n_w, a + EXTRACT_CALL_MAX - m)
-                            piece.append((ex, (w[0][a:b], w[1][a:b], None, w[3][a:b] if len(w) > 3 else None)))
+                            piece.append((ex, (w[0][a:b], w[1][a:b])))
                             m += b - a
                             a = b
                             if m >= EXTRACT_CALL_MAX:
@@ -823,13 +739,6 @@ class Engine(object):
                     raw, counts, boxes = self._detect(item, None)
                     note("detected", k)
                     done.put(("det", item, raw, counts, boxes))
-                    # the LAST shot of a run of known length: its faces are computed ahead, beside its state machine (for the other
-                    # shots extraction is off the critical path anyway, and computing ahead there only competes with the detector);
-                    # planned here while the tracker thread's bulk tracker call for the shot runs
-                    if n is not None and k == n - 1:
-                        plan = self.plan_faces(item, counts, boxes)
-                        if plan is not None:
-                            done.put(("faces", item.job.ex, plan))
                     k += 1
                 done.put(("eof",))
             except BaseException as e:      # noqa: BLE001 -- handed on to the caller's thread through the tracker thread
@@ -871,13 +780,12 @@ class Engine(object):
                 while True:
                     # what this thread could do now.  Bulk tracker work first (the tracking thread waits for it), but never more than
                     # `limit` shots ahead of that thread (a slow state machine -- a crowded shot -- must not let detected shots pile up).
-                    can_spec = bool(waiting) and (waiting[0][0] in ("jobend", "faces") or shots - counters["received"] < limit)
+                    can_spec = bool(waiting) and (waiting[0][0] == "jobend" or shots - counters["received"] < limit)
                     last_call = eof and not waiting                  # nothing will be detected any more: whatever waits goes, whatever its size
                     # Towards the end of a run of known length the faces of the last finished shots are held back until the LAST shot's
                     # bulk tracker work is queued: its state machine (17-21 ms on the host, plus its on-demand tracker calls) then runs
                     # beside ~25 ms of landmark / embedding kernels instead of leaving the GPU idle at the very end.
-                    # (with the last shot's own faces computed ahead in that window too, only ONE finished shot is held back for it)
-                    hold = n is not None and shots < n and counters["extracted"] >= n - (2 if self.speculate_faces else 3) and not last_call
+                    hold = n is not None and shots < n and counters["extracted"] >= n - 3 and not last_call
                     can_extract = bool(pending) and not hold and (last_call or eager or faces_waiting() >= self.extract_min)
                     if last_call:
                         flush()
@@ -893,7 +801,7 @@ class Engine(object):
                         kind = msg[0]
                         if kind == "error":
                             raise msg[1]
-                        if kind in ("det", "jobend", "faces"):
+                        if kind in ("det", "jobend"):
                             waiting.append(msg)                      # (a job's end keeps its place behind the job's last shot)
                         elif kind == "eof":
                             eof = True
@@ -906,10 +814,6 @@ class Engine(object):
                             flush()
                             ends += 1
                             ready.put(("end", w[1]))
-                        elif w[0] == "faces":
-                            note("faces ahead begin")
-                            self.run_faces(w[1], w[2], lock)
-                            note("faces ahead done")
                         else:
                             speculate(w)
                         continue

@@ -234,7 +234,6 @@ def test_many_jobs_through_one_engine_run_equal_one_run_each(extract_min, monkey
     ctx.landmarks = landmarks
     tbd = TrackingByDetection(detect_func=None, track_min_overlap_ratio=0.5, track_max_gap=1.0, trackers=HipTrackers(ctx))
     eng = engine.Engine(ctx, tbd, detect_batch_size=7, extract_min=extract_min)
-    eng.speculate_faces = False                       # (this test counts the faces per library call: nothing computed ahead)
     jobs = [engine.VideoJob(ctx, 640, 360, frames=c[0], times=c[2], key=k) for k, c in enumerate(clips)]
     def source():
         for job, c in zip(jobs, clips):
@@ -364,38 +363,3 @@ def test_interpreter_tuning_is_reference_counted():
             assert not gc.isenabled()
         assert not gc.isenabled() and sys.getswitchinterval() == pytest.approx(1e-4)     # the inner exit restored nothing
     assert (gc.isenabled(), sys.getswitchinterval()) == (before[0], pytest.approx(before[1]))
-
-
-@pytest.mark.parametrize("mode", ["resident", "stream"])
-def test_faces_computed_ahead_from_the_detections_give_the_same_rows(mode, monkeypatch):
-    """Engine._speculate_faces: landmarks + descriptors of a shot's detections are computed right after detection, beside the state machine;
-    `extract` then finds most of its faces already there (ExtractStream.spec) and computes only the rest (boxes merged with tracker boxes,
-    faces the trackers carried).  Same tracks, same faces, same points and descriptors as without it; hits and misses both occur."""
-    frames, dets, times, shots = make_video(9, n_shots=3, n=24, faces=4, p_miss=0.2, p_false=0.1)
-    calls = {"on": [], "off": []}
-    orig = FakeContext.landmarks
-
-    def counting(which):
-        def landmarks(self, frs, boxes):
-            calls[which].append(len(boxes))
-            return orig(self, frs, boxes)
-        return landmarks
-    monkeypatch.setenv("PVF_SPECULATE_FACES", "0")
-    monkeypatch.setattr(FakeContext, "landmarks", counting("off"))
-    base = run_engine(frames, dets, times, shots, mode)
-    monkeypatch.setenv("PVF_SPECULATE_FACES", "1")
-    monkeypatch.setattr(FakeContext, "landmarks", counting("on"))
-    FakeDeviceFrame.live = FakeDeviceFrame.peak = 0
-    other = run_engine(frames, dets, times, shots, mode)
-    assert other[0] == base[0] and other[1] == base[1]
-    assert np.array_equal(other[2][0], base[2][0]) and np.array_equal(other[2][1], base[2][1])
-    eng = other[4]
-    n_faces = len(base[2][0])
-    if mode == "stream":                                   # a stream's length is not known in advance: nothing is computed ahead
-        assert "faces_speculated" not in eng.stats and sum(calls["on"]) == n_faces
-        return
-    last = engine.split_into_shots(times, shots)[-1]
-    assert eng.stats["faces_speculated"] == sum(len(d) for d in dets[last[0]:last[1]]) > 0       # the last shot's detections
-    extra = sum(calls["on"]) - eng.stats["faces_speculated"]          # faces computed when their track existed: the other shots + the misses
-    assert 0 < extra < n_faces and sum(calls["off"]) == n_faces
-    assert not other[3].trk and FakeDeviceFrame.live == 0
