@@ -280,7 +280,8 @@ extern "C" int32_t pvf_ctx_create_prio(int32_t device, int32_t priority_class, p
         int lo = 0, hi = 0;   // numerically lower = higher priority
         HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         // the detector's stream at the lowest priority, the latency-bound side above it (class < 0: both at the lowest)
-        const int prio = priority_class < 0 ? lo : hi;
+        int prio = priority_class < 0 ? lo : hi;
+        if (const char* e = getenv("PVF_MAIN_STREAM_PRIO")) prio = (strcmp(e, "low") == 0) ? lo : hi;     // (measurement switch)
         HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio));
         HIP_CHECK(hipStreamCreateWithPriority(&c->det_stream, hipStreamNonBlocking, lo));
     }

@@ -538,22 +538,30 @@ class TrackingByDetection(object):
         HipTrackers.speculate computed ahead (backward: on the reversed cache)"""
         if dets is None:
             dets = self._detect_shot(cache, flags)
-        g = nx.DiGraph()
+        # the detection graph of the reference (tracking.py:426-429: a node per timestamp, an edge to each of its detections) is kept
+        # as what finish_shot needs of it -- its node ORDER -- and built for real only by finish_shot_graph (2000 add_edge calls per
+        # 250-frame shot cost 3 ms of the tracking thread, on the critical path of a video's last shot)
         det_at = {}
         for (t, _), d in zip(cache, dets):
-            g.add_node(t)
-            for box in d:
-                g.add_edge(t, (t, box, DETECTION))
             det_at[t] = d
         ef, eb = [], []
         pf, pb = plans if plans is not None else (None, None)
         lanes = [self._lane(cache, det_at, FORWARD, ef, backend, pf), self._lane(list(reversed(cache)), det_at, BACKWARD, eb, backend, pb)]
-        return {"graph": g, "ef": ef, "eb": eb, "lanes": lanes}
+        return {"times": [t for t, _ in cache], "det_at": det_at, "ef": ef, "eb": eb, "lanes": lanes}
+
+    @staticmethod
+    def _detection_graph(job):
+        g = nx.DiGraph()
+        for t in job["times"]:
+            g.add_node(t)
+            for box in job["det_at"][t]:
+                g.add_edge(t, (t, box, DETECTION))
+        return g
 
     def finish_shot_graph(self, job):
         """the reference's own data structure: replay the lanes' graph mutations in its order (forward pass, then backward) into the
         networkx graph and take the tracks from it (tracking.py:359-362)"""
-        g = job["graph"]
+        g = self._detection_graph(job)
         for u, v, conf in job["ef"]:
             g.add_edge(u, v, confidence=conf)
         for u, v, conf in job["eb"]:
@@ -568,10 +576,13 @@ class TrackingByDetection(object):
         them afterwards (_fix, _fill_gaps, the final sort) is shared."""
         index = {}
         parent = []
-        for n in job["graph"]:                      # node order so far: timestamps and their detections
-            if isinstance(n, tuple):
-                index[n] = len(parent)
-                parent.append(len(parent))
+        det_at = job["det_at"]
+        for t in job["times"]:                      # node order so far: timestamps and their detections (a box seen twice on a frame is one node)
+            for box in det_at[t]:
+                n = (t, box, DETECTION)
+                if n not in index:
+                    index[n] = len(parent)
+                    parent.append(len(parent))
         for edges in (job["ef"], job["eb"]):
             for u, v, _ in edges:
                 iu = index.get(u)
