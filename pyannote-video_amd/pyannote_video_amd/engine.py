@@ -721,6 +721,7 @@ class Engine(object):
         limit = max(3, 2 * self.group)
         ahead = threading.Semaphore(limit)
         stop = threading.Event()
+        waiting = []                                 # the tracker thread's detections / job ends not yet handled (the error path empties it)
 
         def detector_thread():
             k = 0
@@ -748,7 +749,6 @@ class Engine(object):
             counters = {"received": 0, "extracted": 0, "finals": 0}
             shots = ends = 0
             eager = self.extract_min <= 0
-            waiting = []                             # detections that arrived while the tracking thread is too far behind
             group = []
             eof = False
 
@@ -893,6 +893,15 @@ class Engine(object):
                     if isinstance(item, tuple) and item and item[0] == "shots":
                         for si, _, _ in item[1]:
                             release_shot_frames(si)
+                while True:                          # detected shots nobody took on (both feeding threads have ended)
+                    try:
+                        waiting.append(done.get_nowait())
+                    except queue.Empty:
+                        break
+                for msg in waiting:
+                    if isinstance(msg, tuple) and msg and msg[0] == "det":
+                        release_shot_frames(msg[1])
+                del waiting[:]
                 for job in seen_jobs:
                     try:
                         job.store.release_all()
