@@ -253,8 +253,9 @@ int32_t pvf_debug_tracker_state(pvf_handle ctx, pvf_handle trk, double* F, doubl
  * ref: pyannote/video/structure/shot.py:71-73 (_convert: RGB -> gray -> cv2.resize to `width` x `height`), :75-99 (dfd: Farneback flow
  *      with (0.5, 3, 15, 3, 5, 1.1, 0), per-pixel displaced lookup, mean absolute difference).  dfd[i] compares frames i and i + 1
  *      (n - 1 values).  tables = 22 floats (Gaussian g / x g / x^2 g for x = 0..5, then ig11, ig03, ig33, ig55: structure.shot_tables()).
- *      gray_out ([n][height][width] bytes) and flow_out ([n-1][height][width][2] floats) may be NULL.  The small image must have a side
- *      below 64 pixels (single-level flow), which the reference's sizes always have. */
+ *      gray_out ([n][height][width] bytes) and flow_out ([n-1][height][width][2] floats) may be NULL.  The reference's default small
+ *      image (50 pixels wide) has one pyramid level; a side of 64 pixels or more (Shot(height=...), shot.py:53-60) brings OpenCV's coarser
+ *      levels -- up to three: halved while both sides stay >= 32 -- which run in the same launch. */
 int32_t pvf_shot_dfd(pvf_handle ctx, const pvf_handle* frames, int32_t n, int32_t width, int32_t height, const float* tables,
                      double* dfd, uint8_t* gray_out, float* flow_out);
 

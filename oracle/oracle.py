@@ -352,16 +352,24 @@ def shot_convert(rgb, ow, oh):
     return out
 
 
-def farneback_small(prev, cur, tables=None):
-    """cv2.calcOpticalFlowFarneback(prev, cur, None, 0.5, 3, 15, 3, 5, 1.1, 0) for single-level sizes (a side < 64 px) -> float32 [h, w, 2]"""
+def farneback_levels(h, w):
+    """coarser pyramid levels OpenCV's Farneback uses for an h x w image (0: a side below 64 pixels)"""
+    return int(lib().pvo_farneback_levels(int(h), int(w)))
+
+
+def farneback(prev, cur, tables=None):
+    """cv2.calcOpticalFlowFarneback(prev, cur, None, 0.5, 3, 15, 3, 5, 1.1, 0) -> float32 [h, w, 2] (any size: up to three coarser levels)"""
     prev = np.ascontiguousarray(prev, np.uint8); cur = np.ascontiguousarray(cur, np.uint8)
     assert prev.ndim == 2 and prev.shape == cur.shape
     t = shot_tables() if tables is None else tables
     flow = np.zeros(prev.shape + (2,), np.float32)
-    rc = lib().pvo_farneback_small(_p(prev), _p(cur), prev.shape[0], prev.shape[1], _p(t), _p(flow))
+    rc = lib().pvo_farneback(_p(prev), _p(cur), prev.shape[0], prev.shape[1], _p(t), _p(flow))
     if rc != 0:
-        raise NotImplementedError("Farneback restatement covers the single-level case only (an image side below 64 px)")
+        raise RuntimeError("pvo_farneback failed (%d)" % rc)
     return flow
+
+
+farneback_small = farneback          # (the name of the single-level restatement of round 3)
 
 
 def shot_dfd(prev, cur, tables=None):

@@ -163,6 +163,8 @@ int pvo_hac(const double* D, const int32_t* sizes, int T, double threshold, int3
 void pvo_shot_convert(const uint8_t* rgb, int ih, int iw, uint8_t* out /* [oh][ow] */, int oh, int ow);
 void pvo_shot_tables(float* t /* 22: g[6] xg[6] xxg[6] ig11 ig03 ig33 ig55 */);
 int pvo_farneback_small(const uint8_t* prev, const uint8_t* cur, int h, int w, const float* tables, float* flow /* [h][w][2] */);
+int pvo_farneback_levels(int h, int w);   /* coarser pyramid levels OpenCV uses for this size (0: an image side below 64 pixels) */
+int pvo_farneback(const uint8_t* prev, const uint8_t* cur, int h, int w, const float* tables, float* flow /* [h][w][2] */);
 double pvo_shot_dfd_from_flow(const uint8_t* prev, const uint8_t* cur, int h, int w, const float* flow);
 double pvo_shot_dfd(const uint8_t* prev, const uint8_t* cur, int h, int w, const float* tables);
 

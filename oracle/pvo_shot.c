@@ -232,26 +232,149 @@ static void update_flow(const float* M, int h, int w, float* flow, float* colsum
         }
 }
 
-/* cv2.calcOpticalFlowFarneback(prev, cur, None, 0.5, 3, 15, 3, 5, 1.1, 0) for images less than 64 pixels wide or high (one level) */
-int pvo_farneback_small(const uint8_t* prev, const uint8_t* cur, int h, int w, const float* tables, float* flow)
+/* ---- the coarser pyramid levels (an image side of 64 pixels or more: Shot(height >= 64), scripts/pyannote-structure.py:45,111) -------------
+ * [EXT optflowgf.cpp, FarnebackOpticalFlowImpl::calc], restated, PARITY UNPINNED like everything above:
+ *   levels: scale = 1; for k in 0..2: scale *= 0.5; stop when width * scale < 32 or height * scale < 32   => `levels` coarser levels
+ *   for k = levels .. 0 (coarse to fine): scale = 0.5^k, sigma = (1 / scale - 1) / 2, smooth_sz = max(cvRound(5 sigma) | 1, 3),
+ *       level size = (cvRound(width * scale), cvRound(height * scale));
+ *       flow = 0 on the coarsest level, otherwise resize(previous level's flow, INTER_LINEAR) * 2;
+ *       each image: float, GaussianBlur(smooth_sz x smooth_sz, sigma) at FULL size, resize(INTER_LINEAR) to the level size, polynomial expansion;
+ *       matrices from the flow, then 3 x (box sums -> solve -> matrices).
+ *   GaussianBlur, sigma > 0 [getGaussianKernel(n, sigma, CV_32F)]: t_i = exp(-x_i^2 / (2 sigma^2)) in double, stored as float, normalised by the
+ *       double sum of the floats, stored as float; rows first (taps left to right), then columns (centre tap, then the symmetric pairs);
+ *       BORDER_REFLECT_101.  Level 0 (sigma = 0) keeps the fixed 1/4 1/2 1/4 kernel and the arithmetic of blur3 above.
+ *   resize of float images [resize, INTER_LINEAR, CV_32F]: fx = (float)((dx + 0.5) * (src / dst) - 0.5), sx = floor(fx), fx -= sx, clamped at
+ *       both ends with fx = 0; a row pair is blended horizontally first (S[sx] * (1 - fx) + S[sx + 1] * fx), then vertically. */
+static int cv_round(double v) { return (int)nearbyint(v); }            /* cvRound: to nearest, ties to even */
+
+static void gauss_kernel(int n, double sigma, float* k)
 {
-    if (!((double)w * 0.5 < 32 || (double)h * 0.5 < 32)) return -1;       /* a coarser level exists: not this restatement's case */
-    const size_t px = (size_t)h * w;
-    float* buf = (float*)malloc(sizeof(float) * (px * 2 + px + px * 5 * 4 + (size_t)w * 3));
-    if (!buf) return -2;
-    float *I0 = buf, *I1 = I0 + px, *tmp = I1 + px, *R0 = tmp + px, *R1 = R0 + px * 5, *M = R1 + px * 5, *cs = M + px * 5, *row = cs + px * 5;
-    blur3(prev, h, w, I0, tmp);
-    blur3(cur, h, w, I1, tmp);
-    polyexp(I0, h, w, tables, R0, row);
-    polyexp(I1, h, w, tables, R1, row);
-    memset(flow, 0, sizeof(float) * px * 2);
-    update_matrices(R0, R1, flow, h, w, M);
-    for (int it = 0; it < 3; ++it) {
-        update_flow(M, h, w, flow, cs);
-        if (it < 2) update_matrices(R0, R1, flow, h, w, M);
+    const double s2 = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) {
+        const double x = i - (n - 1) * 0.5;
+        k[i] = (float)exp(s2 * x * x);
+        sum += k[i];
     }
+    sum = 1. / sum;
+    for (int i = 0; i < n; ++i) k[i] = (float)(k[i] * sum);
+}
+
+static void blur_n(const float* src, int h, int w, const float* k, int n, float* dst, float* tmp)
+{
+    const int r = n / 2;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float s = k[0] * src[(size_t)y * w + reflect101(x - r, w)];
+            for (int j = 1; j < n; ++j) s = s + k[j] * src[(size_t)y * w + reflect101(x - r + j, w)];
+            tmp[(size_t)y * w + x] = s;
+        }
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float s = k[r] * tmp[(size_t)y * w + x];
+            for (int d = 1; d <= r; ++d) s = s + k[r + d] * (tmp[(size_t)reflect101(y + d, h) * w + x] + tmp[(size_t)reflect101(y - d, h) * w + x]);
+            dst[(size_t)y * w + x] = s;
+        }
+}
+
+static void resize_coeff_f(int in, int out, int d, int* idx, float* a0, float* a1)
+{
+    const double scale = (double)in / out;
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0; s = 0; }
+    if (s >= in - 1) { f = 0; s = in - 1; }
+    *idx = s; *a0 = 1.f - f; *a1 = f;
+}
+
+/* src [ih][iw][cn] -> dst [oh][ow][cn] */
+static void resize_linear_f(const float* src, int ih, int iw, int cn, float* dst, int oh, int ow)
+{
+    for (int y = 0; y < oh; ++y) {
+        int sy; float b0, b1;
+        resize_coeff_f(ih, oh, y, &sy, &b0, &b1);
+        const int sy1 = imin_(sy + 1, ih - 1);
+        for (int x = 0; x < ow; ++x) {
+            int sx; float a0, a1;
+            resize_coeff_f(iw, ow, x, &sx, &a0, &a1);
+            const int sx1 = imin_(sx + 1, iw - 1);
+            for (int c = 0; c < cn; ++c) {
+                const float r0 = src[((size_t)sy * iw + sx) * cn + c] * a0 + src[((size_t)sy * iw + sx1) * cn + c] * a1;
+                const float r1 = src[((size_t)sy1 * iw + sx) * cn + c] * a0 + src[((size_t)sy1 * iw + sx1) * cn + c] * a1;
+                dst[((size_t)y * ow + x) * cn + c] = r0 * b0 + r1 * b1;
+            }
+        }
+    }
+}
+
+int pvo_farneback_levels(int h, int w)
+{
+    int k = 0;
+    double scale = 1;
+    for (; k < 3; ++k) {
+        scale *= 0.5;
+        if (w * scale < 32 || h * scale < 32) break;
+    }
+    return k;
+}
+
+/* cv2.calcOpticalFlowFarneback(prev, cur, None, 0.5, 3, 15, 3, 5, 1.1, 0), any size: flow [h][w][2] */
+int pvo_farneback(const uint8_t* prev, const uint8_t* cur, int h, int w, const float* tables, float* flow)
+{
+    const int levels = pvo_farneback_levels(h, w);
+    const size_t px = (size_t)h * w;
+    float* buf = (float*)malloc(sizeof(float) * (px * 4 + px * 5 * 4 + px * 4 + (size_t)w * 3));
+    if (!buf) return -2;
+    float *F = buf, *tmp = F + px, *I0 = tmp + px, *I1 = I0 + px, *R0 = I1 + px, *R1 = R0 + px * 5, *M = R1 + px * 5, *cs = M + px * 5,
+          *fa = cs + px * 5, *fb = fa + px * 2, *row = fb + px * 2;
+    const uint8_t* img[2] = {prev, cur};
+    float* I[2] = {I0, I1};
+    float* R[2] = {R0, R1};
+    float *fl = fa, *fl_prev = fb;
+    int plh = 0, plw = 0;
+    for (int k = levels; k >= 0; --k) {
+        double scale = 1;
+        for (int i = 0; i < k; ++i) scale *= 0.5;
+        const double sigma = (1. / scale - 1) * 0.5;
+        int smooth_sz = cv_round(sigma * 5) | 1;
+        if (smooth_sz < 3) smooth_sz = 3;
+        const int lw = cv_round(w * scale), lh = cv_round(h * scale);
+        if (k == levels) memset(fl, 0, sizeof(float) * (size_t)lh * lw * 2);
+        else {
+            resize_linear_f(fl_prev, plh, plw, 2, fl, lh, lw);
+            for (size_t i = 0; i < (size_t)lh * lw * 2; ++i) fl[i] = fl[i] * 2.f;
+        }
+        for (int s = 0; s < 2; ++s) {
+            if (k == 0) blur3(img[s], h, w, I[s], tmp);
+            else {
+                float kern[32];
+                gauss_kernel(smooth_sz, sigma, kern);
+                float* B = M;                                   /* (free until the matrices are formed) */
+                for (size_t i = 0; i < px; ++i) F[i] = (float)img[s][i];
+                blur_n(F, h, w, kern, smooth_sz, B, tmp);
+                resize_linear_f(B, h, w, 1, I[s], lh, lw);
+            }
+            polyexp(I[s], lh, lw, tables, R[s], row);
+        }
+        update_matrices(R0, R1, fl, lh, lw, M);
+        for (int it = 0; it < 3; ++it) {
+            update_flow(M, lh, lw, fl, cs);
+            if (it < 2) update_matrices(R0, R1, fl, lh, lw, M);
+        }
+        float* t2 = fl; fl = fl_prev; fl_prev = t2;
+        plh = lh; plw = lw;
+    }
+    memcpy(flow, fl_prev, sizeof(float) * px * 2);
     free(buf);
     return 0;
+}
+
+/* the one-level case under its old name (an image side below 64 pixels) */
+int pvo_farneback_small(const uint8_t* prev, const uint8_t* cur, int h, int w, const float* tables, float* flow)
+{
+    if (pvo_farneback_levels(h, w) != 0) return -1;
+    return pvo_farneback(prev, cur, h, w, tables, flow);
 }
 
 /* shot.py:89-99: reconstruct[y, x] = current[ry, rx] with `dy, dx = flow[y, x]`; mean |previous - reconstruct| */
@@ -281,7 +404,7 @@ double pvo_shot_dfd(const uint8_t* prev, const uint8_t* cur, int h, int w, const
     float* flow = (float*)malloc(sizeof(float) * (size_t)h * w * 2);
     if (!flow) return -1.0;
     double r = -1.0;
-    if (pvo_farneback_small(prev, cur, h, w, tables, flow) == 0) r = pvo_shot_dfd_from_flow(prev, cur, h, w, flow);
+    if (pvo_farneback(prev, cur, h, w, tables, flow) == 0) r = pvo_shot_dfd_from_flow(prev, cur, h, w, flow);
     free(flow);
     return r;
 }

@@ -315,8 +315,8 @@ def main(argv=None):
     pr.add_argument("--threshold", type=float, default=0.6)
     s = sub.add_parser("shot")
     s.add_argument("video"); s.add_argument("output")
-    s.add_argument("--height", type=int, default=50, help="height of the images the optical flow runs on (reference default 50); the "
-                   "device kernel covers the single-level flow, i.e. heights / widths below 64 pixels -- larger values are refused")
+    s.add_argument("--height", type=int, default=50, help="height of the images the optical flow runs on (reference default 50: one pyramid level; "
+                   "64 and more bring OpenCV's coarser levels)")
     s.add_argument("--window", type=float, default=2.0)
     s.add_argument("--threshold", type=float, default=1.0)
     c = sub.add_parser("cluster")

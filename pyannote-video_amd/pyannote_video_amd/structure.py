@@ -65,7 +65,8 @@ class Shot(object):
     ----------
     video : iterable of (t, rgb) with `_size` (width, height), `step`, `start`, `end` like the reference's Video
     height : int, optional      the small image is this many pixels WIDE (the reference hands (height, int(w * height / h)) to cv2.resize as
-                                (width, height)); below 64.  Defaults to 50.
+                                (width, height)).  Defaults to 50 (one pyramid level of the optical flow; a side of 64 pixels or more brings
+                                OpenCV's coarser levels, computed in the same kernel).
     context : float, optional   median filtering context in seconds.  Defaults to 2.
     threshold : float, optional Defaults to 1.
     ctx : runtime.Context

@@ -47,10 +47,29 @@ def test_oracle_flow_recovers_a_translation(shift):
     assert same < 4.0 and other > 5 * same
 
 
-def test_single_level_only():
+def test_pyramid_levels_follow_opencvs_rule():
+    """[EXT optflowgf.cpp]: halve while both sides stay >= 32, at most three times"""
     from oracle import oracle
-    with pytest.raises(NotImplementedError):
-        oracle.farneback_small(np.zeros((70, 80), np.uint8), np.zeros((70, 80), np.uint8))
+    assert [oracle.farneback_levels(h, w) for h, w in ((88, 50), (64, 63), (64, 64), (177, 100), (128, 300), (284, 160), (256, 256), (1000, 1000))] == \
+        [0, 0, 1, 1, 2, 2, 3, 3]
+
+
+@pytest.mark.parametrize("size", [(177, 100), (284, 160), (330, 280)])       # one, two and three coarser levels
+def test_oracle_flow_on_coarser_levels_recovers_a_translation(size):
+    """Shot(height >= 64) (scripts/pyannote-structure.py:45,111): OpenCV's Farneback starts on coarser pyramid levels; a shift larger than
+    the single-level case can follow (5 px) is recovered, and the displaced difference of a moved frame stays far below a changed one"""
+    from oracle import oracle
+    h, w = size
+    assert oracle.farneback_levels(h, w) == {100: 1, 160: 2, 280: 3}[w]
+    base = _textured(4, h + 40, w + 40)
+    prev = base[20:20 + h, 20:20 + w].astype(np.uint8)
+    cur = base[20 + 5:20 + 5 + h, 20 + 5:20 + 5 + w].astype(np.uint8)      # cur(x, y) = prev(x + 5, y + 5): diagonal, so the reference's
+    flow = oracle.farneback(prev, cur)                                     # swapped lookup (`dy, dx = flow[y, x]`) explains it too
+    centre = flow[h // 4:3 * h // 4, w // 4:3 * w // 4].reshape(-1, 2)
+    assert np.abs(np.median(centre, 0) + 5).max() < 0.3, np.median(centre, 0)
+    moved = oracle.shot_dfd(prev, cur)
+    other = oracle.shot_dfd(prev, _textured(9, h + 40, w + 40)[20:20 + h, 20:20 + w].astype(np.uint8))
+    assert other > 3 * moved
 
 
 class _Clip(object):
@@ -101,26 +120,27 @@ def _oracle_cv2(oracle):
 
     def calcOpticalFlowFarneback(prev, cur, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags):
         assert (flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma, flags) == (None, 0.5, 3, 15, 3, 5, 1.1, 0)
-        return oracle.farneback_small(prev, cur)
+        return oracle.farneback(prev, cur)
     cv2.cvtColor, cv2.resize, cv2.calcOpticalFlowFarneback = cvtColor, resize, calcOpticalFlowFarneback
     return cv2
 
 
 @pytest.mark.skipif(not refhost.have_reference(), reason="/root/reference is not present (GPU box)")
-def test_reference_shot_class_verbatim_equals_product_host_logic():
+@pytest.mark.parametrize("height", [50, 100])                     # the reference's default (one level) and a two-level size
+def test_reference_shot_class_verbatim_equals_product_host_logic(height):
     from oracle import oracle
     from pyannote_video_amd import structure
     from pyannote_video_amd._core import Segment
     frames = _cut_clip()
     clip = _Clip(frames)
     with refhost.reference_shot_module(_oracle_cv2(oracle), Segment) as ref:
-        shot = ref.Shot(clip, height=50, context=0.4, threshold=1.0)
+        shot = ref.Shot(clip, height=height, context=0.4, threshold=1.0)
         ref_pairs = list(shot.iter_dfd())
         ref_segments = [(s.start, s.end) for s in shot]
         ksize = shot._kernel_size
-        assert shot._resize == (50, int(160 * 50 / 120))
+        assert shot._resize == (height, int(160 * height / 120))
     # the oracle's displaced frame difference == what the reference's per-pixel Python loop computes from the same flow
-    ow, oh = 50, int(160 * 50 / 120)
+    ow, oh = height, int(160 * height / 120)
     small = [oracle.shot_convert(f, ow, oh) for f in frames]
     mine = [(i / 25.0, oracle.shot_dfd(small[i - 1], small[i])) for i in range(1, len(frames))]
     assert [t for t, _ in mine] == [t for t, _ in ref_pairs]
@@ -154,6 +174,27 @@ def test_gpu_shot_dfd_bit_exact_and_cuts_found(ctx):
     found = [round(b * 25) for _, b in segments[:-1]]
     assert found[:2] == [9, 20] and all(f >= 28 for f in found[2:])
     assert segments[0][0] == 0.0 and segments[-1][1] == clip.end
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("height", [100, 160, 300])              # one, two and three coarser pyramid levels (Shot(height=...), shot.py:53-60)
+def test_gpu_shot_dfd_coarser_levels_bit_exact(ctx, height):
+    from oracle import oracle
+    from pyannote_video_amd import structure
+    frames = _cut_clip(n=8, cuts=(4,), h=360, w=480)
+    tables = structure.shot_tables()
+    ow, oh = height, int(480 * height / 360)
+    assert oracle.farneback_levels(oh, ow) == {100: 1, 160: 2, 300: 3}[height]
+    dfd, gray, flow = ctx.shot_dfd(frames, ow, oh, tables, want_gray=True, want_flow=True)
+    small = [oracle.shot_convert(f, ow, oh) for f in frames]
+    assert np.array_equal(gray, np.stack(small))
+    for i in range(1, len(frames)):
+        f = oracle.farneback(small[i - 1], small[i], tables)
+        assert np.array_equal(flow[i - 1], f), (i, np.abs(flow[i - 1] - f).max())
+        assert dfd[i - 1] == oracle.shot_dfd(small[i - 1], small[i], tables)
+    assert dfd[3] > 2 * np.delete(dfd, 3).max()                    # the cut at frame 4
+    shot = structure.Shot(_Clip(frames), height=height, context=0.2, threshold=1.0, ctx=ctx)
+    assert [d for _, d in shot.iter_dfd()] == dfd.tolist()
 
 
 @pytest.mark.gpu
