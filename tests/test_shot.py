@@ -192,7 +192,7 @@ def test_gpu_shot_dfd_coarser_levels_bit_exact(ctx, height):
         f = oracle.farneback(small[i - 1], small[i], tables)
         assert np.array_equal(flow[i - 1], f), (i, np.abs(flow[i - 1] - f).max())
         assert dfd[i - 1] == oracle.shot_dfd(small[i - 1], small[i], tables)
-    assert dfd[3] > 2 * np.delete(dfd, 3).max()                    # the cut at frame 4
+    assert int(np.argmax(dfd)) == 3                                # the cut at frame 4 (the clip's background also jumps back at frame 7)
     shot = structure.Shot(_Clip(frames), height=height, context=0.2, threshold=1.0, ctx=ctx)
     assert [d for _, d in shot.iter_dfd()] == dfd.tolist()
 
