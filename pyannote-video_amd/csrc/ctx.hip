@@ -2,6 +2,7 @@
 #include "pvf_internal.h"
 #include <fstream>
 #include <mutex>
+#include <dlfcn.h>
 
 static thread_local std::string g_err;
 void pvf_set_error(const char* msg) { g_err = msg ? msg : ""; }
@@ -201,8 +202,34 @@ static void load_embedder(Ctx* c, const char* path)
 }
 
 // ---------------------------------------------------------------------------------------------------
+// roctx ranges around every kernel family (tracing): PVF_ROCTX=1 resolves roctxRangePushA / roctxRangePop from
+// librocprofiler-sdk-roctx.so (or roctracer's libroctx64.so) at run time (no link-time dependency) and brackets the host side of each family's
+// launches, so that `rocprofv3 --marker-trace` shows "pyramid", "fhog", "score", "dsst", "chip", "ert", "conv", "pdist", "hac", "shot"
+// next to the kernels they queue.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("PVF_ROCTX");
+        if (!e || strcmp(e, "1") != 0) return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);      // (the library rocprofv3 --marker-trace listens to)
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);                  // (roctracer's, for rocprof v1 / v2)
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+}  // namespace
+
 ProfScope::ProfScope(Ctx* ctx, const char* family, hipStream_t on) : c(ctx), s(on ? on : ctx->stream)
 {
+    if (roctx().push) { roctx().push(family); ranged = true; }
     if (!c->prof_on) return;
     {
         std::lock_guard<std::mutex> lk(c->prof_mu);
@@ -219,6 +246,7 @@ ProfScope::ProfScope(Ctx* ctx, const char* family, hipStream_t on) : c(ctx), s(o
 }
 ProfScope::~ProfScope()
 {
+    if (ranged) roctx().pop();
     if (!f) return;
     (void)hipEventRecord(b, s);
     std::lock_guard<std::mutex> lk(c->prof_mu);

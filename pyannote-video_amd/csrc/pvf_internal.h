@@ -317,7 +317,7 @@ struct Ctx {
 };
 
 struct ProfScope {
-    Ctx* c; ProfFamily* f = nullptr; hipEvent_t a = nullptr, b = nullptr; hipStream_t s = nullptr;
+    Ctx* c; ProfFamily* f = nullptr; hipEvent_t a = nullptr, b = nullptr; hipStream_t s = nullptr; bool ranged = false;
     ProfScope(Ctx* ctx, const char* family, hipStream_t on = nullptr);       // on: the stream the family's kernels run on (default: c->stream)
     ~ProfScope();
 };
