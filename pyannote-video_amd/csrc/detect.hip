@@ -6,7 +6,6 @@
 #include <thread>
 #include <cmath>
 #include <cstdlib>
-#include <cstring>
 
 // =====================================================================================================
 // K1: bilinear resize (pyramid_up / pyramid_down<6>), uint8 RGB HWC, double coordinates, (v + 0.5) truncation
@@ -139,132 +138,6 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     }
 }
 
-// ---- round 4: a lane = four output BYTES -------------------------------------------------------------------------------------------
-// The kernel above gives a lane one output pixel: 3 values, packed into 3 bytes, and 48 of the wave's 64 lanes then collect the dword they
-// store from two neighbours through the LDS crossbar (2 ds_bpermute + 4 pack / align instructions per lane and row, a third of the
-// per-row instructions that are not arithmetic).  Here a lane owns one aligned output DWORD -- bytes 4 l .. 4 l + 3 of the wave's 256-byte
-// piece of the row: four (pixel, channel) values that span two neighbouring pixels -- and stores it directly: no crossbar, no byte
-// funnel, one dword store per lane, and the per-row overhead (row table, source-row conversion) is shared by 256 values instead of 192.
-// Every value is computed by exactly the operations of the kernel above (horizontal blend of the two source pixels per source row, cached
-// while consecutive output rows share it; vertical blend; + 0.5; truncation), so the bytes are the same.  A wave's 85.3 pixels span up to
-// 109 source pixels (scale <= 1.25): two dwords per lane and source row.
-template <int RS>
-__global__ void __launch_bounds__(256) resize_rows4_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
-                                                      size_t in_stride, int in_rb, int ih, int iw, uint8_t* __restrict__ out,
-                                                      size_t out_stride, int out_rb, int oh, int ow, double x_scale,
-                                                      const RowTab* __restrict__ rows)
-{
-    constexpr int MAXS = RESIZE_MAXS;
-    __shared__ uint32_t s_rows[4][MAXS][96];                             // a source row's window: <= 84 dwords
-    __shared__ __attribute__((aligned(16))) float s_cvt[4][384 + 8];     // the window as floats (exact: bytes), per wave
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int B0 = (blockIdx.x * 4 + wave) * 256;                        // first output byte of this wave's piece of the row
-    const int row_bytes = ow * 3;
-    const int b = blockIdx.z;
-    if (B0 >= row_bytes) return;                                         // wave-uniform
-    const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
-    const uint8_t* in_end = in + (size_t)ih * in_rb;
-    uint8_t* ob = out + (size_t)b * out_stride + (size_t)B0;
-    // the four values of this lane: byte g = B0 + 4 lane + u belongs to pixel g / 3 (clamped to the last one past the row end: such
-    // bytes are padding), channel g % 3.  They lie in two pixels pa <= pb: per pixel the column arithmetic of the oracle.
-    const int g0 = B0 + 4 * lane;
-    const int pa_raw = (int)(((unsigned)g0 * 43691u) >> 17);             // g0 / 3 (exact below 2^17: rows of up to 43 000 pixels)
-    const int ch0 = g0 - 3 * pa_raw;
-    const int pa = min(pa_raw, ow - 1), pb = min(pa_raw + 1, ow - 1);
-    const double xa = pa * x_scale, xb = pb * x_scale;
-    const int la = (int)floor(xa), lb = (int)floor(xb);
-    const int left0 = __builtin_amdgcn_readfirstlane(la);                // lane 0 holds the wave's first pixel: its smallest source column
-    const double lra = xa - la, lrb = xb - lb;
-    const int roa = (la + 1 <= iw - 1) ? 3 : 0, rob = (lb + 1 <= iw - 1) ? 3 : 0;
-    double lr[4], lr1[4];
-    int dl[4], ro[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const bool second = (ch0 + u) >= 3;                              // value u lies in pixel pa_raw + 1
-        const int ch = second ? ch0 + u - 3 : ch0 + u;
-        lr[u] = second ? lrb : lra;
-        lr1[u] = 1 - lr[u];
-        dl[u] = 3 * ((second ? lb : la) - left0) + ch;                   // floats from the window's first byte to the left sample of value u
-        ro[u] = second ? rob : roa;
-    }
-    const bool stores = g0 < row_bytes;
-    float* cv = s_cvt[wave];
-    typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
-    const uintptr_t last_word = ((uintptr_t)in_end - 1) & ~(uintptr_t)3;
-    const int r0 = blockIdx.y * RS;
-    if (r0 >= oh) return;
-    const int r_end = min(r0 + RS, oh);
-    const int s_first = rows[r0].top, nrows = rows[r_end - 1].bottom - s_first + 1;
-    // every source row the strip needs, requested as one burst: dword `lane` of the window, and dword 64 + lane for the lanes whose
-    // second dword can lie inside it (a dword wholly past the frame is redirected to the frame's last word, never used)
-    uint32_t t0[MAXS], t1[MAXS];
-#pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-        t0[k] = 0; t1[k] = 0;
-        if (k < nrows) {                                                 // wave-uniform
-            const uintptr_t a = (uintptr_t)(in + (size_t)(s_first + k) * in_rb + 3 * left0);
-            uintptr_t q = (a & ~(uintptr_t)3) + 4 * lane;
-            q = q < last_word ? q : last_word;
-            t0[k] = *(gptr_t)q;
-            if (lane < 32) {
-                uintptr_t q2 = (a & ~(uintptr_t)3) + 256 + 4 * lane;
-                q2 = q2 < last_word ? q2 : last_word;
-                t1[k] = *(gptr_t)q2;
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < MAXS; ++k) {
-        s_rows[wave][k][lane] = t0[k];
-        if (lane < 32) s_rows[wave][k][64 + lane] = t1[k];
-    }
-    int s0 = -1, s1 = -1;              // cached source rows
-    double h0[4], h1[4];
-    auto hblend = [&](int srow, double* hh) {
-        const uint32_t w = s_rows[wave][srow - s_first][lane];
-        f32x4 f;
-        f.x = (float)(w & 0xffu); f.y = (float)((w >> 8) & 0xffu);
-        f.z = (float)((w >> 16) & 0xffu); f.w = (float)(w >> 24);
-        *reinterpret_cast<f32x4*>(cv + 4 * lane) = f;
-        if (lane < 32) {
-            const uint32_t w2 = s_rows[wave][srow - s_first][64 + lane];
-            f32x4 f2;
-            f2.x = (float)(w2 & 0xffu); f2.y = (float)((w2 >> 8) & 0xffu);
-            f2.z = (float)((w2 >> 16) & 0xffu); f2.w = (float)(w2 >> 24);
-            *reinterpret_cast<f32x4*>(cv + 256 + 4 * lane) = f2;
-        }
-        __builtin_amdgcn_wave_barrier();                                 // (LDS serves a wave's accesses in order; this only pins the compiler's order)
-        const unsigned al = (unsigned)((uintptr_t)(in + (size_t)srow * in_rb + 3 * left0) & 3u);   // wave-uniform
-        const float* q = cv + al;
-        float tl[4], tr[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { tl[u] = q[dl[u]]; tr[u] = q[dl[u] + ro[u]]; }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int u = 0; u < 4; ++u) hh[u] = lr1[u] * (double)tl[u] + lr[u] * (double)tr[u];
-    };
-    for (int r = r0; r < r_end; ++r) {
-        const RowTab rt = rows[r];                                       // wave-uniform: scalar loads
-        const int top = rt.top, bottom = rt.bottom;
-        const double tb = rt.tb, tb1 = rt.tb1;
-        if (s1 == top) { s0 = s1; h0[0] = h1[0]; h0[1] = h1[1]; h0[2] = h1[2]; h0[3] = h1[3]; s1 = -1; }
-        if (s0 != top) { hblend(top, h0); s0 = top; }
-        if (s1 != bottom) {
-            if (bottom == top) { h1[0] = h0[0]; h1[1] = h0[1]; h1[2] = h0[2]; h1[3] = h0[3]; }
-            else hblend(bottom, h1);
-            s1 = bottom;
-        }
-        uint32_t P = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const double v = tb1 * h0[u] + tb * h1[u];
-            P |= (uint32_t)(uint8_t)(v + 0.5) << (8 * u);
-        }
-        if (stores) *reinterpret_cast<uint32_t*>(ob + (size_t)r * out_rb + 4 * lane) = P;
-    }
-}
-
 static void fill_row_table(std::vector<RowTab>& t, int ih, int oh)
 {
     const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
@@ -291,13 +164,6 @@ static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint
     PVF_REQUIRE(out_rb % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)out & 3) == 0 && out_rb >= (ow * 3 + 3) / 4 * 4, "resize: output rows must be 4-byte aligned");
     // one strip of RS rows per wave: walking 2 / 4 strips with the next strip's source rows in flight behind the current one's arithmetic was
     // measured no faster (65 / 66 / 78 us per 1080p frame for 1 / 2 / 4 strips): the kernel is not waiting for its loads
-    static const bool per_pixel = [] { const char* e = getenv("PVF_RESIZE"); return e && strcmp(e, "px") == 0; }();
-    if (!per_pixel && (size_t)ow * 3 < (1u << 17)) {
-        // a lane = an output dword (round 4): a block covers 1024 bytes of RS output rows
-        dim3 grid((ow * 3 + 1023) / 1024, (oh + RS - 1) / RS, batch);
-        hipLaunchKernelGGL((resize_rows4_k<RS>), grid, dim3(256), 0, c->det_stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
-        return;
-    }
     dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
     hipLaunchKernelGGL((resize_rows_k<RS, 1>), grid, dim3(256), 0, c->det_stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
 }
