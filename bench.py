@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--detect-batch", type=int, default=None, help="frames whose pyramids, features and scores are resident together (one scoring launch per batch; 128 up to 1080p, 32 at 4K)")
     ap.add_argument("--detect-every", type=float, default=0.0, help="`--every` of the track verb: run the detector every that many seconds only (reference "
                     "tracking.py:383-386,425; 0 = every frame, the benched configuration); the trackers carry the faces in between")
+    ap.add_argument("--dense-scoring", action="store_true", help="detector without its f16 screening pass: the exact fp32 chain for every window (csrc/screen.hip; same candidates, bit for bit)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the extra passes through the pyannote-face verbs (track / extract / cluster / process)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): every rank owns --frames frames of an N x --frames video; strong: ONE video of --frames frames "
@@ -162,6 +163,8 @@ def main():
         n_local = args.frames
 
     ctx = Context(device=local_rank)
+    if args.dense_scoring:
+        ctx.detector_screening(False)
     frames = [ctx.wrap_torch(frames_t[i]) for i in range(n_local)]
     pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap, detect_every=args.detect_every)
     # the step needs the float32 descriptors (gathered, clustered on the device), not the float64 host copy of the clustering's table
@@ -229,7 +232,7 @@ def main():
     fps = total_frames / elapsed
 
     fam = {}
-    for name in ("pyramid", "fhog", "score", "chip", "ert", "conv", "dsst", "pdist", "hac"):
+    for name in ("pyramid", "fhog", "score", "score_screened", "chip", "ert", "conv", "dsst", "pdist", "hac"):
         ms, n = 0.0, 0
         for c in ctxs:
             a, b = c.prof_get(name)
@@ -302,6 +305,7 @@ def main():
         "hbm": hbm.report(frames_bytes=int(frames_t.numel()), engine=timed_engine),
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
         "kernel_families_ms": fam,
+        "screening": ctx.detector_screening_stats() if not args.dense_scoring else None,
         "kernel_families_note": "HIP-event time per family on the stream it runs on: the detector families (pyramid, fhog, score) on one stream, the rest on the "
                                 "other; the two streams run side by side, so the sum may exceed the steps' wall time, and a family's time includes "
                                 "what it lost to the other stream's kernels",

@@ -112,6 +112,19 @@ int32_t pvf_detect_batch(pvf_handle ctx, const pvf_handle* frames, int32_t n_fra
 int32_t pvf_detect_many(pvf_handle ctx, const pvf_handle* frames, int32_t n_frames, int32_t batch, int32_t upsample,
                         double adjust_threshold, pvf_rect_i32* out, float* scores, int32_t* counts, int32_t cap);
 
+/* the detector's screening pass (on by default; csrc/screen.hip).  on = 1: every window is first scored on the f16 matrix cores with
+ * a proven error bound, and the exact fp32 chain runs only for the windows whose approximate score comes within the bound of the
+ * threshold; on = 0: the exact chain is evaluated for every window (score_roll_k).  The rectangles, their order and their scores are
+ * the same bits either way -- a call whose list overflows or whose features exceed the bound's assumption is repeated on the dense
+ * kernel.  list_cap > 0 sets the (window, filter) pairs a batch may list (default 1 << 20). */
+int32_t pvf_detector_screening(pvf_handle ctx, int32_t on, int32_t list_cap);
+/* batches screened, (window, filter) pairs listed for exact scoring, calls repeated on the dense kernel -- since the context was created;
+ * bounds[0..n_filters) (may be NULL) = the error bound per filter, in score units; pipe_err (may be NULL) = what the context measured
+ * on its device before the first screened batch: worst |matrix pipe - exact| / sum of magnitudes over an accumulation of 3200 terms
+ * (-1 before that; the bound allows 3200 x 2^-22 = 7.6e-4).  The environment variable PVF_DETECTOR_SCREENING=0 switches screening off
+ * for every context the process creates. */
+int32_t pvf_detector_screening_stats(pvf_handle ctx, int64_t* batches, int64_t* listed, int64_t* retries, double* bounds, double* pipe_err);
+
 /* ---- S2 correlation tracker ------------------------------------------------------------------------ */
 /* ref: tracking.py:250  dlib.correlation_tracker() */
 int32_t pvf_tracker_create(pvf_handle ctx, pvf_handle* trk);

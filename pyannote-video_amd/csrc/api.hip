@@ -45,7 +45,39 @@ static void with_candidate_room(Ctx* c, F&& run)
             while (cap < e.needed) cap *= 2;
             c->det_cand_cap = cap;
         }
+        catch (const ScreenRetry&) {
+            // the screening pass listed more windows than its list holds (a threshold far below the operating point) or met a feature above
+            // the bound its error analysis assumes: this call runs on the dense exact kernel
+            PVF_REQUIRE(!c->det_screen_suspended, "detector: the dense scoring kernel asked for a retry");
+            c->det_screen_suspended = true;
+            ++c->screen_retries;
+            struct Resume { Ctx* c; ~Resume() { c->det_screen_suspended = false; } } resume{c};
+            with_candidate_room(c, run);
+            return;
+        }
     }
+}
+
+extern "C" int32_t pvf_detector_screening(pvf_handle h, int32_t on, int32_t list_cap)
+{
+    API_BEGIN
+    ENTER_DET(c, h);
+    PVF_REQUIRE(list_cap >= 0, "pvf_detector_screening: list_cap must be >= 0");
+    c->det_screen = on != 0;
+    if (list_cap > 0) c->screen_list_cap = list_cap;
+    API_END
+}
+
+extern "C" int32_t pvf_detector_screening_stats(pvf_handle h, int64_t* batches, int64_t* listed, int64_t* retries, double* bounds, double* pipe_err)
+{
+    API_BEGIN
+    ENTER_DET(c, h);
+    if (batches) *batches = c->screen_batches;
+    if (listed) *listed = c->screen_listed;
+    if (retries) *retries = c->screen_retries;
+    if (bounds) for (int f = 0; f < c->det.n_filters; ++f) bounds[f] = c->det.screen_bound[f];
+    if (pipe_err) *pipe_err = c->screen_pipe_err;
+    API_END
 }
 
 extern "C" int32_t pvf_detect_batch(pvf_handle h, const pvf_handle* frames, int32_t n_frames, int32_t upsample, double adjust,

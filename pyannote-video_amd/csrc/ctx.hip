@@ -1,5 +1,6 @@
 // ctx.hip -- context, model containers, frames, HIP-event profiling.
 #include "pvf_internal.h"
+#include "detect_ml.h"
 #include <fstream>
 #include <mutex>
 #include <dlfcn.h>
@@ -109,6 +110,7 @@ static void load_detector(Ctx* c, const char* path)
         if (d.d_bmfma4) (void)hipFree(d.d_bmfma4);
         d.d_bmfma4 = upload<float>(b4.data(), b4.size());
     }
+    screen_prepare_model(d, w.f32());
     d.loaded = true;
 }
 
@@ -313,6 +315,7 @@ extern "C" int32_t pvf_ctx_create_prio(int32_t device, int32_t priority_class, p
         HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio));
         HIP_CHECK(hipStreamCreateWithPriority(&c->det_stream, hipStreamNonBlocking, lo));
     }
+    if (const char* e = getenv("PVF_DETECTOR_SCREENING")) c->det_screen = atoi(e) != 0;     // (what pvf_detector_screening sets: 0 = dense scoring only)
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     uint64_t id = g_next_ctx++;
     g_ctxs[id] = std::move(c);

@@ -1,7 +1,7 @@
 // detect.hip -- K1..K4: image pyramid, FHOG, filter scoring, NMS  (replaces dlib.get_frontal_face_detector()(rgb, 1);
 // reference pyannote/video/face/face.py:54,66).  All arithmetic follows the orders stated in oracle/pvo_fhog.c and
 // oracle/pvo_detect.c so that boxes are bit-identical; the code itself is written for gfx950 (wave64, LDS tiles).
-#include "fhog_dev.h"
+#include "detect_ml.h"
 #include <algorithm>
 #include <thread>
 #include <cmath>
@@ -179,8 +179,7 @@ static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
 // =====================================================================================================
 // K3: filter scoring.  score[f](r,c) = fmaf chain over (m, n, p) -- identical order to the oracle (oracle/pvo_detect.c).
 // =====================================================================================================
-struct ScoreParams { float thresh[8]; int n_filters; int level; int cap; };
-struct CandRec { float score; int32_t filter, level, r, c; };
+// (ScoreParams, CandRec: detect_ml.h)
 
 // =====================================================================================================
 // host side: level schedule, rectangle mapping, canonical sort, NMS
@@ -247,19 +246,6 @@ static void upload_frame_ptrs(Ctx* c, const std::vector<Frame>& frames, const ui
 // fill the CUs the big ones leave idle.
 // A block finds its level with a short scan of block-start offsets passed by value (kernarg / scalar cache).
 // =====================================================================================================
-#define ML_MAX 32
-struct LvDesc {
-    int h, w, rb;                               // level image, row pitch in bytes (multiple of 64)
-    int cells_nr, cells_nc, visible_nr, visible_nc;
-    int fh, fw, hog_nr, hog_nc;                 // feature map (with its zero border) and the cells that carry features
-    int feat_bx, score_bx;
-    int valid_score;
-    int roll_nseg, roll_rows;                   // K3 v5: a column strip is walked in roll_nseg pieces of roll_rows output rows
-    int strips, chunks, chunk_rows, fused_tasks;  // fused FHOG: 64-lane strips of 61 feature columns x chunks of chunk_rows feature rows
-    long long img_off, img_stride;              // bytes
-    long long feat_off, feat_stride;            // floats
-};
-struct MlStarts { int nl; int b0[ML_MAX + 1]; };
 
 // Logical block id of the multi-level kernels.  A contiguous-range-per-XCD order (so that vertically adjacent tiles meet in one
 // L2) was measured 5-8 % SLOWER for the histogram / feature / scoring kernels (the ranges differ in cost per block, and the
@@ -701,6 +687,8 @@ struct MlPlan {
     RowTab* d_rowtab = nullptr;                // row tables of every resize stage: upsampling stages first, then level l from level l - 1
     std::vector<size_t> up_tab, lv_tab;        // offsets (entries) into d_rowtab
     const void* ring_valid_for = nullptr;      // feature buffer whose zero border was written for this plan (fused FHOG)
+    ScreenPlan screen;                         // work items of the screening pass (screen.hip), built when it is first used
+    bool screen_built = false;
     ~MlPlan() { if (d_lv) (void)hipFree(d_lv); if (d_rowtab) (void)hipFree(d_rowtab); }
     MlPlan() = default;
     MlPlan(const MlPlan&) = delete;
@@ -893,6 +881,16 @@ static void det_run_batch_ml(Ctx* c, const std::vector<Frame>& frames, int upsam
     const int B = (int)frames.size();
     MlPlan* p = ml_features(c, frames, upsample);
     if (p->walk_blocks == 0) return;
+    if (c->det_screen && !c->det_screen_suspended) {
+        // the f16 screening pass + the exact chain for what it lists (screen.hip); its counters sit behind the B candidate counts
+        if (!p->screen_built) { screen_plan_build(p->screen, p->lv, B); p->screen_built = true; }
+        if (p->screen.usable) {
+            ProfScope ps(c, "score_screened", c->det_stream);
+            screen_launch(c, p->screen, p->d_lv, B, c->s_feat.as<float>(), sp0, d_counts, d_cands, d_counts + B);
+            ++c->screen_batches;
+            return;
+        }
+    }
     ProfScope ps(c, "score", c->det_stream);
     const size_t lds = (size_t)2 * (((2 * 48 + 11) * 31 + 3) / 4 * 4) * sizeof(float);      // one slab of 107 packed cells of 31 planes, double-buffered
     const float4* b4 = reinterpret_cast<const float4*>(m.d_bmfma4);
@@ -942,6 +940,18 @@ static bool raw_less(const RawDet& x, const RawDet& y)
 
 static void decode_candidates(const DetectorModel& m, int upsample, const CandRec* q, int n, std::vector<RawDet>& v);
 
+// the screening pass's counters of a finished batch: a list that overflowed or a feature above the assumed bound => the call is repeated
+// on the dense kernel (api.hip: with_candidate_room)
+static void screen_verdict(Ctx* c, const int* ctl)
+{
+    if (!c->det_screen || c->det_screen_suspended) return;
+    c->screen_listed += std::min(ctl[SCR_FLAGGED], c->screen_list_cap);
+    if (ctl[SCR_FLAGGED] > c->screen_list_cap || ctl[SCR_VIOLATION] != 0) {
+        HIP_CHECK(hipStreamSynchronize(c->det_stream));                 // (det_run_many: the next batch is in flight on the shared scratch)
+        throw ScreenRetry();
+    }
+}
+
 void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, double adjust, std::vector<std::vector<RawDet>>& raw_sorted)
 {
     const DetectorModel& m = c->det;
@@ -949,20 +959,22 @@ void det_run_batch(Ctx* c, const std::vector<Frame>& frames, int upsample, doubl
     PVF_REQUIRE(!frames.empty(), "no frames");
     const int B = (int)frames.size();
     const int cap = c->det_cand_cap;
-    c->s_cand.ensure((size_t)B * cap * sizeof(CandRec) + (size_t)B * sizeof(int) + 64);
+    const size_t cnt_bytes = (((size_t)(B + SCR_CTL_INTS) * sizeof(int) + 63) / 64) * 64;     // per-frame counts + the screening pass's counters
+    c->s_cand.ensure((size_t)B * cap * sizeof(CandRec) + cnt_bytes + 64);
     int* d_counts = c->s_cand.as<int>();
-    CandRec* d_cands = reinterpret_cast<CandRec*>(c->s_cand.as<uint8_t>() + (((size_t)B * sizeof(int) + 63) / 64) * 64);
-    HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), c->det_stream));
+    CandRec* d_cands = reinterpret_cast<CandRec*>(c->s_cand.as<uint8_t>() + cnt_bytes);
+    HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)(B + SCR_CTL_INTS) * sizeof(int), c->det_stream));
     ScoreParams sp;
     for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
     sp.n_filters = m.n_filters; sp.cap = cap;
     det_run_batch_ml(c, frames, upsample, sp, d_counts, d_cands);
     HIP_CHECK(hipGetLastError());
-    c->h_cand.ensure((size_t)B * cap * sizeof(CandRec) + (size_t)B * sizeof(int) + 64);
+    c->h_cand.ensure((size_t)B * cap * sizeof(CandRec) + cnt_bytes + 64);
     int* h_counts = c->h_cand.as<int>();
-    CandRec* h_cands = reinterpret_cast<CandRec*>(c->h_cand.as<uint8_t>() + (((size_t)B * sizeof(int) + 63) / 64) * 64);
-    HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->det_stream));
+    CandRec* h_cands = reinterpret_cast<CandRec*>(c->h_cand.as<uint8_t>() + cnt_bytes);
+    HIP_CHECK(hipMemcpyAsync(h_counts, d_counts, (size_t)(B + SCR_CTL_INTS) * sizeof(int), hipMemcpyDeviceToHost, c->det_stream));
     HIP_CHECK(hipStreamSynchronize(c->det_stream));
+    screen_verdict(c, h_counts + B);
     raw_sorted.assign(B, {});
     for (int b = 0; b < B; ++b) {
         const int n = h_counts[b];
@@ -1017,7 +1029,7 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
     ScoreParams sp;
     for (int f = 0; f < 8; ++f) sp.thresh[f] = f < m.n_filters ? (float)((double)m.thresh[f] + adjust) : 3.0e38f;
     sp.n_filters = m.n_filters; sp.cap = cap;
-    const size_t cnt_bytes = (((size_t)batch * sizeof(int) + 63) / 64) * 64;
+    const size_t cnt_bytes = (((size_t)(batch + SCR_CTL_INTS) * sizeof(int) + 63) / 64) * 64;     // per-frame counts + the screening pass's counters
     for (int k = 0; k < 2; ++k) {
         c->s_cand2[k].ensure(cnt_bytes + (size_t)batch * cap * sizeof(CandRec));
         c->h_cand2[k].ensure(cnt_bytes + (size_t)batch * PF * sizeof(CandRec));
@@ -1028,12 +1040,12 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
         const int B = (int)fr.size();
         int* d_counts = c->s_cand2[slot].as<int>();
         CandRec* d_cands = reinterpret_cast<CandRec*>(c->s_cand2[slot].as<uint8_t>() + cnt_bytes);
-        HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)B * sizeof(int), c->det_stream));
+        HIP_CHECK(hipMemsetAsync(d_counts, 0, (size_t)(B + SCR_CTL_INTS) * sizeof(int), c->det_stream));
         c->det_slot = slot;
         det_run_batch_ml(c, fr, upsample, sp, d_counts, d_cands);
         HIP_CHECK(hipGetLastError());
         uint8_t* hb = c->h_cand2[slot].as<uint8_t>();
-        HIP_CHECK(hipMemcpyAsync(hb, d_counts, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, c->det_stream));
+        HIP_CHECK(hipMemcpyAsync(hb, d_counts, (size_t)(B + SCR_CTL_INTS) * sizeof(int), hipMemcpyDeviceToHost, c->det_stream));
         HIP_CHECK(hipMemcpy2DAsync(hb + cnt_bytes, (size_t)PF * sizeof(CandRec), d_cands, (size_t)cap * sizeof(CandRec),
                                    (size_t)PF * sizeof(CandRec), (size_t)B, hipMemcpyDeviceToHost, c->det_stream));
         HIP_CHECK(hipEventRecord(c->det_ev[slot], c->det_stream));
@@ -1045,6 +1057,7 @@ void det_run_many(Ctx* c, const std::vector<Frame>& frames, int batch, int upsam
         const int* h_counts = reinterpret_cast<const int*>(hb);
         const CandRec* h_cands = reinterpret_cast<const CandRec*>(hb + cnt_bytes);
         const CandRec* d_cands = reinterpret_cast<const CandRec*>(c->s_cand2[slot].as<uint8_t>() + cnt_bytes);
+        screen_verdict(c, h_counts + B);
         for (int b = 0; b < B; ++b)
             if (h_counts[b] > cap) {
                 HIP_CHECK(hipStreamSynchronize(c->det_stream));         // the next batch is in flight on the shared scratch: let it finish before the call is repeated

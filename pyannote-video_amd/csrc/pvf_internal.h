@@ -20,6 +20,9 @@
 struct PvfError : std::runtime_error { using std::runtime_error::runtime_error; };
 // a frame produced more raw candidates than the context's candidate slots hold: the entry point enlarges them and runs the call again
 struct CandOverflow : PvfError { int needed; explicit CandOverflow(int n) : PvfError("detector: candidate buffer overflow"), needed(n) {} };
+// the screening pass (screen.hip) listed more windows than its list holds, or met a feature above the bound its error analysis assumes:
+// the call runs again on the dense exact kernel
+struct ScreenRetry : PvfError { ScreenRetry() : PvfError("detector: screening pass gave up") {} };
 
 #define HIP_CHECK(expr)                                                                              \
     do {                                                                                             \
@@ -133,6 +136,8 @@ struct DetectorModel {
     std::vector<float> thresh;
     float* d_w = nullptr;    // [nf][frows][fcols][32]
     float* d_bmfma4 = nullptr; // B fragments of score_roll_k: [10][12][2][64 lanes][4 k-steps] (3 shifts x 5 filters per 16-column MFMA tile)
+    uint16_t* d_bscreen = nullptr;     // f16 B fragments of score_screen_k: [10][12][64 lanes][8] (weights x 256)
+    double screen_bound[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // |screening score / 256 - exact chain| <= screen_bound[filter] (screen.hip)
 };
 
 struct ShapeModel {
@@ -239,6 +244,12 @@ struct Ctx {
     hipEvent_t det_ev[2] = {nullptr, nullptr};
     int det_slot = 0;
     int det_cand_cap = 8192;                  // raw candidates per frame the scoring kernel can record (grown on demand, api.hip)
+    // screening pass in front of the exact scoring chain (screen.hip; pvf_detector_screening)
+    bool det_screen = true, det_screen_suspended = false, screen_attr_set = false;
+    int screen_list_cap = 1 << 20;            // (position, filter) pairs a batch may list for exact re-scoring
+    DevBuf s_screen;
+    int64_t screen_batches = 0, screen_listed = 0, screen_retries = 0;
+    double screen_pipe_err = -1;              // measured by screen_probe: worst |pipe - exact| / sum of magnitudes over a K = 3200 accumulation
     int n_cu = 256;
     // released frame buffers by size.  A buffer comes back with the event recorded on the compute stream at its release: whoever takes it
     // next orders its first write behind that event (pool_take), so releasing a frame never waits for the kernels that still read it.

@@ -1,0 +1,456 @@
+// screen.hip -- K3s: a screening pass in front of the detector's exact scoring chain (opt-in: pvf_detector_screening).
+//
+// The detector keeps a window when its score -- a chain of 3100 fmaf in (filter row, filter column, plane) order, oracle/pvo_detect.c
+// (dlib's scan_fhog_pyramid via reference pyannote/video/face/face.py:66) -- reaches the filter's threshold.  Of the 2.07 million
+// (position, filter) pairs of a 1080p frame fewer than a hundred do.  The dense kernel (score_roll_k, detect.hip) evaluates the exact
+// chain everywhere on the fp32 matrix cores: 136 us per frame, a third of the whole step.  Here the same sums are first evaluated
+// APPROXIMATELY on the f16 matrix cores (v_mfma_f32_16x16x32_f16, 16 x the fp32 rate), with an error bound E_f per filter that is
+// derived below from the weights and checked against the data while it is read; every pair whose approximate score reaches
+// threshold - E_f is put on a list, and score_list_k evaluates the exact chain for the list only.  A pair that is not listed has an
+// exact score below the threshold -- so the candidates (position, filter, exact score) are the dense kernel's, bit for bit, whatever
+// the data.  If the list overflows (a threshold lowered into the bulk of the score distribution) or a feature exceeds the bound the
+// derivation assumes, the call is repeated on the dense kernel (ScreenRetry, api.hip): screening never changes a result.
+//
+// The bound.  f = feature (>= 0, <= FM[plane]: 0.4001 for the 27 orientation planes = 4 x min(h, n) * 0.1 / n, 0.8486 for the 4 texture
+// planes = 0.4714 x 18 x 0.1; fhog_dev.h), w = weight, w' = f16(256 w) / 256 (round to nearest, done on the host: the error is KNOWN),
+// f' = f16(f) (v_cvt_pkrtz: |f' - f| <= 2^-10 f, or <= 2^-14 should the pipe flush a subnormal).  S = exact chain, S* = the real sum,
+// S' = what the matrix pipe returns for sum f' w'.
+//   |S  - S*|  <= g(3100) sum |f w|                      (3100 roundings of a recursive fp32 sum, g(n) = n u / (1 - n u), u = 2^-24)
+//   |S' - S*|  <= sum f |w' - w| + sum |w'| max(2^-10 f, 2^-14) + 3200 x 2^-22 x sum f' |w'|
+// the last term allows every addition inside the matrix pipe four times the rounding error of an IEEE fp32 addition (products of two
+// f16 are exact in fp32); tests/test_gpu_screen.py measures the pipe against that allowance.  With f <= FM these are sums over the
+// weights alone: E_f = 1.02 x (all four terms) ~ 0.04 for the reference-shaped model, and on real data S' - S stays below 4e-4.
+//
+// The kernel.  As in score_roll_k three neighbouring output columns share a 16-column tile (column = 5 x shift + filter; K of a filter
+// row = 12 cells x 32 planes = 12 MFMAs of K = 32), a tile's 16 rows are 16 base columns 3 cells apart.  A WAVE walks a strip of up to
+// four such groups (192 output columns) top to bottom; ten output rows are alive at a time (feature row s is filter row m = s - r of
+// output row r); slot q of the accumulators holds the output row r = q (mod 10), and the B fragment it needs at step s (m = (s - q) mod
+// 10) is addressed, not moved: all 120 B fragments (120 KB of f16) sit in LDS, loaded once per block, and a fragment feeds four MFMAs.
+// A fragments come straight from the fp32 feature map: lane (base i, plane octet kq) loads the 32 bytes of cell 3 i + n', converts them
+// (4 v_cvt_pkrtz) and -- because cell 3 i + (n' + 3) is cell 3 (i + 1) + n' -- hands them to base i - 1 with two DPP row moves for n' + 3,
+// + 6, + 9: a feature row is loaded and converted ONCE (3 cell phases x 5 fragments), not four times.  A block is four independent
+// waves (one per SIMD, up to 512 registers each) that pull work items from a counter, largest first.
+#include "detect_ml.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ScreenParams { float flag_at[8]; float lim_lo, lim_hi; int n_items, list_cap; };
+
+#define SCR_B_BYTES (10 * 12 * 64 * 16)          // B fragments: [filter row m][cell n'][lane][8 halfs]
+#define SCR_M_STRIDE (12 * 64 * 16)
+
+__device__ __forceinline__ uint32_t pk_f16(float a, float b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+
+template <int NG>
+__device__ __forceinline__ void screen_walk(const ScreenItem t, const LvDesc* __restrict__ lv, const float* __restrict__ feat_base,
+                                            const uint8_t* s_b, const float th_lane, int* __restrict__ ctl, uint2* __restrict__ list,
+                                            const int list_cap, float& mx_lo, float& mx_hi)
+{
+    constexpr int RSRC_FLAGS = 0x00020000;
+    constexpr int FR = 10, FC = 10;
+    const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+    const int fw = lv[t.lv].fw;
+    const long long feat_off = lv[t.lv].feat_off, feat_stride = lv[t.lv].feat_stride;
+    const float* fb = feat_base + feat_off + (size_t)t.b * feat_stride + ((size_t)t.r_base * fw + t.c_base) * PVF_FHOG_STRIDE;
+    const int row_bytes = (fw - t.c_base) * PVF_FHOG_STRIDE * 4;
+    const int fh_in = t.out_rows + FR - 1;
+    const int c1 = fw - (FC - FC / 2 - 1);
+    const int voff = i * 384 + kq * 32;           // cell 3 i, planes 8 kq .. 8 kq + 7 (bytes within the strip's row)
+    f32x4 acc[10][NG];
+#pragma unroll
+    for (int q = 0; q < 10; ++q)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[q][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // slot q of the accumulators holds the output row that takes filter row m = q at this step: its B fragments sit at a fixed LDS
+    // address (two bases: a ds_read's immediate offset has 16 bits)
+    const uint8_t* b_lo = s_b + lane * 16;
+    const uint8_t* b_hi = s_b + lane * 16 + 5 * SCR_M_STRIDE;
+    // phase `cls` (cells 3 i + cls) of feature row `row`: two 16-byte loads per group; group NG is the tail (bases 16 NG .. 16 NG + 2)
+    auto load_cls = [&](int row, int cls, u32x4 (&raw)[NG + 1][2]) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + (size_t)row * fw * PVF_FHOG_STRIDE), 0,
+                                                                            row < fh_in ? row_bytes : 0, RSRC_FLAGS);
+#pragma unroll
+        for (int g = 0; g <= NG; ++g) {
+            // (everything in the VGPR offset: the scalar offset of a raw buffer access takes no part in the range check)
+            raw[g][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + cls * 128 + g * 6144, 0, 0);
+            raw[g][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + cls * 128 + g * 6144 + 16, 0, 0);
+        }
+    };
+    auto cvt_frag = [&](const u32x4 (&r)[2]) -> u32x4 {
+        const float f0 = __uint_as_float(r[0].x), f1 = __uint_as_float(r[0].y), f2 = __uint_as_float(r[0].z), f3 = __uint_as_float(r[0].w);
+        const float f4 = __uint_as_float(r[1].x), f5 = __uint_as_float(r[1].y), f6 = __uint_as_float(r[1].z), f7 = __uint_as_float(r[1].w);
+        mx_lo = fmaxf(mx_lo, fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fabsf(f2)));
+        mx_hi = fmaxf(mx_hi, fmaxf(fmaxf(fmaxf(fabsf(f3), fabsf(f4)), fmaxf(fabsf(f5), fabsf(f6))), fabsf(f7)));
+        u32x4 o;
+        o.x = pk_f16(f0, f1); o.y = pk_f16(f2, f3); o.z = pk_f16(f4, f5); o.w = pk_f16(f6, f7);
+        return o;
+    };
+    // base i takes over what base i + 1 holds (lane 15: base 0 of the next group): cell 3 (i + 1) + n' = cell 3 i + (n' + 3)
+    auto shift_bases = [&](u32x4 (&a)[NG + 1]) {
+#pragma unroll
+        for (int g = 0; g <= NG; ++g) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int fill = 0;
+                if (g < NG) fill = __builtin_amdgcn_update_dpp(0, (int)a[g + 1][e], 0x11F /* row_shr:15 */, 0xf, 0xf, false);
+                a[g][e] = (uint32_t)__builtin_amdgcn_update_dpp(fill, (int)a[g][e], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+            }
+        }
+    };
+    auto emit = [&](const f32x4 (&a)[NG], int r_out) {
+        float vm = a[0][0];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vm = fmaxf(vm, a[g][e]);
+        const bool hit = vm >= th_lane;
+        if (r_out >= 0 && __builtin_amdgcn_ballot_w64(hit) != 0) {
+            const int jc = lane & 15;
+            const int sft = jc / 5, f = jc % 5;
+            const int r = t.r_base + r_out + FR / 2;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cc = t.c_base + 48 * g + 3 * (4 * kq + e) + sft + FC / 2;
+                    if (a[g][e] >= th_lane && cc < c1) {
+                        const int idx = atomicAdd(&ctl[SCR_FLAGGED], 1);
+                        if (idx < list_cap) list[idx] = make_uint2((uint32_t)t.b, ((uint32_t)t.lv << 27) | ((uint32_t)f << 24) | ((uint32_t)r << 12) | (uint32_t)cc);
+                    }
+                }
+        }
+    };
+
+    u32x4 A[3][NG + 1];
+    {
+        u32x4 raw[NG + 1][2];
+#pragma unroll
+        for (int cls = 0; cls < 3; ++cls) {
+            load_cls(0, cls, raw);
+#pragma unroll
+            for (int g = 0; g <= NG; ++g) A[cls][g] = cvt_frag(raw[g]);
+        }
+    }
+    for (int s = 0; s < fh_in; ++s) {
+        u32x4 An[3][NG + 1];
+        u32x4 raw[NG + 1][2];
+        f32x4 done[NG];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int cls = j % 3;
+            if (j > 0 && cls == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) shift_bases(A[k]);
+            }
+            if (j % 4 == 0) load_cls(s + 1, j / 4, raw);
+            // (slots in descending order: at the last cell a slot's result moves on to the next slot -- the row's next filter row --, the
+            // last slot's is the finished row)
+#pragma unroll
+            for (int q = 9; q >= 0; --q) {
+                const u32x4 bq = *reinterpret_cast<const u32x4*>((q < 5 ? b_lo + q * SCR_M_STRIDE : b_hi + (q - 5) * SCR_M_STRIDE) + j * 1024);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[cls][g]), __builtin_bit_cast(f16x8, bq), acc[q][g], 0, 0, 0);
+                    if (j < 11) acc[q][g] = v;
+                    else if (q == 9) done[g] = v;
+                    else acc[q + 1][g] = v;
+                }
+            }
+            if (j % 4 == 3) {
+#pragma unroll
+                for (int g = 0; g <= NG; ++g) An[j / 4][g] = cvt_frag(raw[g]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[0][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        emit(done, s - (FR - 1));
+#pragma unroll
+        for (int cls = 0; cls < 3; ++cls)
+#pragma unroll
+            for (int g = 0; g <= NG; ++g) A[cls][g] = An[cls][g];
+    }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+score_screen_k(const ScreenItem* __restrict__ items, const LvDesc* __restrict__ lv, const float* __restrict__ feat_base,
+               const u32x4* __restrict__ Bh, ScreenParams sp, int* __restrict__ ctl, uint2* __restrict__ list)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_b[];
+    for (int k = threadIdx.x; k < SCR_B_BYTES / 16; k += 256) reinterpret_cast<u32x4*>(s_b)[k] = Bh[k];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int jc = lane & 15, f = jc % 5;
+    float th_lane = sp.flag_at[0];
+    th_lane = f == 1 ? sp.flag_at[1] : th_lane;
+    th_lane = f == 2 ? sp.flag_at[2] : th_lane;
+    th_lane = f == 3 ? sp.flag_at[3] : th_lane;
+    th_lane = f == 4 ? sp.flag_at[4] : th_lane;
+    th_lane = jc < 15 ? th_lane : 3.0e38f;
+    float mx_lo = 0.f, mx_hi = 0.f;
+    for (;;) {
+        int it = 0;
+        if (lane == 0) it = atomicAdd(&ctl[SCR_CURSOR], 1);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= sp.n_items) break;
+        ScreenItem t;
+        t.lv = __builtin_amdgcn_readfirstlane(items[it].lv); t.b = __builtin_amdgcn_readfirstlane(items[it].b);
+        t.c_base = __builtin_amdgcn_readfirstlane(items[it].c_base); t.r_base = __builtin_amdgcn_readfirstlane(items[it].r_base);
+        t.out_rows = __builtin_amdgcn_readfirstlane(items[it].out_rows); t.ng = __builtin_amdgcn_readfirstlane(items[it].ng);
+        switch (t.ng) {
+        case 1: screen_walk<1>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx_lo, mx_hi); break;
+        case 2: screen_walk<2>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx_lo, mx_hi); break;
+        case 3: screen_walk<3>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx_lo, mx_hi); break;
+        default: screen_walk<4>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx_lo, mx_hi); break;
+        }
+    }
+    // planes 8 kq + 0..2 are orientation planes in every octet; 8 kq + 3..7 are texture planes (and the pad) in the last octet only
+    const float lim_hi = (lane >> 4) == 3 ? sp.lim_hi : sp.lim_lo;
+    if (mx_lo > sp.lim_lo || mx_hi > lim_hi) atomicOr(&ctl[SCR_VIOLATION], 1);
+}
+
+// the exact chain for the listed (position, filter) pairs: one lane per pair, the oracle's order (m, n, p), fmaf
+__global__ void __launch_bounds__(256) score_list_k(const uint2* __restrict__ list, const int* __restrict__ ctl, int list_cap,
+                                                    const LvDesc* __restrict__ lv, const float* __restrict__ feat_base,
+                                                    const float* __restrict__ W, ScoreParams sp, int* __restrict__ counts, CandRec* __restrict__ cands)
+{
+    constexpr int FR = 10, FC = 10;
+    const int n = min(ctl[SCR_FLAGGED], list_cap);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const uint2 q = list[e];
+        const int b = (int)q.x;
+        const int l = (int)(q.y >> 27), f = (int)((q.y >> 24) & 7), r = (int)((q.y >> 12) & 4095), cc = (int)(q.y & 4095);
+        const int fw = lv[l].fw;
+        const float* fp = feat_base + lv[l].feat_off + (size_t)b * lv[l].feat_stride + ((size_t)(r - FR / 2) * fw + (cc - FC / 2)) * PVF_FHOG_STRIDE;
+        const float* wp = W + (size_t)f * FR * FC * PVF_FHOG_STRIDE;
+        float acc = 0.0f;
+        for (int m = 0; m < FR; ++m)
+            for (int nn = 0; nn < FC; ++nn) {
+                const f32x4* fv = reinterpret_cast<const f32x4*>(fp + ((size_t)m * fw + nn) * PVF_FHOG_STRIDE);
+                const f32x4* wv = reinterpret_cast<const f32x4*>(wp + ((size_t)m * FC + nn) * PVF_FHOG_STRIDE);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const f32x4 a = fv[k], w = wv[k];
+                    acc = fmaf(a[0], w[0], acc); acc = fmaf(a[1], w[1], acc); acc = fmaf(a[2], w[2], acc);
+                    if (k < 7) acc = fmaf(a[3], w[3], acc);          // (plane 31 is padding)
+                }
+            }
+        const float th = sp.thresh[f];
+        if (acc >= th) {
+            const int idx = atomicAdd(&counts[b], 1);
+            if (idx < sp.cap) {
+                CandRec rec;
+                rec.score = acc - th; rec.filter = f; rec.level = l; rec.r = r; rec.c = cc;
+                cands[(size_t)b * sp.cap + idx] = rec;
+            }
+        }
+    }
+}
+
+// What the screening kernel takes for granted about the device, checked once per context (a mismatch is an error, not a fallback):
+// (1) lanes (row, k octet) of A and (column, k octet) of B meet in v_mfma_f32_16x16x32_f16 and lane (column, row quad) receives D;
+// (2) a K = 3200 accumulation inside the matrix pipe stays within the allowance of the error bound (2^-22 per addition, relative to
+// the sum of the terms' magnitudes); (3) the two DPP row moves of shift_bases hand base i what base i + 1 held.
+__global__ void screen_probe_k(const u32x4* __restrict__ a, const u32x4* __restrict__ b, int steps, float* __restrict__ d, int* __restrict__ moved)
+{
+    const int lane = threadIdx.x;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < steps; ++s)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[s * 64 + lane]), __builtin_bit_cast(f16x8, b[s * 64 + lane]), acc, 0, 0, 0);
+    for (int e = 0; e < 4; ++e) d[lane * 4 + e] = acc[e];
+    const int fill = __builtin_amdgcn_update_dpp(0, lane + 1000, 0x11F, 0xf, 0xf, false);
+    moved[lane] = __builtin_amdgcn_update_dpp(fill, lane + 100, 0x101, 0xf, 0xf, false);
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------------------------
+static uint16_t f32_to_f16_rne(float v)
+{
+    uint32_t x;
+    memcpy(&x, &v, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((x >> 23) & 0xff) - 127 + 15;
+    uint32_t man = x & 0x7fffffu;
+    if (((x >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {                                  // subnormal half (or zero)
+        if (e < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - e;                  // 24-bit significand -> 10 bits at exponent 1
+        const uint32_t half = man >> shift, rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+        uint32_t h = half;
+        if (rem > mid || (rem == mid && (half & 1))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;      // (a carry into the exponent is the right answer)
+    return (uint16_t)(sign | h);
+}
+static double f16_to_f64(uint16_t h)
+{
+    const int s = (h >> 15) & 1, e = (h >> 10) & 31, m = h & 1023;
+    double v;
+    if (e == 0) v = std::ldexp((double)m, -24);
+    else if (e == 31) v = INFINITY;
+    else v = std::ldexp((double)(m | 1024), e - 25);
+    return s ? -v : v;
+}
+
+static const double SCR_SCALE = 256.0;             // weights are multiplied by 2^8 before the conversion: |w| <= 0.1 sits in f16's subnormal range otherwise
+static const double SCR_FM_LO = 0.4001, SCR_FM_HI = 0.8486;
+
+void screen_prepare_model(DetectorModel& d, const float* w)
+{
+    PVF_REQUIRE(d.n_filters == 5 && d.frows == 10 && d.fcols == 10, "screening: 5 filters of 10 x 10 cells");
+    std::vector<uint16_t> bh((size_t)10 * 12 * 64 * 8, 0);
+    for (int m = 0; m < 10; ++m)
+        for (int j = 0; j < 12; ++j)
+            for (int l = 0; l < 64; ++l) {
+                const int jc = l & 15, kq = l >> 4;
+                if (jc >= 15) continue;
+                const int sft = jc / 5, f = jc % 5, n = j - sft;
+                if (n < 0 || n >= 10) continue;
+                for (int e = 0; e < 8; ++e) {
+                    const int p = 8 * kq + e;
+                    if (p >= 31) continue;
+                    bh[(((size_t)m * 12 + j) * 64 + l) * 8 + e] = f32_to_f16_rne((float)((double)w[(((size_t)f * 10 + m) * 10 + n) * 32 + p] * SCR_SCALE));
+                }
+            }
+    if (d.d_bscreen) (void)hipFree(d.d_bscreen);
+    HIP_CHECK(hipMalloc((void**)&d.d_bscreen, bh.size() * sizeof(uint16_t)));
+    HIP_CHECK(hipMemcpy(d.d_bscreen, bh.data(), bh.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    const double u = std::ldexp(1.0, -24);
+    for (int f = 0; f < d.n_filters; ++f) {
+        double e_w = 0, e_f = 0, a_h = 0, a_w = 0;
+        for (int m = 0; m < 10; ++m)
+            for (int n = 0; n < 10; ++n)
+                for (int p = 0; p < 31; ++p) {
+                    const double wv = (double)w[(((size_t)f * 10 + m) * 10 + n) * 32 + p];
+                    const double wh = f16_to_f64(f32_to_f16_rne((float)(wv * SCR_SCALE))) / SCR_SCALE;
+                    const double fm = p < 27 ? SCR_FM_LO : SCR_FM_HI;
+                    e_w += fm * std::fabs(wh - wv);
+                    e_f += std::fabs(wh) * std::max(fm * std::ldexp(1.0, -10), std::ldexp(1.0, -14));
+                    a_h += fm * std::fabs(wh);
+                    a_w += fm * std::fabs(wv);
+                }
+        const double e_pipe = 3200.0 * std::ldexp(1.0, -22) * a_h * (1.0 + std::ldexp(1.0, -10));
+        const double e_chain = 3100.0 * u / (1.0 - 3100.0 * u) * a_w;
+        d.screen_bound[f] = 1.02 * (e_w + e_f + e_pipe + e_chain) + 1e-6;
+    }
+}
+
+void screen_plan_build(ScreenPlan& sp, const std::vector<LvDesc>& lv, int B)
+{
+    // pieces of <= seg output rows: a piece re-walks the 9 feature rows above it, so pieces are tall where the batch has work enough for
+    // every wave (1024) several times over, and short where it has not
+    long long total = 0;
+    for (const LvDesc& d : lv)
+        if (d.valid_score) total += (long long)((d.fw - 9 + 47) / 48) * (d.fh - 9) * B;
+    int seg = (int)std::min<long long>(64, std::max<long long>(16, total / (4 * 4096)));
+    if (getenv("PVF_SCREEN_SEG")) seg = std::max(2, atoi(getenv("PVF_SCREEN_SEG")));
+    std::vector<ScreenItem> items;
+    sp.usable = lv.size() <= 32;                    // a list entry packs level (5 bits), filter (3), row and column (12 each)
+    for (const LvDesc& d : lv) sp.usable = sp.usable && d.fh < 4096 && d.fw < 4096;
+    if (!sp.usable) return;
+    for (int l = 0; l < (int)lv.size(); ++l) {
+        const LvDesc& d = lv[l];
+        if (!d.valid_score) continue;
+        const int out_c = d.fw - 9, out_r = d.fh - 9;
+        const int nseg = (out_r + seg - 1) / seg, rows = (out_r + nseg - 1) / nseg;
+        for (int c0 = 0; c0 < out_c; c0 += 48 * SCR_SG)
+            for (int r0 = 0; r0 < out_r; r0 += rows)
+                for (int b = 0; b < B; ++b)
+                    items.push_back(ScreenItem{l, b, c0, r0, std::min(rows, out_r - r0), std::min(SCR_SG, (out_c - c0 + 47) / 48)});
+    }
+    std::stable_sort(items.begin(), items.end(), [](const ScreenItem& a, const ScreenItem& b) { return a.ng * (a.out_rows + 9) > b.ng * (b.out_rows + 9); });
+    if (sp.d_items) (void)hipFree(sp.d_items);
+    sp.d_items = nullptr;
+    sp.n_items = (int)items.size();
+    if (items.empty()) return;
+    HIP_CHECK(hipMalloc((void**)&sp.d_items, items.size() * sizeof(ScreenItem)));
+    HIP_CHECK(hipMemcpy(sp.d_items, items.data(), items.size() * sizeof(ScreenItem), hipMemcpyHostToDevice));
+}
+
+static void screen_probe(Ctx* c)
+{
+    const int steps = 100;                          // K = 3200
+    std::vector<uint16_t> ha((size_t)steps * 64 * 8), hb((size_t)steps * 64 * 8);
+    uint32_t rs = 12345u;
+    auto rnd = [&]() { rs = rs * 1664525u + 1013904223u; return (double)(rs >> 8) / 16777216.0; };
+    // columns 0..7 of B positive (a sum of 3200 positive terms: rounding errors of one sign pile up), columns 8..15 of alternating sign
+    for (int s = 0; s < steps; ++s)
+        for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 8; ++e) {
+                ha[((size_t)s * 64 + l) * 8 + e] = f32_to_f16_rne((float)(0.05 + 0.8 * rnd()));
+                const double sgn = ((l & 15) < 8 || ((s + e) & 1)) ? 1.0 : -1.0;
+                hb[((size_t)s * 64 + l) * 8 + e] = f32_to_f16_rne((float)(sgn * (1.0 + 25.0 * rnd())));
+            }
+    uint8_t* dev = nullptr;
+    const size_t fb = ha.size() * 2;
+    HIP_CHECK(hipMalloc((void**)&dev, 2 * fb + 64 * 4 * sizeof(float) + 64 * sizeof(int)));
+    HIP_CHECK(hipMemcpy(dev, ha.data(), fb, hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(dev + fb, hb.data(), fb, hipMemcpyHostToDevice));
+    float* d_d = reinterpret_cast<float*>(dev + 2 * fb);
+    int* d_m = reinterpret_cast<int*>(dev + 2 * fb + 64 * 4 * sizeof(float));
+    hipLaunchKernelGGL(screen_probe_k, dim3(1), dim3(64), 0, c->det_stream, reinterpret_cast<const u32x4*>(dev), reinterpret_cast<const u32x4*>(dev + fb),
+                       steps, d_d, d_m);
+    float hd[256];
+    int hm[64];
+    HIP_CHECK(hipMemcpyAsync(hd, d_d, sizeof hd, hipMemcpyDeviceToHost, c->det_stream));
+    HIP_CHECK(hipMemcpyAsync(hm, d_m, sizeof hm, hipMemcpyDeviceToHost, c->det_stream));
+    HIP_CHECK(hipStreamSynchronize(c->det_stream));
+    (void)hipFree(dev);
+    double worst = 0;
+    for (int l = 0; l < 64; ++l)
+        for (int e = 0; e < 4; ++e) {
+            const int col = l & 15, row = 4 * (l >> 4) + e;
+            double sum = 0, mag = 0;
+            for (int s = 0; s < steps; ++s)
+                for (int kq = 0; kq < 4; ++kq)
+                    for (int k = 0; k < 8; ++k) {
+                        const double t = f16_to_f64(ha[((size_t)s * 64 + kq * 16 + row) * 8 + k]) * f16_to_f64(hb[((size_t)s * 64 + kq * 16 + col) * 8 + k]);
+                        sum += t; mag += std::fabs(t);
+                    }
+            worst = std::max(worst, std::fabs((double)hd[l * 4 + e] - sum) / mag);
+        }
+    c->screen_pipe_err = worst;
+    PVF_REQUIRE(worst <= 3200.0 * std::ldexp(1.0, -22), "screening: v_mfma_f32_16x16x32_f16 does not accumulate as the error bound of the screening pass assumes on this device");
+    bool ok = true;
+    for (int l = 0; l < 64; ++l) ok = ok && hm[l] == ((l & 15) < 15 ? l + 101 : l - 15 + 1000);
+    PVF_REQUIRE(ok, "screening: v_mov_b32_dpp row_shl:1 / row_shr:15 do not move data as the screening kernel expects on this device");
+}
+
+void screen_launch(Ctx* c, const ScreenPlan& plan, const LvDesc* d_lv, int B, const float* feat, const ScoreParams& thr, int* d_counts,
+                   CandRec* d_cands, int* ctl)
+{
+    const DetectorModel& m = c->det;
+    if (plan.n_items == 0) return;
+    if (!c->screen_attr_set) {
+        screen_probe(c);
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_screen_k), hipFuncAttributeMaxDynamicSharedMemorySize, SCR_B_BYTES));
+        c->screen_attr_set = true;
+    }
+    ScreenParams sp;
+    for (int f = 0; f < 8; ++f) {
+        if (f < m.n_filters) {
+            const float at = (float)(((double)thr.thresh[f] - m.screen_bound[f]) * SCR_SCALE);
+            sp.flag_at[f] = std::nextafterf(at, -INFINITY);
+        }
+        else sp.flag_at[f] = 3.0e38f;
+    }
+    sp.lim_lo = (float)SCR_FM_LO; sp.lim_hi = (float)SCR_FM_HI;
+    sp.n_items = plan.n_items;
+    sp.list_cap = c->screen_list_cap;
+    c->s_screen.ensure((size_t)sp.list_cap * sizeof(uint2) + 64);
+    uint2* list = c->s_screen.as<uint2>();
+    const int grid = std::min(c->n_cu, (plan.n_items + 3) / 4);
+    hipLaunchKernelGGL(score_screen_k, dim3(grid), dim3(256), SCR_B_BYTES, c->det_stream, plan.d_items, d_lv, feat,
+                       reinterpret_cast<const u32x4*>(m.d_bscreen), sp, ctl, list);
+    hipLaunchKernelGGL(score_list_k, dim3(256), dim3(256), 0, c->det_stream, list, ctl, sp.list_cap, d_lv, feat, m.d_w, thr, d_counts, d_cands);
+}

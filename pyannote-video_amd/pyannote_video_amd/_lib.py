@@ -50,6 +50,8 @@ _SIGS = {
     "pvf_detect": (C.c_int32, [H, H, C.c_int32, C.c_double, P, P, C.c_int32, P]),
     "pvf_detect_batch": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_double, P, P, P, C.c_int32]),
     "pvf_detect_many": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int32, C.c_double, P, P, P, C.c_int32]),
+    "pvf_detector_screening": (C.c_int32, [H, C.c_int32, C.c_int32]),
+    "pvf_detector_screening_stats": (C.c_int32, [H, P, P, P, P, P]),
     "pvf_tracker_create": (C.c_int32, [H, P]),
     "pvf_tracker_destroy": (C.c_int32, [H, H]),
     "pvf_tracker_create_many": (C.c_int32, [H, C.c_int32, P]),

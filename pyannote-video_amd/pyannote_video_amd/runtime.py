@@ -597,6 +597,20 @@ class Context(object):
         return labels, log[:n.value]
 
     # ---- measurement
+    def detector_screening(self, on=True, list_cap=0):
+        """the detector's screening pass (csrc/screen.hip): windows are first scored on the f16 matrix cores with a proven error bound and
+        only those within the bound of the threshold go through the exact fp32 chain -- same rectangles, order and scores, bit for bit"""
+        check(self._l.pvf_detector_screening(self._h, 1 if on else 0, int(list_cap)))
+
+    def detector_screening_stats(self):
+        """{"batches", "listed", "retries", "bounds", "pipe_err"}: batches screened, (window, filter) pairs that went through the exact
+        chain, calls repeated on the dense kernel, the error bound per filter (score units), the accumulation error the context measured
+        on its matrix pipe (relative to the sum of magnitudes; -1 before the first screened batch)"""
+        b, n, r, pe = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_double(-1.0)
+        bounds = np.zeros(8, np.float64)
+        check(self._l.pvf_detector_screening_stats(self._h, C.byref(b), C.byref(n), C.byref(r), ptr(bounds), C.byref(pe)))
+        return {"batches": b.value, "listed": n.value, "retries": r.value, "bounds": bounds[:5].tolist(), "pipe_err": pe.value}
+
     def prof_enable(self, on=True):
         check(self._l.pvf_prof_enable(self._h, 1 if on else 0))
 
