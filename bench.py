@@ -29,7 +29,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "pyannote-video_amd"))
 
 FP32_PEAK_TFLOPS = 157.3   # dense fp32 (vector == f32 MFMA) peak, MI355X_MICROARCH.md chip table
-PMC_SCORE_FILE = "r04_pmc_score.json"      # rocprofv3 --pmc FETCH_SIZE pass of the scoring kernel, keyed on the hash of csrc/detect.hip
+F16_PEAK_TFLOPS = 2500.0    # dense f16 / bf16 MFMA peak, same table (the 5 PF headline figure includes 2:1 sparsity)
+HBM_PEAK_GBS = 8000.0       # HBM3E, same table
+PMC_KERNELS_FILE = "r04_pmc_kernels.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the detector kernels, keyed on the hash of csrc/detect.hip + screen.hip
+DTYPE_NOTE_DENSE = "f32 (detector, embedder) / f64 (tracker, clustering) / u8 frames"
+DTYPE_NOTE = ("f32 (detector scores, embedder) / f64 (tracker, clustering) / u8 frames; an f16 screening pass with a proven error bound decides which windows the "
+              "detector's exact f32 chain is evaluated for -- results identical to dense f32 scoring (`dense_scoring`)")
+FAMILIES = ("pyramid", "fhog", "score", "score_screened", "chip", "ert", "conv", "dsst", "pdist", "hac")
 EMBED_GFLOP_PER_FACE = 0.542               # the 29-conv ResNet on a 150 x 150 chip
 TRACKER_GFLOP_PER_FRAME = 0.3              # DSST starts + updates of ~8 faces, both passes
 
@@ -40,7 +46,66 @@ def e2e_object(flop_score_per_frame, faces, frames, seconds):
     tf = g * 1e9 * frames / seconds / 1e12 if seconds > 0 else 0.0
     return {"gflop_per_frame": round(g, 3), "tflops": round(tf, 2), "frac_of_fp32_peak": round(tf / FP32_PEAK_TFLOPS, 4),
             "note": "scoring (positions x 3100 MAC x 5 filters) + %.3f GFLOP per embedded face + %.1f GFLOP/frame of tracker FFTs, over the timed steps' "
-                    "wall time of the slowest rank; pyramid / FHOG / landmark work is byte-bound and not counted" % (EMBED_GFLOP_PER_FACE, TRACKER_GFLOP_PER_FRAME)}
+                    "wall time of the slowest rank (the scoring sums counted once per window, whichever matrix cores evaluate them); pyramid / FHOG / landmark work is byte-bound and not counted" % (EMBED_GFLOP_PER_FACE, TRACKER_GFLOP_PER_FRAME)}
+
+
+def detector_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("detect.hip", "screen.hip", "detect_ml.h"):
+        h.update(open(os.path.join(ROOT, "pyannote-video_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def detector_rooflines(fam, height, width, frames_scored, detect_batch):
+    """roofline objects of the detector's four kernels from the HIP-event family times of the timed steps; the first is the one that took
+    the most time -- the step's dominant kernel (the other families are several kernels each, none of them as long).  Algorithmic work
+    per frame from the level schedule:
+      resize_rows_k   (20 launches per batch)  HBM: the frame read, every level written once and read once by the next stage
+      fhog_fused_ml_k (1 launch per batch)     HBM: every level image read once, 31 feature planes of every cell written once
+      score_roll_k    (dense scoring)          fp32 MFMA: positions x 3100 MAC x 5 filters
+      score_screen_k  (+ score_list_k)         f16 MFMA: the same sums (every window is scored), against the f16 peak"""
+    from pyannote_video_amd import pipeline
+    geo = pipeline.detector_geometry(height, width)
+    img = [g[0] * g[1] * 3.0 for g in geo]
+    cells = [max(g[2] - 9, 0) * max(g[3] - 9, 0) for g in geo]
+    flop = sum(g[4] for g in geo) * 3100 * 5 * 2.0
+    work = {"pyramid": ("resize_rows_k (every pyramid level of a %d-frame batch from the level above it, 20 launches)" % detect_batch, "hbm",
+                        height * width * 3.0 + img[0] + sum(img[l - 1] + img[l] for l in range(1, len(img)))),
+            "fhog": ("fhog_fused_ml_k (gradients, cell histograms and 31-plane features of every pyramid level of a %d-frame batch in one pass)" % detect_batch, "hbm",
+                     sum(img) + sum(cells) * 31 * 4.0),
+            "score": ("score_roll_k (HOG filter scoring of every pyramid level of a %d-frame batch, 5 filters x 3100 MAC per position)" % detect_batch, "mfma", flop),
+            "score_screened": ("score_screen_k + score_list_k (every window of a %d-frame batch scored on the f16 matrix cores, the exact fp32 chain for the windows "
+                               "within the error bound of the threshold)" % detect_batch, "mfma", flop)}
+    pm = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", PMC_KERNELS_FILE)))
+        if not (pm["detect_batch"] == detect_batch and pm["frame"] == "%dx%d" % (width, height) and pm.get("detector_sha256_16") == detector_hash()):
+            pm = None            # a changed kernel (or another configuration) drops the figure instead of carrying a stale one
+    except Exception:
+        pm = None
+    out = []
+    for name, (kernel, bound, per_frame) in work.items():
+        ms, launches = fam[name]["ms"], fam[name]["launches"]
+        if ms <= 0 or launches <= 0:
+            continue
+        if bound == "hbm":
+            achieved, peak, unit = per_frame * frames_scored / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            peak = FP32_PEAK_TFLOPS if name == "score" else F16_PEAK_TFLOPS
+            achieved, unit = per_frame * frames_scored / (ms * 1e-3) / 1e12, "TFLOP/s"
+        o = {"kernel": kernel, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4), "traffic": None,
+             "avg_launch_ms": round(ms / launches, 4), "launches": launches, "family_ms": ms,
+             ("algorithmic_bytes_per_launch" if bound == "hbm" else "flop_per_launch"): per_frame * frames_scored / launches}
+        k = pm and pm["kernels"].get(name)
+        if k:
+            o["traffic"] = k["traffic_bytes_per_launch"]
+            o["traffic_attached_from_profiles_not_measured_in_this_run"] = pm["source"]
+            if bound != "hbm":
+                o["algorithmic_bytes_per_launch"] = sum(g[2] * g[3] for g in geo) * 128.0 * frames_scored / launches      # the feature maps read once
+        out.append(o)
+    out.sort(key=lambda o: -o["family_ms"])
+    return out
 
 
 def labels_digest(labels):
@@ -231,13 +296,16 @@ def main():
     total_frames = (args.frames if (args.scaling == "strong" and world > 1) else args.frames * world) * args.steps
     fps = total_frames / elapsed
 
-    fam = {}
-    for name in ("pyramid", "fhog", "score", "score_screened", "chip", "ert", "conv", "dsst", "pdist", "hac"):
-        ms, n = 0.0, 0
-        for c in ctxs:
-            a, b = c.prof_get(name)
-            ms += a; n += b
-        fam[name] = {"ms": round(ms, 3), "launches": int(n)}
+    def families():
+        fam = {}
+        for name in FAMILIES:
+            ms, n = 0.0, 0
+            for c in ctxs:
+                a, b = c.prof_get(name)
+                ms += a; n += b
+            fam[name] = {"ms": round(ms, 3), "launches": int(n)}
+        return fam
+    fam = families()
 
     if rank != 0:
         return
@@ -247,28 +315,32 @@ def main():
     # frames the detector actually scored inside the timed steps (with --detect-every only every k-th frame is: counting all frames
     # would print a `frac` above 1); the engine counts them, summed over the ranks' steps on rank 0 only (every rank does the same work)
     n_score_frames = frames_scored_timed if frames_scored_timed is not None else n_local * args.steps
-    score_ms = fam["score"]["ms"]
-    launches = max(fam["score"]["launches"], 1)
-    achieved = (flop_per_frame * n_score_frames / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
-    roofline = {"kernel": "score_roll_k (HOG filter scoring of every pyramid level of a %d-frame batch, 5 filters x 3100 MAC per position)" % args.detect_batch, "bound": "mfma",
-                "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None,
-                "avg_launch_ms": round(score_ms / launches, 4),
-                "flop_per_launch": flop_per_frame * n_score_frames / launches}
+    rl = detector_rooflines(fam, args.height, args.width, n_score_frames, args.detect_batch)
+    roofline, roofline_other = rl[0], rl[1:]
 
-    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (counters cannot be read inside this process); the
-    # committed measurement is attached only when it was taken on this configuration AND on this source of the kernel (hash of
-    # csrc/detect.hip): a changed kernel drops the figure instead of carrying a stale one.
-    try:
-        import hashlib
-        src_hash = hashlib.sha256(open(os.path.join(ROOT, "pyannote-video_amd", "csrc", "detect.hip"), "rb").read()).hexdigest()[:16]
-        pm = json.load(open(os.path.join(ROOT, "profiles", PMC_SCORE_FILE)))
-        if pm["detect_batch"] == args.detect_batch and pm["frame"] == "%dx%d" % (args.width, args.height) and pm.get("detect_hip_sha256_16") == src_hash:
-            roofline["traffic"] = pm["traffic_bytes_per_launch"]
-            roofline["traffic_attached_from_profiles_not_measured_in_this_run"] = pm["source"]
-            roofline["algorithmic_bytes_per_launch"] = sum(g[2] * g[3] for g in geo) * 128.0 * n_score_frames / launches   # features read once
-    except Exception:
-        pass
+    # the same steps with the screening pass off (the exact fp32 chain for every window): what the screening buys, that the results are
+    # the same, and the dense kernel's own roofline -- two timed steps after one untimed
+    dense = None
+    if world == 1 and not args.dense_scoring and args.detect_every == 0.0:
+        ctx.detector_screening(False)
+        step()
+        ctx.prof_reset(); ctx.prof_enable(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            d_res, d_labels, _tm = step()
+        barrier()
+        d_elapsed = time.perf_counter() - t0
+        ctx.prof_enable(False)
+        ctx.detector_screening(True)
+        d_rl = [o for o in detector_rooflines(families(), args.height, args.width, n_local * 2, args.detect_batch) if o["kernel"].startswith("score_roll_k")]
+        dense = {"value": round(n_local * 2 / d_elapsed, 2), "unit": "frames/s", "steps": 2, "ms_per_step": round(1000.0 * d_elapsed / 2, 2),
+                 "same_tracks_faces_and_labels_as_the_timed_steps": bool(labels_digest(d_labels) == labels_digest(labels) and len(d_res["tracks"]) == len(res["tracks"])
+                                                                      and np.array_equal(np.asarray(d_res["face_boxes"]), np.asarray(res["face_boxes"]))
+                                                                      and np.array_equal(np.asarray(d_res["face_T"]), np.asarray(res["face_T"]))),
+                 "roofline": d_rl[0] if d_rl else None,
+                 "note": "pvf_detector_screening(ctx, 0): score_roll_k evaluates the exact chain of 3100 fmaf for every window on the fp32 matrix cores; the timed steps "
+                         "screen every window on the f16 matrix cores first and run that chain for the listed ones only (csrc/screen.hip) -- same candidates, bit for bit"}
 
     cpu, parity = None, None
     if world == 1 and args.cpu_frames > 0:
@@ -286,7 +358,7 @@ def main():
         "metric": "frames/sec end-to-end detect->embed->cluster, %s" % label,
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
-        "vs_baseline": None, "dtype": "f32 (detector, embedder) / f64 (tracker, clustering) / u8 frames",
+        "vs_baseline": None, "dtype": DTYPE_NOTE if not args.dense_scoring else DTYPE_NOTE_DENSE,
         "data": "synthetic (procedural faces on low-pass backgrounds, seeded; synthetic model weights of dlib's shapes)",
         "config": {"workload": "configs[%d]: synthetic %dx%d %g fps, %d frames, %d shots, %d faces/frame %s, frames resident in HBM"
                                % (1 if args.config == "c2" else 4, args.width, args.height, args.fps, args.frames, args.shots, args.faces,
@@ -296,6 +368,8 @@ def main():
                    "detect_batch": args.detect_batch, "collective": pdist.collective_name(),
                    "devices": min(world, n_dev), "oversubscribed": bool(world > n_dev)},
         "roofline": roofline,
+        "roofline_other": roofline_other,
+        "dense_scoring": dense,
         "e2e": e2e_object(flop_per_frame if args.detect_every == 0.0 else flop_per_frame * n_score_frames / max(n_local * args.steps, 1),
                           int(len(res["face_T"])) * args.steps, n_local * args.steps, elapsed),
         "cpu_baseline": cpu,
@@ -306,7 +380,7 @@ def main():
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
         "kernel_families_ms": fam,
         "screening": ctx.detector_screening_stats() if not args.dense_scoring else None,
-        "kernel_families_note": "HIP-event time per family on the stream it runs on: the detector families (pyramid, fhog, score) on one stream, the rest on the "
+        "kernel_families_note": "HIP-event time per family on the stream it runs on: the detector families (pyramid, fhog, score / score_screened) on one stream, the rest on the "
                                 "other; the two streams run side by side, so the sum may exceed the steps' wall time, and a family's time includes "
                                 "what it lost to the other stream's kernels",
         "results": {"tracks": len(res["tracks"]), "faces_embedded": int(len(res["face_T"])), "clusters": n_clusters,
@@ -501,6 +575,8 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
     from pyannote_video_amd import synth, pipeline, dist as pdist
     from pyannote_video_amd.runtime import Context
     ctx = Context(device=local_rank)
+    if args.dense_scoring:
+        ctx.detector_screening(False)
     mine = pdist.shard_clips(args.clips, world)[rank]
     t_gen = time.time()
     clips, videos, tensors = [], [], []
@@ -535,7 +611,7 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
     ctx.prof_enable(False)
     elapsed = max_over_ranks(elapsed, world, device)
     fam = {}
-    for name in ("pyramid", "fhog", "score", "chip", "ert", "conv", "dsst", "pdist", "hac"):
+    for name in FAMILIES:
         ms, n = ctx.prof_get(name)
         fam[name] = {"ms": round(ms, 3), "launches": int(n)}
     if rank != 0:
@@ -544,8 +620,7 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
     fps = total_frames / elapsed
     geo = pipeline.detector_geometry(args.height, args.width)
     flop_per_frame = sum(g[4] for g in geo) * 3100 * 5 * 2.0
-    score_ms, launches = fam["score"]["ms"], max(fam["score"]["launches"], 1)
-    achieved = (flop_per_frame * len(mine) * args.frames * args.steps / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
+    rl = detector_rooflines(fam, args.height, args.width, len(mine) * args.frames * args.steps, args.detect_batch)
     parity, cpu = None, None
     if args.cpu_frames > 0:
         # parity gate: clip 0, a window around its shot cut, product (frames resident) vs the CPU oracle flow
@@ -563,15 +638,14 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
     out = {"metric": "frames/sec end-to-end detect->embed->cluster, %d independent %dx%d clips farmed one per GPU (BASELINE.json configs[3])" % (args.clips, args.width, args.height),
            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-           "dtype": "f32 (detector, embedder) / f64 (tracker, clustering) / u8 frames",
+           "dtype": DTYPE_NOTE if not args.dense_scoring else DTYPE_NOTE_DENSE,
            "data": "synthetic (seeds 20260925 + clip index)",
            "config": {"workload": "configs[3]: %d clips x %d frames %dx%d %g fps, %d shots and %d faces/frame each, clips round robin over %d GPU(s), frames resident in HBM, "
                                   "per-clip clustering, no collective" % (args.clips, args.frames, args.width, args.height, args.fps, args.shots, args.faces, world),
                       "parallelism": "farm: clip i on rank i %% %d; one engine run per rank (detector of clip i + 1 beside the state machine of clip i)" % world,
                       "detect_batch": args.detect_batch, "collective": "none"},
-           "roofline": {"kernel": "score_roll_k", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "traffic_note": "not measured for this configuration (a --pmc pass of its own)",
-                        "avg_launch_ms": round(score_ms / launches, 4)},
+           "roofline": dict(rl[0], traffic_note="not measured for this configuration (a --pmc pass of its own)"), "roofline_other": rl[1:],
+           "screening": ctx.detector_screening_stats() if not args.dense_scoring else None,
            "e2e": e2e_object(flop_per_frame, sum(int(len(r["face_T"])) for r in results) * args.steps, len(mine) * args.frames * args.steps, elapsed),
            "cpu_baseline": cpu, "parity": parity,
            "kernel_families_ms": fam,
@@ -630,6 +704,8 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     ctx = Context(device=local_rank)
+    if args.dense_scoring:
+        ctx.detector_screening(False)
     pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=args.detect_batch, overlap=not args.no_overlap)
     pipe.return_table = False       # (the float64 host copy of the clustering's table: nobody reads it here)
     per_shot = clip_n // args.shots
@@ -669,7 +745,7 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
     elapsed = max_over_ranks(elapsed, world, device)
     res, labels, tm = last
     fam = {}
-    for name in ("pyramid", "fhog", "score", "chip", "ert", "conv", "dsst", "pdist", "hac"):
+    for name in FAMILIES:
         ms, k = ctx.prof_get(name)
         fam[name] = {"ms": round(ms, 3), "launches": int(k)}
     if rank != 0:
@@ -677,8 +753,7 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
     fps = n * world * args.steps / elapsed
     geo = pipeline.detector_geometry(args.height, args.width)
     flop_per_frame = sum(g[4] for g in geo) * 3100 * 5 * 2.0
-    score_ms, launches = fam["score"]["ms"], max(fam["score"]["launches"], 1)
-    achieved = (flop_per_frame * n * args.steps / (score_ms * 1e-3)) / 1e12 if score_ms > 0 else 0.0
+    rl = detector_rooflines(fam, args.height, args.width, n * args.steps, args.detect_batch)
     parity, cpu, cluster_check = None, None, None
     if world == 1 and args.cpu_frames > 0:
         # parity gate through the STREAMING path: a window across the seam between two loops (last frames of one clip's last shot, first
@@ -701,16 +776,15 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
     out = {"metric": "frames/sec end-to-end detect->embed->cluster, one long 1080p@25fps video in frame ranges (BASELINE.json configs[2])",
            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 (detector, embedder) / f64 (tracker, clustering) / u8 frames",
+           "dtype": DTYPE_NOTE if not args.dense_scoring else DTYPE_NOTE_DENSE,
            "data": "synthetic: %d differently seeded 1000-frame clips (identities from a pool of 250) played one after the other, loop j = clip j %% %d; timestamps and "
                    "track numbers continue; every loop adds its tracks to the global clustering" % (K, K),
            "config": {"workload": "configs[2]: %d frames per GPU (%.1f min of 1080p 25 fps video; %d GPUs x that = the whole video), %d-frame shots, %d faces/frame; frames delivered one by one "
                                   "into HBM buffers of the library (device-to-device from the resident clips), released shot by shot" % (n, n / args.fps / 60.0, world, per_shot, args.faces),
                       "parallelism": "frame ranges cut at shot boundaries x%d + all-gather of track embeddings + one global clustering" % world if world > 1 else "single GPU (one range)",
                       "detect_batch": args.detect_batch, "collective": pdist.collective_name(), "distinct_clips": K},
-           "roofline": {"kernel": "score_roll_k", "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / FP32_PEAK_TFLOPS, 4), "traffic": None, "traffic_note": "not measured for this configuration (a --pmc pass of its own)",
-                        "avg_launch_ms": round(score_ms / launches, 4)},
+           "roofline": dict(rl[0], traffic_note="not measured for this configuration (a --pmc pass of its own)"), "roofline_other": rl[1:],
+           "screening": ctx.detector_screening_stats() if not args.dense_scoring else None,
            "e2e": e2e_object(flop_per_frame, int(len(res["face_T"])) * args.steps, n * args.steps, elapsed),
            "cpu_baseline": cpu, "parity": parity, "cluster_check": cluster_check,
            "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},

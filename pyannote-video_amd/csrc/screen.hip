@@ -28,14 +28,20 @@
 // 10) is addressed, not moved: all 120 B fragments (120 KB of f16) sit in LDS, loaded once per block, and a fragment feeds four MFMAs.
 // A fragments come straight from the fp32 feature map: lane (base i, plane octet kq) loads the 32 bytes of cell 3 i + n', converts them
 // (4 v_cvt_pkrtz) and -- because cell 3 i + (n' + 3) is cell 3 (i + 1) + n' -- hands them to base i - 1 with two DPP row moves for n' + 3,
-// + 6, + 9: a feature row is loaded and converted ONCE (3 cell phases x 5 fragments), not four times.  A block is four independent
-// waves (one per SIMD, up to 512 registers each) that pull work items from a counter, largest first.
+// + 6, + 9: a feature row is loaded and converted ONCE (3 cell phases x 5 fragments), not four times.  The ten B fragments of cell
+// n' + 1 are fetched while cell n' is multiplied.  A block is four independent waves (one per SIMD, up to 512 registers each) that pull
+// work items from a counter, largest first.
+// Measured on the way (125 1080p frames, detector alone, ms per batch; tools/probes/ab_screen.sh): B fragments fetched where they are
+// used 2.59 -> one cell ahead 2.24; feature maxima in f32 -> packed f16 2.15; taller pieces 1.94.  Slower: the walk as a called function
+// (5.4: its LDS pointer becomes a generic one), base columns dealt out to the groups in turn so that only one group needs the DPP moves
+// (3.08: 86 registers spilled), accumulators that stay put with the B fragments and the finished slot addressed dynamically (spills).
 #include "detect_ml.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct ScreenParams { float flag_at[8]; float lim_lo, lim_hi; int n_items, list_cap; };
 
@@ -50,7 +56,7 @@ __device__ __forceinline__ uint32_t pk_f16(float a, float b)
 template <int NG>
 __device__ __forceinline__ void screen_walk(const ScreenItem t, const LvDesc* __restrict__ lv, const float* __restrict__ feat_base,
                                             const uint8_t* s_b, const float th_lane, int* __restrict__ ctl, uint2* __restrict__ list,
-                                            const int list_cap, float& mx_lo, float& mx_hi)
+                                            const int list_cap, u32x4& mx)
 {
     constexpr int RSRC_FLAGS = 0x00020000;
     constexpr int FR = 10, FC = 10;
@@ -83,12 +89,12 @@ __device__ __forceinline__ void screen_walk(const ScreenItem t, const LvDesc* __
         }
     };
     auto cvt_frag = [&](const u32x4 (&r)[2]) -> u32x4 {
-        const float f0 = __uint_as_float(r[0].x), f1 = __uint_as_float(r[0].y), f2 = __uint_as_float(r[0].z), f3 = __uint_as_float(r[0].w);
-        const float f4 = __uint_as_float(r[1].x), f5 = __uint_as_float(r[1].y), f6 = __uint_as_float(r[1].z), f7 = __uint_as_float(r[1].w);
-        mx_lo = fmaxf(mx_lo, fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fabsf(f2)));
-        mx_hi = fmaxf(mx_hi, fmaxf(fmaxf(fmaxf(fabsf(f3), fabsf(f4)), fmaxf(fabsf(f5), fabsf(f6))), fabsf(f7)));
         u32x4 o;
-        o.x = pk_f16(f0, f1); o.y = pk_f16(f2, f3); o.z = pk_f16(f4, f5); o.w = pk_f16(f6, f7);
+        o.x = pk_f16(__uint_as_float(r[0].x), __uint_as_float(r[0].y)); o.y = pk_f16(__uint_as_float(r[0].z), __uint_as_float(r[0].w));
+        o.z = pk_f16(__uint_as_float(r[1].x), __uint_as_float(r[1].y)); o.w = pk_f16(__uint_as_float(r[1].z), __uint_as_float(r[1].w));
+        // the largest feature seen, per packed register (v_pk_max_f16): checked against the bound's assumption when the kernel ends
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mx[k] = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(f16x2, mx[k]), __builtin_bit_cast(f16x2, o[k])));
         return o;
     };
     // base i takes over what base i + 1 holds (lane 15: base 0 of the next group): cell 3 (i + 1) + n' = cell 3 i + (n' + 3)
@@ -137,6 +143,12 @@ __device__ __forceinline__ void screen_walk(const ScreenItem t, const LvDesc* __
             for (int g = 0; g <= NG; ++g) A[cls][g] = cvt_frag(raw[g]);
         }
     }
+    auto b_frag = [&](int q, int j) -> u32x4 {
+        return *reinterpret_cast<const u32x4*>((q < 5 ? b_lo + q * SCR_M_STRIDE : b_hi + (q - 5) * SCR_M_STRIDE) + j * 1024);
+    };
+    u32x4 bn[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) bn[q] = b_frag(q, 0);
     for (int s = 0; s < fh_in; ++s) {
         u32x4 An[3][NG + 1];
         u32x4 raw[NG + 1][2];
@@ -149,14 +161,16 @@ __device__ __forceinline__ void screen_walk(const ScreenItem t, const LvDesc* __
                 for (int k = 0; k < 3; ++k) shift_bases(A[k]);
             }
             if (j % 4 == 0) load_cls(s + 1, j / 4, raw);
-            // (slots in descending order: at the last cell a slot's result moves on to the next slot -- the row's next filter row --, the
-            // last slot's is the finished row)
+            u32x4 bc[10];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) bc[q] = bn[q];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) bn[q] = b_frag(q, (j + 1) % 12);
 #pragma unroll
             for (int q = 9; q >= 0; --q) {
-                const u32x4 bq = *reinterpret_cast<const u32x4*>((q < 5 ? b_lo + q * SCR_M_STRIDE : b_hi + (q - 5) * SCR_M_STRIDE) + j * 1024);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    const f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[cls][g]), __builtin_bit_cast(f16x8, bq), acc[q][g], 0, 0, 0);
+                    const f32x4 v = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A[cls][g]), __builtin_bit_cast(f16x8, bc[q]), acc[q][g], 0, 0, 0);
                     if (j < 11) acc[q][g] = v;
                     else if (q == 9) done[g] = v;
                     else acc[q + 1][g] = v;
@@ -193,7 +207,7 @@ score_screen_k(const ScreenItem* __restrict__ items, const LvDesc* __restrict__ 
     th_lane = f == 3 ? sp.flag_at[3] : th_lane;
     th_lane = f == 4 ? sp.flag_at[4] : th_lane;
     th_lane = jc < 15 ? th_lane : 3.0e38f;
-    float mx_lo = 0.f, mx_hi = 0.f;
+    u32x4 mx = {0u, 0u, 0u, 0u};                    // f16 pairs; features are >= 0
     for (;;) {
         int it = 0;
         if (lane == 0) it = atomicAdd(&ctl[SCR_CURSOR], 1);
@@ -204,15 +218,21 @@ score_screen_k(const ScreenItem* __restrict__ items, const LvDesc* __restrict__ 
         t.c_base = __builtin_amdgcn_readfirstlane(items[it].c_base); t.r_base = __builtin_amdgcn_readfirstlane(items[it].r_base);
         t.out_rows = __builtin_amdgcn_readfirstlane(items[it].out_rows); t.ng = __builtin_amdgcn_readfirstlane(items[it].ng);
         switch (t.ng) {
-        case 1: screen_walk<1>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx_lo, mx_hi); break;
-        case 2: screen_walk<2>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx_lo, mx_hi); break;
-        case 3: screen_walk<3>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx_lo, mx_hi); break;
-        default: screen_walk<4>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx_lo, mx_hi); break;
+        case 1: screen_walk<1>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx); break;
+        case 2: screen_walk<2>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx); break;
+        case 3: screen_walk<3>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx); break;
+        default: screen_walk<4>(t, lv, feat_base, s_b, th_lane, ctl, list, sp.list_cap, mx); break;
         }
     }
-    // planes 8 kq + 0..2 are orientation planes in every octet; 8 kq + 3..7 are texture planes (and the pad) in the last octet only
+    // a lane's eight planes 8 kq + 0..7 sit in mx as (0,1) (2,3) (4,5) (6,7): 0..2 are orientation planes in every octet, 3..7 are texture
+    // planes (and the pad) in the last octet only.  The conversion rounds towards zero, so the limits are f16 values one step below the
+    // bounds the error analysis assumes (screen_prepare_model): a feature above the assumed bound converts to something above the limit.
+    auto lo16 = [](uint32_t v) { return (float)__builtin_bit_cast(f16x2, v)[0]; };
+    auto hi16 = [](uint32_t v) { return (float)__builtin_bit_cast(f16x2, v)[1]; };
+    const float m_lo = fmaxf(fmaxf(lo16(mx.x), hi16(mx.x)), lo16(mx.y));
+    const float m_hi = fmaxf(fmaxf(hi16(mx.y), fmaxf(lo16(mx.z), hi16(mx.z))), fmaxf(lo16(mx.w), hi16(mx.w)));
     const float lim_hi = (lane >> 4) == 3 ? sp.lim_hi : sp.lim_lo;
-    if (mx_lo > sp.lim_lo || mx_hi > lim_hi) atomicOr(&ctl[SCR_VIOLATION], 1);
+    if (m_lo > sp.lim_lo || m_hi > lim_hi) atomicOr(&ctl[SCR_VIOLATION], 1);
 }
 
 // the exact chain for the listed (position, filter) pairs: one lane per pair, the oracle's order (m, n, p), fmaf
@@ -303,7 +323,10 @@ static double f16_to_f64(uint16_t h)
 }
 
 static const double SCR_SCALE = 256.0;             // weights are multiplied by 2^8 before the conversion: |w| <= 0.1 sits in f16's subnormal range otherwise
-static const double SCR_FM_LO = 0.4001, SCR_FM_HI = 0.8486;
+// features: <= 0.4 (1 + 4 u) for the orientation planes, <= 0.84853 for the texture planes.  The kernel checks what it reads against the f16
+// values SCR_LIM_* (one f16 step below the bounds SCR_FM_* the error analysis uses; above anything FHOG can produce)
+static const double SCR_FM_LO = 0.4004, SCR_FM_HI = 0.8492;
+static const float SCR_LIM_LO = 0.400146484375f /* 1639 x 2^-12 */, SCR_LIM_HI = 0.8486328125f /* 1738 x 2^-11 */;
 
 void screen_prepare_model(DetectorModel& d, const float* w)
 {
@@ -347,13 +370,17 @@ void screen_prepare_model(DetectorModel& d, const float* w)
 
 void screen_plan_build(ScreenPlan& sp, const std::vector<LvDesc>& lv, int B)
 {
-    // pieces of <= seg output rows: a piece re-walks the 9 feature rows above it, so pieces are tall where the batch has work enough for
-    // every wave (1024) several times over, and short where it has not
-    long long total = 0;
-    for (const LvDesc& d : lv)
-        if (d.valid_score) total += (long long)((d.fw - 9 + 47) / 48) * (d.fh - 9) * B;
-    int seg = (int)std::min<long long>(64, std::max<long long>(16, total / (4 * 4096)));
-    if (getenv("PVF_SCREEN_SEG")) seg = std::max(2, atoi(getenv("PVF_SCREEN_SEG")));
+    // pieces of <= seg output rows.  A piece re-walks the 9 feature rows above it and starts with 9 steps of partial work, so pieces are as
+    // tall as the batch allows: the tallest that still leave about three items per wave (1024 waves) -- measured on 125 1080p frames
+    // (tools/probes/ab_screen.sh): 24 rows 2.67 ms, 64 rows 2.19, 160 rows 1.95, whole strips 1.94
+    int seg = 16;
+    for (int cand : {512, 160, 96, 64, 48, 32, 24}) {
+        long long n = 0;
+        for (const LvDesc& d : lv)
+            if (d.valid_score) n += (long long)((d.fw - 9 + 48 * SCR_SG - 1) / (48 * SCR_SG)) * ((d.fh - 9 + cand - 1) / cand) * B;
+        if (n >= 3 * 1024) { seg = cand; break; }
+    }
+    if (getenv("PVF_SCREEN_SEG") && atoi(getenv("PVF_SCREEN_SEG")) > 0) seg = std::max(2, atoi(getenv("PVF_SCREEN_SEG")));
     std::vector<ScreenItem> items;
     sp.usable = lv.size() <= 32;                    // a list entry packs level (5 bits), filter (3), row and column (12 each)
     for (const LvDesc& d : lv) sp.usable = sp.usable && d.fh < 4096 && d.fw < 4096;
@@ -444,7 +471,10 @@ void screen_launch(Ctx* c, const ScreenPlan& plan, const LvDesc* d_lv, int B, co
         }
         else sp.flag_at[f] = 3.0e38f;
     }
-    sp.lim_lo = (float)SCR_FM_LO; sp.lim_hi = (float)SCR_FM_HI;
+    sp.lim_lo = SCR_LIM_LO; sp.lim_hi = SCR_LIM_HI;
+    if (const char* e = getenv("PVF_SCREEN_LIMIT_SCALE")) {        // test switch: limits low enough for real features to cross them (the retry path)
+        sp.lim_lo *= (float)atof(e); sp.lim_hi *= (float)atof(e);
+    }
     sp.n_items = plan.n_items;
     sp.list_cap = c->screen_list_cap;
     c->s_screen.ensure((size_t)sp.list_cap * sizeof(uint2) + 64);

@@ -80,3 +80,22 @@ def test_list_overflow_repeats_the_call_on_the_dense_kernel(ctx, small_video):
     finally:
         ctx.detector_screening(True)
     frame.release()
+
+
+def test_feature_above_the_assumed_bound_repeats_the_call_on_the_dense_kernel(ctx, small_video, monkeypatch):
+    """the error bound assumes FHOG features <= 0.4 / 0.849; the kernel checks every feature it reads and gives the call up otherwise.
+    Real features never get there, so the limits are scaled down (PVF_SCREEN_LIMIT_SCALE, read at every launch) until they do."""
+    frame = ctx.upload(small_video.frame(2))
+    ctx.detector_screening(False)
+    dense = _raw(ctx, frame, 0.0)
+    ctx.detector_screening(True)
+    s0 = ctx.detector_screening_stats()
+    monkeypatch.setenv("PVF_SCREEN_LIMIT_SCALE", "0.25")
+    got = _raw(ctx, frame, 0.0)
+    s1 = ctx.detector_screening_stats()
+    monkeypatch.delenv("PVF_SCREEN_LIMIT_SCALE")
+    again = _raw(ctx, frame, 0.0)
+    s2 = ctx.detector_screening_stats()
+    assert got == dense and again == dense
+    assert s1["retries"] == s0["retries"] + 1 and s2["retries"] == s1["retries"] and s2["batches"] == s1["batches"] + 1
+    frame.release()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU session that produces everything profiles/ holds for a round: usage  bash tools/measure_round.sh r03 [quick]
-#   tests (-m gpu) + smoke; a FETCH_SIZE pass over the bench workload, turned into profiles/<tag>_pmc_score.json (bench.py attaches it
-#   as roofline.traffic when the hash of csrc/detect.hip matches); the default bench line (cpu_baseline / parity / host_ingest / dropin_cli);
+#   tests (-m gpu) + smoke; a FETCH_SIZE and a WRITE_SIZE pass over the bench workload, turned into profiles/<tag>_pmc_kernels.json (bench.py
+#   attaches it as roofline.traffic when the hash of the detector's sources matches); the default bench line (cpu_baseline / parity / host_ingest / dropin_cli);
 #   the other BASELINE.json configurations (c3 streamed long video, c4 clip farm, c5 4K crowd); a rocprofv3 kernel-trace summary of the default
 #   workload; WRITE_SIZE, matrix-pipe and SQ counter passes (every --pmc pass on its own, with --kernel-trace only); the C5 clustering stressor.
 TAG=${1:-r04}
@@ -14,22 +14,10 @@ cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prof /tmp/pmca /tmp/pmcb /tmp/pmcc /tmp/pmcd /tmp/pmce
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmca -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin --steps 1 --warmup 0 > /tmp/pa.log 2>&1
 DB=$(find /tmp/pmca -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_fetch_size.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcb -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin --steps 1 --warmup 0 > /tmp/pb.log 2>&1
+DB=$(find /tmp/pmcb -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_write_size.txt 2>&1
 cd $R
-python - $O/pmc_fetch_size.txt $TAG <<'PY'
-import hashlib, json, re, sys
-kb = None
-for line in open(sys.argv[1]):
-    if "score_roll_k" in line:
-        kb = float(re.search(r"FETCH_SIZE=([0-9.e+]+)", line).group(1)); n = int(re.search(r"n=(\d+)", line).group(1))
-if kb is not None:
-    d = {"kernel": "score_roll_k", "detect_batch": 128, "frame": "1920x1080", "launches_in_pass": n, "fetch_size_kb_per_launch": kb,
-         "traffic_bytes_per_launch": kb * 1024 * 2,
-         "detect_hip_sha256_16": hashlib.sha256(open("pyannote-video_amd/csrc/detect.hip", "rb").read()).hexdigest()[:16],
-         "source": "profiles/%s_pmc_fetch_size.txt (rocprofv3 --kernel-trace --pmc FETCH_SIZE over `bench.py --steps 1`, a pass of its own; average over the "
-                   "launches of the step; x2 gfx950 correction of MI355X_MICROARCH.md section HBM)" % sys.argv[2]}
-    for path in ("profiles/%s_pmc_score.json" % sys.argv[2], "gpurun_out/%s/pmc_score.json" % sys.argv[2]):
-        json.dump(d, open(path, "w"), indent=1)
-PY
+python tools/pmc_kernels_json.py $O/pmc_fetch_size.txt $O/pmc_write_size.txt $TAG
 timeout 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "=== bench rc=$?" >> $O/summary.log
 if [ "$2" != "quick" ]; then
   timeout 600 python bench.py --config c5 > $O/bench_c5.json 2> $O/bench_c5.err; echo "=== bench c5 rc=$?" >> $O/summary.log
@@ -42,8 +30,6 @@ t overlap 200 python tools/probes/overlap_probe.py 3 $O/overlap_probe.json
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin > $R/$O/prof_bench.log 2>&1
 DB=$(find /tmp/prof -name "*_results.db" | head -1); python $R/tools/rocprof_top.py $DB > $R/$O/rocprof_kernel_stats.txt 2>&1; python $R/tools/gpu_gaps.py $DB 15 > $R/$O/gpu_gaps.txt 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pmcb -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin --steps 1 --warmup 0 > /tmp/pb.log 2>&1
-DB=$(find /tmp/pmcb -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_write_size.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmcc -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin --steps 1 --warmup 0 > /tmp/pc.log 2>&1
 DB=$(find /tmp/pmcc -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_mfma_busy.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS -d /tmp/pmcd -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin --steps 1 --warmup 0 > /tmp/pd.log 2>&1
