@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--detect-every", type=float, default=0.0, help="`--every` of the track verb: run the detector every that many seconds only (reference "
                     "tracking.py:383-386,425; 0 = every frame, the benched configuration); the trackers carry the faces in between")
     ap.add_argument("--dense-scoring", action="store_true", help="detector without its f16 screening pass: the exact fp32 chain for every window (csrc/screen.hip; same candidates, bit for bit)")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip the three extra steps with the screening pass off (`dense_scoring` in the line)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the extra passes through the pyannote-face verbs (track / extract / cluster / process)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): every rank owns --frames frames of an N x --frames video; strong: ONE video of --frames frames "
@@ -321,7 +322,7 @@ def main():
     # the same steps with the screening pass off (the exact fp32 chain for every window): what the screening buys, that the results are
     # the same, and the dense kernel's own roofline -- two timed steps after one untimed
     dense = None
-    if world == 1 and not args.dense_scoring and args.detect_every == 0.0:
+    if world == 1 and not args.dense_scoring and not args.no_dense_leg and args.detect_every == 0.0:
         ctx.detector_screening(False)
         step()
         ctx.prof_reset(); ctx.prof_enable(True)

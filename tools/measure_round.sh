@@ -28,7 +28,7 @@ fi
 t c5 400 python tools/c5_cluster.py $O/c5_cluster.json
 t overlap 200 python tools/probes/overlap_probe.py 3 $O/overlap_probe.json
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin > $R/$O/prof_bench.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin --no-dense-leg > $R/$O/prof_bench.log 2>&1
 DB=$(find /tmp/prof -name "*_results.db" | head -1); python $R/tools/rocprof_top.py $DB > $R/$O/rocprof_kernel_stats.txt 2>&1; python $R/tools/gpu_gaps.py $DB 15 > $R/$O/gpu_gaps.txt 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmcc -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin --steps 1 --warmup 0 > /tmp/pc.log 2>&1
 DB=$(find /tmp/pmcc -name "*_results.db" | head -1); python $R/tools/pmc_summary.py $DB > $R/$O/pmc_mfma_busy.txt 2>&1

@@ -24,17 +24,20 @@ def main():
         return sum(n * kb for name, (n, kb) in table.items() if key in name)
     def launches(table, key):
         return sum(n for name, (n, kb) in table.items() if key in name)
-    batches = launches(fetch, "fhog_fused_ml_k")
-    fam = {"pyramid": ["resize_rows_k"], "fhog": ["fhog_fused_ml_k"], "score": ["score_roll_k"], "score_screened": ["score_screen_k", "score_list_k"]}
+    # batches of the pass that ran a family: the launches of the one kernel it launches once per batch (the pass holds bench.py's
+    # dense-scoring leg as well: score_roll_k and score_screen_k each see a part of the batches, the pyramid and FHOG kernels all of them)
+    fam = {"pyramid": (["resize_rows_k"], "fhog_fused_ml_k"), "fhog": (["fhog_fused_ml_k"], "fhog_fused_ml_k"), "score": (["score_roll_k"], "score_roll_k"),
+           "score_screened": (["score_screen_k", "score_list_k"], "score_screen_k")}
     kernels = {}
-    for name, keys in fam.items():
+    for name, (keys, per_batch) in fam.items():
+        batches = launches(fetch, per_batch)
         f = sum(total_kb(fetch, k) for k in keys); w = sum(total_kb(write, k) for k in keys)
-        if f == 0 and w == 0:
+        if batches == 0 or (f == 0 and w == 0):
             continue
-        kernels[name] = {"kernels": keys, "fetch_size_kb_per_launch": f / batches, "write_size_kb_per_launch": w / batches,
+        kernels[name] = {"kernels": keys, "batches_in_pass": batches, "fetch_size_kb_per_launch": f / batches, "write_size_kb_per_launch": w / batches,
                          "traffic_bytes_per_launch": (2.0 * f + w) * 1024.0 / batches}
     import bench
-    d = {"detect_batch": 128, "frame": "1920x1080", "batches_in_pass": batches, "kernels": kernels, "detector_sha256_16": bench.detector_hash(),
+    d = {"detect_batch": 128, "frame": "1920x1080", "kernels": kernels, "detector_sha256_16": bench.detector_hash(),
          "source": "profiles/%s_pmc_fetch_size.txt + profiles/%s_pmc_write_size.txt (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --steps 1`, "
                    "a pass each; per batch of the step; FETCH_SIZE x 2: the gfx950 correction of MI355X_MICROARCH.md section HBM; WRITE_SIZE as reported)" % (tag, tag)}
     for path in ("profiles/%s_pmc_kernels.json" % tag, "gpurun_out/%s/pmc_kernels.json" % tag):
