@@ -136,7 +136,8 @@ struct DetectorModel {
     std::vector<float> thresh;
     float* d_w = nullptr;    // [nf][frows][fcols][32]
     float* d_bmfma4 = nullptr; // B fragments of score_roll_k: [10][12][2][64 lanes][4 k-steps] (3 shifts x 5 filters per 16-column MFMA tile)
-    uint16_t* d_bscreen = nullptr;     // f16 B fragments of score_screen_k: [10][12][64 lanes][8] (weights x 256)
+    uint16_t* d_bscreen = nullptr;     // f16 B fragments of score_screen_k: [10][12][64 lanes][8] (weights x screen_scale)
+    double screen_scale = 1.0;         // the power of two the weights were multiplied by before their conversion to f16
     double screen_bound[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // |screening score / 256 - exact chain| <= screen_bound[filter] (screen.hip)
 };
 

@@ -12,7 +12,7 @@
 // derivation assumes, the call is repeated on the dense kernel (ScreenRetry, api.hip): screening never changes a result.
 //
 // The bound.  f = feature (>= 0, <= FM[plane]: 0.4001 for the 27 orientation planes = 4 x min(h, n) * 0.1 / n, 0.8486 for the 4 texture
-// planes = 0.4714 x 18 x 0.1; fhog_dev.h), w = weight, w' = f16(256 w) / 256 (round to nearest, done on the host: the error is KNOWN),
+// planes = 0.4714 x 18 x 0.1; fhog_dev.h), w = weight, w' = f16(2^k w) / 2^k (round to nearest, done on the host: the error is KNOWN; k: the largest weight lands below 2^7),
 // f' = f16(f) (v_cvt_pkrtz: |f' - f| <= 2^-10 f, or <= 2^-14 should the pipe flush a subnormal).  S = exact chain, S* = the real sum,
 // S' = what the matrix pipe returns for sum f' w'.
 //   |S  - S*|  <= g(3100) sum |f w|                      (3100 roundings of a recursive fp32 sum, g(n) = n u / (1 - n u), u = 2^-24)
@@ -322,7 +322,6 @@ static double f16_to_f64(uint16_t h)
     return s ? -v : v;
 }
 
-static const double SCR_SCALE = 256.0;             // weights are multiplied by 2^8 before the conversion: |w| <= 0.1 sits in f16's subnormal range otherwise
 // features: <= 0.4 (1 + 4 u) for the orientation planes, <= 0.84853 for the texture planes.  The kernel checks what it reads against the f16
 // values SCR_LIM_* (one f16 step below the bounds SCR_FM_* the error analysis uses; above anything FHOG can produce)
 static const double SCR_FM_LO = 0.4004, SCR_FM_HI = 0.8492;
@@ -331,6 +330,17 @@ static const float SCR_LIM_LO = 0.400146484375f /* 1639 x 2^-12 */, SCR_LIM_HI =
 void screen_prepare_model(DetectorModel& d, const float* w)
 {
     PVF_REQUIRE(d.n_filters == 5 && d.frows == 10 && d.fcols == 10, "screening: 5 filters of 10 x 10 cells");
+    // weights are multiplied by a power of two before the conversion (exact; undone in the threshold): the largest that keeps the largest
+    // weight at or below 2^7 -- the shipped model's |w| <= 0.1 would otherwise sit at the edge of f16's subnormal range, and no weight may
+    // overflow f16 whatever the model
+    double wmax = 0;
+    for (size_t k = 0; k < (size_t)d.n_filters * 10 * 10 * 32; ++k) wmax = std::max(wmax, std::fabs((double)w[k]));
+    PVF_REQUIRE(std::isfinite(wmax), "detector weights are not finite");
+    int sh = 0;
+    if (wmax > 0) { int ex; (void)std::frexp(wmax, &ex); sh = 7 - ex; }        // wmax = m * 2^ex, 0.5 <= m < 1  =>  wmax * 2^sh < 2^7
+    sh = std::max(-100, std::min(100, sh));
+    const double SCR_SCALE = std::ldexp(1.0, sh);
+    d.screen_scale = SCR_SCALE;
     std::vector<uint16_t> bh((size_t)10 * 12 * 64 * 8, 0);
     for (int m = 0; m < 10; ++m)
         for (int j = 0; j < 12; ++j)
@@ -466,7 +476,7 @@ void screen_launch(Ctx* c, const ScreenPlan& plan, const LvDesc* d_lv, int B, co
     ScreenParams sp;
     for (int f = 0; f < 8; ++f) {
         if (f < m.n_filters) {
-            const float at = (float)(((double)thr.thresh[f] - m.screen_bound[f]) * SCR_SCALE);
+            const float at = (float)(((double)thr.thresh[f] - m.screen_bound[f]) * m.screen_scale);
             sp.flag_at[f] = std::nextafterf(at, -INFINITY);
         }
         else sp.flag_at[f] = 3.0e38f;
