@@ -62,7 +62,7 @@ extern "C" int32_t pvf_detector_screening(pvf_handle h, int32_t on, int32_t list
 {
     API_BEGIN
     ENTER_DET(c, h);
-    PVF_REQUIRE(list_cap >= 0, "pvf_detector_screening: list_cap must be >= 0");
+    PVF_REQUIRE(list_cap >= 0 && list_cap <= (1 << 26), "pvf_detector_screening: list_cap must be 0 (keep) .. 2^26");
     c->det_screen = on != 0;
     if (list_cap > 0) c->screen_list_cap = list_cap;
     API_END

@@ -99,3 +99,13 @@ def test_feature_above_the_assumed_bound_repeats_the_call_on_the_dense_kernel(ct
     assert got == dense and again == dense
     assert s1["retries"] == s0["retries"] + 1 and s2["retries"] == s1["retries"] and s2["batches"] == s1["batches"] + 1
     frame.release()
+
+
+def test_library_bounds_equal_the_restated_derivation(ctx):
+    """the per-filter bounds the library computes at model load == tests/screen_bound.py (whose analytic part test_screen_bound.py holds
+    against the oracle on every window of a frame, on the CPU)"""
+    import screen_bound as sb
+    from pyannote_video_amd import models
+    W = np.ascontiguousarray(models.load_container(models.DEFAULT_DETECTOR)["det.w"], np.float32).reshape(5, 10, 10, 32)
+    got = np.array(ctx.detector_screening_stats()["bounds"])
+    assert np.allclose(got, sb.bounds(W), rtol=1e-9, atol=0)
