@@ -50,10 +50,16 @@ def e2e_object(flop_score_per_frame, faces, frames, seconds):
 
 
 def detector_hash():
+    """sha256[:16] of the detector's sources WITHOUT their comments and blank space: the key of the attached counter measurements (a
+    reworded comment is not a changed kernel)"""
     import hashlib
+    import re
     h = hashlib.sha256()
     for name in ("detect.hip", "screen.hip", "detect_ml.h"):
-        h.update(open(os.path.join(ROOT, "pyannote-video_amd", "csrc", name), "rb").read())
+        src = open(os.path.join(ROOT, "pyannote-video_amd", "csrc", name), "r").read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        h.update(re.sub(r"\s+", " ", src).encode())
     return h.hexdigest()[:16]
 
 

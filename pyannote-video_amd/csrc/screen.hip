@@ -1,4 +1,4 @@
-// screen.hip -- K3s: a screening pass in front of the detector's exact scoring chain (opt-in: pvf_detector_screening).
+// screen.hip -- K3s: a screening pass in front of the detector's exact scoring chain (the default; pvf_detector_screening switches it).
 //
 // The detector keeps a window when its score -- a chain of 3100 fmaf in (filter row, filter column, plane) order, oracle/pvo_detect.c
 // (dlib's scan_fhog_pyramid via reference pyannote/video/face/face.py:66) -- reaches the filter's threshold.  Of the 2.07 million
@@ -11,21 +11,24 @@
 // the data.  If the list overflows (a threshold lowered into the bulk of the score distribution) or a feature exceeds the bound the
 // derivation assumes, the call is repeated on the dense kernel (ScreenRetry, api.hip): screening never changes a result.
 //
-// The bound.  f = feature (>= 0, <= FM[plane]: 0.4001 for the 27 orientation planes = 4 x min(h, n) * 0.1 / n, 0.8486 for the 4 texture
-// planes = 0.4714 x 18 x 0.1; fhog_dev.h), w = weight, w' = f16(2^k w) / 2^k (round to nearest, done on the host: the error is KNOWN; k: the largest weight lands below 2^7),
+// The bound.  f = feature (>= 0, <= FM[plane]: 0.4004 for the 27 orientation planes = 4 x min(h, n) * 0.1 / n, 0.8492 for the 4 texture
+// planes = 0.4714 x 18 x 0.1 (fhog_dev.h), each with room for the f16 step the kernel's own check of the data loses), w = weight,
+// w' = f16(2^k w) / 2^k (round to nearest, done on the host: the error is KNOWN; k: the largest weight lands below 2^7),
 // f' = f16(f) (v_cvt_pkrtz: |f' - f| <= 2^-10 f, or <= 2^-14 should the pipe flush a subnormal).  S = exact chain, S* = the real sum,
 // S' = what the matrix pipe returns for sum f' w'.
 //   |S  - S*|  <= g(3100) sum |f w|                      (3100 roundings of a recursive fp32 sum, g(n) = n u / (1 - n u), u = 2^-24)
 //   |S' - S*|  <= sum f |w' - w| + sum |w'| max(2^-10 f, 2^-14) + 3200 x 2^-22 x sum f' |w'|
 // the last term allows every addition inside the matrix pipe four times the rounding error of an IEEE fp32 addition (products of two
-// f16 are exact in fp32); tests/test_gpu_screen.py measures the pipe against that allowance.  With f <= FM these are sums over the
-// weights alone: E_f = 1.02 x (all four terms) ~ 0.04 for the reference-shaped model, and on real data S' - S stays below 4e-4.
+// f16 are exact in fp32); screen_probe measures the device's pipe against that allowance before the first screened batch.  With f <= FM these are sums over the
+// weights alone: E_f = 1.02 x (all four terms) ~ 0.045 for the reference-shaped model, and on real data S' - S stays below 4e-4.
+// tests/screen_bound.py restates the computation; tests/test_screen_bound.py holds its analytic part against the oracle on every window of a frame.
 //
 // The kernel.  As in score_roll_k three neighbouring output columns share a 16-column tile (column = 5 x shift + filter; K of a filter
 // row = 12 cells x 32 planes = 12 MFMAs of K = 32), a tile's 16 rows are 16 base columns 3 cells apart.  A WAVE walks a strip of up to
 // four such groups (192 output columns) top to bottom; ten output rows are alive at a time (feature row s is filter row m = s - r of
-// output row r); slot q of the accumulators holds the output row r = q (mod 10), and the B fragment it needs at step s (m = (s - q) mod
-// 10) is addressed, not moved: all 120 B fragments (120 KB of f16) sit in LDS, loaded once per block, and a fragment feeds four MFMAs.
+// output row r); slot q of the accumulators holds the row that takes filter row m = q at this step, and at a row's last cell the MFMA writes
+// slot q's result into slot q + 1 (slot 9's is the finished row).  All 120 B fragments (120 KB of f16) sit in LDS, loaded once per block,
+// and a fragment feeds four MFMAs.
 // A fragments come straight from the fp32 feature map: lane (base i, plane octet kq) loads the 32 bytes of cell 3 i + n', converts them
 // (4 v_cvt_pkrtz) and -- because cell 3 i + (n' + 3) is cell 3 (i + 1) + n' -- hands them to base i - 1 with two DPP row moves for n' + 3,
 // + 6, + 9: a feature row is loaded and converted ONCE (3 cell phases x 5 fragments), not four times.  The ten B fragments of cell
