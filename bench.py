@@ -55,7 +55,7 @@ def detector_hash():
     import hashlib
     import re
     h = hashlib.sha256()
-    for name in ("detect.hip", "screen.hip", "detect_ml.h"):
+    for name in ("detect.hip", "screen.hip", "detect_ml.h", "fhog_dev.h"):
         src = open(os.path.join(ROOT, "pyannote-video_amd", "csrc", name), "r").read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         src = re.sub(r"//[^\n]*", "", src)

@@ -270,10 +270,11 @@ __device__ __forceinline__ int ml_level(const MlStarts& st, int g)
 //   - fetches the 8 pairs of the lane to its right (DPP wave shift): together they are the 16 columns of its cell's window;
 //   - adds the 16 votes to the bins of the cell whose UPPER half the row lies in and of the cell whose LOWER half it lies in.
 // A cell therefore receives its votes in row-major order of its own 16 x 16 window -- the order dlib's scatter loop produces
-// (oracle/pvo_fhog.c) -- while every pixel's gradient is computed exactly once.  The bins live in LDS, [bin][lane] (conflict-free), in
-// two arrays for even and odd cell rows: a vote is a ds_read / v_add / ds_write on the lane's own word, the chains of the two cells
-// a row votes into are independent, and LDS executes a wave's accesses in order, so no wait sits between one vote's write and
-// the next vote's read.  (ds_add_f32 gives the same sums -- it is an IEEE add -- but the LDS atomic unit retires so few lanes per
+// (oracle/pvo_fhog.c) -- while every pixel's gradient is computed exactly once.  The bins live in LDS, [bin][lane] (conflict-free), the
+// even and the odd cell rows' in two halves of ONE array a constant distance apart: a vote reads, adds to and writes the lane's own word
+// in both cells with one ds_read2st64 / ds_write2st64 pair off one address (round 4; two arrays before: two addresses, four LDS
+// instructions), the chains of the two cells a row votes into are independent, and LDS executes a wave's accesses in order, so no wait
+// sits between one vote's write and the next vote's read.  Bin offsets are kept in bytes (no shift per vote).  (ds_add_f32 gives the same sums -- it is an IEEE add -- but the LDS atomic unit retires so few lanes per
 // clock that the kernel ran 5 x slower with it: measured 713 us per 1080p frame.)  When a cell is complete its 18 bins move into registers;
 // a finished cell row's features (4-way block normalisation over the 3 x 3 neighbourhood of cell energies: rows from the two
 // previous cell rows kept in registers, columns from the neighbouring lanes) are written straight to the feature map.
@@ -286,17 +287,17 @@ __device__ __forceinline__ int ml_level(const MlStarts& st, int g)
 #define FUSED_OUT 61
 // value of the lane to the right / left (v_mov_b32_dpp wave_shl:1 / wave_shr:1; the last / first lane, which has no source, gets 0).
 // The direction is checked once per context on the device (dpp_probe_k): a mismatch is an error, not a fallback.
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, false); }
-__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false); }
+// (bound_ctrl: a lane without a source reads 0 -- no zeroed destination to prepare, one v_mov less per move)
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 
 
 __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
                                                        float* __restrict__ feat_base, const uint8_t* __restrict__ lut2, int oy, int ox)
 {
     constexpr int RSRC_FLAGS = 0x00020000;
-    // the bins of the two cell rows a pixel row votes into: two arrays, so that the compiler knows their updates never alias
-    __shared__ float s_even[4][18][64];                            // cell rows with even index
-    __shared__ float s_odd[4][18][64];                             // cell rows with odd index
+    // the bins of the two cell rows a pixel row votes into
+    __shared__ float s_bins[2][4][18][64];                         // [parity of the cell row][wave][bin][lane]: the two parities a constant distance apart
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = ml_block(st);
@@ -323,8 +324,8 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
     // give negative offsets, which are huge as unsigned: out of range for the row's buffer descriptor => zeros.  Both offsets go
     // through the VGPR: the range check does not see an SGPR offset, so -16 + an SGPR 16 would be rejected although it is byte 0.
     const int voff = 3 * x_first - 4, voff2 = voff + 16;
-    float* accE = &s_even[wave][0][lane];                          // bin k of this lane: accE[64 * k]
-    float* accO = &s_odd[wave][0][lane];
+    float* accE = &s_bins[0][wave][0][lane];                       // bin k of this lane: accE[64 * k]
+    float* accO = &s_bins[1][wave][0][lane];
 #pragma unroll
     for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accO[64 * k] = 0.0f; }
 
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
         float v; int o;
         grad_lookup(u3, d3, l3, r3, lut2, &v, &o);
         *mo = (row_ok && ((xmask >> p) & 1u)) ? v : 0.0f;
-        *bof = o << 6;                                             // float offset of the bin's row of 64 lanes
+        *bof = o << 8;                                             // BYTE offset of the bin's row of 64 lanes (no shift left per vote)
     };
     // the votes of a row are a chain of LDS read-add-writes (latency bound); the gradients of the NEXT row are pure VALU work plus a table
     // look-up: they are computed in between, one pixel per two votes, so that a wave fills its own LDS waits and the look-ups of a row are
@@ -406,10 +407,12 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
                 }
                 const float fx = ((float)p + 0.5f) / 8.0f;
                 const float wx = (j < 8) ? fx : 1.0f - fx;
-                const float vl = accL[bv], vu = accU[bv];
+                float* const pl = reinterpret_cast<float*>(reinterpret_cast<char*>(accL) + bv);
+                float* const pu = reinterpret_cast<float*>(reinterpret_cast<char*>(accU) + bv);
+                const float vl = *pl, vu = *pu;
                 if ((j & 1) == 0) grad_px(nu, nc, nd, j >> 1, nok, &mn[j >> 1], &bn[j >> 1]);
-                accL[bv] = vl + ((1.0f - fy) * wx) * mv;
-                accU[bv] = vu + (fy * wx) * mv;
+                *pl = vl + ((1.0f - fy) * wx) * mv;
+                *pu = vu + (fy * wx) * mv;
             }
 #pragma unroll
             for (int p = 0; p < 8; ++p) { mc[p] = mn[p]; bc[p] = bn[p]; }
@@ -699,6 +702,7 @@ struct MlPlan {
 struct MlPlanCache {
     std::map<std::vector<int>, std::unique_ptr<MlPlan>> plans;
     int dpp_probe = -1;                        // 1: v_mov_b32_dpp wave_shl/wave_shr move data as the fused kernel expects
+    int sqrt_probe = -1;                       // 1: sqrt_exact_small is correctly rounded on 0 .. 2 * 255^2
 };
 void ml_plans_free(Ctx* c)
 {
@@ -823,22 +827,35 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
     return p;
 }
 
-// does `v_mov_b32_dpp ... wave_shl:1 / wave_shr:1` hand lane i the value of lane i + 1 / i - 1 (lanes without a source keeping 0)?
+// What the fused FHOG kernel takes for granted about the device, checked once per context (a mismatch is an error, not a fallback):
+// `v_mov_b32_dpp ... wave_shl:1 / wave_shr:1` with bound_ctrl hand lane i the value of lane i + 1 / i - 1 (lanes without a source: 0), and
+// sqrt_exact_small (fhog_dev.h: the hardware estimate stepped UP when one exact residual asks for it) is the correctly rounded root of
+// every squared gradient magnitude 0 .. 2 * 255^2.
 __global__ void dpp_probe_k(int* out)
 {
     const int lane = threadIdx.x;
     out[lane] = (int)from_next_lane((uint32_t)(lane + 100));
     out[64 + lane] = (int)from_prev_lane((uint32_t)(lane + 100));
 }
+#define SQRT_PROBE_N (2 * 255 * 255 + 1)
+__global__ void sqrt_probe_k(float* out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < SQRT_PROBE_N) out[i] = sqrt_exact_small((float)i);
+}
 static void check_dpp_direction(Ctx* c)
 {
     MlPlanCache* pc = c->ml_plans;
     if (pc->dpp_probe < 0) {
         int* d = nullptr;                                // (a buffer of its own, once per context: every scratch buffer is somebody's state)
-        HIP_CHECK(hipMalloc((void**)&d, 128 * sizeof(int)));
+        HIP_CHECK(hipMalloc((void**)&d, 128 * sizeof(int) + SQRT_PROBE_N * sizeof(float)));
+        float* ds = reinterpret_cast<float*>(d + 128);
         hipLaunchKernelGGL(dpp_probe_k, dim3(1), dim3(64), 0, c->det_stream, d);
+        hipLaunchKernelGGL(sqrt_probe_k, dim3((SQRT_PROBE_N + 255) / 256), dim3(256), 0, c->det_stream, ds);
         int h[128];
+        std::vector<float> hs(SQRT_PROBE_N);
         HIP_CHECK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->det_stream));
+        HIP_CHECK(hipMemcpyAsync(hs.data(), ds, SQRT_PROBE_N * sizeof(float), hipMemcpyDeviceToHost, c->det_stream));
         HIP_CHECK(hipStreamSynchronize(c->det_stream));
         (void)hipFree(d);
         bool ok = true;
@@ -847,8 +864,12 @@ static void check_dpp_direction(Ctx* c)
             ok = ok && h[64 + i] == (i > 0 ? i + 99 : 0);
         }
         pc->dpp_probe = ok ? 1 : 0;
+        bool sq = true;
+        for (int i = 0; i < SQRT_PROBE_N; ++i) sq = sq && hs[i] == (float)std::sqrt((double)i);      // (exact: double sqrt, one rounding)
+        pc->sqrt_probe = sq ? 1 : 0;
     }
     PVF_REQUIRE(pc->dpp_probe == 1, "v_mov_b32_dpp wave_shl / wave_shr do not move data as the FHOG kernel expects on this device");
+    PVF_REQUIRE(pc->sqrt_probe == 1, "v_sqrt_f32 is not within one step below the correctly rounded root on this device: the FHOG kernel's one-sided correction does not hold");
 }
 
 // pyramid + FHOG features of every level of the batch (s_feat at plan->lv[l].feat_off); returns the plan

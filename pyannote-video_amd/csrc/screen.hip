@@ -106,8 +106,8 @@ __device__ __forceinline__ void screen_walk(const ScreenItem t, const LvDesc* __
         for (int g = 0; g <= NG; ++g) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                int fill = 0;
-                if (g < NG) fill = __builtin_amdgcn_update_dpp(0, (int)a[g + 1][e], 0x11F /* row_shr:15 */, 0xf, 0xf, false);
+                int fill = 0;           // (bound_ctrl: the lanes row_shr:15 has no source for read 0 -- no zeroed destination to prepare)
+                if (g < NG) fill = __builtin_amdgcn_update_dpp(0, (int)a[g + 1][e], 0x11F /* row_shr:15 */, 0xf, 0xf, true);
                 a[g][e] = (uint32_t)__builtin_amdgcn_update_dpp(fill, (int)a[g][e], 0x101 /* row_shl:1 */, 0xf, 0xf, false);
             }
         }

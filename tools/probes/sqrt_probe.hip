@@ -19,11 +19,17 @@ int main()
     hipLaunchKernelGGL(probe, dim3((n + 255) / 256), dim3(256), 0, 0, n, d);
     std::vector<float> h(n);
     hipMemcpy(h.data(), d, n * sizeof(float), hipMemcpyDeviceToHost);
-    int bad = 0, first = -1;
+    int bad = 0, first = -1, above = 0, below = 0, far = 0;
     for (int i = 0; i < n; ++i) {
         const float want = (float)std::sqrt((double)i);          // correctly rounded: sqrt in double, then one rounding (exact for these inputs)
-        if (h[i] != want) { if (first < 0) first = i; ++bad; }
+        if (h[i] != want) {
+            if (first < 0) first = i;
+            ++bad;
+            if (h[i] > want) ++above; else ++below;
+            if (h[i] != std::nextafterf(want, 0.0f) && h[i] != std::nextafterf(want, 1e30f)) ++far;
+        }
     }
-    printf("v_sqrt_f32 on integers 0..%d: %d of %d differ from the correctly rounded value (first at %d)\n", n - 1, bad, n, first);
+    printf("v_sqrt_f32 on integers 0..%d: %d of %d differ from the correctly rounded value (first at %d): %d above it, %d below it, %d by more than one step\n",
+           n - 1, bad, n, first, above, below, far);
     return 0;
 }
