@@ -18,8 +18,9 @@
 // S' = what the matrix pipe returns for sum f' w'.
 //   |S  - S*|  <= g(3100) sum |f w|                      (3100 roundings of a recursive fp32 sum, g(n) = n u / (1 - n u), u = 2^-24)
 //   |S' - S*|  <= sum f |w' - w| + sum |w'| max(2^-10 f, 2^-14) + 3200 x 2^-22 x sum f' |w'|
-// the last term allows every addition inside the matrix pipe four times the rounding error of an IEEE fp32 addition (products of two
-// f16 are exact in fp32); screen_probe measures the device's pipe against that allowance before the first screened batch.  With f <= FM these are sums over the
+// the last term is the allowance for the matrix pipe's own additions: a sum takes part in at most 3100 + 120 of them that can round (its
+// non-zero products and the hand-overs between the 120 MFMAs; adding one of the tile's zero entries is exact), each allowed just under four
+// times the rounding error of an IEEE fp32 addition -- 3200 x 2^-22 in total (products of two f16 are exact in fp32); screen_probe measures the device's pipe against that allowance before the first screened batch.  With f <= FM these are sums over the
 // weights alone: E_f = 1.02 x (all four terms) ~ 0.045 for the reference-shaped model, and on real data S' - S stays below 4e-4.
 // tests/screen_bound.py restates the computation; tests/test_screen_bound.py holds its analytic part against the oracle on every window of a frame.
 //

@@ -3,7 +3,8 @@ S = the exact chain (3100 fmaf), S' = what the f16 matrix cores return for the s
 when S' >= threshold - bound[filter].  The terms (see the header of screen.hip):
   e_w     sum FM |w' - w|                       w' = f16(scale * w) / scale, round to nearest (numpy's float16 conversion), scale = 2^k
   e_f     sum |w'| max(2^-10 FM, 2^-14)         features converted with round-towards-zero; a subnormal may be flushed
-  e_pipe  3200 * 2^-22 * sum FM |w'| (1 + 2^-10)  every addition in the matrix pipe allowed 4 x an IEEE fp32 rounding error
+  e_pipe  3200 * 2^-22 * sum FM |w'| (1 + 2^-10)  the <= 3220 rounding additions of a sum inside the matrix pipe (3100 non-zero products, 120
+          hand-overs between MFMAs; adding a zero entry is exact) allowed just under 4 x an IEEE fp32 rounding error each
   e_chain g(3100) sum FM |w|                    the exact chain's own distance from the real sum, g(n) = n u / (1 - n u), u = 2^-24
 FM = 0.4004 for the 27 orientation planes, 0.8492 for the 4 texture planes (the FHOG normalisation's maxima + the f16 step the kernel's
 check of the data loses)."""
