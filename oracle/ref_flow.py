@@ -171,9 +171,10 @@ def track_text(tracks):
     return lines
 
 
-def extract(track_lines, frames, times, landmarks, embed, pool=None):
+def extract(track_lines, frames, times, landmarks, embed, pool=None, keep=None):
     """-> (landmark lines, embedding lines), literal text like the CLI writes.  pool: optional executor, faces of one frame are
-    independent (all-core CPU baseline)"""
+    independent (all-core CPU baseline).  keep: optional list that receives (T, track, float32 descriptor) per face, the values
+    before the '%.5f' of the file (whole-clip fixtures, oracle/golden.py)"""
     h, w = frames[0].shape[:2]
     rows = []
     for line in track_lines:
@@ -212,6 +213,8 @@ def extract(track_lines, frames, times, landmarks, embed, pool=None):
         for (ident, box), (pts, e) in zip(faces, list(pool.map(one, faces)) if pool is not None else [one(f) for f in faces]):
             lm_lines.append('%.3f %d' % (T, ident) + ''.join(' %.5f %.5f' % (x / w, y / h) for x, y in pts))
             em_lines.append('%.3f %d' % (T, ident) + ''.join(' %.5f' % float(v) for v in e))
+            if keep is not None:
+                keep.append((T, ident, np.array(e, np.float32)))
     return lm_lines, em_lines
 
 

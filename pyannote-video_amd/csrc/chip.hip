@@ -96,11 +96,20 @@ __global__ void __launch_bounds__(256) pyr_down2_k(const DevPyrJob* __restrict__
     int acc[3] = {0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
+        // the five pixels of a source row are 15 consecutive bytes: four (unaligned) dwords at +0, +4, +8 and +11 cover exactly them
+        // (round 4 read them as 15 byte loads: 75 per output pixel)
         const uint8_t* p = j.src + ((size_t)(j.y0 + 2 * r + i) * j.stride_w + (j.x0 + 2 * c)) * 3;
+        const uint32_t d0 = *reinterpret_cast<const uint32_t*>(p), d1 = *reinterpret_cast<const uint32_t*>(p + 4);
+        const uint32_t d2 = *reinterpret_cast<const uint32_t*>(p + 8), d3 = *reinterpret_cast<const uint32_t*>(p + 11);
+        const int px[5][3] = {{(int)(d0 & 0xffu), (int)((d0 >> 8) & 0xffu), (int)((d0 >> 16) & 0xffu)},
+                              {(int)(d0 >> 24), (int)(d1 & 0xffu), (int)((d1 >> 8) & 0xffu)},
+                              {(int)((d1 >> 16) & 0xffu), (int)(d1 >> 24), (int)(d2 & 0xffu)},
+                              {(int)((d2 >> 8) & 0xffu), (int)((d2 >> 16) & 0xffu), (int)(d2 >> 24)},
+                              {(int)((d3 >> 8) & 0xffu), (int)((d3 >> 16) & 0xffu), (int)(d3 >> 24)}};
         int row[3] = {0, 0, 0};
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
-            row[0] += k[q] * p[q * 3]; row[1] += k[q] * p[q * 3 + 1]; row[2] += k[q] * p[q * 3 + 2];
+            row[0] += k[q] * px[q][0]; row[1] += k[q] * px[q][1]; row[2] += k[q] * px[q][2];
         }
         acc[0] += k[i] * row[0]; acc[1] += k[i] * row[1]; acc[2] += k[i] * row[2];
     }
@@ -123,11 +132,16 @@ __global__ void __launch_bounds__(256) transform_k(const DevXfJob* __restrict__ 
     if (!(fx >= 0 && fy >= 0 && fx + 1 < j.sw && fy + 1 < j.sh)) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
     const int left = (int)fx, top = (int)fy;
     const double lr = px - left, tb = py - top;
+    // the two pixels of a source row are 6 consecutive bytes: two (unaligned) dwords at +0 and +2 cover exactly them
     const uint8_t* ptl = j.src + ((size_t)(j.y0 + top) * j.stride_w + (j.x0 + left)) * 3;
     const uint8_t* pbl = ptl + (size_t)j.stride_w * 3;
+    const uint32_t t0 = *reinterpret_cast<const uint32_t*>(ptl), t1 = *reinterpret_cast<const uint32_t*>(ptl + 2);
+    const uint32_t b0 = *reinterpret_cast<const uint32_t*>(pbl), b1 = *reinterpret_cast<const uint32_t*>(pbl + 2);
+    const uint32_t tl3[3] = {t0 & 0xffu, (t0 >> 8) & 0xffu, (t0 >> 16) & 0xffu}, tr3[3] = {t0 >> 24, (t1 >> 16) & 0xffu, t1 >> 24};
+    const uint32_t bl3[3] = {b0 & 0xffu, (b0 >> 8) & 0xffu, (b0 >> 16) & 0xffu}, br3[3] = {b0 >> 24, (b1 >> 16) & 0xffu, b1 >> 24};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double tl = ptl[k], tr = ptl[3 + k], bl = pbl[k], br = pbl[3 + k];
+        const double tl = tl3[k], tr = tr3[k], bl = bl3[k], br = br3[k];
         const double v = (1 - tb) * ((1 - lr) * tl + lr * tr) + tb * ((1 - lr) * bl + lr * br);
         o[k] = (uint8_t)v;
     }

@@ -472,19 +472,36 @@ extern "C" int32_t pvf_frame_device_ptr(pvf_handle h, pvf_handle frame, const vo
 }
 
 // frames_mu held.  The buffer goes back to the pool behind an event on the compute stream, so the call never waits for the kernels
-// that were queued on this frame; the next user of the buffer does (Ctx::pool_take).
-static void release_frame_locked(Ctx* c, pvf_handle frame)
+// that were queued on this frame; the next user of the buffer does (Ctx::pool_take).  Returns true for memory the caller owns
+// (pvf_frame_wrap_device): compute calls no longer end with a stream synchronisation, so kernels that read the frame may still be
+// queued, and the caller is free to reuse the memory as soon as the release returns -- the release must wait for both streams, which
+// it does AFTER dropping frames_mu (wait_streams_unlocked): the detector thread's frame look-ups, the decoder's uploads and the pool
+// are not held up behind a queued detector batch.
+static bool release_frame_locked(Ctx* c, pvf_handle frame)
 {
     auto it = c->frames.find(frame);
     PVF_REQUIRE(it != c->frames.end(), "unknown frame handle");
     Frame f = it->second;
     c->frames.erase(it);
     if (f.ready) { (void)hipEventSynchronize(f.ready); (void)hipEventDestroy(f.ready); }     // released before any kernel read it: let the upload finish
-    if (f.owned) c->pool_give((uint8_t*)f.d, (size_t)f.h * f.w * 3);
-    // memory the caller owns (pvf_frame_wrap_device): compute calls no longer end with a stream synchronisation, so kernels that read this
-    // frame may still be queued -- the caller is free to reuse the memory as soon as this returns, hence the wait (pooled buffers go back
-    // behind an event instead and never wait)
-    else { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->det_stream); }
+    if (f.owned) { c->pool_give((uint8_t*)f.d, (size_t)f.h * f.w * 3); return false; }
+    return true;
+}
+
+// what was queued on either stream up to now (an event each; the frame's table entry is gone, so nothing newer can read it); frames_mu NOT held
+static void wait_streams_unlocked(Ctx* c)
+{
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {c->stream, c->det_stream};
+    for (int i = 0; i < 2; ++i) {
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[i], st[i]) != hipSuccess) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            ev[i] = nullptr;
+            (void)hipStreamSynchronize(st[i]);
+        }
+    }
+    for (int i = 0; i < 2; ++i)
+        if (ev[i]) { (void)hipEventSynchronize(ev[i]); (void)hipEventDestroy(ev[i]); }
 }
 
 extern "C" int32_t pvf_frame_release(pvf_handle h, pvf_handle frame)
@@ -492,8 +509,12 @@ extern "C" int32_t pvf_frame_release(pvf_handle h, pvf_handle frame)
     API_BEGIN
     Ctx* c = pvf_ctx(h);
     HIP_CHECK(hipSetDevice(c->device));
-    std::lock_guard<std::mutex> lk(c->frames_mu);
-    release_frame_locked(c, frame);
+    bool wait;
+    {
+        std::lock_guard<std::mutex> lk(c->frames_mu);
+        wait = release_frame_locked(c, frame);
+    }
+    if (wait) wait_streams_unlocked(c);
     API_END
 }
 
@@ -503,8 +524,12 @@ extern "C" int32_t pvf_frame_release_many(pvf_handle h, const pvf_handle* frames
     Ctx* c = pvf_ctx(h);
     HIP_CHECK(hipSetDevice(c->device));
     PVF_REQUIRE(n >= 0 && (frames || n == 0), "pvf_frame_release_many: bad arguments");
-    std::lock_guard<std::mutex> lk(c->frames_mu);
-    for (int i = 0; i < n; ++i) release_frame_locked(c, frames[i]);
+    bool wait = false;
+    {
+        std::lock_guard<std::mutex> lk(c->frames_mu);
+        for (int i = 0; i < n; ++i) wait = release_frame_locked(c, frames[i]) || wait;
+    }
+    if (wait) wait_streams_unlocked(c);
     API_END
 }
 

@@ -2,7 +2,7 @@
 // (reference pyannote/video/tracking.py:250-251 start_track, :203 update -> PSR, :165,231 get_position).
 // Double precision like dlib; 64x64 2-D FFTs live in LDS (65-element row pitch), every sum keeps the order stated in
 // oracle/pvo_dsst.c, exp() is the shared deterministic polynomial -- so PSR and positions are bit-identical.
-#include "pvf_internal.h"
+#include "fhog_dev.h"
 #include <cmath>
 
 #define FS 64
@@ -173,33 +173,45 @@ __device__ __forceinline__ void fft32_seq(double2* x, const double* __restrict__
     }
 }
 
-// ---- translation features: plane i of tracker b -> mask * value -> s (natural positions).  Features are plane-major
-// ([b][31][64*64] floats, fhog_device(..., planes = true)): a plane is 16 KB of consecutive floats; plane 31 is the grey chip.
+// ---- translation features: plane i of tracker b -> mask * value -> s (natural positions).  The features arrive as the compact
+// record of fhog1_compact_k (fhog.hip: float S[4096], float T[4][4096], uint8 bin[4096]; 84 KB per tracker, re-read per plane out of
+// L2): orientation plane i < 18 is S where the pixel's bin is i, plane 18 + j is S where bin % 9 is j, planes 27..30 are the textures,
+// plane 31 the grey chip -- the values the 31-plane form of round 4 held, which never exist in memory now.
+__device__ __forceinline__ float plane_value(const uint8_t* __restrict__ rec, const uint8_t* __restrict__ chip, int i, int q)
+{
+    const float* S = reinterpret_cast<const float*>(rec);
+    const int sl = TRKF_SLOT(q);
+    if (i < 27) {
+        const int a = rec[TRKF_A + sl];
+        const int key = i < 18 ? a : (a >= 9 ? a - 9 : a);
+        const float v = S[sl];
+        return key == (i < 18 ? i : i - 18) ? v : 0.0f;
+    }
+    if (i < 31) return S[(size_t)(i - 26) * TRKF_PLANE + sl];
+    const uint8_t* p = chip + (size_t)q * 3;
+    return (float)(((unsigned)p[0] + p[1] + p[2]) / 3) / 255.0f;
+}
+
 template <int NT = 256>
-__device__ __forceinline__ void load_plane_lds(double2* s, const uint8_t* __restrict__ chip, const float* __restrict__ fb, int i,
+__device__ __forceinline__ void load_plane_lds(double2* s, const uint8_t* __restrict__ chip, const uint8_t* __restrict__ rec, int i,
                                                const double* __restrict__ mask64)
 {
 #pragma unroll
     for (int k = 0; k < FS * FS / NT; ++k) {
         const int q = threadIdx.x + NT * k;
-        float v;
-        if (i < 31) v = fb[(size_t)i * FS * FS + q];
-        else {
-            const uint8_t* p = chip + (size_t)q * 3;
-            v = (float)(((unsigned)p[0] + p[1] + p[2]) / 3) / 255.0f;
-        }
+        const float v = plane_value(rec, chip, i, q);
         s[(q >> 6) * LP + (q & 63)] = make_double2((double)v * mask64[q], 0.0);
     }
 }
 
 // plane spectra to HBM: only the full (filter-updating) update needs them twice, see dsst_update_many
-__global__ void __launch_bounds__(256) trans_planes_fft_k(const uint8_t* __restrict__ chips, const float* __restrict__ feat,
+__global__ void __launch_bounds__(256) trans_planes_fft_k(const uint8_t* __restrict__ chips, const uint8_t* __restrict__ feat,
                                                           const double* __restrict__ mask64, const double* __restrict__ tw64,
                                                           double2* __restrict__ F)
 {
     extern __shared__ __attribute__((aligned(16))) double2 s[];
     const int i = blockIdx.x, b = blockIdx.y;
-    load_plane_lds(s, chips + (size_t)b * FS * FS * 3, feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE, i, mask64);
+    load_plane_lds(s, chips + (size_t)b * FS * FS * 3, feat + (size_t)b * TRKF_BYTES, i, mask64);
     __syncthreads();
     fft2d_lds(s, tw64, false);
     double2* out = F + ((size_t)b * NPL + i) * FS * FS;
@@ -354,7 +366,8 @@ __global__ void __launch_bounds__(256) peak_k(const TrkJob* __restrict__ jobs, c
 
 // ---- start_track in one pass per tracker: the block walks the 32 planes; a plane's spectrum goes straight from LDS into
 // A_i = G * F_i and into the running |F|^2 sum (plane order) and is never written out.
-// HBM per tracker: 0.5 MB of features in, 2.06 MB of filters out (three-kernel form: + 2 MB F written and read, + G).
+// HBM per tracker: 84 KB of compact features in (round 4: 0.5 MB of planes), 2.06 MB of filters out (three-kernel form: + 2 MB F
+// written and read, + G).
 // 512 threads: one line task per thread and FFT phase, 8 spectrum points per thread -- four waves per SIMD hide the LDS and
 // fp64 latencies of the butterfly chains (a 256-thread form needed > 256 registers and ran one wave per SIMD).
 #define FUSED_NT 512
@@ -375,16 +388,28 @@ __device__ __forceinline__ FusedOwn fused_own()
 
 // plane i of the tracker's features -> mask * value -> s.  All eight loads of a thread are issued before the first is used
 // (the plane test is block-uniform: no branch inside the element loop).
-__device__ __forceinline__ void fused_load_plane(double2* s, const uint8_t* __restrict__ chip, const float* __restrict__ fb, int i,
+__device__ __forceinline__ void fused_load_plane(double2* s, const uint8_t* __restrict__ chip, const uint8_t* __restrict__ rec, int i,
                                                  const double* __restrict__ mask64)
 {
     const int tid = threadIdx.x;
     float v[FUSED_PT];
     double m[FUSED_PT];
+    static_assert(FUSED_NT == 512 && FUSED_PT == 8, "the record's slot order is made for 512 threads x 8 pixels");
     if (i < 31) {
-        const float* pl = fb + (size_t)i * FS * FS + tid;
+        // the thread's eight pixels tid + 512 k: 32 consecutive bytes of a float array, 8 of the bins (TRKF_SLOT)
+        const float4* pl = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(rec) + (i < 27 ? 0 : (size_t)(i - 26) * TRKF_PLANE) + tid * 8);
+        const float4 lo = pl[0], hi = pl[1];
+        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        if (i < 27) {
+            const uint2 ab = *reinterpret_cast<const uint2*>(rec + TRKF_A + tid * 8);
+            const int want = i < 18 ? i : i - 18;
 #pragma unroll
-        for (int k = 0; k < FUSED_PT; ++k) v[k] = pl[FUSED_NT * k];
+            for (int k = 0; k < FUSED_PT; ++k) {
+                const int a = (int)(((k < 4 ? ab.x : ab.y) >> (8 * (k & 3))) & 0xffu);
+                const int key = i < 18 ? a : (a >= 9 ? a - 9 : a);
+                v[k] = key == want ? v[k] : 0.0f;
+            }
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < FUSED_PT; ++k) {
@@ -398,7 +423,7 @@ __device__ __forceinline__ void fused_load_plane(double2* s, const uint8_t* __re
     for (int k = 0; k < FUSED_PT; ++k) s[(tid >> 6) * LP + (tid & 63) + FUSED_LDS(k)] = make_double2((double)v[k] * m[k], 0.0);
 }
 
-__global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) start_fused_k(const TrkJob* __restrict__ jobs, const uint8_t* __restrict__ chips, const float* __restrict__ feat,
+__global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) start_fused_k(const TrkJob* __restrict__ jobs, const uint8_t* __restrict__ chips, const uint8_t* __restrict__ feat,
                                                           const double* __restrict__ mask64, const double* __restrict__ tw64)
 {
     extern __shared__ __attribute__((aligned(16))) double2 s[];
@@ -419,7 +444,7 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
     for (int k = 0; k < FUSED_PT; ++k) bsum[k] = 0;
     double2* A = reinterpret_cast<double2*>(j.state + TRK_A) + own.q0;
     const uint8_t* chip = chips + (size_t)b * FS * FS * 3;
-    const float* fb = feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE;
+    const uint8_t* fb = feat + (size_t)b * TRKF_BYTES;
     for (int i = 0; i < NPL; ++i) {
         const double* mk = mask64;
         asm volatile("" : "+s"(mk));               // the window is re-read per plane (L1/L2 hits), not kept in 16 registers across the loop
@@ -442,7 +467,7 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
 
 // ---- deferred update in one pass per tracker: plane spectra are multiplied into the response sum as they appear (plane order,
 // like corr_k), then normalised, inverted and searched in the same block.  Filters are only read (2.06 MB per tracker).
-__global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) update_fused_k(const TrkJob* __restrict__ jobs, const uint8_t* __restrict__ chips, const float* __restrict__ feat,
+__global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4, 4))) update_fused_k(const TrkJob* __restrict__ jobs, const uint8_t* __restrict__ chips, const uint8_t* __restrict__ feat,
                                                            const double* __restrict__ mask64, const double* __restrict__ tw64, double* __restrict__ results)
 {
     extern __shared__ __attribute__((aligned(16))) double2 s[];
@@ -455,7 +480,7 @@ __global__ void __launch_bounds__(FUSED_NT) __attribute__((amdgpu_waves_per_eu(4
     const FusedOwn own = fused_own();
     const double2* A = reinterpret_cast<const double2*>(j.state + TRK_A) + own.q0;
     const uint8_t* chip = chips + (size_t)b * FS * FS * 3;
-    const float* fb = feat + (size_t)b * FS * FS * PVF_FHOG_STRIDE;
+    const uint8_t* fb = feat + (size_t)b * TRKF_BYTES;
     double gr[FUSED_PT], gi[FUSED_PT];
 #pragma unroll
     for (int k = 0; k < FUSED_PT; ++k) { gr[k] = 0; gi[k] = 0; }
@@ -513,33 +538,143 @@ __device__ __forceinline__ void scale_rect_d(double r[4], double s)
     r[0] = cx - w / 2; r[1] = cy - h / 2; r[2] = cx + w / 2; r[3] = cy + h / 2;
 }
 
-// 32 scale chips (23x23) around the tracker's current position, sampled straight from the frame
-__global__ void __launch_bounds__(256) scale_chips_k(const TrkJob* __restrict__ jobs, double alpha_pow_m16, uint8_t* __restrict__ chips)
+// ---- scale samples: chip, gradients, histograms and features of one 23 x 23 sample in ONE wave, nothing in HBM but the 16 x 32 floats
+// the scale transform reads (round 4: scale_chips_k -> fhog_grad4_k<4> -> fhog_hist_k<4> -> fhog_feat_k, the chip, its (magnitude, bin)
+// planes and its cell histograms written to HBM and read back: 0.3 MB per tracker and call, 2.7 ms per 2000 trackers).
+//   1. (SAMPLE) the wave samples its chip from the frame: 32 rectangles around the tracker's position, the arithmetic of dlib's
+//      pyramid-free extract_image_chip path exactly as the oracle states it (oracle/pvo_dsst.c scale_sample) -> bytes in LDS;
+//      (!SAMPLE: stage access of the parity tests, the chip is given)
+//   2. gradient magnitude + orientation bin of the pixels that vote (1 .. 21 of 23: visible = min(6 * 4, 23) - 1), into a 36 x 36 plane
+//      shifted by 3 * 4 / 2 = 6 so that histogram cell (hy, hx) owns rows 4 hy .. 4 hy + 7, columns 4 hx .. 4 hx + 7
+//   3. lane = histogram cell (8 x 8 cells = 64 lanes): its 64 votes in row-major order into acc[bin][lane] -- the order dlib's scatter
+//      loop adds in (oracle/pvo_fhog.c) -- then the cell's energy
+//   4. lanes 0..15: cell_features() of the 4 x 4 output cells; slot 31 of a cell (the pad of the 32-float record) carries the grey
+//      value of chip pixel (cell row, cell column), the 32nd "plane" of the scale filter (SAMPLE only; 0 for stage access)
+// LDS per wave: 9.9 KB (16 waves per CU): the plane is 32 x 32 -- only rows / columns 7 .. 27 ever hold a vote, a cell window's
+// coordinates 32 .. 35 read row / column 31 (zero) instead; the chip's bytes share their room with the bins' sums (dead by then).
+#define SPL 32
+template <bool SAMPLE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+scale_fhog_k(const TrkJob* __restrict__ jobs, double alpha_pow_m16, const uint8_t* __restrict__ chips_in, const uint8_t* __restrict__ lut, float* __restrict__ feat)
 {
-    const int k = blockIdx.x, b = blockIdx.y;
-    const TrkJob j = jobs[b];
-    double ppp[4] = {j.pos[0], j.pos[1], j.pos[2], j.pos[3]};
-    scale_rect_d(ppp, alpha_pow_m16);
-    for (int i = 0; i < k; ++i) scale_rect_d(ppp, ALPHA);
-    const double m0 = (ppp[2] - ppp[0]) / (double)(SWIN - 1), m3 = (ppp[3] - ppp[1]) / (double)(SWIN - 1);
-    uint8_t* out = chips + ((size_t)b * NSC + k) * SWIN * SWIN * 3;
-    for (int q = threadIdx.x; q < SWIN * SWIN; q += 256) {
-        const int r = q / SWIN, c = q % SWIN;
-        const double px = m0 * c + 0.0 * r + ppp[0];
-        const double py = 0.0 * c + m3 * r + ppp[1];
-        const double fx = floor(px), fy = floor(py);
-        uint8_t* o = out + (size_t)q * 3;
-        if (!(fx >= 0 && fy >= 0 && fx + 1 < j.w && fy + 1 < j.h)) { o[0] = 0; o[1] = 0; o[2] = 0; continue; }
-        const int left = (int)fx, top = (int)fy;
-        const double lr = px - left, tb = py - top;
-        const uint8_t* ptl = j.img + ((size_t)top * j.w + left) * 3;
-        const uint8_t* pbl = ptl + (size_t)j.w * 3;
-        for (int ch = 0; ch < 3; ++ch) {
-            const double tl = ptl[ch], tr = ptl[3 + ch], bl = pbl[ch], br = pbl[3 + ch];
-            const double v = (1 - tb) * ((1 - lr) * tl + lr * tr) + tb * ((1 - lr) * bl + lr * br);
-            o[ch] = (uint8_t)v;
+    __shared__ __attribute__((aligned(16))) float acc_s[4][18][64];          // first: the chip's 23 x 23 x 3 bytes
+    __shared__ float mag_s[4][SPL * SPL];
+    __shared__ uint8_t bin_s[4][SPL * SPL];
+    __shared__ float nrm_s[4][36];
+    static_assert(sizeof(float) * 18 * 64 >= SWIN * SWIN * 3, "the chip fits where the sums will be");
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + w, b = blockIdx.y;
+    uint8_t* chip = reinterpret_cast<uint8_t*>(&acc_s[w][0][0]);
+    float* mag = mag_s[w];
+    uint8_t* bin = bin_s[w];
+    for (int q = lane; q < SPL * SPL; q += 64) { mag[q] = 0.0f; bin[q] = 0; }
+    if (SAMPLE) {
+        const TrkJob& j = jobs[b];
+        const double* jp = j.pos;
+        const uint8_t* img = j.img;
+        const int jw = j.w, jh = j.h;
+        double ppp[4] = {jp[0], jp[1], jp[2], jp[3]};
+        scale_rect_d(ppp, alpha_pow_m16);
+        for (int i = 0; i < k; ++i) scale_rect_d(ppp, ALPHA);
+        const double m0 = (ppp[2] - ppp[0]) / (double)(SWIN - 1), m3 = (ppp[3] - ppp[1]) / (double)(SWIN - 1);
+        for (int q = lane; q < SWIN * SWIN; q += 64) {
+            const int r = q / SWIN, c = q % SWIN;
+            const double px = m0 * c + 0.0 * r + ppp[0];
+            const double py = 0.0 * c + m3 * r + ppp[1];
+            const double fx = floor(px), fy = floor(py);
+            uint8_t* o = chip + q * 3;
+            if (!(fx >= 0 && fy >= 0 && fx + 1 < jw && fy + 1 < jh)) { o[0] = 0; o[1] = 0; o[2] = 0; continue; }
+            const int left = (int)fx, top = (int)fy;
+            const double lr = px - left, tb = py - top;
+            // the two pixels of a source row are 6 consecutive bytes: two (unaligned) dwords at +0 and +2 cover exactly them
+            const uint8_t* ptl = img + ((size_t)top * jw + left) * 3;
+            const uint8_t* pbl = ptl + (size_t)jw * 3;
+            const uint32_t t0 = *reinterpret_cast<const uint32_t*>(ptl), t1 = *reinterpret_cast<const uint32_t*>(ptl + 2);
+            const uint32_t b0 = *reinterpret_cast<const uint32_t*>(pbl), b1 = *reinterpret_cast<const uint32_t*>(pbl + 2);
+            const uint32_t tl3[3] = {t0 & 0xffu, (t0 >> 8) & 0xffu, (t0 >> 16) & 0xffu}, tr3[3] = {t0 >> 24, (t1 >> 16) & 0xffu, t1 >> 24};
+            const uint32_t bl3[3] = {b0 & 0xffu, (b0 >> 8) & 0xffu, (b0 >> 16) & 0xffu}, br3[3] = {b0 >> 24, (b1 >> 16) & 0xffu, b1 >> 24};
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const double tl = tl3[ch], tr = tr3[ch], bl = bl3[ch], br = br3[ch];
+                const double v = (1 - tb) * ((1 - lr) * tl + lr * tr) + tb * ((1 - lr) * bl + lr * br);
+                o[ch] = (uint8_t)v;
+            }
         }
+    } else {
+        const uint8_t* src = chips_in + ((size_t)b * NSC + k) * SWIN * SWIN * 3;
+        for (int q = lane; q < SWIN * SWIN * 3; q += 64) chip[q] = src[q];
     }
+    __syncthreads();
+    float grey = 0.0f;
+    if (SAMPLE && lane < 16) {
+        const uint8_t* p = chip + ((lane >> 2) * SWIN + (lane & 3)) * 3;
+        grey = (float)(((unsigned)p[0] + p[1] + p[2]) / 3) / 255.0f;
+    }
+    for (int q = lane; q < 21 * 21; q += 64) {
+        const int y = 1 + q / 21, x = 1 + q % 21;
+        float v2; int o;
+        pixel_grad(chip + (y - 1) * SWIN * 3, chip + y * SWIN * 3, chip + (y + 1) * SWIN * 3, 3 * x, lut, &v2, &o);
+        mag[(y + 6) * SPL + x + 6] = sqrtf(v2);
+        bin[(y + 6) * SPL + x + 6] = (uint8_t)o;
+    }
+    __syncthreads();                                   // the chip is dead: its room becomes the sums
+#pragma unroll
+    for (int o = 0; o < 18; ++o) acc_s[w][o][lane] = 0.0f;
+    {
+        const int hy = lane >> 3, hx = lane & 7;
+        int cx[8];
+#pragma unroll
+        for (int wx = 0; wx < 8; ++wx) cx[wx] = min(4 * hx + wx, SPL - 1);
+#pragma unroll
+        for (int wy = 0; wy < 8; ++wy) {
+            const float fy = ((float)(wy % 4) + 0.5f) / 4.0f;
+            const float wyv = (wy < 4) ? fy : 1.0f - fy;
+            const int row = min(4 * hy + wy, SPL - 1) * SPL;
+#pragma unroll
+            for (int wx = 0; wx < 8; ++wx) {
+                const float fx = ((float)(wx % 4) + 0.5f) / 4.0f;
+                const float wxv = (wx < 4) ? fx : 1.0f - fx;
+                const int o = bin[row + cx[wx]];
+                acc_s[w][o][lane] = acc_s[w][o][lane] + (wyv * wxv) * mag[row + cx[wx]];
+            }
+        }
+        float e = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 9; ++o) {
+            const float s2 = acc_s[w][o][lane] + acc_s[w][o + 9][lane];
+            e = e + s2 * s2;
+        }
+        if (hy >= 1 && hy <= 6 && hx >= 1 && hx <= 6) nrm_s[w][(hy - 1) * 6 + (hx - 1)] = e;
+    }
+    __syncthreads();
+    if (lane < 16) {
+        const int y = lane >> 2, x = lane & 3;
+        float n[9], h[18], o[32];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) n[i * 3 + jj] = nrm_s[w][(y + i) * 6 + (x + jj)];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) h[q] = acc_s[w][q][(y + 2) * 8 + (x + 2)];
+        cell_features(h, n, o);
+        if (SAMPLE) o[31] = grey;
+        float4* dst = reinterpret_cast<float4*>(feat + (((size_t)b * NSC + k) * 16 + lane) * PVF_FHOG_STRIDE);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dst[q] = make_float4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+    }
+}
+
+// stage access (pvf_debug_fhog at cell 4, 23 x 23, padding 1): n images, 32 per grid row like the tracker's calls
+void fhog_scale_chips(Ctx* c, const uint8_t* d_chips, int n, float* d_feat)
+{
+    // the kernel addresses image (b, k) as b * 32 + k: n images = rows of 32, the tail of the last row reads and writes within scratch
+    const int rows = (n + NSC - 1) / NSC;
+    c->s_trk0.ensure((size_t)rows * NSC * SWIN * SWIN * 3);
+    c->s_trk2.ensure((size_t)rows * NSC * 16 * PVF_FHOG_STRIDE * sizeof(float));
+    HIP_CHECK(hipMemcpyAsync(c->s_trk0.p, d_chips, (size_t)n * SWIN * SWIN * 3, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL((scale_fhog_k<false>), dim3(NSC / 4, rows), dim3(256), 0, c->stream, (const TrkJob*)nullptr, 0.0, c->s_trk0.as<uint8_t>(),
+                       orientation_lut(c), c->s_trk2.as<float>());
+    HIP_CHECK(hipMemcpyAsync(d_feat, c->s_trk2.p, (size_t)n * 16 * PVF_FHOG_STRIDE * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
 }
 
 // the 32-point transform of fft32_seq on a register-resident line: every index is a compile-time constant after unrolling, so the 32
@@ -569,22 +704,16 @@ __device__ __forceinline__ void fft32_regs(double2 (&x)[NSC], const double* __re
     }
 }
 
-// Fs[idx][k] = feature(idx) of scale chip k * mask_scale[k]; FFT over k; one thread per idx
-__global__ void __launch_bounds__(128) scale_fft_k(const uint8_t* __restrict__ chips, const float* __restrict__ feat,
-                                                   const double* __restrict__ mask_scale, const double* __restrict__ tw32,
+// Fs[idx][k] = feature(idx) of scale chip k * mask_scale[k]; FFT over k; one thread per idx (idx = cell * 32 + plane; plane 31 = the grey
+// value scale_fhog_k left in the record's pad slot)
+__global__ void __launch_bounds__(128) scale_fft_k(const float* __restrict__ feat, const double* __restrict__ mask_scale, const double* __restrict__ tw32,
                                                    double2* __restrict__ Fs)
 {
     const int b = blockIdx.y, idx = blockIdx.x * 128 + threadIdx.x;
-    const int cell = idx >> 5, jp = idx & 31, r = cell >> 2, c = cell & 3;
     double2 x[NSC];
 #pragma unroll
     for (int k = 0; k < NSC; ++k) {
-        float v;
-        if (jp < 31) v = feat[(((size_t)b * NSC + k) * 16 + cell) * PVF_FHOG_STRIDE + jp];
-        else {
-            const uint8_t* q = chips + (((size_t)b * NSC + k) * SWIN * SWIN + (size_t)r * SWIN + c) * 3;
-            v = (float)(((unsigned)q[0] + q[1] + q[2]) / 3) / 255.0f;
-        }
+        const float v = feat[((size_t)b * NSC + k) * SDIM + idx];
         x[k] = make_double2((double)v * mask_scale[k], 0.0);
     }
     fft32_regs(x, tw32);
@@ -758,7 +887,7 @@ static void scale_rect_h(double r[4], double s)
     r[0] = cx - w / 2; r[1] = cy - h / 2; r[2] = cx + w / 2; r[3] = cy + h / 2;
 }
 
-struct DsstBuffers { uint8_t* chips64; uint8_t* chips_sc; float* feat; double2* F; double2* G0; double2* G1; double2* Fs; double* results; double* pos; TrkJob* jobs; };
+struct DsstBuffers { uint8_t* chips64; uint8_t* feat; double2* F; double2* G0; double2* G1; double2* Fs; double* results; double* pos; TrkJob* jobs; };
 
 static DsstBuffers prepare(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes,
                            std::vector<TrkJob>& jobs, std::vector<ChipJob>& cj, bool need_F)
@@ -782,17 +911,18 @@ static DsstBuffers prepare(Ctx* c, const std::vector<Tracker*>& t, const std::ve
         for (int k = 0; k < 4; ++k) j.box[k] = p[k];
     }
     DsstBuffers b;
-    const size_t chips64 = (size_t)n * FS * FS * 3, chips_sc = (size_t)n * NSC * SWIN * SWIN * 3;
-    c->s_trk0.ensure(chips64 + chips_sc + 256);
+    const size_t chips64 = (size_t)n * FS * FS * 3;
+    c->s_trk0.ensure(chips64 + 256);
     b.chips64 = c->s_trk0.as<uint8_t>();
-    b.chips_sc = b.chips64 + (chips64 + 63) / 64 * 64;
     // a buffer of the tracker's own (round 4).  Up to round 3 this was the detector's s_feat: the chips' features overwrote the ZERO BORDER
     // of the detector's level-0 feature maps without telling it (feat_ring_owner), so the next detector batch of the same plan scored
     // the windows that reach into the border -- the top rows of the first frames -- on tracker features.  Invisible at the shipped
     // threshold on faces away from the frame's edge; found by tests/test_gpu_parity.py::test_detector_with_hundreds_of_candidates_at_
-    // the_threshold after a tracker test.  512 KB per tracker of a call.
-    c->s_trkfeat.ensure((size_t)n * FS * FS * PVF_FHOG_STRIDE * sizeof(float));
-    b.feat = c->s_trkfeat.as<float>();
+    // the_threshold after a tracker test.  84 KB per tracker of a call: the compact translation record
+    // (TRKF_BYTES), then -- the translation pass done -- the 32 x 16 x 32 floats of the scale samples (64 KB) in the same place.
+    static_assert(TRKF_BYTES >= (size_t)NSC * 16 * PVF_FHOG_STRIDE * sizeof(float), "the scale features reuse the translation record's room");
+    c->s_trkfeat.ensure((size_t)n * TRKF_BYTES);
+    b.feat = c->s_trkfeat.as<uint8_t>();
     b.F = nullptr;
     if (need_F) {                                  // plane spectra in HBM: the full update only (2 MB per tracker)
         c->s_trk1.ensure((size_t)n * NPL * FS * FS * sizeof(double2));
@@ -822,18 +952,17 @@ static void translation_features(Ctx* c, const DsstBuffers& b, const std::vector
 {
     chip_extract_batch(c, cj, b.chips64);
     ProfScope ps(c, "dsst");
-    fhog_device(c, b.chips64, n, FS, FS, 1, 3, 3, b.feat, c->s_hist, c->s_norm, 0, true);
+    fhog1_compact(c, b.chips64, n, b.feat);
     if (b.F) hipLaunchKernelGGL(trans_planes_fft_k, dim3(NPL, n), dim3(256), LDS_FFT, c->stream, b.chips64, b.feat, c->ttab.d_mask64, c->ttab.d_tw64, b.F);
 }
 
 static void scale_features(Ctx* c, const DsstBuffers& b, int n)
 {
     ProfScope ps(c, "dsst");
-    hipLaunchKernelGGL(scale_chips_k, dim3(NSC, n), dim3(256), 0, c->stream, b.jobs, c->ttab.alpha_pow_m16, b.chips_sc);
-    float* feat = b.feat; // reuse: n*32 images of 4x4x32 floats
-    fhog_device(c, b.chips_sc, n * NSC, SWIN, SWIN, 4, 1, 1, feat, c->s_hist, c->s_norm);
-    hipLaunchKernelGGL(scale_fft_k, dim3(SDIM / 128, n), dim3(128), 0, c->stream, b.chips_sc, feat,
-                       c->ttab.d_mask_scale, c->ttab.d_tw32, b.Fs);
+    float* feat = reinterpret_cast<float*>(b.feat);     // reuse: n x 32 samples of 4 x 4 x 32 floats (the translation pass is done with it)
+    hipLaunchKernelGGL((scale_fhog_k<true>), dim3(NSC / 4, n), dim3(256), 0, c->stream, b.jobs, c->ttab.alpha_pow_m16, (const uint8_t*)nullptr,
+                       orientation_lut(c), feat);
+    hipLaunchKernelGGL(scale_fft_k, dim3(SDIM / 128, n), dim3(128), 0, c->stream, feat, c->ttab.d_mask_scale, c->ttab.d_tw32, b.Fs);
 }
 
 static void ensure_fft_lds()

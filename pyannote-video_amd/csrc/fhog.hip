@@ -1,6 +1,7 @@
-// fhog.hip -- FHOG of small images, one launch sequence per batch of equally sized images: the correlation tracker's chips
-// (cell 1: 64 x 64 translation windows; cell 4: 23 x 23 scale samples; reference tracking.py:203,250-251) and the stage-access
-// entry used by the parity tests (any of cell 1 / 4 / 8).  The detector's pyramid has its own fused kernel (detect.hip).
+// fhog.hip -- FHOG outside the detector: the correlation tracker's translation window (cell 1, 64 x 64: one kernel, compact record;
+// reference tracking.py:203,250-251), the orientation tables, and the generic three-pass form behind the stage-access entry of the
+// parity tests (cell 4 / 8, any size).  The detector's pyramid has its own fused kernel (detect.hip), the tracker's scale samples
+// theirs (dsst.hip scale_fhog_k).
 #include "fhog_dev.h"
 #include <algorithm>
 #include <cmath>
@@ -57,22 +58,6 @@ const uint8_t* orientation_lut_tiled(Ctx* c)
     HIP_CHECK(hipMalloc((void**)&c->d_grad_lut, lut.size()));
     HIP_CHECK(hipMemcpy(c->d_grad_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
     return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
-}
-
-__device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, const uint8_t* __restrict__ row_c,
-                                           const uint8_t* __restrict__ row_d, int x3, const uint8_t* __restrict__ lut, float* v2, int* bo)
-{
-    // row_* point at the byte rows; x3 = 3*x (pixel x of the centre row); colour channel with the largest |g|^2, first wins
-    int bx = (int)row_c[x3 + 3] - (int)row_c[x3 - 3], by = (int)row_d[x3] - (int)row_u[x3];
-    int bv = bx * bx + by * by;
-#pragma unroll
-    for (int k = 1; k < 3; ++k) {
-        const int cx = (int)row_c[x3 + 3 + k] - (int)row_c[x3 - 3 + k], cy = (int)row_d[x3 + k] - (int)row_u[x3 + k];
-        const int cv = cx * cx + cy * cy;
-        if (cv > bv) { bv = cv; bx = cx; by = cy; }
-    }
-    *v2 = (float)bv;
-    *bo = lut[(by + 255) * 511 + (bx + 255)];
 }
 
 // The per-image FHOG kernels below run on 1-D grids over (image, row, column): the images they see in production are the
@@ -262,63 +247,111 @@ __global__ void __launch_bounds__(256) fhog_feat_k(const float* __restrict__ his
     for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
 }
 
-// cell size 1 (correlation tracker translation chip): every pixel is a cell
-__global__ void __launch_bounds__(256) fhog1_grad_k(const uint8_t* __restrict__ img, size_t img_stride, int ih, int iw,
-                                                    float* __restrict__ norm, uint8_t* __restrict__ angle, size_t px_stride, const uint8_t* __restrict__ lut,
-                                                    int n_img)
+// ---- cell size 1, 64 x 64 chip, padding 3 (the correlation tracker's translation window): every pixel is a cell whose histogram is
+// ONE bin holding |g| (oracle/pvo_fhog.c fhog_cell1).  cell_features() of such a histogram has at most 6 non-zero outputs:
+//   o[a] and o[18 + a % 9]  = S = (m0 + m1) + (m2 + m3),  m_k = min(|g|, nn_k) * nv_k     (the other 25 orientation planes are sums of
+//                                                                                          min(0, nn_k) * nv_k = +0)
+//   o[27 + k]               = m_k * tscale                (t_k = 0 + ... + ((m_k + 0) + 0) + ... : adding +0 changes nothing)
+// so the kernel writes the COMPACT record (S, the four textures, the bin a) -- 21 bytes per pixel instead of 124 -- and the tracker's
+// plane loop rebuilds plane i as (a == i ? S : 0).  Bit for bit what the 31-plane form held (tests: test_fhog_bit_exact at (1, 3, 64 x 64)
+// expands the record again; tracker PSR / positions / filter state against the oracle).  One block per chip: squared magnitudes of the
+// 64 x 64 pixels in LDS, then the features; nothing but the record goes to HBM (round 4: |g|^2 + bin planes written, read back 9 times,
+// 508 KB of planes per tracker).
+// Record layout: pixel q = 64 y + x sits at slot TRKF_SLOT(q) = (q & 511) * 8 + (q >> 9) of each array, so that the eight pixels
+// q0 + 512 k a thread of the tracker's 512-thread kernels owns (dsst.hip FUSED_*) are 32 consecutive bytes of S / T and 8 of the bins.
+__global__ void __launch_bounds__(256) fhog1_compact_k(const uint8_t* __restrict__ img, size_t img_stride, const uint8_t* __restrict__ lut,
+                                                       uint8_t* __restrict__ out)
 {
-    int x, y, b;
-    if (!flat_index(iw, ih, n_img, &x, &y, &b)) return;
-    float v = 0.0f;
-    int o = 0;
-    if (y >= 1 && y < ih - 1 && x >= 1 && x < iw - 1) {
-        const uint8_t* im = img + (size_t)b * img_stride;
-        pixel_grad(im + (size_t)(y - 1) * iw * 3, im + (size_t)y * iw * 3, im + (size_t)(y + 1) * iw * 3, x * 3, lut, &v, &o);
+    __shared__ float nrm[64 * 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* im = img + (size_t)b * img_stride;
+    int ang[16];
+    // thread <-> pixels: two groups g = tid, tid + 256 of eight pixels g + 512 k (in both passes: a pixel's bin stays in its thread)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int q = tid + 256 * (k >> 3) + 512 * (k & 7), y = q >> 6, x = q & 63;
+        float v = 0.0f;
+        int o = 0;
+        if (y >= 1 && y < 63 && x >= 1 && x < 63)
+            pixel_grad(im + (size_t)(y - 1) * 64 * 3, im + (size_t)y * 64 * 3, im + (size_t)(y + 1) * 64 * 3, x * 3, lut, &v, &o);
+        nrm[q] = v;
+        ang[k] = o;
     }
-    norm[(size_t)b * px_stride + (size_t)y * iw + x] = v;
-    angle[(size_t)b * px_stride + (size_t)y * iw + x] = (uint8_t)o;
+    __syncthreads();
+    float* S = reinterpret_cast<float*>(out + (size_t)b * TRKF_BYTES);
+    uint8_t* A = out + (size_t)b * TRKF_BYTES + TRKF_A;
+    const float eps = 0.0001f, tscale = (float)(2 * 0.2357);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float s[8], t[4][8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int q = tid + 256 * g + 512 * kk, y = q >> 6, x = q & 63;
+            s[kk] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[c][kk] = 0.0f;
+            if (y >= 1 && y <= 62 && x >= 1 && x <= 62) {
+                float n[9];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) n[i * 3 + j] = nrm[(y - 1 + i) * 64 + (x - 1 + j)];
+                const float mag = sqrtf(n[4]);
+                const float z1[4] = {n[4], n[1], n[3], n[0]};
+                const float z2[4] = {n[5], n[2], n[4], n[1]};
+                const float z3[4] = {n[7], n[4], n[6], n[3]};
+                const float z4[4] = {n[8], n[5], n[7], n[4]};
+                float m[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float nn = 0.2f * sqrtf((((z1[c] + z2[c]) + z3[c]) + z4[c]) + eps);
+                    const float nv = 0.1f / nn;
+                    m[c] = fminf(mag, nn) * nv;
+                    t[c][kk] = m[c] * tscale;
+                }
+                s[kk] = (m[0] + m[1]) + (m[2] + m[3]);
+            }
+        }
+        const int slot = (tid + 256 * g) * 8;
+        float4* d = reinterpret_cast<float4*>(S + slot);
+        d[0] = make_float4(s[0], s[1], s[2], s[3]);
+        d[1] = make_float4(s[4], s[5], s[6], s[7]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float4* dt = reinterpret_cast<float4*>(S + (size_t)(1 + c) * TRKF_PLANE + slot);
+            dt[0] = make_float4(t[c][0], t[c][1], t[c][2], t[c][3]);
+            dt[1] = make_float4(t[c][4], t[c][5], t[c][6], t[c][7]);
+        }
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { lo |= (uint32_t)ang[8 * g + kk] << (8 * kk); hi |= (uint32_t)ang[8 * g + 4 + kk] << (8 * kk); }
+        *reinterpret_cast<uint2*>(A + slot) = make_uint2(lo, hi);
+    }
 }
 
-__global__ void __launch_bounds__(256) fhog1_feat_k(const float* __restrict__ norm, const uint8_t* __restrict__ angle, size_t px_stride,
-                                                    int iw, float* __restrict__ feat, size_t feat_stride, int fw, int hog_nr, int hog_nc,
-                                                    int oy, int ox, int fh, int n_img, int planes)
+// stage access (pvf_debug_fhog at the tracker's shape): the compact record back into [64][64][32]
+__global__ void __launch_bounds__(256) fhog1_expand_k(const uint8_t* __restrict__ rec, float* __restrict__ feat)
 {
-    int px, py, b;
-    if (!flat_index(fw, fh, n_img, &px, &py, &b)) return;
-    const int x = px - ox, y = py - oy;
-    // planes: [image][31][fh * fw] (a plane is contiguous: the correlation tracker transforms plane by plane) instead of [image][cell][32]
-    float* pl = feat + (size_t)b * feat_stride + (size_t)py * fw + px;
-    const size_t plane = (size_t)fh * fw;
-    if (x < 0 || y < 0 || x >= hog_nc || y >= hog_nr) {
-        if (planes) {
+    const int q = blockIdx.x * 256 + threadIdx.x, sl = TRKF_SLOT(q);
+    const float* S = reinterpret_cast<const float*>(rec);
+    const int a = rec[TRKF_A + sl];
+    float o[32];
 #pragma unroll
-            for (int k = 0; k < 31; ++k) pl[k * plane] = 0.f;
-            return;
-        }
-        float4* z = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)py * fw + px) * PVF_FHOG_STRIDE);
+    for (int k = 0; k < 32; ++k) o[k] = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) z[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-    float n[9], h[18], o[32];
-    const float* nb = norm + (size_t)b * px_stride;
+    for (int k = 0; k < 18; ++k) if (k == a) o[k] = S[sl];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 9; ++k) if (k == (a >= 9 ? a - 9 : a)) o[18 + k] = S[sl];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) n[i * 3 + j] = nb[(size_t)(y + i) * iw + (x + j)];
-    const int a = angle[(size_t)b * px_stride + (size_t)(y + 1) * iw + (x + 1)];
-    const float mag = sqrtf(n[4]);
-#pragma unroll
-    for (int k = 0; k < 18; ++k) h[k] = (k == a) ? mag : 0.0f;
-    cell_features(h, n, o);
-    if (planes) {
-#pragma unroll
-        for (int k = 0; k < 31; ++k) pl[k * plane] = o[k];
-        return;
-    }
-    float4* dst = reinterpret_cast<float4*>(feat + (size_t)b * feat_stride + ((size_t)(y + oy) * fw + (x + ox)) * PVF_FHOG_STRIDE);
+    for (int c = 0; c < 4; ++c) o[27 + c] = S[(size_t)(1 + c) * TRKF_PLANE + sl];
+    float4* dst = reinterpret_cast<float4*>(feat + (size_t)q * PVF_FHOG_STRIDE);
 #pragma unroll
     for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+void fhog1_compact(Ctx* c, const uint8_t* d_chips, int n, uint8_t* d_rec)
+{
+    hipLaunchKernelGGL(fhog1_compact_k, dim3(n), dim3(256), 0, c->stream, d_chips, (size_t)64 * 64 * 3, orientation_lut(c), d_rec);
 }
 
 void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw)
@@ -335,10 +368,11 @@ void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw)
     *fw = hog_nc + pad_c - 1;
 }
 
+// generic form (any size, cell 4 or 8): the stage-access entry of the parity tests.  Production shapes have kernels of their own: the
+// detector's pyramid (detect.hip), the tracker's translation chip (fhog1_compact_k above) and its scale samples (dsst.hip scale_fhog_k).
 void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat, DevBuf& hist, DevBuf& norm,
-                 size_t img_stride_in, bool planes)
+                 size_t img_stride_in)
 {
-    PVF_REQUIRE(!planes || cell == 1, "fhog: plane-major output exists for cell size 1 only");
     DevBuf& grad = c->s_grad;
     const uint8_t* lut = orientation_lut(c);
     int fh, fw;
@@ -347,16 +381,7 @@ void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, in
     const size_t feat_stride = (size_t)fh * fw * PVF_FHOG_STRIDE;
     const int oy = (pad_r - 1) / 2, ox = (pad_c - 1) / 2;
     const size_t img_stride = img_stride_in ? img_stride_in : (size_t)h * w * 3;
-    if (cell == 1) {
-        const size_t px = (size_t)h * w;
-        norm.ensure(px * n * sizeof(float));
-        hist.ensure(px * n);
-        hipLaunchKernelGGL(fhog1_grad_k, flat_grid(w, h, n), dim3(256), 0, c->stream, d_img, img_stride, h, w, norm.as<float>(), hist.as<uint8_t>(), px, lut, n);
-        hipLaunchKernelGGL(fhog1_feat_k, flat_grid(fw, fh, n), dim3(256), 0, c->stream, norm.as<float>(), hist.as<uint8_t>(), px, w, d_feat, feat_stride, fw,
-                           h - 2, w - 2, oy, ox, fh, n, planes ? 1 : 0);
-        return;
-    }
-    PVF_REQUIRE(cell == 8 || cell == 4, "fhog: cell size 1, 4 or 8");
+    PVF_REQUIRE(cell == 8 || cell == 4, "fhog: cell size 4 or 8 (cell 1: the tracker's 64 x 64 chip only)");
     const int cells_nr = (int)((double)h / (double)cell + 0.5), cells_nc = (int)((double)w / (double)cell + 0.5);
     const int hr = cells_nr + 2, hc = cells_nc + 2;
     const int visible_nr = std::min(cells_nr * cell, h) - 1, visible_nc = std::min(cells_nc * cell, w) - 1;
@@ -393,9 +418,19 @@ void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, 
     const size_t nf = (size_t)(*fh) * (*fw) * PVF_FHOG_STRIDE;
     c->s_feat.ensure(nf * sizeof(float));
     c->feat_ring_owner = nullptr;            // s_feat is shared with the detector's feature maps: their zero border is gone after this
-    fhog_device(c, c->s_pyr.as<uint8_t>(), 1, h, w, cell, pad_r, pad_c, c->s_feat.as<float>(), c->s_hist, c->s_norm, 0);
+    if (cell == 1) {
+        // the tracker's translation window is the one cell-1 shape this library computes: its own kernel, record expanded again
+        PVF_REQUIRE(h == 64 && w == 64 && pad_r == 3 && pad_c == 3, "fhog: cell size 1 exists for the tracker's 64 x 64 chip with padding 3 only");
+        c->s_trkfeat.ensure(TRKF_BYTES);
+        fhog1_compact(c, c->s_pyr.as<uint8_t>(), 1, c->s_trkfeat.as<uint8_t>());
+        hipLaunchKernelGGL(fhog1_expand_k, dim3(64 * 64 / 256), dim3(256), 0, c->stream, c->s_trkfeat.as<uint8_t>(), c->s_feat.as<float>());
+    } else if (cell == 4 && h == 23 && w == 23 && pad_r == 1 && pad_c == 1) {
+        fhog_scale_chips(c, c->s_pyr.as<uint8_t>(), 1, c->s_feat.as<float>());          // the tracker's scale sample: its kernel (dsst.hip)
+    } else {
+        fhog_device(c, c->s_pyr.as<uint8_t>(), 1, h, w, cell, pad_r, pad_c, c->s_feat.as<float>(), c->s_hist, c->s_norm, 0);
+    }
+    HIP_CHECK(hipGetLastError());
     out.resize(nf);
     HIP_CHECK(hipMemcpyAsync(out.data(), c->s_feat.p, nf * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_CHECK(hipStreamSynchronize(c->stream));
 }
-

@@ -12,6 +12,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 const uint8_t* orientation_lut(Ctx* c);
 const uint8_t* orientation_lut_tiled(Ctx* c);
 
+// gradient of the colour channel with the largest |g|^2 (first wins): squared magnitude and orientation bin (row-major table)
+__device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, const uint8_t* __restrict__ row_c,
+                                           const uint8_t* __restrict__ row_d, int x3, const uint8_t* __restrict__ lut, float* v2, int* bo)
+{
+    // row_* point at the byte rows; x3 = 3*x (pixel x of the centre row); colour channel with the largest |g|^2, first wins
+    int bx = (int)row_c[x3 + 3] - (int)row_c[x3 - 3], by = (int)row_d[x3] - (int)row_u[x3];
+    int bv = bx * bx + by * by;
+#pragma unroll
+    for (int k = 1; k < 3; ++k) {
+        const int cx = (int)row_c[x3 + 3 + k] - (int)row_c[x3 - 3 + k], cy = (int)row_d[x3 + k] - (int)row_u[x3 + k];
+        const int cv = cx * cx + cy * cy;
+        if (cv > bv) { bv = cv; bx = cx; by = cy; }
+    }
+    *v2 = (float)bv;
+    *bo = lut[(by + 255) * 511 + (bx + 255)];
+}
+
 // correctly rounded sqrt of an integer-valued float in 0 .. 2 * 255^2 (a gradient's squared magnitude).  On this domain v_sqrt_f32 is
 // never above the correctly rounded root and at most one step below it (20 919 of the 130 051 inputs: tools/probes/sqrt_probe.hip;
 // checked for every input once per context, detect.hip: check_device_assumptions -- a mismatch is an error), so ONE exact residual

@@ -224,6 +224,10 @@ extern "C" int32_t pvf_frame_resize(pvf_handle h, pvf_handle frame, int32_t out_
     hipLaunchKernelGGL(cv_resize_linear_k, dim3((out_w + 255) / 256, out_h), dim3(256), 0, c->det_stream, f.d, f.h, f.w, d, out_h, out_w, dxi, dxc, dyi, dyc);
     HIP_CHECK(hipGetLastError());
     Frame g; g.d = d; g.h = out_h; g.w = out_w; g.owned = true; g.pooled = true;
+    // the copy is written on the detector stream; a consumer on the main stream (tracker start / update, landmarks, shot) must come
+    // after it whoever calls in whatever order: Ctx::frame() makes both streams wait for `ready` on first use and destroys it
+    HIP_CHECK(hipEventCreateWithFlags(&g.ready, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(g.ready, c->det_stream));
     *out = c->add_frame(g);
     API_END
 }

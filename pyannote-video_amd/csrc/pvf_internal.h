@@ -194,6 +194,11 @@ constexpr size_t TRK_AS = TRK_B + (size_t)64 * 64;
 constexpr size_t TRK_BS = TRK_AS + (size_t)512 * 32 * 2;
 constexpr size_t TRK_POS = TRK_BS + 32;
 constexpr size_t TRK_DOUBLES = TRK_POS + 4;
+// translation-window features of one tracker call, compact (fhog.hip fhog1_compact_k): float S[4096], float T[4][4096], uint8 bin[4096]
+constexpr size_t TRKF_PLANE = (size_t)64 * 64;
+constexpr size_t TRKF_A = 5 * TRKF_PLANE * sizeof(float);
+constexpr size_t TRKF_BYTES = TRKF_A + TRKF_PLANE;
+#define TRKF_SLOT(q) ((((q) & 511) << 3) | ((q) >> 9))      // where pixel q = 64 y + x sits in each array of the record
 
 // chip extraction plan (host geometry -> device pyramid + bilinear), see chip.hip
 struct ChipJob {
@@ -351,9 +356,13 @@ void det_nms(const DetectorModel& m, const std::vector<RawDet>& sorted, std::vec
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* h, int* w);
 void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::vector<float>* out, int* fh, int* fw);
 void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, int pad_c, std::vector<float>& out, int* fh, int* fw);
-// device fhog used by dsst.hip too: img u8 [n][h][w][3] -> feat [n][fh][fw][32]
+// generic device fhog (cell 4 / 8; stage access): img u8 [n][h][w][3] -> feat [n][fh][fw][32]
 void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat,
-                 DevBuf& hist, DevBuf& norm, size_t img_stride_in = 0, bool planes = false);
+                 DevBuf& hist, DevBuf& norm, size_t img_stride_in = 0);
+// the tracker's translation windows: chips u8 [n][64][64][3] -> compact records [n][TRKF_BYTES] (fhog.hip)
+void fhog1_compact(Ctx* c, const uint8_t* d_chips, int n, uint8_t* d_rec);
+// the tracker's scale samples given as images (stage access): u8 [n][23][23][3] -> feat [n][4][4][32] (dsst.hip scale_fhog_k)
+void fhog_scale_chips(Ctx* c, const uint8_t* d_chips, int n, float* d_feat);
 void fhog_dims(int ih, int iw, int cell, int pad_r, int pad_c, int* fh, int* fw);
 // chips (chip.hip)
 ChipJob chip_plan(const Frame& f, const ChipDetails& d);

@@ -725,12 +725,15 @@ class Engine(object):
 
         def detector_thread():
             k = 0
+            item = None                     # the shot in this thread's hands: handed on with ("det", ...) or given back on the way out
             try:
                 for item in source:
                     if stop.is_set():
+                        release_shot_frames(item)
                         return
                     if isinstance(item, JobEnd):
                         done.put(("jobend", item.job))
+                        item = None
                         continue
                     while not ahead.acquire(timeout=0.05):
                         if stop.is_set():
@@ -740,9 +743,16 @@ class Engine(object):
                     raw, counts, boxes = self._detect(item, None)
                     note("detected", k)
                     done.put(("det", item, raw, counts, boxes))
+                    item = None
                     k += 1
                 done.put(("eof",))
             except BaseException as e:      # noqa: BLE001 -- handed on to the caller's thread through the tracker thread
+                # the shot that was being detected (with the device-resized copies _detect made for it) goes back to the pool here:
+                # nobody else has seen it, and cyclic GC is off during a run
+                try:
+                    release_shot_frames(item)
+                except Exception:           # noqa: BLE001 -- the first error is the one to report
+                    pass
                 done.put(("error", e))
 
         def gpu_thread():
