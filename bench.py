@@ -40,13 +40,37 @@ EMBED_GFLOP_PER_FACE = 0.542               # the 29-conv ResNet on a 150 x 150 c
 TRACKER_GFLOP_PER_FRAME = 0.3              # DSST starts + updates of ~8 faces, both passes
 
 
-def e2e_object(flop_score_per_frame, faces, frames, seconds):
-    """whole-step arithmetic against the fp32 peak: scoring + embedding + tracker FLOPs of the frames processed / the step's wall time"""
+def e2e_object(flop_score_per_frame, faces, frames, seconds, bytes_per_frame=None):
+    """the whole step against BOTH roofs SURVEY.md section 8d names: arithmetic (scoring + embedding + tracker FLOPs of the frames processed)
+    against the fp32 matrix peak -- the governing roof while the scoring runs dense in fp32 -- and the algorithmic HBM bytes of a frame
+    against the HBM peak, the governing roof once the screening pass has moved the scoring sums to the f16 matrix cores"""
     g = (flop_score_per_frame * frames + EMBED_GFLOP_PER_FACE * 1e9 * faces + TRACKER_GFLOP_PER_FRAME * 1e9 * frames) / max(frames, 1) / 1e9
     tf = g * 1e9 * frames / seconds / 1e12 if seconds > 0 else 0.0
-    return {"gflop_per_frame": round(g, 3), "tflops": round(tf, 2), "frac_of_fp32_peak": round(tf / FP32_PEAK_TFLOPS, 4),
-            "note": "scoring (positions x 3100 MAC x 5 filters) + %.3f GFLOP per embedded face + %.1f GFLOP/frame of tracker FFTs, over the timed steps' "
-                    "wall time of the slowest rank (the scoring sums counted once per window, whichever matrix cores evaluate them); pyramid / FHOG / landmark work is byte-bound and not counted" % (EMBED_GFLOP_PER_FACE, TRACKER_GFLOP_PER_FRAME)}
+    o = {"gflop_per_frame": round(g, 3), "tflops": round(tf, 2), "frac_of_fp32_peak": round(tf / FP32_PEAK_TFLOPS, 4),
+         "note": "scoring (positions x 3100 MAC x 5 filters) + %.3f GFLOP per embedded face + %.1f GFLOP/frame of tracker FFTs, over the timed steps' "
+                 "wall time of the slowest rank (the scoring sums counted once per window, whichever matrix cores evaluate them); pyramid / FHOG / landmark work is byte-bound and not counted" % (EMBED_GFLOP_PER_FACE, TRACKER_GFLOP_PER_FRAME)}
+    if bytes_per_frame:
+        gbs = bytes_per_frame * frames / seconds / 1e9 if seconds > 0 else 0.0
+        o.update({"hbm_bytes_per_frame": round(bytes_per_frame), "hbm_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                  "hbm_roof_frames_per_s": round(HBM_PEAK_GBS * 1e9 / bytes_per_frame, 1),
+                  "hbm_note": "algorithmic bytes of one frame (DESIGN.md section 3): pyramid (frame read, every level written once and read once) + FHOG (levels read, 31 feature "
+                              "planes written) + the feature maps read once by the scoring + tracker filters (2.06 MB per start / update) + chips and activations "
+                              "of the embedder; against the 8 TB/s HBM peak (SURVEY.md section 8d prices this roof at 0.3 GB per frame and 6.3 TB/s achievable: about 21 k frames/s)"})
+    return o
+
+
+def frame_bytes(height, width, faces_per_frame):
+    """algorithmic HBM bytes of one frame of the whole path (the byte roof of `e2e`)"""
+    from pyannote_video_amd import pipeline
+    geo = pipeline.detector_geometry(height, width)
+    img = [g[0] * g[1] * 3.0 for g in geo]
+    cells = [max(g[2] - 9, 0) * max(g[3] - 9, 0) for g in geo]
+    pyramid = height * width * 3.0 + img[0] + sum(img[l - 1] + img[l] for l in range(1, len(img)))
+    fhog = sum(img) + sum(cells) * 31 * 4.0
+    score = sum(g[2] * g[3] for g in geo) * 128.0
+    tracker = faces_per_frame * 2 * 2 * 2.06e6           # forward + backward pass: a start (filters written) and a first update (read) per detection
+    embed = faces_per_frame * (150 * 150 * 3 + 6.5e6)    # chip + the activations of the 29 layers written once and read once or twice (NHWC f32, about 2.6 MB written per face; weights stay in cache)
+    return pyramid + fhog + score + tracker + embed
 
 
 def detector_hash():
@@ -76,13 +100,16 @@ def detector_rooflines(fam, height, width, frames_scored, detect_batch):
     img = [g[0] * g[1] * 3.0 for g in geo]
     cells = [max(g[2] - 9, 0) * max(g[3] - 9, 0) for g in geo]
     flop = sum(g[4] for g in geo) * 3100 * 5 * 2.0
-    work = {"pyramid": ("resize_rows_k (every pyramid level of a %d-frame batch from the level above it, 20 launches)" % detect_batch, "hbm",
+    def per_launch(name):
+        n = fam[name]["launches"]
+        return int(round(frames_scored / float(n))) if n > 0 else detect_batch       # frames of one launch as launched (a 250-frame shot runs as 125 + 125, not 128 + 122)
+    work = {"pyramid": ("resize_rows_k (every pyramid level of a %d-frame batch from the level above it, 20 launches)" % per_launch("pyramid"), "hbm",
                         height * width * 3.0 + img[0] + sum(img[l - 1] + img[l] for l in range(1, len(img)))),
-            "fhog": ("fhog_fused_ml_k (gradients, cell histograms and 31-plane features of every pyramid level of a %d-frame batch in one pass)" % detect_batch, "hbm",
+            "fhog": ("fhog_fused_ml_k (gradients, cell histograms and 31-plane features of every pyramid level of a %d-frame batch in one pass)" % per_launch("fhog"), "hbm",
                      sum(img) + sum(cells) * 31 * 4.0),
-            "score": ("score_roll_k (HOG filter scoring of every pyramid level of a %d-frame batch, 5 filters x 3100 MAC per position)" % detect_batch, "mfma", flop),
+            "score": ("score_roll_k (HOG filter scoring of every pyramid level of a %d-frame batch, 5 filters x 3100 MAC per position)" % per_launch("score"), "mfma", flop),
             "score_screened": ("score_screen_k + score_list_k (every window of a %d-frame batch scored on the f16 matrix cores, the exact fp32 chain for the windows "
-                               "within the error bound of the threshold)" % detect_batch, "mfma", flop)}
+                               "within the error bound of the threshold)" % per_launch("score_screened"), "mfma", flop)}
     pm = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", PMC_KERNELS_FILE)))
@@ -246,8 +273,10 @@ def main():
         tm = {}
         t_step = time.perf_counter()
         res = pipe.run(frames, times, video.frame_rate, shots, timings=tm, cluster=False, last_shard=(rank == world - 1), reorder=(world == 1))
+        t0 = time.perf_counter()
         T, ids, X, offsets = pdist.gather_rows(res["face_T"], res["face_id"], res["embeddings"], len(res["tracks"]), device=device,
                                                file_T=res["file_T"] if world > 1 else None, file_id=res["file_id"] if world > 1 else None)
+        tm["exchange_s"] = time.perf_counter() - t0          # the all-gather of the 528-byte face rows (waits for the slowest rank's shard)
         t0 = time.perf_counter()
         labels = pdist.global_cluster(pipe.clustering, T, ids, X)
         tm["cluster_s"] = time.perf_counter() - t0
@@ -270,6 +299,7 @@ def main():
         c.prof_enable(True)
     barrier()
     hbm = HbmSampler(ctx)
+    scr_before = ctx.detector_screening_stats() if not args.dense_scoring else None
     t0 = time.perf_counter()
     last = None
     prof_path = os.environ.get("PVF_PYPROF")
@@ -289,11 +319,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     hbm.stop()
+    scr_after = ctx.detector_screening_stats() if not args.dense_scoring else None
     timed_engine = pipe.last_engine
     for c in ctxs:
         c.prof_enable(False)
+    elapsed_local = elapsed
     elapsed = max_over_ranks(elapsed, world, device)
     res, labels, tm = last
+    per_rank = None
+    if world > 1:
+        # what a bad scaling curve is read from without a second run: every rank's own time, its share, and where its last step went
+        import torch.distributed as tdist
+        mine = {"rank": rank, "ms_per_step": round(1000.0 * elapsed_local / args.steps, 2), "frames": int(n_local), "tracks": len(res["tracks"]),
+                "faces": int(len(res["face_T"])), "last_step_s": {k: round(float(tm.get(k, 0.0)), 4) for k in ("track_s", "extract_s", "exchange_s", "cluster_s", "step_wall_s")}}
+        per_rank = [None] * world
+        tdist.all_gather_object(per_rank, mine)
     if os.environ.get("PVF_DUMP") and rank == 0:
         ident_of_track = {}
         np.savez_compressed(os.environ["PVF_DUMP"], X=res["X"], emb=res["embeddings"], face_id=res["face_id"], face_T=res["face_T"],
@@ -349,9 +389,20 @@ def main():
                  "note": "pvf_detector_screening(ctx, 0): score_roll_k evaluates the exact chain of 3100 fmaf for every window on the fp32 matrix cores; the timed steps "
                          "screen every window on the f16 matrix cores first and run that chain for the listed ones only (csrc/screen.hip) -- same candidates, bit for bit"}
 
+    # ---- the WHOLE clip against the CPU oracle: the timed steps' own result (tracks, faces, landmarks, descriptors, labels) and the
+    # detector's raw candidates of every frame against the fixture the oracle flow wrote for all 1000 frames (tests/golden/c2_full.npz,
+    # made by tests/golden/make_full_clip.py: minutes of CPU, so it is frozen, not recomputed here); the dense leg the same way
+    full_clip = None
+    if world == 1 and args.config == "c2" and args.detect_every == 0.0 and not args.small_models:
+        full_clip = full_clip_parity(ctx, frames, res, labels, args, d_res=d_res if dense else None, d_labels=d_labels if dense else None)
+
     cpu, parity = None, None
     if world == 1 and args.cpu_frames > 0:
         cpu, parity = cpu_baseline_and_parity(video, frames_t, ctx, pipe, lp, ep, args)
+    if full_clip is not None:
+        parity = dict(parity or {}, full_clip=full_clip)
+        if cpu is not None:
+            cpu["whole_clip_fixture"] = {k: full_clip.get(k) for k in ("fixture", "frames", "all_exact", "raw_candidates", "embed_l2_max", "oracle_seconds", "oracle_threads")}
     host = None
     if world == 1 and not args.no_host_ingest and args.config == "c2":
         host = host_ingest_pass(ctx, pipe, frames_t, times, video, shots, args)
@@ -378,13 +429,17 @@ def main():
         "roofline_other": roofline_other,
         "dense_scoring": dense,
         "e2e": e2e_object(flop_per_frame if args.detect_every == 0.0 else flop_per_frame * n_score_frames / max(n_local * args.steps, 1),
-                          int(len(res["face_T"])) * args.steps, n_local * args.steps, elapsed),
+                          int(len(res["face_T"])) * args.steps, n_local * args.steps, elapsed,
+                          bytes_per_frame=frame_bytes(args.height, args.width, len(res["face_T"]) / float(max(n_local, 1))) if args.detect_every == 0.0 else None),
         "cpu_baseline": cpu,
         "parity": parity,
         "host_ingest": host,
         "dropin_cli": dropin,
         "hbm": hbm.report(frames_bytes=int(frames_t.numel()), engine=timed_engine),
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
+        "per_rank": per_rank,
+        "per_rank_note": None if per_rank is None else "exchange_s = the all-gather of the face rows (includes waiting for the slowest rank's shard); cluster_s = this rank's "
+                         "share of the pair distances (split by triangle area) + the all-gather of the distance rows + the agglomeration every rank repeats",
         "kernel_families_ms": fam,
         "screening": ctx.detector_screening_stats() if not args.dense_scoring else None,
         "kernel_families_note": "HIP-event time per family on the stream it runs on: the detector families (pyramid, fhog, score / score_screened) on one stream, the rest on the "
@@ -395,7 +450,57 @@ def main():
                     "identities_in_video": len(set(tr["ident"] for shot in video.tracks for tr in shot))},
         "setup_seconds": {"generate_frames_in_hbm": round(t_gen, 1)},
     }
+    # (window, filter) pairs per frame that went through the exact fp32 chain inside the timed steps: what the screening pass's gain depends on
+    out["listed_per_frame"] = (round((scr_after["listed"] - scr_before["listed"]) / float(frames_scored_timed), 2)
+                               if scr_after and frames_scored_timed else None)
+    out["dense_scoring_value"] = dense["value"] if dense else None
+    if out["roofline"] is not None:
+        out["roofline"]["step_with_dense_scoring_frames_per_s"] = out["dense_scoring_value"]
+        out["roofline"]["screening_listed_pairs_per_frame"] = out.get("listed_per_frame")
+    # last key of the line (the driver keeps the line's tail verbatim): the whole-clip verdict in one short string
+    out["full_clip_parity"] = full_clip_summary(full_clip)
     print(json.dumps(out))
+
+
+def full_clip_parity(ctx, frames, res, labels, args, d_res=None, d_labels=None):
+    """product (the timed steps' last result) against the whole-clip fixture of the CPU oracle flow; None when the benched clip is not the
+    fixture's (other --frames / size / faces) or the fixture is absent"""
+    from oracle import golden
+    import numpy as np
+    want = golden.CLIPS["c2_full"]
+    mine = dict(width=args.width, height=args.height, n_frames=args.frames, n_shots=args.shots, faces=args.faces, seed=20260925, frame_rate=args.fps)
+    if mine != want or not golden.available("c2_full"):
+        return {"fixture": None, "why": "no fixture for this clip (tests/golden/make_full_clip.py c2_full writes the one of the default configuration)"}
+    g = golden.load("c2_full")
+    out = golden.compare(g, res, labels)
+    t0 = time.perf_counter()
+    raw = ctx.detect_raw_many(frames, 125 if args.detect_batch >= 125 else args.detect_batch)
+    out["raw_candidates"] = golden.compare_raw(g, [golden.raw_key(r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4]) for r in raw])
+    out["raw_candidates_total"] = int(g["raw_counts"].sum())
+    out["raw_pass_seconds"] = round(time.perf_counter() - t0, 3)
+    if d_res is not None:
+        dd = golden.compare(g, d_res, d_labels)
+        out["dense_scoring_leg"] = "exact" if dd["all_exact"] else {k: dd[k] for k in ("tracks", "face_rows", "landmarks", "embed_l2_max", "labels")}
+        ctx.detector_screening(False)
+        rawd = ctx.detect_raw_many(frames, 125 if args.detect_batch >= 125 else args.detect_batch)
+        ctx.detector_screening(True)
+        out["raw_candidates_dense"] = golden.compare_raw(g, [golden.raw_key(r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4]) for r in rawd])
+    out["oracle_seconds"] = round(float(g["oracle_seconds"]), 1)
+    out["oracle_threads"] = int(g["oracle_threads"])
+    out["all_exact"] = bool(out["all_exact"] and out["raw_candidates"] == "exact" and out.get("dense_scoring_leg", "exact") == "exact"
+                            and out.get("raw_candidates_dense", "exact") == "exact")
+    return out
+
+
+def full_clip_summary(fc):
+    if not fc or not fc.get("fixture"):
+        return "no whole-clip fixture for this configuration"
+    if fc["all_exact"]:
+        return "%s EXACT over all %d frames: %d tracks, %d faces (rows, landmarks), labels, %d raw candidates%s; embed L2 max %.2e" % (
+            fc["fixture"], fc["frames"], fc["n_tracks"], fc["n_faces"], fc["raw_candidates_total"],
+            " (screened and dense)" if "raw_candidates_dense" in fc else "", fc["embed_l2_max"])
+    bad = [k for k in ("tracks", "face_rows", "landmarks", "labels", "raw_candidates", "dense_scoring_leg", "raw_candidates_dense") if fc.get(k, "exact") != "exact"]
+    return "%s MISMATCH in %s (embed L2 max %s)" % (fc["fixture"], ", ".join(bad) or "embedding", fc.get("embed_l2_max"))
 
 
 def max_over_ranks(seconds, world, device):

@@ -197,13 +197,19 @@ int32_t pvf_pair_mean_dist_metric(pvf_handle ctx, const double* X, int32_t N, in
 /* ref: clustering.py:116-119,138-148  FaceClustering(threshold)(starting_point, features): average-linkage HAC from the
  * track partition, stop when the closest pair's mean distance exceeds `threshold`;
  * labels[t] = smallest track index of t's cluster; merge_log optional [(T-1)*4] = (a, b, dist, new_size) */
-/* The two halves of pvf_cluster_tracks for several GPUs sharing one global clustering (dist.py): the UPPER-TRIANGLE entries D[i][j],
- * i < j, of the tracks i in [track0, track1) (D: T x T, row-major; entries j <= i of those rows are written as zeros, other rows are
- * left untouched) from the gathered embeddings, and the agglomeration of a complete D (pvf_cluster_dist) or of the assembled upper
- * triangle (pvf_cluster_upper mirrors it first).  Every entry is produced by the same chain of additions as in the single call, so
- * row ranges computed by different ranks stitch into the single call's matrix bit for bit. */
+/* The two halves of pvf_cluster_tracks for several GPUs sharing one global clustering (dist.py).
+ * pvf_pair_mean_dist_rows: the COMPLETE rows [track0, track1) of the T x T matrix of pvf_pair_mean_dist (D: T x T, row-major; other
+ *   rows are left untouched) -- entries j > i computed, entries j < i the mirror of D[j][i] (clustering.py:111-112), diagonal 0; what
+ *   this entry has returned since round 2 (round 4 silently left the part below the diagonal zero: restored in round 5).
+ * pvf_pair_upper_rows: only the UPPER-TRIANGLE entries D[i][j], i < j, of those rows (entries j <= i written as zeros): the share a
+ *   rank contributes when the ranks split the pairs by triangle area -- nothing is computed twice.
+ * Then the agglomeration of a complete D (pvf_cluster_dist) or of the assembled upper triangle (pvf_cluster_upper mirrors it first).
+ * Every entry is produced by the same chain of additions as in the single call, so row ranges computed by different ranks stitch
+ * into the single call's matrix bit for bit. */
 int32_t pvf_pair_mean_dist_rows(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
                                 int32_t track0, int32_t track1, double* D);
+int32_t pvf_pair_upper_rows(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
+                            int32_t track0, int32_t track1, double* D);
 int32_t pvf_cluster_dist(pvf_handle ctx, const double* D, const int32_t* row_start, int32_t T, double threshold,
                          int32_t* labels, double* merge_log, int32_t* n_merges);
 /* U: T x T with the entries i < j set (anything below the diagonal is ignored), in host (on_device = 0) or device memory */
@@ -258,6 +264,12 @@ int32_t pvf_debug_fhog(pvf_handle ctx, const uint8_t* img, int32_t h, int32_t w,
                        int32_t pad_c, float* out, int32_t* fh, int32_t* fw);          /* out [fh][fw][32] */
 int32_t pvf_debug_detect_raw(pvf_handle ctx, pvf_handle frame, int32_t upsample, double adjust, float* scores,
                              int32_t* meta /* cap*8: filter,level,r,c,l,t,r,b */, int32_t cap, int32_t* n);
+/* the same for any number of frames through the BATCHED path the engine runs (pvf_detect_many without its non-maximum suppression,
+ * screening pass included): counts[n_frames]; rows [cap][5] = (level, filter, row, column, score bits) frame after frame in the
+ * detector's canonical order; *total = all candidates (more than cap: only the first cap rows were written).  What the whole-clip
+ * fixtures pin (tests/golden/c2_full.npz: the scanner's candidates before NMS, reference face.py:64-67). */
+int32_t pvf_debug_detect_raw_many(pvf_handle ctx, const pvf_handle* frames, int32_t n_frames, int32_t batch, int32_t upsample,
+                                  double adjust, int32_t* counts, int32_t* rows, int64_t cap, int64_t* total);
 int32_t pvf_debug_extract_chip(pvf_handle ctx, pvf_handle frame, const double rect[4], double cs, double sn,
                                int32_t rows, int32_t cols, uint8_t* out);
 int32_t pvf_debug_tracker_state(pvf_handle ctx, pvf_handle trk, double* F, double* A, double* B);

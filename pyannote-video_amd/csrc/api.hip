@@ -155,6 +155,33 @@ extern "C" int32_t pvf_debug_detect_raw(pvf_handle h, pvf_handle frame, int32_t 
     API_END
 }
 
+extern "C" int32_t pvf_debug_detect_raw_many(pvf_handle h, const pvf_handle* frames, int32_t n_frames, int32_t batch, int32_t upsample, double adjust,
+                                             int32_t* counts, int32_t* rows, int64_t cap, int64_t* total)
+{
+    API_BEGIN
+    ENTER_DET(c, h);
+    PVF_REQUIRE(n_frames > 0 && batch > 0 && frames && counts && total && (rows || cap == 0), "pvf_debug_detect_raw_many: bad arguments");
+    PVF_REQUIRE(upsample >= 0 && upsample <= 2, "pvf_debug_detect_raw_many: upsample must be 0..2");
+    std::vector<Frame> fr(n_frames);
+    for (int i = 0; i < n_frames; ++i) fr[i] = c->frame(frames[i]);
+    std::vector<std::vector<RawDet>> raw;
+    with_candidate_room(c, [&]() { det_run_many(c, fr, batch, upsample, adjust, raw, false); });
+    int64_t k = 0;
+    for (int i = 0; i < n_frames; ++i) {
+        counts[i] = (int32_t)raw[i].size();
+        for (const RawDet& d : raw[i]) {
+            if (k < cap) {
+                int32_t* m = rows + (size_t)k * 5;
+                m[0] = d.level; m[1] = d.filter; m[2] = d.r; m[3] = d.c;
+                memcpy(&m[4], &d.score, 4);
+            }
+            ++k;
+        }
+    }
+    *total = k;
+    API_END
+}
+
 extern "C" int32_t pvf_debug_pyramid_level(pvf_handle h, pvf_handle frame, int32_t upsample, int32_t level, uint8_t* out, int32_t* oh,
                                            int32_t* ow)
 {
@@ -681,13 +708,34 @@ extern "C" int32_t pvf_pair_mean_dist_metric(pvf_handle h, const double* X, int3
     API_END
 }
 
+extern "C" int32_t pvf_pair_upper_rows(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
+                                       int32_t track0, int32_t track1, double* D)
+{
+    API_BEGIN
+    ENTER(c, h);
+    PVF_REQUIRE(X && row_start && D, "pvf_pair_upper_rows: bad arguments");
+    pair_mean_dist_dev(c, table_f64(X), N, dim, row_start, T, host_full(D), nullptr, track0, track1, 0, false);
+    API_END
+}
+
+// complete rows: the entries below the diagonal of rows [track0, track1) are D[j][i] of the rows j < i, so the upper-triangle rows
+// [0, track1) are computed on the device, mirrored there, and the asked-for rows copied out
 extern "C" int32_t pvf_pair_mean_dist_rows(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
                                            int32_t track0, int32_t track1, double* D)
 {
     API_BEGIN
     ENTER(c, h);
     PVF_REQUIRE(X && row_start && D, "pvf_pair_mean_dist_rows: bad arguments");
-    pair_mean_dist_dev(c, table_f64(X), N, dim, row_start, T, host_full(D), nullptr, track0, track1, 0, false);
+    if (track1 < 0) track1 = T;
+    PVF_REQUIRE(0 <= track0 && track0 <= track1 && track1 <= T, "pvf_pair_mean_dist_rows: bad track range");
+    double* dD = nullptr;
+    PairOutput none; none.out = nullptr;
+    pair_mean_dist_dev(c, table_f64(X), N, dim, row_start, T, none, &dD, 0, track1, 0, false);
+    if (track1 > track0) {
+        mirror_upper_dev(c, dD, T);
+        HIP_CHECK(hipMemcpyAsync(D + (size_t)track0 * T, dD + (size_t)track0 * T, (size_t)(track1 - track0) * T * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     API_END
 }
 

@@ -280,7 +280,7 @@ static void prof_drain(Ctx* c)
     catch (const std::exception& e) { pvf_set_error(e.what()); return -1; } \
     catch (...) { pvf_set_error("unknown error"); return -2; }
 
-extern "C" int32_t pvf_version(void) { return 410; }      // round 4: two streams per context, upper-triangle pair means, float32 in-memory clustering entries; 410: the detector's screening pass (pvf_detector_screening*)
+extern "C" int32_t pvf_version(void) { return 500; }      // round 5: pvf_pair_upper_rows (pvf_pair_mean_dist_rows returns complete rows again), pvf_detect_raw_many;      // round 4: two streams per context, upper-triangle pair means, float32 in-memory clustering entries; 410: the detector's screening pass (pvf_detector_screening*)
 
 extern "C" int32_t pvf_device_count(int32_t* n)
 {

@@ -12,15 +12,24 @@
 // =====================================================================================================
 // One lane = one output column, walking RS consecutive output rows.  The horizontal blend of a source row,
 //   H_s = (1 - lr) * S[s][left] + lr * S[s][right],
-// depends only on (s, column) and consecutive output rows share source rows, so each H_s is evaluated once and kept in registers
-// (two-entry cache; the hit test depends on the row only => wave-uniform); the value written is
+// depends only on (s, column) and consecutive output rows share source rows, so each H_s is evaluated once and kept in registers;
+// the value written is
 //   v = (1 - tb) * H_top + tb * H_bottom ; out = (uint8)(v + 0.5)      (oracle/pvo_image.c).
-// Byte-sized loads and stores (9 vector-memory instructions per pixel) made an earlier form texture-addresser bound and every
-// source row fetch exposed a full memory latency.  Here a wave first requests EVERY source row its RS output rows need (one
-// coalesced dword per lane and row: the 64 columns of a wave span < 256 source bytes for scales <= 1.25) and parks them in LDS;
-// after that single wait the strip runs on LDS + VALU only.  A lane picks its two neighbouring source pixels (6 bytes) from
-// three LDS dwords with a byte funnel shift; the 64 result pixels of a wave leave as 48 aligned dwords: each lane packs its 3
-// bytes, lanes 0..47 collect the two packed pixels their dword straddles through the LDS crossbar (ds_bpermute) and store once.
+// A wave first requests EVERY source row its RS output rows need (one coalesced dword per lane and row: the 64 columns of a wave span
+// < 256 source bytes for scales <= 1.25) and parks them in LDS; after that single wait the strip runs on LDS + VALU only.
+//
+// Round 5: the arithmetic above is untouched (the same fp64 products and sums in the same order: bit-exact by construction); what went
+// away is what stood around it -- 69 -> about 45 vector instructions per 64-pixel row (hipcc -S):
+//   * source rows are requested through a buffer descriptor over the frame (a dword past the frame reads as 0, never used): one
+//     buffer_load with a SCALAR row offset per row instead of a 64-bit address, a compare against the frame's last word and two selects
+//     per lane and row (7 vector instructions per requested row -> 0);
+//   * a lane reads its two source pixels as six BYTES straight out of the parked dwords (ds_read_u8: the LDS unit extracts them) and
+//     converts them with v_cvt_f64_u32 -- round 3's form converted the window to floats (4 v_cvt_f32_ubyte), parked those (16-byte
+//     write), read six back and converted again (6 v_cvt_f64_f32): 13 -> 8 vector instructions per new source row, the same six LDS reads;
+//   * the walk follows the SOURCE rows and its body exists twice with the two H register triples in swapped roles: nothing is ever
+//     copied (round 3's two-entry cache moved 3 doubles and ran 6 selects per output row);
+//   * the 64 result pixels leave as 48 aligned dwords through LDS: a lane writes its 3 bytes (ds_write_b8), lanes 0..47 read one dword
+//     each and store it -- no packing, no ds_bpermute pair, no funnel shift (8 vector instructions -> 0, two more LDS instructions).
 // Needs 4-byte aligned output rows (level images of the batched path have a padded row pitch).
 #define RESIZE_MAXS 22
 // per output row of a resize stage, computed once on the host with the oracle's double arithmetic (y = r * y_scale; top = floor(y);
@@ -34,9 +43,10 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
                                                      size_t out_stride, int out_rb, int oh, int ow, double x_scale,
                                                      const RowTab* __restrict__ rows)
 {
+    static_assert(NSTRIP == 1, "one strip of RS rows per wave (more strips per wave were measured no faster: DESIGN.md section 3)");
     constexpr int MAXS = RESIZE_MAXS;
-    __shared__ uint32_t s_rows[4][MAXS][64];
-    __shared__ __attribute__((aligned(16))) float s_cvt[4][256 + 8];     // one source row's window as floats (exact: bytes), per wave
+    __shared__ uint32_t s_rows[4][MAXS][64];                     // a wave's source rows: 256-byte windows, dword per lane
+    __shared__ uint32_t s_out[4][64];                            // a wave's output row: 64 pixels x 3 bytes = 48 dwords
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = blockIdx.x * 256 + wave * 64;               // first column of this wave's segment
@@ -44,97 +54,89 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     if (c0 >= ow) return;                                      // wave-uniform
     const int c = min(c0 + lane, ow - 1);                      // lanes past the row end recompute the last column (never stored)
     const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
-    const uint8_t* in_end = in + (size_t)ih * in_rb;
     uint8_t* ob = out + (size_t)b * out_stride + (size_t)c0 * 3;
     const double x = c * x_scale;
     const int left = (int)floor(x);
     const int left0 = __builtin_amdgcn_readfirstlane(left);    // lane 0 holds column c0: the smallest source column of the wave
     const bool has_right = (left + 1 <= iw - 1);
     const double lr = x - left, lr1 = 1 - lr;
-    // output dword d of the segment (lane d < 48) straddles packed pixels a = 4d / 3 and a + 1, starting at byte 4d - 3a of pixel a
-    const int pa_lane = (4 * lane) / 3, phase = 4 * lane - 3 * pa_lane;
-    const int bp0 = 4 * min(pa_lane, 63), bp1 = 4 * min(pa_lane + 1, 63);
     const int seg_bytes = min(ow - c0, 64) * 3;
     const bool stores = (4 * lane < seg_bytes);
-    // this lane's two source pixels inside the window: `dl` floats from the window's first byte to the left pixel's first channel
-    // (without the row's alignment offset, added per row); a lane without a right neighbour blends its own pixel with itself
-    // (oracle/pvo_image.c): its "right" pixel is read from the left one's slots
-    const int dl = 3 * (left - left0), ro = has_right ? 3 : 0;
-    float* cv = s_cvt[wave];
-    typedef const __attribute__((address_space(1))) uint32_t* gptr_t;
-    const uintptr_t last_word = ((uintptr_t)in_end - 1) & ~(uintptr_t)3;
-    // A wave walks NSTRIP strips of RS output rows, top to bottom.  The source rows of a strip are requested as one burst (one coalesced
-    // dword per lane and row: the 64 columns of a wave span < 256 source bytes for scales <= 1.25; branch-free: a dword that lies wholly
-    // past the frame is redirected to the frame's last word, never used) -- and the burst of strip k + 1 is in flight while strip k is
-    // computed, so only the first burst's latency is exposed (round 2: one strip per wave, every wave waited for its burst).
-    uint32_t t[MAXS];
-    auto request = [&](int r0) {
-        const int r_end = min(r0 + RS, oh);
-        const int s_first = rows[r0].top, nrows = rows[r_end - 1].bottom - s_first + 1;
+    // the frame behind a buffer descriptor whose base is 4-byte aligned (`delta` = what the alignment cut off): a row's window starts at
+    // the aligned dword that holds the wave's first source byte; dwords past the frame's end read as zero
+    const unsigned delta = (unsigned)((uintptr_t)in & 3u);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((uintptr_t)in - delta), 0, (int)(delta + (unsigned)ih * (unsigned)in_rb), 0x00020000);
+    const int lane4 = 4 * lane;
+    const int r0 = blockIdx.y * RS, r_end = min(r0 + RS, oh);
+    const int s_first = rows[r0].top, nrows = rows[r_end - 1].bottom - s_first + 1;
+    const unsigned win0 = delta + (unsigned)s_first * (unsigned)in_rb + 3u * (unsigned)left0;          // byte offset of row s_first's first needed byte
+    {
+        uint32_t t[MAXS];
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) {
             t[k] = 0;
-            if (k < nrows) {                                   // wave-uniform
-                const uintptr_t a = (uintptr_t)(in + (size_t)(s_first + k) * in_rb + 3 * left0);
-                uintptr_t q = (a & ~(uintptr_t)3) + 4 * lane;
-                q = q < last_word ? q : last_word;
-                t[k] = *(gptr_t)q;
-            }
+            if (k < nrows) t[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, (int)((win0 + (unsigned)k * (unsigned)in_rb) & ~3u), 0);     // wave-uniform test and offset
         }
-    };
-    const int r_first = blockIdx.y * (RS * NSTRIP);
-    request(r_first);
-#pragma unroll 1
-    for (int st = 0; st < NSTRIP; ++st) {
-        const int r0 = r_first + st * RS;
-        if (r0 >= oh) break;                                   // wave-uniform
-        const int r_end = min(r0 + RS, oh);
-        const int s_first = rows[r0].top;
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) s_rows[wave][k][lane] = t[k];
-        if (st + 1 < NSTRIP && r0 + RS < oh) request(r0 + RS);
-        int s0 = -1, s1 = -1;              // cached source rows
-        double h0[3], h1[3];
-        // The horizontal blend of a source row.  Round 2 had every lane dig its six bytes out of three staged dwords (12 shift / mask / select
-        // instructions) and convert each to double (6): per OUTPUT pixel.  Now the wave converts the row's 256-byte window once -- a lane
-        // turns its dword into four floats (v_cvt_f32_ubyte0..3, exact) and parks them -- and a lane reads its six values back by index.
-        auto hblend = [&](int srow, double* hh) {
-            const uint32_t w = s_rows[wave][srow - s_first][lane];
-            f32x4 f;
-            f.x = (float)(w & 0xffu); f.y = (float)((w >> 8) & 0xffu);         // (the compiler emits v_cvt_f32_ubyte0 .. 3)
-            f.z = (float)((w >> 16) & 0xffu); f.w = (float)(w >> 24);
-            *reinterpret_cast<f32x4*>(cv + 4 * lane) = f;
-            __builtin_amdgcn_wave_barrier();                        // (LDS serves a wave's accesses in order; this only pins the compiler's order)
-            const unsigned al = (unsigned)((uintptr_t)(in + (size_t)srow * in_rb + 3 * left0) & 3u);   // wave-uniform
-            const float* q = cv + al + dl;
-            const double tl0 = (double)q[0], tl1 = (double)q[1], tl2 = (double)q[2];
-            const double tr0 = (double)q[ro], tr1 = (double)q[ro + 1], tr2 = (double)q[ro + 2];
-            __builtin_amdgcn_wave_barrier();
-            hh[0] = lr1 * tl0 + lr * tr0;
-            hh[1] = lr1 * tl1 + lr * tr1;
-            hh[2] = lr1 * tl2 + lr * tr2;
-        };
-        for (int r = r0; r < r_end; ++r) {
-            const RowTab rt = rows[r];                              // wave-uniform: scalar loads
-            const int top = rt.top, bottom = rt.bottom;
-            const double tb = rt.tb, tb1 = rt.tb1;
-            if (s1 == top) { s0 = s1; h0[0] = h1[0]; h0[1] = h1[1]; h0[2] = h1[2]; s1 = -1; }
-            if (s0 != top) { hblend(top, h0); s0 = top; }
-            if (s1 != bottom) {
-                if (bottom == top) { h1[0] = h0[0]; h1[1] = h0[1]; h1[2] = h0[2]; }
-                else hblend(bottom, h1);
-                s1 = bottom;
-            }
-            uint32_t P = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // this lane's two source pixels inside a window, in bytes from the window's first NEEDED byte (the row's alignment offset is added
+    // per row); a lane without a right neighbour blends its own pixel with itself (oracle/pvo_image.c)
+    const uint8_t* wl = reinterpret_cast<const uint8_t*>(&s_rows[wave][0][0]) + 3 * (left - left0);
+    const uint8_t* wr = wl + (has_right ? 3 : 0);
+    uint8_t* so = reinterpret_cast<uint8_t*>(&s_out[wave][0]) + 3 * lane;
+    const uint32_t* sd = &s_out[wave][0] + lane;
+    auto hblend = [&](int srow, double* hh) {
+        const int k = srow - s_first;                                              // wave-uniform
+        const unsigned off = 256u * (unsigned)k + ((win0 + (unsigned)k * (unsigned)in_rb) & 3u);
+        // six single-byte LDS reads (volatile: the compiler would fuse neighbours into 16-bit reads and spend vector instructions taking them apart again)
+        typedef const volatile __attribute__((address_space(3))) uint8_t* lds_bytes;
+        lds_bytes pl = (lds_bytes)(wl + off);
+        lds_bytes pr = (lds_bytes)(wr + off);
+        const uint32_t l0 = pl[0], l1 = pl[1], l2 = pl[2], q0 = pr[0], q1 = pr[1], q2 = pr[2];
+        hh[0] = lr1 * (double)l0 + lr * (double)q0;
+        hh[1] = lr1 * (double)l1 + lr * (double)q1;
+        hh[2] = lr1 * (double)l2 + lr * (double)q2;
+    };
+    auto emit = [&](int r, double tb, double tb1, const double* ht, const double* hb) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const double v = tb1 * h0[k] + tb * h1[k];
-                P |= (uint32_t)(uint8_t)(v + 0.5) << (8 * k);
-            }
-            const uint32_t Pa = (uint32_t)__builtin_amdgcn_ds_bpermute(bp0, (int)P), Pb = (uint32_t)__builtin_amdgcn_ds_bpermute(bp1, (int)P);
-            const uint32_t dw = __builtin_amdgcn_alignbyte(Pb >> 8, Pa | (Pb << 24), (unsigned)phase);
-            if (stores) *reinterpret_cast<uint32_t*>(ob + (size_t)r * out_rb + 4 * lane) = dw;
+        for (int k = 0; k < 3; ++k) {
+            const double v = tb1 * ht[k] + tb * hb[k];
+            so[k] = (uint8_t)(v + 0.5);
         }
+        __builtin_amdgcn_wave_barrier();                               // (LDS serves a wave's accesses in order; this only pins the compiler's order)
+        const uint32_t dw = *sd;
+        __builtin_amdgcn_wave_barrier();
+        if (stores) *reinterpret_cast<uint32_t*>(ob + (size_t)r * out_rb + lane4) = dw;
+    };
+    // The walk goes down the SOURCE rows: with H of row s at hand the row below it (s + 1, or s itself on the image's last row: the table's
+    // `bottom`) is blended into the other register triple and every output row whose `top` is s is written; then the two triples swap
+    // ROLES -- the loop body exists twice, once per role, so no value is ever copied (round 3: a two-entry cache keyed by the output
+    // row's (top, bottom), 3 doubles moved and 6 selects per output row).  Every H is evaluated once, in row order, as before.
+    int r = r0, srow = s_first;
+    double hA[3], hB[3];
+    const __attribute__((address_space(4))) RowTab* crows = (const __attribute__((address_space(4))) RowTab*)rows;
+    // table entries come through the scalar cache (constant address space: this kernel's stores cannot touch the table), the next
+    // row's entry requested before the current row's arithmetic so that its latency hides behind it
+    struct RowVals { int top; double tb, tb1; };
+    auto row_of = [&](int rr) { RowVals v; v.top = crows[rr].top; v.tb = crows[rr].tb; v.tb1 = crows[rr].tb1; return v; };
+    RowVals rt = row_of(r);
+    auto step = [&](const double* hc, double* hn) {
+        hblend(min(srow + 1, ih - 1), hn);
+        while (r < r_end && rt.top == srow) {
+            const RowVals nx = row_of(min(r + 1, oh - 1));
+            emit(r, rt.tb, rt.tb1, hc, hn);
+            rt = nx;
+            ++r;
+        }
+        ++srow;
+    };
+    hblend(srow, hA);
+    while (r < r_end) {
+        step(hA, hB);
+        if (r >= r_end) break;
+        step(hB, hA);
     }
 }
 
@@ -326,6 +328,10 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
     const int voff = 3 * x_first - 4, voff2 = voff + 16;
     float* accE = &s_bins[0][wave][0][lane];                       // bin k of this lane: accE[64 * k]
     float* accO = &s_bins[1][wave][0][lane];
+    constexpr int PAR_DIST = 4 * 18 * 64;                          // floats between a word of the even-parity half and the same word of the odd one
+    const unsigned acc_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&s_bins[0][wave][0][lane];     // LDS byte address of the lane's bin 0, even half
+    int minus4 = -4;                                               // in a vector register, opaque to the compiler: the operand of the v_add_u32_dpp that turns the right
+    asm volatile("" : "+v"(minus4));                               // neighbour's bin address into this lane's (folded into an LDS offset it would split the paired accesses)
 #pragma unroll
     for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accO[64 * k] = 0.0f; }
 
@@ -364,7 +370,9 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
         float v; int o;
         grad_lookup(u3, d3, l3, r3, lut2, &v, &o);
         *mo = (row_ok && ((xmask >> p) & 1u)) ? v : 0.0f;
-        *bof = o << 8;                                             // BYTE offset of the bin's row of 64 lanes (no shift left per vote)
+        // the ADDRESS of this lane's word of the bin in the even-parity half (one v_lshl_add_u32: bin << 8 + the lane's base); the odd half
+        // is a constant distance on (ds_read2st64 / ds_write2st64), and the lane to the LEFT finds the same bin of ITS cell 4 bytes below
+        *bof = (int)(acc_base + ((unsigned)o << 8));
     };
     // the votes of a row are a chain of LDS read-add-writes (latency bound); the gradients of the NEXT row are pure VALU work plus a table
     // look-up: they are computed in between, one pixel per two votes, so that a wave fills its own LDS waits and the look-ups of a row are
@@ -380,7 +388,7 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
     // The first band's lower half (cell row y0) and the last band's upper half (cell row y0 + R + 3) belong to cells this chunk
     // does not need; they are accumulated all the same (no branches in the vote loop): the first is read and dropped, the last
     // is never read.  Rows without gradients vote with magnitude 0 (x + 0 = x: nothing changes).
-    auto band = [&](int gb, float* accU, float* accL) {
+    auto band = [&](int gb, float* accU, float* accL, const bool upper_is_odd) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int y = 8 * gb + i - 12;                         // the row whose votes are cast in this step (gradients in mc / bc)
@@ -403,12 +411,15 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
                 if (j < 8) { mv = mc[p]; bv = bc[p]; }
                 else {
                     mv = __uint_as_float(from_next_lane(__float_as_uint(mc[p])));
-                    bv = (int)from_next_lane((uint32_t)bc[p]);
+                    bv = (int)from_next_lane((uint32_t)bc[p]) + minus4;         // (v_add_u32_dpp: the move and the add are one instruction)
                 }
                 const float fx = ((float)p + 0.5f) / 8.0f;
                 const float wx = (j < 8) ? fx : 1.0f - fx;
-                float* const pl = reinterpret_cast<float*>(reinterpret_cast<char*>(accL) + bv);
-                float* const pu = reinterpret_cast<float*>(reinterpret_cast<char*>(accU) + bv);
+                // bv addresses the even-parity half; accL / accU differ from it by the constant distance between the halves
+                typedef __attribute__((address_space(3))) float* lds_f;
+                lds_f const pe = (lds_f)(uintptr_t)(unsigned)bv;
+                lds_f const pl = upper_is_odd ? pe : pe + PAR_DIST;
+                lds_f const pu = upper_is_odd ? pe + PAR_DIST : pe;
                 const float vl = *pl, vu = *pu;
                 if ((j & 1) == 0) grad_px(nu, nc, nd, j >> 1, nok, &mn[j >> 1], &bn[j >> 1]);
                 *pl = vl + ((1.0f - fy) * wx) * mv;
@@ -446,8 +457,8 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
         for (int k = 0; k < 18; ++k) { hprev[k] = accL[64 * k]; accL[64 * k] = 0.0f; }
     };
     for (int gb = g_first; gb <= g_last; ++gb) {
-        if (gb & 1) band(gb, accO, accE);                           // upper half -> the odd cell row gb, lower half -> the even row gb - 1
-        else band(gb, accE, accO);
+        if (gb & 1) band(gb, accO, accE, true);                     // upper half -> the odd cell row gb, lower half -> the even row gb - 1
+        else band(gb, accE, accO, false);
     }
 #undef BYTE_OF
 }

@@ -3,9 +3,12 @@
 // gathered rows feed the clustering kernels where they land); two collectives per gather: the counts, then the payload in exact sizes.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -46,6 +49,34 @@ Comm* get(pvfd_handle h)
     return it->second.get();
 }
 
+// A collective that never completes (a rank that died, went a different way through its shots, or posted other sizes) must not hang the
+// job silently: the stream is POLLED -- the communicator's asynchronous error state beside it -- and after PVF_DIST_TIMEOUT_S seconds
+// (default 120) the communicator is aborted and the call fails with an error that names this rank and what it was waiting for.
+void wait_collective(Comm* c, const char* what, const std::string& detail)
+{
+    double limit = 120.0;
+    if (const char* e = getenv("PVF_DIST_TIMEOUT_S")) { const double v = atof(e); if (v > 0) limit = v; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spin = 0;; ++spin) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return;
+        if (q != hipErrorNotReady) throw Err(std::string(what) + ": " + hipGetErrorString(q));
+        ncclResult_t async = ncclSuccess;
+        if (ncclCommGetAsyncError(c->comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
+            (void)ncclCommAbort(c->comm); c->comm = nullptr;
+            throw Err(std::string(what) + ": rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) + ": communicator error: " + ncclGetErrorString(async) + " (" + detail + ")");
+        }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > limit) {
+            (void)ncclCommAbort(c->comm); c->comm = nullptr;
+            throw Err(std::string(what) + ": rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) + " gave up after " + std::to_string((int)waited) +
+                      " s (PVF_DIST_TIMEOUT_S): a peer never joined this collective (" + detail + "); the communicator was aborted");
+        }
+        if (spin < 2000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+}
+
 void gather_counts(Comm* c, int64_t n_rows, int64_t* counts)
 {
     c->grow(&c->d_send, &c->send_cap, sizeof(int64_t));
@@ -53,7 +84,7 @@ void gather_counts(Comm* c, int64_t n_rows, int64_t* counts)
     HIPC(hipMemcpyAsync(c->d_send, &n_rows, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     NCCLC(ncclAllGather(c->d_send, c->d_recv, 1, ncclInt64, c->comm, c->stream));
     HIPC(hipMemcpyAsync(counts, c->d_recv, sizeof(int64_t) * c->world, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    wait_collective(c, "pvfd_allgather_counts", "all-gather of one int64 per rank: mine = " + std::to_string(n_rows));
 }
 } // namespace
 
@@ -112,6 +143,7 @@ extern "C" int32_t pvfd_allgather_counts(pvfd_handle h, int64_t n, int64_t* coun
     Comm* c = get(h);
     HIPC(hipSetDevice(c->device));
     if (!counts) throw Err("pvfd_allgather_counts: bad arguments");
+    if (!c->comm) throw Err("pvfd_allgather_counts: the communicator was aborted by an earlier failure");
     gather_counts(c, n, counts);
     API_END
 }
@@ -125,6 +157,7 @@ extern "C" int32_t pvfd_allgatherv_dev(pvfd_handle h, const void* d_send, const 
     API_BEGIN
     Comm* c = get(h);
     HIPC(hipSetDevice(c->device));
+    if (!c->comm) throw Err("pvfd_allgatherv_dev: the communicator was aborted by an earlier failure");
     if (!nbytes || !d_recv) throw Err("pvfd_allgatherv_dev: bad arguments");
     for (int r = 0; r < c->world; ++r) if (nbytes[r] < 0) throw Err("pvfd_allgatherv_dev: negative count");
     if (nbytes[c->rank] > 0 && !d_send) throw Err("pvfd_allgatherv_dev: no send buffer");
@@ -137,6 +170,8 @@ extern "C" int32_t pvfd_allgatherv_dev(pvfd_handle h, const void* d_send, const 
         off += (size_t)nbytes[r];
     }
     NCCLC(ncclGroupEnd());
-    HIPC(hipStreamSynchronize(c->stream));
+    std::string detail = "grouped broadcasts, bytes per rank =";
+    for (int r = 0; r < c->world; ++r) detail += " " + std::to_string((long long)nbytes[r]);
+    wait_collective(c, "pvfd_allgatherv_dev", detail);
     API_END
 }

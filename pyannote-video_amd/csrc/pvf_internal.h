@@ -138,7 +138,7 @@ struct DetectorModel {
     float* d_bmfma4 = nullptr; // B fragments of score_roll_k: [10][12][2][64 lanes][4 k-steps] (3 shifts x 5 filters per 16-column MFMA tile)
     uint16_t* d_bscreen = nullptr;     // f16 B fragments of score_screen_k: [10][12][64 lanes][8] (weights x screen_scale)
     double screen_scale = 1.0;         // the power of two the weights were multiplied by before their conversion to f16
-    double screen_bound[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // |screening score / 256 - exact chain| <= screen_bound[filter] (screen.hip)
+    double screen_bound[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // |screening score / screen_scale - exact chain| <= screen_bound[filter] (screen.hip)
 };
 
 struct ShapeModel {
@@ -255,7 +255,8 @@ struct Ctx {
     int screen_list_cap = 1 << 20;            // (position, filter) pairs a batch may list for exact re-scoring
     DevBuf s_screen;
     int64_t screen_batches = 0, screen_listed = 0, screen_retries = 0;
-    double screen_pipe_err = -1;              // measured by screen_probe: worst |pipe - exact| / sum of magnitudes over a K = 3200 accumulation
+    double screen_pipe_err = -1;              // measured by screen_probe: worst |pipe - exact| / sum of magnitudes over its K = 3200 accumulations (five cases)
+    bool screen_pipe_flushes_subnormals = false;      // screen_probe case 4 (the bound carries the term e_sub either way)
     int n_cu = 256;
     // released frame buffers by size.  A buffer comes back with the event recorded on the compute stream at its release: whoever takes it
     // next orders its first write behind that event (pool_take), so releasing a frame never waits for the kernels that still read it.

@@ -75,6 +75,7 @@ _SIGS = {
     "pvf_pair_mean_dist": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, P]),
     "pvf_pair_mean_dist_metric": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P]),
     "pvf_pair_mean_dist_rows": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P]),
+    "pvf_pair_upper_rows": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P]),
     "pvf_cluster_dist": (C.c_int32, [H, P, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_cluster_tracks": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_cluster_upper": (C.c_int32, [H, P, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
@@ -90,6 +91,7 @@ _SIGS = {
     "pvf_debug_level_features": (C.c_int32, [H, H, C.c_int32, C.c_int32, P, P, P]),
     "pvf_debug_fhog": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
     "pvf_debug_detect_raw": (C.c_int32, [H, H, C.c_int32, C.c_double, P, P, C.c_int32, P]),
+    "pvf_debug_detect_raw_many": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int32, C.c_double, P, P, C.c_int64, P]),
     "pvf_debug_extract_chip": (C.c_int32, [H, H, P, C.c_double, C.c_double, C.c_int32, C.c_int32, P]),
     "pvf_debug_tracker_state": (C.c_int32, [H, H, P, P, P]),
     "pvf_shot_dfd": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int32, P, P, P, P]),

@@ -97,7 +97,7 @@ class FaceClustering(object):
             # several GPUs, every one holding all rows: each computes the distance-matrix rows of its share of the tracks
             # (balanced by row count), the rows are exchanged, and every rank agglomerates the same complete matrix
             t0, t1 = self.shard.track_range(row_start)
-            U = self.shard.assemble(ctx.pair_mean_dist_rows(Xs, row_start, t0, t1)[t0:t1], row_start)
+            U = self.shard.assemble(ctx.pair_upper_rows(Xs, row_start, t0, t1)[t0:t1], row_start)
             labels, log = ctx.cluster_upper(U, row_start, cut)
         self.history = [(int(track_ids[int(a)]), int(track_ids[int(b)]), float(d)) for a, b, d, _ in log]
         if self.force:

@@ -330,6 +330,23 @@ class Context(object):
         return [(float(scores[i]), int(meta[i, 0]), int(meta[i, 1]), int(meta[i, 2]), int(meta[i, 3]),
                  tuple(int(v) for v in meta[i, 4:8])) for i in range(k)]
 
+    def detect_raw_many(self, frames, batch, upsample=1, adjust_threshold=0.0, cap=1 << 16):
+        """the scanner's candidates BEFORE non-maximum suppression through the batched path (screening pass included): per frame an int32
+        [n, 5] table (level, filter, row, column, score bits) in the detector's canonical order"""
+        n = len(frames)
+        counts = np.zeros(n, np.int32)
+        total = C.c_int64(0)
+        with self._staging():
+            hs = self._handles(frames)
+            while True:
+                rows = np.zeros((cap, 5), np.int32)
+                check(self._l.pvf_debug_detect_raw_many(self._h, ptr(hs), n, int(batch), int(upsample), float(adjust_threshold), ptr(counts), ptr(rows), cap, C.byref(total)))
+                if total.value <= cap:
+                    break
+                cap = int(total.value)
+        off = np.concatenate([[0], np.cumsum(counts)])
+        return [rows[off[i]:off[i + 1]] for i in range(n)]
+
     def pyramid_level(self, frame, upsample, level):
         f = self.stage(frame)
         oh, ow = C.c_int32(0), C.c_int32(0)
@@ -578,12 +595,19 @@ class Context(object):
         return labels, log[:n.value]
 
     def pair_mean_dist_rows(self, X, row_start, track0, track1):
-        """upper-triangle entries (j > i) of rows [track0, track1) of the T x T track-pair mean-distance matrix (everything else zero)"""
+        """the complete rows [track0, track1) of the T x T track-pair mean-distance matrix (other rows zero): j > i computed, j < i mirrored"""
+        return self._pair_rows(self._l.pvf_pair_mean_dist_rows, X, row_start, track0, track1)
+
+    def pair_upper_rows(self, X, row_start, track0, track1):
+        """upper-triangle entries (j > i) of rows [track0, track1) of that matrix (everything else zero): a rank's share of a split clustering"""
+        return self._pair_rows(self._l.pvf_pair_upper_rows, X, row_start, track0, track1)
+
+    def _pair_rows(self, fn, X, row_start, track0, track1):
         X = np.ascontiguousarray(X, np.float64)
         rs = np.ascontiguousarray(row_start, np.int32)
         T = len(rs) - 1
         D = np.zeros((T, T), np.float64)
-        check(self._l.pvf_pair_mean_dist_rows(self._h, ptr(X), X.shape[0], X.shape[1], ptr(rs), T, int(track0), int(track1), ptr(D)))
+        check(fn(self._h, ptr(X), X.shape[0], X.shape[1], ptr(rs), T, int(track0), int(track1), ptr(D)))
         return D
 
     def cluster_dist(self, D, row_start, threshold):

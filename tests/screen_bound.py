@@ -3,6 +3,8 @@ S = the exact chain (3100 fmaf), S' = what the f16 matrix cores return for the s
 when S' >= threshold - bound[filter].  The terms (see the header of screen.hip):
   e_w     sum FM |w' - w|                       w' = f16(scale * w) / scale, round to nearest (numpy's float16 conversion), scale = 2^k
   e_f     sum |w'| max(2^-10 FM, 2^-14)         features converted with round-towards-zero; a subnormal may be flushed
+  e_sub   sum over f16-SUBNORMAL w' of FM |w'|  a pipe that flushes subnormal inputs loses the whole product (at most 1.6e-4 for any model:
+          only weights 2^21 below the largest are subnormal after the power-of-two scaling); carried whether or not the device flushes
   e_pipe  3200 * 2^-22 * sum FM |w'| (1 + 2^-10)  the <= 3220 rounding additions of a sum inside the matrix pipe (3100 non-zero products, 120
           hand-overs between MFMAs; adding a zero entry is exact) allowed just under 4 x an IEEE fp32 rounding error each
   e_chain g(3100) sum FM |w|                    the exact chain's own distance from the real sum, g(n) = n u / (1 - n u), u = 2^-24
@@ -39,8 +41,8 @@ def plane_max():
 
 
 def terms(W):
-    """W: [filters, 10, 10, 32] float32 -> dict of the four terms per filter (float64 arrays)"""
-    Wq, _ = quantised(W)
+    """W: [filters, 10, 10, 32] float32 -> dict of the five terms per filter (float64 arrays)"""
+    Wq, scale = quantised(W)
     W64 = W.astype(np.float64)
     fm = plane_max()
     keep = np.arange(32) < 31
@@ -49,12 +51,14 @@ def terms(W):
     e_f = (np.abs(Wq) * np.maximum(fm * 2.0 ** -10, 2.0 ** -14))[..., keep].sum(axis=(1, 2, 3))
     a_h = (fm * np.abs(Wq))[..., keep].sum(axis=(1, 2, 3))
     a_w = (fm * np.abs(W64))[..., keep].sum(axis=(1, 2, 3))
-    return {"e_w": e_w, "e_f": e_f, "e_pipe": 3200.0 * 2.0 ** -22 * a_h * (1.0 + 2.0 ** -10), "e_chain": 3100.0 * u / (1.0 - 3100.0 * u) * a_w}
+    sub = (Wq != 0) & (np.abs(Wq) * scale < 2.0 ** -14)
+    e_sub = (fm * np.abs(Wq) * sub)[..., keep].sum(axis=(1, 2, 3))
+    return {"e_w": e_w, "e_f": e_f, "e_sub": e_sub, "e_pipe": 3200.0 * 2.0 ** -22 * a_h * (1.0 + 2.0 ** -10), "e_chain": 3100.0 * u / (1.0 - 3100.0 * u) * a_w}
 
 
 def bounds(W):
     t = terms(W)
-    return 1.02 * (t["e_w"] + t["e_f"] + t["e_pipe"] + t["e_chain"]) + 1e-6
+    return 1.02 * (t["e_w"] + t["e_f"] + t["e_sub"] + t["e_pipe"] + t["e_chain"]) + 1e-6
 
 
 def f16_towards_zero(x):

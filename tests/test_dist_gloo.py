@@ -181,3 +181,74 @@ def test_clip_farm_assignment_covers_every_clip_once_and_balances():
     assert pdist.shard_clips(41, 4, frames=frames) == parts        # deterministic: every rank computes the same table
     with pytest.raises(ValueError):
         pdist.shard_clips(3, 2, frames=[1, 2])
+
+
+WORKER8 = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "pyannote-video_amd"))
+import torch
+import torch.distributed as dist
+from pyannote_video_amd import dist as pd
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+shares = json.loads(open(sys.argv[3]).read())
+mine = shares[rank]
+rng = np.random.default_rng(1000 + rank)
+rows, n_tracks = mine["rows"], mine["tracks"]
+T = (rng.random(rows) + 10 * rank) if rows else np.zeros(0)
+ids = rng.integers(0, max(n_tracks, 1), rows) if rows else np.zeros(0, np.int64)
+X = rng.normal(size=(rows, 128)).astype(np.float32)
+gT, gid, gX, offsets = pd.gather_rows(T, ids, X, n_tracks)
+gX = gX.numpy()
+# the split distance step's exchange on the host form: every rank contributes its rows of a T x T table (DistanceShard.assemble)
+row_start = np.array(json.loads(open(sys.argv[4]).read()), np.int32)
+Tt = len(row_start) - 1
+sh = pd.DistanceShard(rank, world, device="cpu")
+t0, t1 = sh.track_range(row_start)
+full = np.arange(Tt * Tt, dtype=np.float64).reshape(Tt, Tt)
+U = sh.assemble(full[t0:t1], row_start)
+before = sum(s["rows"] for s in shares[:rank])
+out = {"rank": rank, "n": int(len(gT)), "offsets": offsets, "ids": gid.tolist(), "sumX": float(gX.astype(np.float64).sum()),
+       "mine_back": bool(np.array_equal(gX[before:before + rows], X)), "range": [int(t0), int(t1)], "assembled": bool(np.array_equal(U, full))}
+open(sys.argv[2] + ".%d" % rank, "w").write(json.dumps(out))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_gather_rows_and_distance_shares_world8_uneven_and_empty(tmp_path):
+    """The exchange step at the world size the scaling run uses, with shares a real job can produce: ranks without a single face (a
+    frame range with no detection), a rank with one row, very uneven row counts.  Every rank must see the same global rows in rank order
+    with its ids moved by the prefix sum of the track counts, and the split distance step's all-gather (rows cut by equal triangle area,
+    some shares empty when there are fewer tracks than ranks would need) must reassemble the table on every rank."""
+    import json
+    from pyannote_video_amd import dist as pd
+    shares = [{"rows": 11, "tracks": 3}, {"rows": 0, "tracks": 0}, {"rows": 1, "tracks": 1}, {"rows": 40, "tracks": 7},
+              {"rows": 0, "tracks": 0}, {"rows": 5, "tracks": 5}, {"rows": 17, "tracks": 2}, {"rows": 3, "tracks": 1}]
+    row_start = np.concatenate([[0], np.cumsum([30, 1, 2, 50, 4, 3])]).tolist()          # 6 tracks for 8 ranks: some ranks get no track
+    (tmp_path / "shares.json").write_text(json.dumps(shares))
+    (tmp_path / "rows.json").write_text(json.dumps(row_start))
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8)
+    out = str(tmp_path / "out")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                           "--master-port", "29621", str(script), ROOT, out, str(tmp_path / "shares.json"), str(tmp_path / "rows.json")],
+                          env=dict(os.environ, MASTER_ADDR="127.0.0.1", PVF_DIST_COLLECTIVE="torch", OMP_NUM_THREADS="1"), timeout=600)
+    res = [json.loads(open(out + ".%d" % r).read()) for r in range(8)]
+    want_off = np.concatenate([[0], np.cumsum([s["tracks"] for s in shares])[:-1]]).tolist()
+    total = sum(s["rows"] for s in shares)
+    for r in res:
+        assert r["n"] == total and r["offsets"] == want_off
+        assert r["ids"] == res[0]["ids"] and abs(r["sumX"] - res[0]["sumX"]) < 1e-9
+        assert r["mine_back"] and r["assembled"]
+    # the ids of rank r's rows lie in [offset_r, offset_r + tracks_r)
+    o = 0
+    for r, s in enumerate(shares):
+        seg = res[0]["ids"][o:o + s["rows"]]
+        assert all(want_off[r] <= i < want_off[r] + max(s["tracks"], 1) for i in seg)
+        o += s["rows"]
+    # the track ranges tile [0, T) in rank order; empty shares are allowed
+    ranges = [r["range"] for r in res]
+    assert ranges[0][0] == 0 and ranges[-1][1] == len(row_start) - 1 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    bounds = pd.DistanceShard(0, 8).bounds(np.array(row_start))
+    assert [list(x) for x in zip(bounds, bounds[1:])] == ranges

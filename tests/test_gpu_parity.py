@@ -291,9 +291,11 @@ def test_pair_mean_dist_and_hac(ctx, oracle):
         for r in range(world):
             t0, t1 = DistanceShard(r, world).track_range(rs)
             covered.append((t0, t1))
-            part = ctx.pair_mean_dist_rows(X, rs, t0, t1)      # the entries j > i of the rows [t0, t1), zeros elsewhere
+            part = ctx.pair_upper_rows(X, rs, t0, t1)          # the entries j > i of the rows [t0, t1), zeros elsewhere
             assert not part[:t0].any() and not part[t1:].any() and not np.tril(part).any()
             U[t0:t1] = part[t0:t1]
+            full = ctx.pair_mean_dist_rows(X, rs, t0, t1)      # the same rows complete (below the diagonal: the mirror), other rows untouched
+            assert np.array_equal(full[t0:t1], D[t0:t1]) and not full[:t0].any() and not full[t1:].any()
         assert covered[0][0] == 0 and covered[-1][1] == T and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
         assert np.array_equal(U, np.triu(D, 1))
         l2, log2 = ctx.cluster_upper(U, rs, 0.6)               # mirror + agglomeration
@@ -340,9 +342,13 @@ def test_pair_mean_dist_matrix_core_kernel_all_block_shapes(ctx, oracle):
     for cuts in ([0, 4, 9, 22], [0, 1, 20, 22], [0, 10, 22]):
         Ds = np.zeros_like(D)
         for t0, t1 in zip(cuts, cuts[1:]):
-            Ds[t0:t1] = ctx.pair_mean_dist_rows(X, rs, t0, t1)[t0:t1]
+            Ds[t0:t1] = ctx.pair_upper_rows(X, rs, t0, t1)[t0:t1]
         assert np.array_equal(Ds, np.triu(D, 1))           # upper-triangle shares; mirrored == the whole matrix
         assert np.array_equal(Ds + Ds.T, D)
+        Df = np.zeros_like(D)
+        for t0, t1 in zip(cuts, cuts[1:]):
+            Df[t0:t1] = ctx.pair_mean_dist_rows(X, rs, t0, t1)[t0:t1]      # complete rows stitch into the whole matrix
+        assert np.array_equal(Df, D)
     # cosine distance (north_star's metric): mean of 1 - cos over the block
     Dc = ctx.pair_mean_dist(X, rs, metric=1)
     Xn = X / np.linalg.norm(X, axis=1, keepdims=True)

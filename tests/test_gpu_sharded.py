@@ -157,6 +157,33 @@ def test_bench_launches_ranks_itself_and_two_ranks_equal_one(tmp_path):
         assert p.returncode != 0 and "GPU" in p.stderr
 
 
+def test_eight_ranks_through_the_launcher_equal_one(tmp_path):
+    """The shape of the first 8-GPU run, on one GPU: `bench.py --gpus 8 --oversubscribe --scaling strong` on one 2000-frame video of 8
+    shots (960 x 540, so that eight contexts fit one device) -- eight ranks take one shot each, exchange their rows, split the distance
+    step by triangle area (8 shares) and cluster globally; the labels digest equals the 1-rank run's, and the line carries every rank's own
+    time and where its last step went."""
+    common = ["--frames", "2000", "--shots", "8", "--width", "960", "--height", "540", "--steps", "1", "--warmup", "0", "--cpu-frames", "0",
+              "--no-dropin", "--no-host-ingest", "--no-dense-leg", "--scaling", "strong", "--detect-batch", "32"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env.pop("PVF_DIST_COLLECTIVE", None)
+
+    def run(extra):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, env=env, timeout=1500, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-3000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    l8 = run(["--gpus", "8", "--oversubscribe"])
+    l1 = run(["--gpus", "1"])
+    assert l8["n_gpus"] == 8 and l8["config"]["oversubscribed"] is True and l8["scaling"] == "strong"
+    assert l8["results"]["tracks_clustered_globally"] == l1["results"]["tracks_clustered_globally"] > 0
+    assert l8["results"]["labels_sha256_16"] == l1["results"]["labels_sha256_16"]
+    assert l8["results"]["clusters"] == l1["results"]["clusters"]
+    pr = l8["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(8)) and sum(r["frames"] for r in pr) == 2000
+    assert sum(r["tracks"] for r in pr) == l1["results"]["tracks"] and sum(r["faces"] for r in pr) == l1["results"]["faces_embedded"]
+    assert all("exchange_s" in r["last_step_s"] and "cluster_s" in r["last_step_s"] for r in pr)
+    assert l1["per_rank"] is None
+
+
 def test_cluster_stress_reduced_config5(ctx, oracle):
     """config 5 at reduced scale: T = 1500 tracks x 4 rows around 120 centres, distances bracket the 0.6 threshold"""
     rng = np.random.default_rng(17)
