@@ -328,10 +328,6 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
     const int voff = 3 * x_first - 4, voff2 = voff + 16;
     float* accE = &s_bins[0][wave][0][lane];                       // bin k of this lane: accE[64 * k]
     float* accO = &s_bins[1][wave][0][lane];
-    constexpr int PAR_DIST = 4 * 18 * 64;                          // floats between a word of the even-parity half and the same word of the odd one
-    const unsigned acc_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&s_bins[0][wave][0][lane];     // LDS byte address of the lane's bin 0, even half
-    int minus4 = -4;                                               // in a vector register, opaque to the compiler: the operand of the v_add_u32_dpp that turns the right
-    asm volatile("" : "+v"(minus4));                               // neighbour's bin address into this lane's (folded into an LDS offset it would split the paired accesses)
 #pragma unroll
     for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accO[64 * k] = 0.0f; }
 
@@ -370,9 +366,7 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
         float v; int o;
         grad_lookup(u3, d3, l3, r3, lut2, &v, &o);
         *mo = (row_ok && ((xmask >> p) & 1u)) ? v : 0.0f;
-        // the ADDRESS of this lane's word of the bin in the even-parity half (one v_lshl_add_u32: bin << 8 + the lane's base); the odd half
-        // is a constant distance on (ds_read2st64 / ds_write2st64), and the lane to the LEFT finds the same bin of ITS cell 4 bytes below
-        *bof = (int)(acc_base + ((unsigned)o << 8));
+        *bof = o << 8;                                             // BYTE offset of the bin's row of 64 lanes (no shift left per vote)
     };
     // the votes of a row are a chain of LDS read-add-writes (latency bound); the gradients of the NEXT row are pure VALU work plus a table
     // look-up: they are computed in between, one pixel per two votes, so that a wave fills its own LDS waits and the look-ups of a row are
@@ -388,7 +382,7 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
     // The first band's lower half (cell row y0) and the last band's upper half (cell row y0 + R + 3) belong to cells this chunk
     // does not need; they are accumulated all the same (no branches in the vote loop): the first is read and dropped, the last
     // is never read.  Rows without gradients vote with magnitude 0 (x + 0 = x: nothing changes).
-    auto band = [&](int gb, float* accU, float* accL, const bool upper_is_odd) {
+    auto band = [&](int gb, float* accU, float* accL) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int y = 8 * gb + i - 12;                         // the row whose votes are cast in this step (gradients in mc / bc)
@@ -411,15 +405,12 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
                 if (j < 8) { mv = mc[p]; bv = bc[p]; }
                 else {
                     mv = __uint_as_float(from_next_lane(__float_as_uint(mc[p])));
-                    bv = (int)from_next_lane((uint32_t)bc[p]) + minus4;         // (v_add_u32_dpp: the move and the add are one instruction)
+                    bv = (int)from_next_lane((uint32_t)bc[p]);
                 }
                 const float fx = ((float)p + 0.5f) / 8.0f;
                 const float wx = (j < 8) ? fx : 1.0f - fx;
-                // bv addresses the even-parity half; accL / accU differ from it by the constant distance between the halves
-                typedef __attribute__((address_space(3))) float* lds_f;
-                lds_f const pe = (lds_f)(uintptr_t)(unsigned)bv;
-                lds_f const pl = upper_is_odd ? pe : pe + PAR_DIST;
-                lds_f const pu = upper_is_odd ? pe + PAR_DIST : pe;
+                float* const pl = reinterpret_cast<float*>(reinterpret_cast<char*>(accL) + bv);
+                float* const pu = reinterpret_cast<float*>(reinterpret_cast<char*>(accU) + bv);
                 const float vl = *pl, vu = *pu;
                 if ((j & 1) == 0) grad_px(nu, nc, nd, j >> 1, nok, &mn[j >> 1], &bn[j >> 1]);
                 *pl = vl + ((1.0f - fy) * wx) * mv;
@@ -457,8 +448,8 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
         for (int k = 0; k < 18; ++k) { hprev[k] = accL[64 * k]; accL[64 * k] = 0.0f; }
     };
     for (int gb = g_first; gb <= g_last; ++gb) {
-        if (gb & 1) band(gb, accO, accE, true);                     // upper half -> the odd cell row gb, lower half -> the even row gb - 1
-        else band(gb, accE, accO, false);
+        if (gb & 1) band(gb, accO, accE);                           // upper half -> the odd cell row gb, lower half -> the even row gb - 1
+        else band(gb, accE, accO);
     }
 #undef BYTE_OF
 }

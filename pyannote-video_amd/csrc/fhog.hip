@@ -40,12 +40,10 @@ const uint8_t* orientation_lut(Ctx* c)
     return c->d_orient_lut;
 }
 
-// The same table in 8 x 8 tiles (one 64-byte line each), addressed by the WRAPPED 18-bit word P = (512 by + bx) mod 2^18 the kernel
-// already has -- no bias is added on the device: the map (by, bx) -> P is one to one on [-255, 255]^2 (the words span 261 631 < 2^18
-// values), and with Y = P >> 9, X = P & 511 the entry sits at (Y >> 3) << 12 | (X >> 3) << 6 | (Y & 7) << 3 | (X & 7).  Neighbouring
-// pixels mostly have small, similar gradients, so a wave's 64 look-ups touch a handful of lines (four clusters, one per sign pair)
-// instead of one line per table row (the row-major form cost ~50 L1 accesses per gather and made the gradient pass texture-addresser
-// bound).  (Round 4 indexed by Y = by + 255, X = bx + 255: one more vector instruction per pixel for the bias.)
+// The same table in 8 x 8 tiles (one 64-byte line each): with Y = by + 255, X = bx + 255 the entry sits at
+// (Y >> 3) << 12 | (X >> 3) << 6 | (Y & 7) << 3 | (X & 7).  Neighbouring pixels mostly have small, similar gradients, so a
+// wave's 64 look-ups touch a handful of lines instead of one line per table row (the row-major form cost ~50 L1 accesses
+// per gather and made the gradient pass texture-addresser bound).
 const uint8_t* orientation_lut_tiled(Ctx* c)
 {
     std::lock_guard<std::recursive_mutex> lk(g_lut_mu);
@@ -54,15 +52,9 @@ const uint8_t* orientation_lut_tiled(Ctx* c)
     std::vector<uint8_t> ol((size_t)511 * 511);
     HIP_CHECK(hipMemcpy(ol.data(), c->d_orient_lut, ol.size(), hipMemcpyDeviceToHost));
     std::vector<uint8_t> lut((size_t)64 * 64 * 64, 0);
-    std::vector<uint8_t> seen(lut.size(), 0);
-    for (int by = -255; by <= 255; ++by)
-        for (int bx = -255; bx <= 255; ++bx) {
-            const uint32_t P = (uint32_t)(by * 512 + bx) & 0x3FFFFu;
-            const uint32_t off = (P & 0x3F007u) | ((P & 0x1F8u) << 3) | ((P >> 6) & 0x38u);
-            PVF_REQUIRE(!seen[off], "orientation table: two gradients share a slot");
-            seen[off] = 1;
-            lut[off] = ol[(size_t)(by + 255) * 511 + (bx + 255)];
-        }
+    for (int Y = 0; Y < 511; ++Y)
+        for (int X = 0; X < 511; ++X)
+            lut[((size_t)(Y >> 3) << 12) | ((size_t)(X >> 3) << 6) | ((Y & 7) << 3) | (X & 7)] = ol[(size_t)Y * 511 + X];
     HIP_CHECK(hipMalloc((void**)&c->d_grad_lut, lut.size()));
     HIP_CHECK(hipMemcpy(c->d_grad_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
     return reinterpret_cast<const uint8_t*>(c->d_grad_lut);

@@ -54,14 +54,8 @@ __device__ __forceinline__ void grad_lookup(const int u[3], const int d[3], cons
     }
     const int bv = max(cv[0], max(cv[1], cv[2]));                  // v_max3_i32
     const int bi = (cv[0] == bv) ? ci[0] : ((cv[1] == bv) ? ci[1] : ci[2]);
-    // the tiled table is addressed by the wrapped word itself (fhog.hip orientation_lut_tiled): bits 12..17 and 0..2 stay, 3..8 move up
-    // by three, 9..11 down by six -- two shifts, one and, two v_and_or_b32 with their masks in scalar registers (round 4: a bias added
-    // first, then three ands, two shifts and a v_or3: seven instructions, now five)
-    const unsigned P = (unsigned)bi;
-    unsigned off, t4;
-    const unsigned t3 = (P >> 6) & 0x38u;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(t4) : "v"(P << 3), "s"(0xFC0u), "v"(t3));
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(off) : "v"(P), "s"(0x3F007u), "v"(t4));
+    const unsigned P = (unsigned)(bi + 255 * 512 + 255);           // Y << 9 | X
+    const unsigned off = (P & 0x3F007u) | ((P & 0x1F8u) << 3) | ((P >> 6) & 0x38u);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lut_t, 0, 64 * 64 * 64, 0x00020000);
     *o = (int)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
     *v = sqrt_exact_small((float)bv);
