@@ -177,7 +177,8 @@ def main():
     ap.add_argument("--parity-seed", type=int, default=None, help="seed of the extra 8-frame parity window placed at random in the clip (default: from the clock; printed in the line)")
     ap.add_argument("--distinct-clips", type=int, default=6, help="c3: how many differently seeded 1000-frame clips (identities drawn from a pool of 250) the long video "
                     "cycles through; 23 makes every loop of the default 22 500 frames its own clip (143 GB resident source)")
-    ap.add_argument("--cluster-check-frames", type=int, default=3000, help="c3: the tracks of the first that many frames are clustered again by the CPU oracle (0: skip)")
+    ap.add_argument("--cluster-check-frames", type=int, default=-1, help="c3: the tracks of the first that many frames are clustered again by the CPU oracle "
+                    "(default -1: ALL tracks of the range -- 720 tracks, 180 000 rows at the default 22 500 frames: about a minute of the host's cores; 0: skip)")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST SWITCH: with --gpus N on a box with fewer than N devices, run the N ranks anyway, all on device 0 (gloo rendezvous, "
                          "torch.distributed collectives: two ranks of one RCCL communicator cannot share a device).  Exercises the launcher, the "
@@ -462,27 +463,29 @@ def main():
     print(json.dumps(out))
 
 
-def full_clip_parity(ctx, frames, res, labels, args, d_res=None, d_labels=None):
-    """product (the timed steps' last result) against the whole-clip fixture of the CPU oracle flow; None when the benched clip is not the
-    fixture's (other --frames / size / faces) or the fixture is absent"""
+def full_clip_parity(ctx, frames, res, labels, args, d_res=None, d_labels=None, name="c2_full", seed=20260925):
+    """product (the timed steps' last result) against the whole-clip fixture of the CPU oracle flow; a note instead when the benched clip
+    is not the fixture's (other --frames / size / faces) or the fixture is absent"""
     from oracle import golden
     import numpy as np
-    want = golden.CLIPS["c2_full"]
-    mine = dict(width=args.width, height=args.height, n_frames=args.frames, n_shots=args.shots, faces=args.faces, seed=20260925, frame_rate=args.fps)
-    if mine != want or not golden.available("c2_full"):
-        return {"fixture": None, "why": "no fixture for this clip (tests/golden/make_full_clip.py c2_full writes the one of the default configuration)"}
-    g = golden.load("c2_full")
+    want = golden.CLIPS[name]
+    mine = dict(width=args.width, height=args.height, n_frames=args.frames, n_shots=args.shots, faces=args.faces, seed=seed, frame_rate=args.fps)
+    if mine != want or not golden.available(name):
+        return {"fixture": None, "why": "no fixture for this clip (tests/golden/make_full_clip.py %s writes the one of the default configuration)" % name}
+    g = golden.load(name)
     out = golden.compare(g, res, labels)
+    batch = 125 if args.detect_batch >= 125 else args.detect_batch
     t0 = time.perf_counter()
-    raw = ctx.detect_raw_many(frames, 125 if args.detect_batch >= 125 else args.detect_batch)
+    raw = ctx.detect_raw_many(frames, batch)
     out["raw_candidates"] = golden.compare_raw(g, [golden.raw_key(r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4]) for r in raw])
     out["raw_candidates_total"] = int(g["raw_counts"].sum())
     out["raw_pass_seconds"] = round(time.perf_counter() - t0, 3)
     if d_res is not None:
         dd = golden.compare(g, d_res, d_labels)
         out["dense_scoring_leg"] = "exact" if dd["all_exact"] else {k: dd[k] for k in ("tracks", "face_rows", "landmarks", "embed_l2_max", "labels")}
+    if d_res is not None or name != "c2_full":
         ctx.detector_screening(False)
-        rawd = ctx.detect_raw_many(frames, 125 if args.detect_batch >= 125 else args.detect_batch)
+        rawd = ctx.detect_raw_many(frames, batch)
         ctx.detector_screening(True)
         out["raw_candidates_dense"] = golden.compare_raw(g, [golden.raw_key(r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4]) for r in rawd])
     out["oracle_seconds"] = round(float(g["oracle_seconds"]), 1)
@@ -747,6 +750,12 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
         parity, dt, threads = oracle_window_parity([np.ascontiguousarray(ft[i].cpu().numpy()) for i in idx], times, shots, v.frame_rate, v.frame_size, res, lp, ep,
                                                    label="clip 0, frames %d..%d (a window around its cut), product vs CPU oracle flow" % (idx[0], idx[-1]))
         cpu = {"value": round(n / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port", "sample": "the same %d-frame 720p window, whole flow" % n}
+    if rank == 0 and not args.dense_scoring and not args.small_models:
+        # clip 0 (this rank's first) over ALL its frames against the fixture of the CPU oracle flow (tests/golden/c4_clip0.npz)
+        fc = full_clip_parity(ctx, clips[0]["frames"], results[0], results[0]["labels"], args, name="c4_clip0", seed=20260925)
+        parity = dict(parity or {}, full_clip=fc)
+    else:
+        fc = None
     out = {"metric": "frames/sec end-to-end detect->embed->cluster, %d independent %dx%d clips farmed one per GPU (BASELINE.json configs[3])" % (args.clips, args.width, args.height),
            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(1000.0 * elapsed / args.steps, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -765,6 +774,7 @@ def bench_farm(args, rank, local_rank, world, device, lp, ep):
            "results": {"clips": len(results), "tracks": sum(len(r["tracks"]) for r in results), "faces_embedded": sum(int(len(r["face_T"])) for r in results),
                        "clusters_per_clip": [len(set(r["labels"].values())) for r in results][:8]},
            "setup_seconds": {"generate_frames_in_hbm": round(t_gen, 1)}}
+    out["full_clip_parity"] = full_clip_summary(fc)
     print(json.dumps(out))
 
 
@@ -881,8 +891,8 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
         parity, dt, threads = oracle_window_parity(frames_np, times, wshots, args.fps, videos[0].frame_size, r, lp, ep,
                                                    label="frames %d..%d of the long video (across the seam between two clips: a cut), streamed product vs CPU oracle flow" % (idx[0], idx[-1]))
         cpu = {"value": round(m / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port", "sample": "the same %d-frame window, whole flow" % m}
-    if world == 1 and args.cluster_check_frames > 0 and len(res["face_T"]):
-        cluster_check = oracle_cluster_check(pipe, res, args.cluster_check_frames / args.fps)
+    if world == 1 and args.cluster_check_frames != 0 and len(res["face_T"]):
+        cluster_check = oracle_cluster_check(pipe, res, args.cluster_check_frames / args.fps if args.cluster_check_frames > 0 else float("inf"))
     peak_frames = res.get("peak_frames_resident")
     idents = set(tr["ident"] for v in videos for shot in v.tracks for tr in shot)       # identity k looks the same in every clip
     out = {"metric": "frames/sec end-to-end detect->embed->cluster, one long 1080p@25fps video in frame ranges (BASELINE.json configs[2])",

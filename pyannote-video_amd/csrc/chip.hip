@@ -85,34 +85,41 @@ ChipJob chip_plan(const Frame& f, const ChipDetails& d)
 struct DevPyrJob { const uint8_t* src; int stride_w, x0, y0; uint8_t* dst; int dh, dw; };
 struct DevXfJob { const uint8_t* src; int stride_w, x0, y0, sw, sh; double m[4], b[2]; };
 
-// pyramid_down<2>: separable 1-4-6-4-1 in integers, /256 truncating (exact)
+// pyramid_down<2>: separable 1-4-6-4-1 in integers, /256 truncating (exact: every partial sum is an integer below 2^16, any order
+// of the additions gives the same value).  A block of 256 threads makes a tile of 32 x 8 output pixels of one job: first the
+// HORIZONTAL sums of the 19 source rows the tile needs (19 x 32 x 3 integers, parked in LDS; a sum's five source pixels are 15
+// consecutive bytes = four unaligned dwords at +0, +4, +8, +11), then every thread adds five of them for its output pixel.
+// Round 4 had every output pixel read its 5 x 5 source pixels itself, byte by byte: 75 loads per pixel; now 9.5 dword loads.
+#define PD_TW 32
+#define PD_TH 8
 __global__ void __launch_bounds__(256) pyr_down2_k(const DevPyrJob* __restrict__ jobs)
 {
+    __shared__ uint16_t hs[2 * PD_TH + 3][PD_TW][4];            // horizontal sums (<= 16 x 255): [source row][output column][channel]
     const DevPyrJob j = jobs[blockIdx.z];
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (j.dst == nullptr || r >= j.dh || c >= j.dw) return;
-    const int k[5] = {1, 4, 6, 4, 1};
-    int acc[3] = {0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        // the five pixels of a source row are 15 consecutive bytes: four (unaligned) dwords at +0, +4, +8 and +11 cover exactly them
-        // (round 4 read them as 15 byte loads: 75 per output pixel)
-        const uint8_t* p = j.src + ((size_t)(j.y0 + 2 * r + i) * j.stride_w + (j.x0 + 2 * c)) * 3;
+    const int c0 = blockIdx.x * PD_TW, r0 = blockIdx.y * PD_TH;
+    if (j.dst == nullptr || r0 >= j.dh || c0 >= j.dw) return;   // block-uniform
+    const int tid = threadIdx.x;
+    const int rows_in = min(2 * PD_TH + 3, 2 * (j.dh - r0) + 3);     // source rows 2 r0 .. 2 r0 + rows_in - 1 exist for the output rows of this tile
+    for (int idx = tid; idx < (2 * PD_TH + 3) * PD_TW; idx += 256) {
+        const int sr = idx / PD_TW, oc = idx % PD_TW;
+        if (sr >= rows_in || c0 + oc >= j.dw) continue;
+        const uint8_t* p = j.src + ((size_t)(j.y0 + 2 * r0 + sr) * j.stride_w + (j.x0 + 2 * (c0 + oc))) * 3;
         const uint32_t d0 = *reinterpret_cast<const uint32_t*>(p), d1 = *reinterpret_cast<const uint32_t*>(p + 4);
         const uint32_t d2 = *reinterpret_cast<const uint32_t*>(p + 8), d3 = *reinterpret_cast<const uint32_t*>(p + 11);
-        const int px[5][3] = {{(int)(d0 & 0xffu), (int)((d0 >> 8) & 0xffu), (int)((d0 >> 16) & 0xffu)},
-                              {(int)(d0 >> 24), (int)(d1 & 0xffu), (int)((d1 >> 8) & 0xffu)},
-                              {(int)((d1 >> 16) & 0xffu), (int)(d1 >> 24), (int)(d2 & 0xffu)},
-                              {(int)((d2 >> 8) & 0xffu), (int)((d2 >> 16) & 0xffu), (int)(d2 >> 24)},
-                              {(int)((d3 >> 8) & 0xffu), (int)((d3 >> 16) & 0xffu), (int)(d3 >> 24)}};
-        int row[3] = {0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            row[0] += k[q] * px[q][0]; row[1] += k[q] * px[q][1]; row[2] += k[q] * px[q][2];
-        }
-        acc[0] += k[i] * row[0]; acc[1] += k[i] * row[1]; acc[2] += k[i] * row[2];
+        // pixel q, channel k = byte 3 q + k of the 15 (d3 holds bytes 11 .. 14)
+        const uint32_t h0 = (d0 & 0xffu) + 4 * (d0 >> 24) + 6 * ((d1 >> 16) & 0xffu) + 4 * ((d2 >> 8) & 0xffu) + ((d3 >> 8) & 0xffu);
+        const uint32_t h1 = ((d0 >> 8) & 0xffu) + 4 * (d1 & 0xffu) + 6 * (d1 >> 24) + 4 * ((d2 >> 16) & 0xffu) + ((d3 >> 16) & 0xffu);
+        const uint32_t h2 = ((d0 >> 16) & 0xffu) + 4 * ((d1 >> 8) & 0xffu) + 6 * (d2 & 0xffu) + 4 * (d2 >> 24) + (d3 >> 24);
+        *reinterpret_cast<uint2*>(&hs[sr][oc][0]) = make_uint2(h0 | (h1 << 16), h2);
     }
+    __syncthreads();
+    const int c = c0 + (tid & (PD_TW - 1)), rl = tid >> 5, r = r0 + rl;
+    if (r >= j.dh || c >= j.dw) return;
+    const int oc = tid & (PD_TW - 1);
+    uint32_t acc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        acc[k] = hs[2 * rl][oc][k] + 4u * hs[2 * rl + 1][oc][k] + 6u * hs[2 * rl + 2][oc][k] + 4u * hs[2 * rl + 3][oc][k] + hs[2 * rl + 4][oc][k];
     uint8_t* o = j.dst + ((size_t)r * j.dw + c) * 3;
     o[0] = (uint8_t)(acc[0] / 256); o[1] = (uint8_t)(acc[1] / 256); o[2] = (uint8_t)(acc[2] / 256);
 }
@@ -241,7 +248,7 @@ void chip_extract_batch(Ctx* c, const std::vector<ChipJob>& jobs, uint8_t* d_out
     ProfScope ps(c, "chip");
     for (int l = 0; l < max_levels; ++l) {
         if (max_h[l] <= 0 || max_w[l] <= 0) continue;
-        hipLaunchKernelGGL(pyr_down2_k, dim3((max_w[l] + 63) / 64, max_h[l], n), dim3(64), 0, c->stream,
+        hipLaunchKernelGGL(pyr_down2_k, dim3((max_w[l] + PD_TW - 1) / PD_TW, (max_h[l] + PD_TH - 1) / PD_TH, n), dim3(256), 0, c->stream,
                            reinterpret_cast<const DevPyrJob*>(c->s_chip.as<uint8_t>() + (size_t)l * n * sizeof(DevPyrJob)));
     }
     hipLaunchKernelGGL(transform_k, dim3((cols + 63) / 64, rows, n), dim3(64), 0, c->stream,

@@ -55,3 +55,47 @@ def test_hip_reproduces_golden(gold, ctx):
     labels, _ = ctx.cluster_tracks(gold["clu_X"], gold["clu_row_start"], 0.6)
     assert np.array_equal(labels, gold["clu_labels"])
     assert np.allclose(ctx.pair_mean_dist(gold["clu_X"], gold["clu_row_start"]), gold["clu_D"], rtol=1e-12, atol=1e-13)
+
+
+def test_whole_clip_fixtures_are_the_oracles_output_on_sampled_frames(oracle):
+    """tests/golden/c2_full.npz / c4_clip0.npz (oracle/golden.py; the GPU tests and bench.py compare the product with them over ALL frames)
+    re-derived from the oracle on a few frames here: the detector's raw candidates of the frame, and the 68 points + descriptor of the
+    frame's first face row.  Pins the fixture files to the oracle sources of this tree (a changed oracle without a regenerated fixture
+    fails here, on CPU)."""
+    import os, sys, tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import golden
+    from pyannote_video_amd import synth, models
+    lp, ep = models.ensure_synthetic_models(os.path.join(tempfile.gettempdir(), "pvface_models_golden"), small=False)
+    det = oracle.Detector(models.load_container(models.DEFAULT_DETECTOR))
+    sp = oracle.ShapePredictor(models.load_model_file(lp, "shape_predictor"))
+    emb = oracle.Embedder(models.load_model_file(ep, "embedder"))
+    checked = 0
+    for name, picks in (("c2_full", (0, 613)), ("c4_clip0", (124,))):
+        if not golden.available(name):
+            continue
+        g = golden.load(name)
+        v = synth.SyntheticVideo(**golden.CLIPS[name])
+        assert list(g["video"][:5]) == [v.size[0], v.size[1], v.n_frames, v.n_shots, v.faces]
+        assert len(g["raw_counts"]) == v.n_frames and int(g["raw_counts"].sum()) == len(g["raw_rows"])
+        tracks = golden.tracks_of(g)
+        assert sum(len(t) for t in tracks) == len(g["track_rows"])
+        w, h = v.frame_size
+        for i in picks:
+            f = v.frame(i)
+            raw = det.detect_raw(f, 1)
+            sc = np.array([d[0] for d in raw], np.float32)
+            rows = golden.raw_key([d[2] for d in raw], [d[1] for d in raw], [d[3] for d in raw], [d[4] for d in raw], sc.view(np.int32))
+            assert golden.raw_digest(rows) == g["raw_digest"][i], (name, i)
+            k = int(np.nonzero(g["face_frame"] == i)[0][0])                  # first face row of the frame
+            ident = int(g["face_id"][k])
+            row = [r for r in g["track_rows"].tolist() if r[0] == i and r[1] == ident][0]
+            # the box extract() hands to the landmark model: the track file's 3-decimal float32 value times the frame size, truncated
+            box = tuple(int(float(np.float32("%.3f" % (c / s))) * s) for c, s in zip(row[2:6], (w, h, w, h)))
+            pts = sp(f, box)
+            assert np.array_equal(pts, g["landmarks"][k].astype(np.int32)), (name, i)
+            assert np.array_equal(emb(f, pts).view(np.uint32), g["embeddings"][k].view(np.uint32)), (name, i)
+            checked += 1
+    if not checked:
+        import pytest
+        pytest.skip("no whole-clip fixture in tests/golden")
