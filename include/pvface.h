@@ -194,6 +194,35 @@ int32_t pvf_pair_mean_dist(pvf_handle ctx, const double* X, int32_t N, int32_t d
  * (BASELINE.json north_star's wording; 128-D rows).  pvf_cluster_dist agglomerates either matrix. */
 int32_t pvf_pair_mean_dist_metric(pvf_handle ctx, const double* X, int32_t N, int32_t dim, const int32_t* row_start,
                                   int32_t T, int32_t metric, double* D);
+/* ---- the host state machine of one shot, array in / array out (csrc/shotgraph.hip) ----------------------------------------------
+ * ref: pyannote/video/tracking.py:184-259 (_track: one pass over a shot), :261-357 (_fix, _fill_gaps, components, (min_t, max_t) sort);
+ *      scripts/pyannote-face.py:125-127,142-145,262-266 (the track file's numbers).  No device work: pure host code, callable without a
+ *      context.  A pass ("lane") is resumable: the trackers' starts and first updates are issued ahead in bulk (the plan, fed by the
+ *      caller), and the lane only comes back for trackers that outlive their first update.
+ * direction / node kinds: 1 forward, 2 detection, 3 backward (the reference's status order). */
+int32_t pvf_lane_create(int32_t n_frames, const int32_t* det_counts /* per shot frame */, const double* det_boxes /* [sum][4], frame after frame */,
+                        int32_t direction, double min_confidence, double min_overlap_ratio, int32_t deferring, pvf_handle* lane);
+int32_t pvf_lane_destroy(pvf_handle lane);
+/* plan of the PROCESSING frames [p0, p0 + n_p) (backward pass: frame n - 1 - p): has_update[n_p]; for the detections of those frames in
+ * processing order the tracker handle and its first update's confidence + position (ignored where has_update is 0) */
+int32_t pvf_lane_feed_plan(pvf_handle lane, int32_t p0, int32_t n_p, const uint8_t* has_update, const uint64_t* handles, const double* psr,
+                           const double* pos);
+/* run until the pass ends or needs the caller: *request 0 done, 1 update (reply_psr / reply_pos [n][4] with the NEXT call), 2 commit,
+ * 3 plan wanted from processing frame *plan_from; req_handles / req_frames (shot frame indices) name the trackers of requests 1 and 2 */
+int32_t pvf_lane_advance(pvf_handle lane, const double* reply_psr, const double* reply_pos, int32_t n_reply, int32_t* request,
+                         uint64_t* req_handles, int32_t* req_frames, int32_t cap, int32_t* n_req, int32_t* plan_from);
+int32_t pvf_lane_take_dead(pvf_handle lane, uint64_t* out, int32_t cap, int32_t* n);      /* killed trackers, to be released by the caller */
+int32_t pvf_lane_edges(pvf_handle lane, int32_t* n_edges, int32_t* u_frame_kind, double* u_box, int32_t* v_frame_kind, double* v_box,
+                       double* conf, int32_t cap);                                         /* add_edge calls of the pass, in order */
+/* tracks of the shot from its two finished passes: rows [cap][6] = (frame, l, t, r, b, status code: forwards | detections << 8 |
+ * backwards << 16 | error << 24); track k = rows track_start[k] .. track_start[k + 1]; counts beyond the caps: nothing written */
+int32_t pvf_shot_tracks(pvf_handle lane_forward, pvf_handle lane_backward, const double* times, int32_t n_frames, double max_gap,
+                        int32_t* rows, int32_t cap, int32_t* n_rows, int32_t* track_start, int32_t track_cap, int32_t* n_tracks);
+/* file_box = float64(float32(round(box / detection size, 3))), pixel_box = int(file_box * frame size): what `track` writes and `extract` reads */
+int32_t pvf_track_rows(const int32_t* boxes, int64_t n, int32_t det_width, int32_t det_height, int32_t width, int32_t height,
+                       double* file_box, int32_t* pixel_box);
+int32_t pvf_round_decimals(const double* in, int64_t n, int32_t decimals, double* out);    /* Python's round(float, decimals), array form */
+
 /* ref: clustering.py:116-119,138-148  FaceClustering(threshold)(starting_point, features): average-linkage HAC from the
  * track partition, stop when the closest pair's mean distance exceeds `threshold`;
  * labels[t] = smallest track index of t's cluster; merge_log optional [(T-1)*4] = (a, b, dist, new_size) */

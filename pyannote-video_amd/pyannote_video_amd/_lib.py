@@ -76,6 +76,15 @@ _SIGS = {
     "pvf_pair_mean_dist_metric": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P]),
     "pvf_pair_mean_dist_rows": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P]),
     "pvf_pair_upper_rows": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, C.c_int32, P]),
+    "pvf_lane_create": (C.c_int32, [C.c_int32, P, P, C.c_int32, C.c_double, C.c_double, C.c_int32, P]),
+    "pvf_lane_destroy": (C.c_int32, [H]),
+    "pvf_lane_feed_plan": (C.c_int32, [H, C.c_int32, C.c_int32, P, P, P, P]),
+    "pvf_lane_advance": (C.c_int32, [H, P, P, C.c_int32, P, P, P, C.c_int32, P, P]),
+    "pvf_lane_take_dead": (C.c_int32, [H, P, C.c_int32, P]),
+    "pvf_lane_edges": (C.c_int32, [H, P, P, P, P, P, P, C.c_int32]),
+    "pvf_shot_tracks": (C.c_int32, [H, H, P, C.c_int32, C.c_double, P, C.c_int32, P, P, C.c_int32, P]),
+    "pvf_track_rows": (C.c_int32, [P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
+    "pvf_round_decimals": (C.c_int32, [P, C.c_int64, C.c_int32, P]),
     "pvf_cluster_dist": (C.c_int32, [H, P, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_cluster_tracks": (C.c_int32, [H, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
     "pvf_cluster_upper": (C.c_int32, [H, P, C.c_int32, P, C.c_int32, C.c_double, P, P, P]),
@@ -182,6 +191,27 @@ def associate(trackers, detections, ratio):
         k += 4
     check(lib().pvf_associate(a, na, b, nb, float(ratio), out))
     return [(t, d) for t, d in enumerate(out[:na]) if d >= 0]
+
+
+def round_decimals(x, decimals):
+    """round(float(v), decimals) for every v of an array (Python's round: the correctly rounded decimal, ties decided on the exact binary
+    value) -- pvf_round_decimals"""
+    x = np.ascontiguousarray(x, np.float64)
+    out = np.empty_like(x)
+    if x.size:
+        check(lib().pvf_round_decimals(ptr(x), x.size, int(decimals), ptr(out)))
+    return out
+
+
+def track_rows(boxes, det_width, det_height, width, height):
+    """integer boxes [n, 4] of track rows -> (file_box float64 [n, 4] = float32('%.3f' % (box / detection size)), pixel_box int32 [n, 4] =
+    int(file_box * frame size)): what `pyannote-face track` writes and `extract` rebuilds (pvf_track_rows)"""
+    b = np.ascontiguousarray(boxes, np.int32).reshape(-1, 4)
+    fb = np.empty(b.shape, np.float64)
+    pb = np.empty(b.shape, np.int32)
+    if len(b):
+        check(lib().pvf_track_rows(ptr(b), len(b), int(det_width), int(det_height), int(width), int(height), ptr(fb), ptr(pb)))
+    return fb, pb
 
 
 def format_rows(t, identifier, values, decimals=5):

@@ -125,6 +125,41 @@ class ExtractStream(object):
         """GPU part: landmarks + embeddings of one batch of faces returned by prepare(); batches must arrive in order"""
         compute_many(self.ctx, [(self, work)])
 
+    def prepare_rows(self, tracks, shot_times, rows, starts, det_size):
+        """prepare() for a shot whose tracks came from the library as arrays (tracking_by_detection.shot_tracks_native: rows = frame,
+        l, t, r, b, status code; track k = rows starts[k] .. starts[k + 1]): the same track-file rows and timestamp groups, their numbers
+        made by the library in two calls (pvf_round_decimals, pvf_track_rows) instead of 9 Python operations per row"""
+        from .tracking_by_detection import status_of
+        from . import _lib
+        base = len(self.tracks)
+        m = len(rows)
+        Tq = _lib.round_decimals(np.asarray(shot_times, np.float64)[rows[:, 0]], 3) if m else np.zeros(0)
+        q32, pix = _lib.track_rows(rows[:, 1:5], det_size[0], det_size[1], self.w, self.h)
+        ids = (base + np.repeat(np.arange(len(starts) - 1), np.diff(starts))).tolist()
+        Tl = Tq.tolist()
+        boxes = [tuple(b) for b in q32.tolist()]
+        status = [status_of(c) for c in rows[:, 5].tolist()]
+        self.file_T.extend(Tl)
+        self.file_id.extend(ids)
+        self.rows_file.extend(zip(Tl, ids, boxes, status))
+        self.tracks.extend(tracks)
+        order = np.argsort(Tq, kind="stable").tolist()
+        pl = [tuple(b) for b in pix.tolist()]
+        groups = self.groups
+        k = 0
+        while k < m:
+            T = Tl[order[k]]
+            g = []
+            while k < m and Tl[order[k]] == T:
+                i = order[k]
+                g.append((ids[i], pl[i]))
+                k += 1
+            if groups and groups[-1][0] == T:
+                groups[-1][1].extend(g)           # cannot happen for disjoint shots; keeps the grouping rule exact anyway
+            else:
+                groups.append((T, g))
+        return self._emit(len(self.groups) - 1)
+
     def prepare(self, tracks):
         """host part for the normalised tracks of the next shot (in shot order): the track-file rows, their timestamp groups,
         and the faces that can be extracted now"""
@@ -227,6 +262,16 @@ def compute_many(ctx, items):
         a += m
 
 
+def detection_arrays_of(n_frames, raw):
+    """(counts int32 [n_frames], boxes float64 [sum, 4]) from the arrays of Context.detect_many(arrays=True): what the library's passes take"""
+    counts = np.zeros(n_frames, np.int32)
+    if raw is None:
+        return counts, np.zeros((0, 4), np.float64)
+    out, cnt, idx = raw
+    counts[idx] = cnt
+    return counts, out[np.arange(out.shape[1])[None, :] < np.asarray(cnt)[:, None]].astype(np.float64)
+
+
 def detections_as_lists(n_frames, raw):
     """[[(l, t, r, b) Python ints]] per frame from the arrays of Context.detect_many(arrays=True): raw = (boxes, counts, frame indices)"""
     dets = [[] for _ in range(n_frames)]
@@ -307,9 +352,19 @@ class VideoJob(object):
                 self.store.add(si.base + j, f, si.owned or getattr(f, "transient", False))
             self.times.extend(t for t, _ in si.cache)
 
-    def shot_tracked(self, si, tracks, normalize):
-        """host thread: the shot's tracks exist.  Returns the extraction work of the faces that may be computed now (or None)."""
-        norm = [normalize(tr, self.tw, self.th) for tr in tracks]
+    def shot_tracked(self, si, tracks, normalize, native=None):
+        """host thread: the shot's tracks exist.  Returns the extraction work of the faces that may be computed now (or None).
+        native: (rows, track_start) when the tracks came from the library as arrays (the same tracks; their numbers are then made there)"""
+        if native is not None:
+            rows, starts = native
+            # == normalize(): box / detection size in float64 (one array division instead of four per row)
+            nb = (rows[:, 1:5].astype(np.float64) / np.array([self.tw, self.th, self.tw, self.th], np.float64)).tolist()
+            norm, i = [], 0
+            for tr in tracks:
+                norm.append([(t, tuple(nb[i + j]), st) for j, (t, _, st) in enumerate(tr)])
+                i += len(tr)
+        else:
+            norm = [normalize(tr, self.tw, self.th) for tr in tracks]
         if self.on_tracks is not None:
             self.on_tracks(norm)
         self.t_tracked = _time.perf_counter()
@@ -318,6 +373,8 @@ class VideoJob(object):
             if self.streaming:
                 self.store.release_below(si.base + len(si.cache))
             return None
+        if native is not None:
+            return self.ex.prepare_rows(norm, [t for t, _ in si.cache], native[0], native[1], (self.tw, self.th))
         return self.ex.prepare(norm)
 
 
@@ -441,7 +498,8 @@ class WindowedPlan(object):
             self._advance()
         return self.cur.pop(t)
 
-    def _advance(self):
+    def _window(self):
+        """the next window's frames [lo, hi) and its trackers' arrays (None: no detection in it)"""
         lo, hi, n = self.hi, self.hi, len(self.counts)
         total = 0
         while hi < n and (hi == lo or total + self.counts[hi] <= self.window):
@@ -450,10 +508,30 @@ class WindowedPlan(object):
         self.hi = hi
         self.windows += 1
         if total == 0:
-            return
+            return lo, hi, None
         k0, k1 = int(self.starts[lo]), int(self.starts[hi])
         owner = np.repeat(np.arange(lo, hi), self.counts[lo:hi])
-        hs, psr, pos = self.backend.speculate_window(self.fh, owner, self.boxes[k0:k1], n)
+        return lo, hi, self.backend.speculate_window(self.fh, owner, self.boxes[k0:k1], n)
+
+    def native_feed(self, lane, p):
+        """a pass run by the library (tracking_by_detection.NativeLane) asks for the plan from processing frame p on: the next window"""
+        assert p >= self.hi, (p, self.hi)
+        n = len(self.counts)
+        while self.hi <= p:                                  # (windows of frames without a detection are never asked for: passed over here)
+            lo, hi, arrays = self._window()
+            has = np.arange(lo, hi) != n - 1
+            if arrays is None:
+                lane.feed(lo, has, np.zeros(0, np.uint64), np.zeros(0), np.zeros((0, 4)))
+            else:
+                lane.feed(lo, has, arrays[0], arrays[1], arrays[2])
+
+    def _advance(self):
+        lo, hi, arrays = self._window()
+        n = len(self.counts)
+        if arrays is None:
+            return
+        k0 = int(self.starts[lo])
+        hs, psr, pos = arrays
         hl = hs.tolist()
         for i in range(lo, hi):
             m = int(self.counts[i])
@@ -602,12 +680,11 @@ class Engine(object):
             raw, counts, boxes = self._detect(si)
             si.job.accept(si)
             plans = self._speculate(si, backend, backend, raw, counts, boxes)
-            dets = detections_as_lists(len(si.cache), raw)
-            jb = self.tracking.begin_shot(si.cache, si.flags, dets, backend, plans)
+            jb = self.tracking.begin_shot(si.cache, si.flags, None, backend, plans, det_arrays=detection_arrays_of(len(si.cache), raw))
             self.tracking._run_lanes(jb["lanes"], backend)
             tracks = self.tracking.finish_shot(jb)
             self._release_detection_frames(si)
-            work = si.job.shot_tracked(si, tracks, self.tracking._normalize_track)
+            work = si.job.shot_tracked(si, tracks, self.tracking._normalize_track, (jb["rows"], jb["track_start"]) if "rows" in jb else None)
             if work is not None:
                 si.job.ex.compute(work)
                 si.job.store.release_below(work[2])
@@ -875,14 +952,15 @@ class Engine(object):
                     if si.job not in seen_jobs:
                         seen_jobs.append(si.job)
                     si.job.accept(si)
-                    jbs.append(self.tracking.begin_shot(si.cache, si.flags, detections_as_lists(len(si.cache), raw), lane_backend, plans))
+                    jbs.append(self.tracking.begin_shot(si.cache, si.flags, None, lane_backend, plans, det_arrays=detection_arrays_of(len(si.cache), raw)))
                 self.tracking._run_lanes([lane for jb in jbs for lane in jb["lanes"]], lane_backend)
                 note("lanes done", k)
                 for (si, _, _), jb in zip(members, jbs):
                     tracks = self.tracking.finish_shot(jb)
                     note("tracked", k)
                     self._release_detection_frames(si)
-                    done.put(("work", si.job, si.job.shot_tracked(si, tracks, self.tracking._normalize_track)))
+                    native = (jb["rows"], jb["track_start"]) if "rows" in jb else None
+                    done.put(("work", si.job, si.job.shot_tracked(si, tracks, self.tracking._normalize_track, native)))
                     note("prepared", k)
                     k += 1
             ok = True

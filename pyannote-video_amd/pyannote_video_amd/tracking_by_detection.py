@@ -211,6 +211,17 @@ class ArrayPlan(object):
         self.times, self.counts, self.starts, self.hs, self.psr, self.pos, self.edge = times, counts, starts, handles, psr, pos, edge
         self._index = self._hl = None
 
+    def native_feed(self, lane, p):
+        """the whole plan in the lane's processing order (forward: as stored; backward: the frames reversed, a frame's trackers in place)"""
+        n = len(self.counts)
+        if lane.direction == BACKWARD:
+            starts = self.starts
+            idx = np.concatenate([np.arange(starts[i], starts[i + 1]) for i in range(n - 1, -1, -1)]) if len(self.hs) else np.zeros(0, np.int64)
+            has = np.arange(n - 1, -1, -1) != self.edge
+            lane.feed(0, has, self.hs[idx], self.psr[idx], self.pos[idx])
+        else:
+            lane.feed(0, np.arange(n) != self.edge, self.hs, self.psr, self.pos)
+
     def __getitem__(self, t):
         if self._index is None:
             self._index = {t: i for i, t in enumerate(self.times)}
@@ -223,6 +234,124 @@ class ArrayPlan(object):
         if i == self.edge:
             return self._hl[k:k + m], None, None
         return self._hl[k:k + m], self.psr[k:k + m], self.pos[k:k + m]
+
+
+_KIND = {FORWARD: 1, DETECTION: 2, BACKWARD: 3}
+_KIND_NAME = {1: FORWARD, 2: DETECTION, 3: BACKWARD}
+_status_cache = {}
+
+
+def status_of(code):
+    """status string of a track row from the library's code (csrc/shotgraph.hip): counts of forward / detection / backward nodes of the
+    timestamp joined in the reference's order (tracking.py:282-287), wrapped in error(...) when two of its boxes do not overlap"""
+    s = _status_cache.get(code)
+    if s is None:
+        parts = [FORWARD] * (code & 255) + [DETECTION] * ((code >> 8) & 255) + [BACKWARD] * ((code >> 16) & 255)
+        s = "+".join(parts)
+        if code >> 24:
+            s = "error({0})".format(s)
+        _status_cache[code] = s
+    return s
+
+
+def detection_arrays(dets):
+    """[[box]] per frame -> (counts int32 [n], boxes float64 [sum, 4]): what the library's lanes take"""
+    counts = np.array([len(d) for d in dets], np.int32)
+    boxes = np.array([b for d in dets for b in d], np.float64).reshape(-1, 4)
+    return counts, boxes
+
+
+class NativeLane(object):
+    """one pass over one shot run by the library (csrc/shotgraph.hip: the state machine of `_lane`, array in / array out); this object
+    feeds it the plan and serves its requests through the lane protocol of `_lane`, so the same scheduler drives both forms"""
+
+    def __init__(self, n_frames, counts, boxes, direction, min_confidence, ratio, deferring=True):
+        import ctypes as C
+        self.n = int(n_frames)
+        self.counts = np.ascontiguousarray(counts, np.int32)
+        boxes = np.ascontiguousarray(boxes, np.float64).reshape(-1, 4)
+        self.total = int(self.counts.sum())
+        self.boxes = boxes
+        self.direction = direction
+        h = C.c_uint64(0)
+        _lib.check(_lib.lib().pvf_lane_create(self.n, _lib.ptr(self.counts), _lib.ptr(boxes), _KIND[direction], float(min_confidence), float(ratio),
+                                              1 if deferring else 0, C.byref(h)))
+        self.handle = h.value
+        cap = max(self.total, 1)
+        self._req_h = np.zeros(cap, np.uint64)
+        self._req_f = np.zeros(cap, np.int32)
+        self._dead = np.zeros(max(self.total, 1), np.uint64)
+
+    def close(self):
+        if self.handle:
+            _lib.lib().pvf_lane_destroy(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def feed(self, p0, has_update, handles, psr, pos):
+        has_update = np.ascontiguousarray(has_update, np.uint8)
+        handles = np.ascontiguousarray(handles, np.uint64)
+        psr = np.ascontiguousarray(psr, np.float64)
+        pos = np.ascontiguousarray(pos, np.float64)
+        _lib.check(_lib.lib().pvf_lane_feed_plan(self.handle, int(p0), len(has_update), _lib.ptr(has_update), _lib.ptr(handles), _lib.ptr(psr), _lib.ptr(pos)))
+
+    def advance(self, reply=None):
+        """-> (request, handles uint64 [k], shot frame indices int32 [k], plan_from)"""
+        import ctypes as C
+        req, n_req, pf = C.c_int32(0), C.c_int32(0), C.c_int32(-1)
+        if reply is None:
+            rp, rb, nr = None, None, 0
+        else:
+            rp = np.ascontiguousarray(reply[0], np.float64)
+            rb = np.ascontiguousarray(reply[1], np.float64).reshape(-1, 4)
+            nr = len(rp)
+        _lib.check(_lib.lib().pvf_lane_advance(self.handle, _lib.ptr(rp) if nr else None, _lib.ptr(rb) if nr else None, nr, C.byref(req),
+                                               _lib.ptr(self._req_h), _lib.ptr(self._req_f), len(self._req_h), C.byref(n_req), C.byref(pf)))
+        k = n_req.value
+        return req.value, self._req_h[:k].copy(), self._req_f[:k].copy(), pf.value
+
+    def take_dead(self):
+        import ctypes as C
+        n = C.c_int32(0)
+        _lib.check(_lib.lib().pvf_lane_take_dead(self.handle, _lib.ptr(self._dead), len(self._dead), C.byref(n)))
+        return self._dead[:n.value].tolist()
+
+    def edges(self, times):
+        """the pass's add_edge calls as the Python form records them: [(u, v, confidence)] with nodes (t, box, status)"""
+        import ctypes as C
+        n = C.c_int32(0)
+        _lib.check(_lib.lib().pvf_lane_edges(self.handle, C.byref(n), None, None, None, None, None, 0))
+        k = n.value
+        ufk, vfk = np.zeros((k, 2), np.int32), np.zeros((k, 2), np.int32)
+        ub, vb, cf = np.zeros((k, 4), np.float64), np.zeros((k, 4), np.float64), np.zeros(k, np.float64)
+        if k:
+            _lib.check(_lib.lib().pvf_lane_edges(self.handle, C.byref(n), _lib.ptr(ufk), _lib.ptr(ub), _lib.ptr(vfk), _lib.ptr(vb), _lib.ptr(cf), k))
+
+        def node(fk, b):
+            box = tuple(int(v) for v in b) if fk[1] == 2 else tuple(b)
+            return (times[fk[0]], box, _KIND_NAME[fk[1]])
+        return [(node(ufk[i].tolist(), ub[i].tolist()), node(vfk[i].tolist(), vb[i].tolist()), float(cf[i])) for i in range(k)]
+
+
+def shot_tracks_native(lane_forward, lane_backward, times, max_gap):
+    """tracks of a shot from its two finished native passes: (rows int32 [m, 6] = frame, l, t, r, b, status code; track_start int32 [T + 1])"""
+    import ctypes as C
+    times = np.ascontiguousarray(times, np.float64)
+    cap = 2 * max(lane_forward.total, 1) + 16
+    while True:
+        rows = np.zeros((cap, 6), np.int32)
+        starts = np.zeros(cap + 1, np.int32)
+        n_rows, n_tracks = C.c_int32(0), C.c_int32(0)
+        _lib.check(_lib.lib().pvf_shot_tracks(lane_forward.handle, lane_backward.handle, _lib.ptr(times), len(times), float(max_gap), _lib.ptr(rows), cap,
+                                              C.byref(n_rows), _lib.ptr(starts), cap, C.byref(n_tracks)))
+        if n_rows.value <= cap and n_tracks.value <= cap:
+            return rows[:n_rows.value], starts[:n_tracks.value + 1]
+        cap = max(n_rows.value, n_tracks.value) + 16
 
 
 class ObjectTrackers(object):
@@ -332,6 +461,7 @@ class TrackingByDetection(object):
         self.track_min_overlap_ratio = track_min_overlap_ratio
         self.track_max_gap = track_max_gap
         self._trackers_backend = trackers
+        self.python_lanes = False          # True: the passes of planned shots run in Python too (tests compare the two forms)
 
     # ---- geometry -------------------------------------------------------------------------------------
     def _match(self, rectangle1, rectangle2):
@@ -444,6 +574,26 @@ class TrackingByDetection(object):
             if release is None:
                 yield ('release', h)
 
+    def _lane_native(self, lane, frames, backend, plan):
+        """the same pass run by the library (NativeLane): a coroutine with the protocol of `_lane` -- it only yields when a tracker
+        outlives its first update (commit / update requests) -- so LaneScheduler batches the requests of native and Python lanes alike.
+        frames: the shot's frames in FORWARD order (the library names frames by their index in the shot)."""
+        reply = None
+        release = backend.release
+        while True:
+            req, hs, fs, plan_from = lane.advance(reply)
+            reply = None
+            for h in lane.take_dead():
+                release(h)
+            if req == 0:
+                return
+            if req == 3:
+                plan.native_feed(lane, plan_from)
+            elif req == 2:
+                yield ('commit', hs.tolist(), [frames[i] for i in fs.tolist()])
+            else:
+                reply = yield ('update', hs.tolist(), [frames[i] for i in fs.tolist()])
+
     @staticmethod
     def _run_lanes(lanes, backend):
         """Advance all lane coroutines in lock-step; merge their requests into one update batch + one start batch per round."""
@@ -533,11 +683,28 @@ class TrackingByDetection(object):
                 out[i] = [tuple(d) for d in self.detect_func(cache[i][1])]
         return out
 
-    def begin_shot(self, cache, flags, dets=None, backend=None, plans=None):
+    def begin_shot(self, cache, flags, dets=None, backend=None, plans=None, det_arrays=None):
         """graph with the detections of one shot + its two lane coroutines (not started); plans = (forward, backward) results of
         HipTrackers.speculate computed ahead (backward: on the reversed cache)"""
-        if dets is None:
-            dets = self._detect_shot(cache, flags)
+        pf, pb = plans if plans is not None else (None, None)
+        native = (pf is not None and pb is not None and hasattr(pf, "native_feed") and hasattr(pb, "native_feed") and backend is not None
+                  and hasattr(backend, "commit_many") and hasattr(backend, "release") and not self.python_lanes)
+        if dets is None and not (native and det_arrays is not None):
+            if det_arrays is not None:
+                st = np.concatenate([[0], np.cumsum(det_arrays[0])]).tolist()
+                bl = np.asarray(det_arrays[1]).astype(np.int64).tolist()
+                dets = [[tuple(b) for b in bl[st[i]:st[i + 1]]] for i in range(len(cache))]
+            else:
+                dets = self._detect_shot(cache, flags)
+        if native:
+            # both passes' starts and first updates were issued ahead: the passes run in the library (csrc/shotgraph.hip), this thread
+            # only serves the trackers that outlive their first update
+            counts, boxes = det_arrays if det_arrays is not None else detection_arrays(dets)
+            frames = [f for _, f in cache]
+            lf = NativeLane(len(cache), counts, boxes, FORWARD, self.track_min_confidence, self.track_min_overlap_ratio)
+            lb = NativeLane(len(cache), counts, boxes, BACKWARD, self.track_min_confidence, self.track_min_overlap_ratio)
+            return {"times": [t for t, _ in cache], "native": (lf, lb),
+                    "lanes": [self._lane_native(lf, frames, backend, pf), self._lane_native(lb, frames, backend, pb)]}
         # the detection graph of the reference (tracking.py:426-429: a node per timestamp, an edge to each of its detections) is kept
         # as what finish_shot needs of it -- its node ORDER -- and built for real only by finish_shot_graph (2000 add_edge calls per
         # 250-frame shot cost 3 ms of the tracking thread, on the critical path of a video's last shot)
@@ -545,7 +712,6 @@ class TrackingByDetection(object):
         for (t, _), d in zip(cache, dets):
             det_at[t] = d
         ef, eb = [], []
-        pf, pb = plans if plans is not None else (None, None)
         lanes = [self._lane(cache, det_at, FORWARD, ef, backend, pf), self._lane(list(reversed(cache)), det_at, BACKWARD, eb, backend, pb)]
         return {"times": [t for t, _ in cache], "det_at": det_at, "ef": ef, "eb": eb, "lanes": lanes}
 
@@ -558,9 +724,23 @@ class TrackingByDetection(object):
                 g.add_edge(t, (t, box, DETECTION))
         return g
 
+    @staticmethod
+    def _python_view(job):
+        """a job whose passes ran in the library, in the shape the Python forms read: the detections per timestamp and the two passes'
+        add_edge calls as lists of (u, v, confidence) (tests compare the two forms through it)"""
+        if "native" in job and "ef" not in job:
+            lf, lb = job["native"]
+            times = job["times"]
+            starts = np.concatenate([[0], np.cumsum(lf.counts)]).tolist()
+            boxes = lf.boxes.astype(np.int64).tolist()          # (detector boxes are integers)
+            job["det_at"] = {t: [tuple(b) for b in boxes[starts[i]:starts[i + 1]]] for i, t in enumerate(times)}
+            job["ef"], job["eb"] = lf.edges(times), lb.edges(times)
+        return job
+
     def finish_shot_graph(self, job):
         """the reference's own data structure: replay the lanes' graph mutations in its order (forward pass, then backward) into the
         networkx graph and take the tracks from it (tracking.py:359-362)"""
+        job = self._python_view(job)
         g = self._detection_graph(job)
         for u, v, conf in job["ef"]:
             g.add_edge(u, v, confidence=conf)
@@ -574,6 +754,17 @@ class TrackingByDetection(object):
         node enters the graph with the first add_edge that names it: detections frame by frame (begin_shot), then the forward edges,
         then the backward ones.  A union-find over that same node order gives the same components in the same order; what happens to
         them afterwards (_fix, _fill_gaps, the final sort) is shared."""
+        if "native" in job:
+            lf, lb = job["native"]
+            rows, starts = shot_tracks_native(lf, lb, job["times"], self.track_max_gap)
+            job["rows"], job["track_start"] = rows, starts
+            times = job["times"]
+            rl = rows.tolist()
+            tracks = []
+            for k in range(len(starts) - 1):
+                tracks.append([(times[f], (l, tp, r, b), status_of(c)) for f, l, tp, r, b, c in rl[starts[k]:starts[k + 1]]])
+            lf.close(); lb.close()
+            return tracks
         index = {}
         parent = []
         det_at = job["det_at"]
