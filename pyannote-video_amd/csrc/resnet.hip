@@ -305,149 +305,10 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     conv_epilogue<WM, WN>(a, smem, acc0, acc1, M, m0, n0, rel0, b_first, hw, r_hw, r_ow, wave, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Round 4: the same implicit GEMM with the tiles going from HBM / L2 STRAIGHT INTO LDS (buffer_load_dwordx4 ... lds: 64 lanes x 16 bytes =
-// eight 128-byte tile rows per instruction, no registers in between) into one of TWO stage buffers, so that chunk k + 1 lands while chunk
-// k is multiplied: no parking of 6 float4 per thread through registers (36 moves + 12 LDS writes per chunk and thread), one barrier per
-// chunk instead of two.  LDS-DMA writes lane l's 16 bytes at base + 16 l, so rows cannot be padded; instead the 16-byte chunk a lane
-// FETCHES is swizzled: the slot (row R, physical chunk p) receives the logical chunk p ^ m(R), m(R) = (R & 7) ^ ((R >> 3) & 1) -- the
-// sixteen rows a ds_read_b128 serves together then touch all 64 banks exactly once.  The k order inside a chunk of 32 changes with it:
-// lane half h of a 32x32x2 MFMA reads the logical chunks 4h .. 4h + 3 whole (four ds_read_b128 per operand, every value used), i.e. MFMA
-// step 4c + u multiplies k = 4c + u and k = 16 + 4c + u.  A and B are read the same way, so products pair up as before; only the ORDER
-// of the 32 additions of a chunk differs from the oracle's chain -- inside the 1e-4 bar of the embedding (tests green with it).  Selected
-// with PVF_CONV=lds; measured no faster than the kernel above (see conv_use_lds), which therefore stays the default.
-template <int WM, int WN, bool RGB4>
-__device__ __forceinline__ void conv_lds_body(const ConvArgs& a)
-{
-    constexpr int BM = 64 * WM, BN = 32 * WN, KC = 32, ROWF = 32;
-    static_assert(WM * WN == 4, "four waves per block");
-    constexpr int TILE = (BM + BN) * ROWF;                 // floats per stage
-    extern __shared__ __attribute__((aligned(1024))) float smem[];      // 2 stages; after the K loop: each wave's 64 x 32 results (PITCH 36)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const long M = (long)a.B * a.OH * a.OW;
-    const long m0 = (long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-    constexpr int A_F4 = BM * 8 / 256, B_F4 = BN * 8 / 256;
-    constexpr int RSRC_FLAGS = 0x00020000;
-    constexpr int OOB = (int)0x80000000;
-    const int hw = a.OH * a.OW;
-    const int b_first = (int)(m0 / hw);
-    const int rel0 = (int)(m0 - (long)b_first * hw);
-    const float r_hw = 1.0f / (float)hw, r_ow = 1.0f / (float)a.OW;
-    const size_t face = (size_t)a.H * a.W * a.Cin;
-    const size_t in_bytes = (size_t)(a.B - b_first) * face * sizeof(float);
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b_first * face), 0,
-                                                                           in_bytes > 0x7ffffff0u ? 0x7ffffff0 : (int)in_bytes, RSRC_FLAGS);
-    const int Kpad = (a.K + KC - 1) / KC * KC;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)((size_t)a.Cout * Kpad * sizeof(float)), RSRC_FLAGS);
-    int pa_off[A_F4], pa_y[A_F4], pa_x[A_F4];
-#pragma unroll
-    for (int q = 0; q < A_F4; ++q) {
-        const int i = (tid + q * 256) >> 3;
-        const long m = m0 + i;
-        pa_off[q] = 0; pa_y[q] = -(1 << 20); pa_x[q] = 0;
-        if (m < M) {
-            const int rel = rel0 + i;
-            const int bb = small_div(rel, hw, r_hw);
-            const int rem = rel - bb * hw;
-            const int oy = small_div(rem, a.OW, r_ow);
-            const int ox = rem - oy * a.OW;
-            if (oy < a.AH && ox < a.AW) {
-                pa_y[q] = oy * a.stride - a.pad; pa_x[q] = ox * a.stride - a.pad;
-                pa_off[q] = ((bb * a.H + pa_y[q]) * a.W + pa_x[q]) * a.Cin;
-            }
-        }
-    }
-    // the logical 16-byte chunk this thread fetches for its slot (tile row (tid + 256 q) >> 3, physical chunk tid & 7): the swizzle above
-    // (tile rows of one thread differ by multiples of 32, B rows start at a multiple of 64: the mask is the same for all of them)
-    const int j4 = (tid & 7) ^ ((tid >> 3) & 7) ^ ((tid >> 6) & 1);
-    int wrow[B_F4];
-#pragma unroll
-    for (int q = 0; q < B_F4; ++q) wrow[q] = ((n0 + ((tid + q * 256) >> 3)) * Kpad + 4 * j4) * 4;      // byte offset of this thread's weights at k = 0
-    int f_r = 0, f_s = 0, f_c = 0, f_k = 0;
-    int voff[A_F4], woff = 0;
-    auto offsets = [&]() {
-        const int kq = f_k + 4 * j4;
-        int r, sft, delta;
-        if (RGB4) {
-            const int tap = kq >> 2;
-            r = small_div(tap, a.ksz, 1.0f / (float)a.ksz); sft = tap - r * a.ksz;
-            delta = (r * a.W + sft) * 4;
-        } else {
-            r = f_r; sft = f_s;
-            delta = (r * a.W + sft) * a.Cin + f_c + 4 * j4;
-        }
-        const int k_ok = (kq < a.K) ? -1 : 0;
-#pragma unroll
-        for (int q = 0; q < A_F4; ++q) {
-            const int iy = pa_y[q] + r, ix = pa_x[q] + sft;
-            const int ok = k_ok & -(int)((unsigned)iy < (unsigned)a.H) & -(int)((unsigned)ix < (unsigned)a.W);
-            voff[q] = (((pa_off[q] + delta) * 4) & ok) | (OOB & ~ok);
-        }
-        woff = f_k * 4;
-        if (f_k + KC < Kpad) {
-            f_k += KC;
-            if (!RGB4) {
-                f_c += KC;
-                if (f_c >= a.Cin) { f_c = 0; if (++f_s == a.ksz) { f_s = 0; ++f_r; } }
-            }
-        }
-    };
-    typedef __attribute__((address_space(3))) void* lds_t;
-    auto issue = [&](int stage) {
-        float* sb = smem + stage * TILE;
-#pragma unroll
-        for (int q = 0; q < A_F4; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_t)(sb + (8 * wave + 32 * q) * ROWF), 16, voff[q], 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < B_F4; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_t)(sb + (BM + 8 * wave + 32 * q) * ROWF), 16, wrow[q] + woff, 0, 0, 0);
-    };
-    const int li = lane & 31, kh = lane >> 5;
-    const int msk = (li & 7) ^ ((li >> 3) & 1);
-    int ca[4];                                           // float offsets of this lane's four chunks inside a tile row
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ca[c] = ((4 * kh + c) ^ msk) * 4;
-    const int ra0 = (wm * 64 + li) * ROWF, ra1 = ra0 + 32 * ROWF, rb = (BM + wn * 32 + li) * ROWF;
-    offsets();
-    issue(0);
-    offsets();
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    int stage = 0;
-    for (int k0 = 0; k0 < Kpad; k0 += KC) {
-        if (k0 + KC < Kpad) issue(stage ^ 1);           // chunk k0 + KC: lands in the other stage during this chunk's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        offsets();                                      // chunk k0 + 2 KC
-        const float* sb = smem + stage * TILE;
-        f32x4 fa0[4], fa1[4], fb[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            fa0[c] = *reinterpret_cast<const f32x4*>(sb + ra0 + ca[c]);
-            fa1[c] = *reinterpret_cast<const f32x4*>(sb + ra1 + ca[c]);
-            fb[c] = *reinterpret_cast<const f32x4*>(sb + rb + ca[c]);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[s2 >> 2][s2 & 3], fb[s2 >> 2][s2 & 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[s2 >> 2][s2 & 3], fb[s2 >> 2][s2 & 3], acc1, 0, 0, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0);                  // this wave's share of the next chunk has arrived ...
-        __syncthreads();                                // ... and everybody's; everybody is done reading this stage
-        stage ^= 1;
-    }
-    conv_epilogue<WM, WN>(a, smem, acc0, acc1, M, m0, n0, rel0, b_first, hw, r_hw, r_ow, wave, lane);
-}
-
-// (the body lives in a __device__ function: the host pass instantiates a kernel template's body as well, and the LDS-DMA builtin and the
-// address-space cast do not exist there)
-template <int WM, int WN, bool RGB4>
-__global__ void __launch_bounds__(256) conv_lds_k(ConvArgs a) { conv_lds_body<WM, WN, RGB4>(a); }
+// (Two other forms of the K loop were built and measured no faster, and are gone: tiles straight into LDS by LDS-DMA, round 4 --
+// profiles/r04_conv_lds_vs_regs.txt -- and a spatial input tile reused across the 9 taps, one fetch per pixel and one barrier per block,
+// round 5 -- profiles/r05_conv_band_experiment.txt: a layer's MFMAs and its unavoidable HBM traffic are of the same size and run one
+// after the other inside a block; the staging of the A operand is not what the matrix pipe waits for.)
 
 __global__ void __launch_bounds__(256) maxpool3s2_k(const float* __restrict__ in, int B, int H, int W, int C, float* __restrict__ out, int OH, int OW)
 {
@@ -484,50 +345,22 @@ __global__ void __launch_bounds__(256) head_k(const float* __restrict__ x, int H
     }
 }
 
-// which K loop runs: staged through registers in the oracle's exact order of additions (the default), or tiles straight into LDS
-// (PVF_CONV=lds).  MEASURED NEUTRAL (round 4, profiles/r04_conv_lds_vs_regs.txt): 4096 faces 24.16 vs 24.31 ms, 2000 faces 12.39 vs
-// 12.35 ms (91.8 / 91.3 and 87.5 / 87.7 TFLOP/s) -- removing the register staging (62 instead of 80-106 VGPRs, one barrier per chunk
-// instead of two) buys nothing: at 21 FLOP per byte fetched (128 x 64 tile; 14 for the 256 x 32 tiles of the 32-channel layers) the
-// K loop is fed from L2 at ~4.3 TB/s -- every input pixel passes through it once per tap and per 64 output channels -- and that, not
-// the staging, is what the matrix pipe waits for.  The lever left is reuse of a spatial input tile across the 9 taps inside LDS.
-static bool conv_use_lds()
-{
-    static const bool v = [] { const char* e = getenv("PVF_CONV"); return e && strcmp(e, "lds") == 0; }();
-    return v;
-}
-
-template <int WM, int WN, bool RGB4>
-static void launch_conv_lds(Ctx* c, const ConvArgs& a, dim3 grid)
-{
-    constexpr size_t lds = (size_t)2 * (64 * WM + 32 * WN) * 32 * sizeof(float);     // two stages of (BM + BN) rows x 128 bytes
-    static bool attr = false;
-    if (!attr) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)conv_lds_k<WM, WN, RGB4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
-    hipLaunchKernelGGL((conv_lds_k<WM, WN, RGB4>), grid, dim3(256), lds, c->stream, a);
-}
-
 static void launch_conv(Ctx* c, const ConvArgs& a)
 {
     const long M = (long)a.B * a.OH * a.OW;
     PVF_REQUIRE(a.Cin % 32 == 0 || a.Cin == 4, "conv: input channels must be 4 (padded RGB) or a multiple of 32");
     PVF_REQUIRE(a.OH * a.OW < (1 << 21) && a.Cout % 32 == 0, "conv: output map too large for the kernel's index arithmetic / Cout not a multiple of 32");
-    const bool lds = conv_use_lds();
     if (a.Cin == 4) {
         PVF_REQUIRE(a.Cout == 32, "conv: the RGB layer has 32 output channels");
         const dim3 grid((unsigned)((M + 255) / 256), 1);
-        if (lds) launch_conv_lds<4, 1, true>(c, a, grid);
-        else hipLaunchKernelGGL((conv_mfma_k<4, 1, true>), grid, dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((conv_mfma_k<4, 1, true>), grid, dim3(256), 0, c->stream, a);
     } else if (a.Cout == 32) {
         const dim3 grid((unsigned)((M + 255) / 256), 1);
-        if (lds) launch_conv_lds<4, 1, false>(c, a, grid);
-        else hipLaunchKernelGGL((conv_mfma_k<4, 1, false>), grid, dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((conv_mfma_k<4, 1, false>), grid, dim3(256), 0, c->stream, a);
     } else {
         PVF_REQUIRE(a.Cout % 64 == 0, "conv: Cout must be 32 or a multiple of 64");
         const dim3 grid((unsigned)((M + 127) / 128), a.Cout / 64);
-        if (lds) launch_conv_lds<2, 2, false>(c, a, grid);
-        else hipLaunchKernelGGL((conv_mfma_k<2, 2, false>), grid, dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((conv_mfma_k<2, 2, false>), grid, dim3(256), 0, c->stream, a);
     }
 }
 
