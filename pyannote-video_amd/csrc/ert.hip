@@ -72,8 +72,18 @@ __global__ void __launch_bounds__(256) ert_k(const ErtJob* __restrict__ jobs, in
         for (int k = tid; k < P2; k += blockDim.x) {
             float acc = cur[k];
             const float* lb = leaves + (size_t)it * n_trees * n_leaf * P2 + k;
-#pragma unroll 4
-            for (int t = 0; t < n_trees; ++t) acc = acc + lb[((size_t)t * n_leaf + leaf[t]) * P2];
+            // the sum is a chain in tree order (the oracle's), but its 500 operands are independent loads out of a 65 MB table (L2 / MALL):
+            // twenty of them are in flight per lane before the first is added (round 4: four -- the loop waited for memory latency 125
+            // times per cascade and face: 9.4 ms per 8000 faces)
+            int t = 0;
+            for (; t + 20 <= n_trees; t += 20) {
+                float v[20];
+#pragma unroll
+                for (int j = 0; j < 20; ++j) v[j] = lb[((size_t)(t + j) * n_leaf + leaf[t + j]) * P2];
+#pragma unroll
+                for (int j = 0; j < 20; ++j) acc = acc + v[j];
+            }
+            for (; t < n_trees; ++t) acc = acc + lb[((size_t)t * n_leaf + leaf[t]) * P2];
             cur[k] = acc;
         }
     }
