@@ -722,14 +722,52 @@ __global__ void __launch_bounds__(128) scale_fft_k(const float* __restrict__ fea
     for (int k = 0; k < NSC; ++k) out[k] = x[k];
 }
 
-__device__ __forceinline__ void scale_target_seq(double2* g, double pos, const double* __restrict__ tw32)
+// The 32-point transform of fft32_seq by the lanes of ONE wave on a line in LDS: lane i < 32 moves element brev5(i) to i, then lane t < 16
+// does butterfly t of each stage -- the same butterflies, operands and twiddles as the sequential form, each evaluated exactly once, so the
+// values are bit-identical; only who computes them changed.  (Rounds 1-4: one thread ran the 80 butterflies and the 32 exponentials of
+// the scale target one after the other while its block waited: most of scale_start_k / scale_update_k's time.)  LDS serves a wave's
+// accesses in order; the wave barriers pin the compiler's order.  Call with all lanes of the wave.
+__device__ __forceinline__ void fft32_wave(double2* x, const double* __restrict__ tw, bool inverse, int lane)
 {
-    for (int i = 0; i < NSC; ++i) {
-        const double dist = fabs((double)i - pos);
-        g[i] = make_double2(det_exp(-dist / 1.000), 0.0);
+    double2 v = make_double2(0.0, 0.0);
+    if (lane < NSC) v = x[(int)(__brev((unsigned)lane) >> 27)];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < NSC) x[lane] = v;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int st = 1; st <= 5; ++st) {
+        const int m = 1 << st, half = m >> 1, tstep = NSC / m;
+        if (lane < NSC / 2) {
+            const int g = lane / half, j = lane - g * half, k = g * m;
+            const double wr = tw[2 * j * tstep], wi = inverse ? tw[2 * j * tstep + 1] : -tw[2 * j * tstep + 1];
+            const double2 a = x[k + j], b = x[k + j + half];
+            const double tr = wr * b.x - wi * b.y;
+            const double ti = wr * b.y + wi * b.x;
+            x[k + j] = make_double2(a.x + tr, a.y + ti);
+            x[k + j + half] = make_double2(a.x - tr, a.y - ti);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    fft32_seq(g, tw32, false);
-    for (int i = 0; i < NSC; ++i) g[i].y = -g[i].y;
+    if (inverse && lane < NSC) {
+        const double sc = 1.0 / NSC;
+        double2 w = x[lane];
+        w.x *= sc; w.y *= sc;
+        x[lane] = w;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the scale filter's target exp(-|i - pos|), transformed and conjugated (oracle/pvo_dsst.c scale_target), by one wave
+__device__ __forceinline__ void scale_target_wave(double2* g, double pos, const double* __restrict__ tw32, int lane)
+{
+    if (lane < NSC) {
+        const double dist = fabs((double)lane - pos);
+        g[lane] = make_double2(det_exp(-dist / 1.000), 0.0);
+    }
+    __builtin_amdgcn_wave_barrier();
+    fft32_wave(g, tw32, false, lane);
+    if (lane < NSC) g[lane].y = -g[lane].y;
+    __builtin_amdgcn_wave_barrier();
 }
 
 __global__ void __launch_bounds__(256) scale_start_k(const TrkJob* __restrict__ jobs, const double2* __restrict__ Fs, const double* __restrict__ tw32)
@@ -738,7 +776,7 @@ __global__ void __launch_bounds__(256) scale_start_k(const TrkJob* __restrict__ 
     const int b = blockIdx.x, tid = threadIdx.x;
     double* st = jobs[b].state;
     double2* As = reinterpret_cast<double2*>(st + TRK_AS);
-    if (tid == 0) scale_target_seq(Gs, NSC / 2, tw32);
+    if (tid < 64) scale_target_wave(Gs, NSC / 2, tw32, tid);
     __syncthreads();
     for (int e = tid; e < SDIM * NSC; e += 256) {
         const int k = e & 31;
@@ -746,10 +784,15 @@ __global__ void __launch_bounds__(256) scale_start_k(const TrkJob* __restrict__ 
         As[e] = make_double2(Gs[k].x * f.x - Gs[k].y * f.y, Gs[k].x * f.y + Gs[k].y * f.x);
     }
     if (tid < NSC) {
+        // a chain of 512 additions in index order (the oracle's), fed by independent loads: sixteen in flight before the first is added
         double bsum = 0;
-        for (int i = 0; i < SDIM; ++i) {
-            const double2 f = Fs[((size_t)b * SDIM + i) * NSC + tid];
-            bsum = bsum + (f.x * f.x + f.y * f.y);
+        const double2* fp = Fs + (size_t)b * SDIM * NSC + tid;
+        for (int i = 0; i < SDIM; i += 16) {
+            double2 f[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) f[j] = fp[(size_t)(i + j) * NSC];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bsum = bsum + (f[j].x * f[j].x + f[j].y * f[j].y);
         }
         st[TRK_BS + tid] = bsum;
     }
@@ -764,18 +807,25 @@ __global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__
     double2* As = reinterpret_cast<double2*>(st + TRK_AS);
     if (tid < NSC) {
         double gr = 0, gi = 0;
-        for (int i = 0; i < SDIM; ++i) {
-            const double2 f = Fs[((size_t)b * SDIM + i) * NSC + tid];
-            const double2 a = As[(size_t)i * NSC + tid];
-            gr = gr + (f.x * a.x + f.y * a.y);
-            gi = gi + (f.y * a.x - f.x * a.y);
+        const double2* fp = Fs + (size_t)b * SDIM * NSC + tid;
+        const double2* ap = As + tid;
+        for (int i = 0; i < SDIM; i += 8) {                 // (the sums are chains in index order; their operands are loaded eight steps ahead)
+            double2 f[8], a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { f[j] = fp[(size_t)(i + j) * NSC]; a[j] = ap[(size_t)(i + j) * NSC]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                gr = gr + (f[j].x * a[j].x + f[j].y * a[j].y);
+                gi = gi + (f[j].y * a[j].x - f[j].x * a[j].y);
+            }
         }
         const double rec = 1.0 / (st[TRK_BS + tid] + REG_SCALE);
         Gs[tid] = make_double2(gr * rec, gi * rec);
     }
     __syncthreads();
+    __shared__ double s_pos;
+    if (tid < 64) fft32_wave(Gs, tw32, true, tid);
     if (tid == 0) {
-        fft32_seq(Gs, tw32, true);
         int bk = 0;
         for (int k = 1; k < NSC; ++k) if (Gs[k].x > Gs[bk].x) bk = k;
         double pos = bk;
@@ -797,9 +847,13 @@ __global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__
         ps[0] = r[0]; ps[1] = r[1]; ps[2] = r[2]; ps[3] = r[3];
         results[(size_t)b * 8 + 1] = r[0]; results[(size_t)b * 8 + 2] = r[1]; results[(size_t)b * 8 + 3] = r[2]; results[(size_t)b * 8 + 4] = r[3];
         results[(size_t)b * 8 + 7] = pos;
-        if (update_model) scale_target_seq(Gs, pos, tw32);
+        s_pos = pos;
     }
     if (!update_model) return;                  // deferred update: position and confidence only, filters untouched
+    if (tid < 64) {
+        __builtin_amdgcn_wave_barrier();
+        scale_target_wave(Gs, s_pos, tw32, tid);        // (lane 0 of this wave wrote s_pos: LDS serves the wave's accesses in order)
+    }
     __syncthreads();
     for (int e = tid; e < SDIM * NSC; e += 256) {
         const int k = e & 31;
@@ -811,9 +865,13 @@ __global__ void __launch_bounds__(256) scale_update_k(const TrkJob* __restrict__
     }
     if (tid < NSC) {
         double bq = st[TRK_BS + tid] * (1 - NU_SCALE);
-        for (int i = 0; i < SDIM; ++i) {
-            const double2 f = Fs[((size_t)b * SDIM + i) * NSC + tid];
-            bq = bq + NU_SCALE * (f.x * f.x + f.y * f.y);
+        const double2* fp = Fs + (size_t)b * SDIM * NSC + tid;
+        for (int i = 0; i < SDIM; i += 16) {
+            double2 f[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) f[j] = fp[(size_t)(i + j) * NSC];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bq = bq + NU_SCALE * (f[j].x * f[j].x + f[j].y * f[j].y);
         }
         st[TRK_BS + tid] = bq;
     }
