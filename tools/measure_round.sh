@@ -4,7 +4,7 @@
 #   attaches it as roofline.traffic when the hash of the detector's sources matches); the default bench line (cpu_baseline / parity / host_ingest / dropin_cli);
 #   the other BASELINE.json configurations (c3 streamed long video, c4 clip farm, c5 4K crowd); a rocprofv3 kernel-trace summary of the default
 #   workload; WRITE_SIZE, matrix-pipe and SQ counter passes (every --pmc pass on its own, with --kernel-trace only); the C5 clustering stressor.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=gpurun_out/$TAG; mkdir -p $O
 t() { name=$1; lim=$2; shift; shift; echo "=== $name" >> $O/summary.log; s=$(date +%s); ( timeout $lim "$@" ) > $O/$name.log 2>&1; echo "rc=$? $(( $(date +%s) - s ))s" >> $O/summary.log; tail -3 $O/$name.log | cut -c1-600 >> $O/summary.log; }
@@ -26,6 +26,10 @@ if [ "$2" != "quick" ]; then
   t every 300 python bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-host-ingest --no-dropin --detect-every 0.5
 fi
 t c5 400 python tools/c5_cluster.py $O/c5_cluster.json
+t detector 100 python tools/bench_detector.py 125 8
+t dsst 100 python tools/bench_dsst.py 2000 4
+t embed 100 python tools/bench_embed.py 4096 3
+t ert 100 python tools/bench_ert.py 8000 3
 t overlap 200 python tools/probes/overlap_probe.py 3 $O/overlap_probe.json
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --cpu-frames 0 --no-host-ingest --no-dropin --no-dense-leg > $R/$O/prof_bench.log 2>&1
