@@ -956,28 +956,35 @@ def oracle_cluster_check(pipe, res, t_end):
 
 
 def merge_order_verdict(logg, logr, tol=1e-10):
-    """the product's merge log against the oracle's: "exact", or -- when the only differences are the ORDER of merges whose distances are
-    equal to `tol` relative (the long video replays its clips: a track and its replay have the same descriptors, so whole groups of merges
-    tie in exact arithmetic and the last bits of two different summation orders decide which comes first) -- "exact up to ties", with
-    the number of tied groups; anything else is a MISMATCH"""
+    """the product's merge log (a, b, distance, new size) against the oracle's: "exact" when the same pairs merge in the same order.
+    The long video replays its clips: a track and its replay have the same descriptors, so D(A, B) = D(A', B) = D(A, B') = D(A', B') in
+    exact arithmetic -- the oracle breaks such ties by position (first minimum in row-major order), the product's tiled sums break them
+    by their last bits, and WHICH of the tied pairs merges first (even which copies pair up) is then not defined by the algorithm.  What is
+    defined, and compared here group by group of merges at equal distance (`tol` relative): the distances themselves and the sizes of
+    the clusters that come out -- together with the final labels (compared by the caller) the dendrogram up to its ties."""
     import numpy as np
     if len(logg) != len(logr):
         return "MISMATCH (%d vs %d merges)" % (len(logg), len(logr))
-    if len(logg) == 0 or np.array_equal(logg[:, :2], logr[:, :2]):
+    if len(logg) == 0:
         return "exact"
+    same_pairs = np.array_equal(logg[:, :2], logr[:, :2])
     i, groups, n = 0, 0, len(logr)
     while i < n:
         j = i + 1
         while j < n and abs(logr[j, 2] - logr[i, 2]) <= tol * max(abs(logr[i, 2]), 1e-300):
             j += 1
-        a = sorted(map(tuple, logg[i:j, :2].astype(np.int64).tolist()))
-        b = sorted(map(tuple, logr[i:j, :2].astype(np.int64).tolist()))
-        if a != b or np.max(np.abs(logg[i:j, 2] - logr[i:j, 2])) > tol * max(abs(logr[i, 2]), 1e-300):
+        scale = max(abs(logr[i, 2]), 1e-300)
+        if np.max(np.abs(np.sort(logg[i:j, 2]) - np.sort(logr[i:j, 2]))) > tol * scale or sorted(logg[i:j, 3].tolist()) != sorted(logr[i:j, 3].tolist()):
             return "MISMATCH at merge %d" % i
-        if j - i > 1 and not np.array_equal(logg[i:j, :2], logr[i:j, :2]):
+        if j - i > 1:
             groups += 1
         i = j
-    return "exact up to the order inside %d group(s) of merges at equal distance (%.0e relative)" % (groups, tol)
+    if same_pairs:
+        return "exact"
+    first = int(np.nonzero((logg[:, :2] != logr[:, :2]).any(axis=1))[0][0])
+    return ("equal up to ties: the same merge distances (%.0e relative) and cluster sizes in the same order over all %d merges; %d group(s) of merges at equal "
+            "distance (replayed clips tie exactly), the pair ids differ from merge %d on (which copies pair up inside a tie names the later clusters differently)"
+            % (tol, n, groups, first))
 
 
 def host_ingest_pass(ctx, pipe, frames_t, times, video, shots, args):
