@@ -394,8 +394,10 @@ def main():
     # detector's raw candidates of every frame against the fixture the oracle flow wrote for all 1000 frames (tests/golden/c2_full.npz,
     # made by tests/golden/make_full_clip.py: minutes of CPU, so it is frozen, not recomputed here); the dense leg the same way
     full_clip = None
-    if world == 1 and args.config == "c2" and args.detect_every == 0.0 and not args.small_models:
-        full_clip = full_clip_parity(ctx, frames, res, labels, args, d_res=d_res if dense else None, d_labels=d_labels if dense else None)
+    if world == 1 and args.detect_every == 0.0 and not args.small_models:
+        # configs[1]: the whole clip; configs[4]: the clip's first shot (250 of its 500 4K frames: the oracle needs an hour for them)
+        full_clip = full_clip_parity(ctx, frames, res, labels, args, d_res=d_res if dense else None, d_labels=d_labels if dense else None,
+                                     name="c2_full" if args.config == "c2" else "c5_shot0")
 
     cpu, parity = None, None
     if world == 1 and args.cpu_frames > 0:
@@ -463,17 +465,22 @@ def main():
     print(json.dumps(out))
 
 
-def full_clip_parity(ctx, frames, res, labels, args, d_res=None, d_labels=None, name="c2_full", seed=20260925):
+def full_clip_parity(ctx, frames, res, labels, args, d_res=None, d_labels=None, name="c2_full", seed=20260925, identities=12, n_frames=None):
     """product (the timed steps' last result) against the whole-clip fixture of the CPU oracle flow; a note instead when the benched clip
-    is not the fixture's (other --frames / size / faces) or the fixture is absent"""
+    is not the fixture's (other --frames / size / faces) or the fixture is absent.  A fixture that covers the FIRST shots of the benched
+    video (c3_clip0: the long video's first 1000 frames; c5_shot0: the 4K clip's first shot) is compared with that part of the result
+    (golden.prefix_of: tracks, face rows, landmarks, descriptors, raw candidates; not the labels, which the longer run decides over more tracks)."""
     from oracle import golden
     import numpy as np
-    want = golden.CLIPS[name]
-    mine = dict(width=args.width, height=args.height, n_frames=args.frames, n_shots=args.shots, faces=args.faces, seed=seed, frame_rate=args.fps)
-    if mine != want or not golden.available(name):
+    mine = dict(width=args.width, height=args.height, n_frames=n_frames or args.frames, n_shots=args.shots, faces=args.faces, seed=seed, frame_rate=args.fps,
+                identities=identities)
+    if not golden.matches(name, **mine) or not golden.available(name):
         return {"fixture": None, "why": "no fixture for this clip (tests/golden/make_full_clip.py %s writes the one of the default configuration)" % name}
     g = golden.load(name)
-    out = golden.compare(g, res, labels)
+    take = int(g["video"][2])
+    prefix = take < len(frames) or name == "c3_clip0"
+    out = golden.compare(g, res, labels, prefix=prefix)
+    frames = frames[:take]
     batch = 125 if args.detect_batch >= 125 else args.detect_batch
     t0 = time.perf_counter()
     raw = ctx.detect_raw_many(frames, batch)
@@ -481,7 +488,7 @@ def full_clip_parity(ctx, frames, res, labels, args, d_res=None, d_labels=None, 
     out["raw_candidates_total"] = int(g["raw_counts"].sum())
     out["raw_pass_seconds"] = round(time.perf_counter() - t0, 3)
     if d_res is not None:
-        dd = golden.compare(g, d_res, d_labels)
+        dd = golden.compare(g, d_res, d_labels, prefix=prefix)
         out["dense_scoring_leg"] = "exact" if dd["all_exact"] else {k: dd[k] for k in ("tracks", "face_rows", "landmarks", "embed_l2_max", "labels")}
     if d_res is not None or name != "c2_full":
         ctx.detector_screening(False)
@@ -499,8 +506,9 @@ def full_clip_summary(fc):
     if not fc or not fc.get("fixture"):
         return "no whole-clip fixture for this configuration"
     if fc["all_exact"]:
-        return "%s EXACT over all %d frames: %d tracks, %d faces (rows, landmarks), labels, %d raw candidates%s; embed L2 max %.2e" % (
-            fc["fixture"], fc["frames"], fc["n_tracks"], fc["n_faces"], fc["raw_candidates_total"],
+        return "%s EXACT over all %d frames%s: %d tracks, %d faces (rows, landmarks)%s, %d raw candidates%s; embed L2 max %.2e" % (
+            fc["fixture"], fc["frames"], " (the run's first ones)" if fc.get("prefix_of_a_longer_run") else "", fc["n_tracks"], fc["n_faces"],
+            "" if fc.get("prefix_of_a_longer_run") else ", labels", fc["raw_candidates_total"],
             " (screened and dense)" if "raw_candidates_dense" in fc else "", fc["embed_l2_max"])
     bad = [k for k in ("tracks", "face_rows", "landmarks", "labels", "raw_candidates", "dense_scoring_leg", "raw_candidates_dense") if fc.get(k, "exact") != "exact"]
     return "%s MISMATCH in %s (embed L2 max %s)" % (fc["fixture"], ", ".join(bad) or "embedding", fc.get("embed_l2_max"))
@@ -893,6 +901,13 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
         cpu = {"value": round(m / dt, 4), "unit": "frames/s", "cores": int(threads), "kind": "port", "sample": "the same %d-frame window, whole flow" % m}
     if world == 1 and args.cluster_check_frames != 0 and len(res["face_T"]):
         cluster_check = oracle_cluster_check(pipe, res, args.cluster_check_frames / args.fps if args.cluster_check_frames > 0 else float("inf"))
+    full_clip = None
+    if rank == 0 and first == 0 and n >= clip_n and not args.dense_scoring and not args.small_models:
+        # the first 1000-frame clip of the long video, as the STREAMED run produced it, against the oracle flow's output over all its frames
+        # (tests/golden/c3_clip0.npz); the raw-candidate pass runs on the clip's resident frames
+        clip_frames = [ctx.wrap_torch(clips_t[0][i]) for i in range(clip_n)]
+        full_clip = full_clip_parity(ctx, clip_frames, res, None, args, name="c3_clip0", identities=250, n_frames=clip_n)
+        parity = dict(parity or {}, full_clip=full_clip)
     peak_frames = res.get("peak_frames_resident")
     idents = set(tr["ident"] for v in videos for shot in v.tracks for tr in shot)       # identity k looks the same in every clip
     out = {"metric": "frames/sec end-to-end detect->embed->cluster, one long 1080p@25fps video in frame ranges (BASELINE.json configs[2])",
@@ -917,6 +932,7 @@ def bench_stream(args, rank, local_rank, world, device, lp, ep):
                        "tracks_clustered_globally": len(labels), "labels_sha256_16": labels_digest(labels),
                        "identities_in_video": len(idents)},
            "setup_seconds": {"generate_clips_in_hbm": round(t_gen, 1)}}
+    out["full_clip_parity"] = full_clip_summary(full_clip)
     print(json.dumps(out))
 
 

@@ -4,6 +4,8 @@ tests/golden/<name>.npz (layout: oracle/golden.py).  Needs no GPU and no /root/r
 
     python tests/golden/make_full_clip.py c2_full      # BASELINE.json configs[1]: 1000 frames 1080p (about 20-40 min on 8 cores)
     python tests/golden/make_full_clip.py c4_clip0     # configs[3]: clip 0 of the 720p farm, 250 frames
+    python tests/golden/make_full_clip.py c3_clip0     # configs[2]: the first 1000-frame clip of the long streamed video
+    python tests/golden/make_full_clip.py c5_shot0     # configs[4]: the first shot (250 frames) of the 4K crowd clip (about an hour)
 
 The frames are `SyntheticVideo.frame(i)`, byte-identical to what `frames_torch` puts into HBM for the bench (tests/test_engine.py pins
 that); the models are the seeded synthetic ones of `models.ensure_synthetic_models` (full 15 x 500 x 500 landmark model).  What follows
@@ -47,7 +49,7 @@ class RecordingDetector(object):
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "c2_full"
     va = golden.CLIPS[name]
-    v = synth.SyntheticVideo(**va)
+    v, take = golden.video_of(name)
     threads = oracle.usable_cpus(cap=1024)
     oracle.lib().pvo_set_threads(threads)
     lp, ep = models.ensure_synthetic_models(os.path.join(tempfile.gettempdir(), "pvface_models_golden"), small=False)
@@ -60,12 +62,13 @@ def main():
     assert det(f0) == oracle.Detector(models.load_container(models.DEFAULT_DETECTOR))(f0)
     det.raw = []
     t0 = time.perf_counter()
-    frames = [v.frame(i) for i in range(v.n_frames)]
-    times = [v.timestamp(i) for i in range(v.n_frames)]
+    frames = [v.frame(i) for i in range(take)]
+    times = [v.timestamp(i) for i in range(take)]
+    shots = golden.shots_of(v, take)
     print("%s: %d frames rendered (%.0f s), oracle flow on %d threads" % (name, len(frames), time.perf_counter() - t0, threads), flush=True)
     pool = concurrent.futures.ThreadPoolExecutor(min(threads, 32)) if threads > 1 else None
     t0 = time.perf_counter()
-    tracks = ref_flow.track_video(frames, times, v.shots(), det, lambda: oracle.Tracker(tabs), v.frame_rate,
+    tracks = ref_flow.track_video(frames, times, shots, det, lambda: oracle.Tracker(tabs), v.frame_rate,
                                   min_conf=pipeline.CLI_MIN_CONFIDENCE, ratio=pipeline.CLI_MIN_OVERLAP_RATIO, max_gap=pipeline.CLI_MAX_GAP, pool=pool)
     print("  detect + tracking: %.0f s, %d tracks" % (time.perf_counter() - t0, len(tracks)), flush=True)
     keep = []
@@ -73,7 +76,7 @@ def main():
     labels = ref_flow.cluster(em, 0.6)
     dt = time.perf_counter() - t0
     print("  whole flow: %.0f s, %d faces, %d clusters" % (dt, len(em), len(set(labels.values()))), flush=True)
-    assert len(det.raw) == v.n_frames
+    assert len(det.raw) == take
     g = golden.pack(va, tracks, lm, keep, labels, det.raw, v.frame_rate, v.frame_size, seconds=dt, threads=threads)
     np.savez_compressed(golden.path(name), **g)
     print("wrote", golden.path(name), os.path.getsize(golden.path(name)), "bytes")

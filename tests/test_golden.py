@@ -71,13 +71,13 @@ def test_whole_clip_fixtures_are_the_oracles_output_on_sampled_frames(oracle):
     sp = oracle.ShapePredictor(models.load_model_file(lp, "shape_predictor"))
     emb = oracle.Embedder(models.load_model_file(ep, "embedder"))
     checked = 0
-    for name, picks in (("c2_full", (0, 613)), ("c4_clip0", (124,))):
+    for name, picks in (("c2_full", (0, 613)), ("c4_clip0", (124,)), ("c3_clip0", (377,)), ("c5_shot0", (101,))):
         if not golden.available(name):
             continue
         g = golden.load(name)
-        v = synth.SyntheticVideo(**golden.CLIPS[name])
-        assert list(g["video"][:5]) == [v.size[0], v.size[1], v.n_frames, v.n_shots, v.faces]
-        assert len(g["raw_counts"]) == v.n_frames and int(g["raw_counts"].sum()) == len(g["raw_rows"])
+        v, take = golden.video_of(name)
+        assert list(g["video"][:5]) == [v.size[0], v.size[1], take, v.n_shots, v.faces]
+        assert len(g["raw_counts"]) == take and int(g["raw_counts"].sum()) == len(g["raw_rows"])
         tracks = golden.tracks_of(g)
         assert sum(len(t) for t in tracks) == len(g["track_rows"])
         w, h = v.frame_size
@@ -99,3 +99,40 @@ def test_whole_clip_fixtures_are_the_oracles_output_on_sampled_frames(oracle):
     if not checked:
         import pytest
         pytest.skip("no whole-clip fixture in tests/golden")
+
+
+def test_fixture_comparison_of_a_longer_run():
+    """oracle/golden.py compare(prefix=True): a fixture of a run's first shots against the longer run's result -- the fixture's tracks are
+    the run's first ones, the faces before the fixture's last frame are compared in (frame, track) order (the order inside a timestamp
+    is an artefact of pandas' unstable sort of the whole table), later tracks / faces and the labels are left alone; any difference inside
+    the covered part is reported"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import golden
+    if not golden.available("c4_clip0"):
+        import pytest
+        pytest.skip("no fixture")
+    g = golden.load("c4_clip0")
+    fr = float(g["frame_rate"])
+    tracks = golden.tracks_of(g)
+    n = len(g["face_frame"])
+    rng = np.random.default_rng(3)
+    # the longer run: the clip's faces with the rows of every timestamp shuffled, then the faces of the clip's last frame (which the
+    # standalone clip's `extract` never yields) and of later shots with later track ids
+    order = np.lexsort((rng.random(n), g["face_frame"]))
+    extra = 40
+    res = {"tracks": tracks + [[(20.0 + k / fr, (0.1, 0.1, 0.2, 0.2), "detection") for k in range(5)]],
+           "face_T": np.concatenate([g["face_frame"][order] / fr, np.full(8, (int(g["video"][2]) - 1) / fr), 20.0 + np.arange(extra) / fr]),
+           "face_id": np.concatenate([g["face_id"][order], np.arange(8), np.full(extra, len(tracks))]),
+           "landmarks": np.concatenate([g["landmarks"][order].astype(np.int32), np.zeros((8 + extra, 68, 2), np.int32)]),
+           "embeddings": np.concatenate([g["embeddings"][order], np.zeros((8 + extra, 128), np.float32)]),
+           "labels": {0: 0}}
+    c = golden.compare(g, res, prefix=True)
+    assert c["all_exact"] and c["tracks"] == "exact" and c["face_rows"] == "exact" and c["landmarks"] == "exact" and "labels" not in c
+    assert c["embed_l2_max"] == 0.0 and c["n_faces"] == n
+    res["landmarks"][5, 3, 0] += 1
+    bad = golden.compare(g, res, prefix=True)
+    assert not bad["all_exact"] and bad["landmarks"] != "exact"
+    res["landmarks"][5, 3, 0] -= 1
+    res["tracks"][2] = res["tracks"][2][:-1]
+    assert golden.compare(g, res, prefix=True)["tracks"] != "exact"

@@ -1,7 +1,8 @@
 """GPU: the WHOLE benched clip against the CPU oracle, every frame of it.
 
 tests/golden/c2_full.npz (BASELINE.json configs[1]: 1920x1080, 1000 frames, 4 shots, 8 faces, seed 20260925 -- the clip bench.py
-times) and tests/golden/c4_clip0.npz (configs[3]: clip 0 of the 720p farm) hold what the CPU oracle flow returns for ALL their frames
+times), c4_clip0.npz (configs[3]: clip 0 of the 720p farm), c3_clip0.npz (configs[2]: the first 1000-frame clip of the long video) and
+c5_shot0.npz (configs[4]: the first 250-frame shot of the 4K / 40 faces clip) hold what the CPU oracle flow returns for ALL their frames
 (tests/golden/make_full_clip.py, oracle/golden.py): every track row, every face row with its 68 points and its descriptor, every
 cluster label, and per frame the detector's raw candidates before non-maximum suppression.  The product must reproduce all of it --
 with the screening pass (the default: a data-dependent filter decides which windows get the exact arithmetic) and without:
@@ -32,19 +33,20 @@ from pyannote_video_amd import synth, models, pipeline
 from pyannote_video_amd.runtime import Context
 from oracle import golden
 g = golden.load(name)
-video = synth.SyntheticVideo(**golden.CLIPS[name])
-ft = video.frames_torch(torch.device("cuda", 0))
+video, take = golden.video_of(name)
+ft = video.frames_torch(torch.device("cuda", 0), indices=range(take))
 lp, ep = models.ensure_synthetic_models(os.path.join(tempfile.gettempdir(), "pvface_models_fullclip"), small=False)
 ctx = Context(device=0)
-frames = [ctx.wrap_torch(ft[i]) for i in range(video.n_frames)]
-times = [video.timestamp(i) for i in range(video.n_frames)]
-pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=128)
+frames = [ctx.wrap_torch(ft[i]) for i in range(take)]
+times = [video.timestamp(i) for i in range(take)]
+batch = 128 if video.size[0] <= 1920 else 32
+pipe = pipeline.FacePipeline(ctx, lp, ep, detect_batch_size=batch)
 out = {}
 for leg, on in (("screened", True), ("dense", False)):
     ctx.detector_screening(on)
-    res = pipe.run(frames, times, video.frame_rate, video.shots())
+    res = pipe.run(frames, times, video.frame_rate, golden.shots_of(video, take))
     c = golden.compare(g, res)
-    raw = ctx.detect_raw_many(frames, 125)
+    raw = ctx.detect_raw_many(frames, 125 if batch == 128 else batch)
     c["raw_candidates"] = golden.compare_raw(g, [golden.raw_key(r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4]) for r in raw])
     out[leg] = c
 out["screening"] = ctx.detector_screening_stats()
@@ -64,7 +66,7 @@ def _run(name):
     return json.loads(line[len("RESULT "):])
 
 
-@pytest.mark.parametrize("name", ["c2_full", "c4_clip0"])
+@pytest.mark.parametrize("name", ["c2_full", "c4_clip0", "c3_clip0", "c5_shot0"])
 def test_whole_clip_equals_the_oracle_flow(name):
     out = _run(name)
     for leg in ("screened", "dense"):
