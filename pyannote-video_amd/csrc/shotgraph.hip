@@ -265,6 +265,7 @@ void fix_track(std::vector<Node>& nodes, double ratio, std::vector<Row>& out)
             for (size_t k = i + 1; k < j; ++k) s = s + nodes[k].box[c];
             r.box[c] = round_half_even(j - i == 1 ? s : s / (double)(j - i));
         }
+        PVF_REQUIRE(cnt[KIND_FWD] < 256 && cnt[KIND_DET] < 256 && cnt[KIND_BWD] < 256, "shot tracks: more than 255 nodes of one kind at one timestamp of a track");
         r.status = cnt[KIND_FWD] | (cnt[KIND_DET] << 8) | (cnt[KIND_BWD] << 16) | ((err ? 1 : 0) << 24);
         out.push_back(r);
         i = j;
