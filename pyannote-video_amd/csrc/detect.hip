@@ -29,7 +29,12 @@
 //   * the walk follows the SOURCE rows and its body exists twice with the two H register triples in swapped roles: nothing is ever
 //     copied (round 3's two-entry cache moved 3 doubles and ran 6 selects per output row);
 //   * the 64 result pixels leave as 48 aligned dwords through LDS: a lane writes its 3 bytes (ds_write_b8), lanes 0..47 read one dword
-//     each and store it -- no packing, no ds_bpermute pair, no funnel shift (8 vector instructions -> 0, two more LDS instructions).
+//     each and store it -- no packing, no ds_bpermute pair, no funnel shift (8 vector instructions -> 0, two more LDS instructions);
+//   * (later in round 5) the output image sits behind a descriptor as well -- the row offset is a scalar operand of the store, a lane
+//     past the segment's end stores out of range instead of being masked off -- and the vertical weights are read by the products from
+//     scalar registers: 42 -> about 36 vector instructions per row.  That bought 2 %: with the three pipes measured one at a time
+//     (profiles/r05_resize_bounds_experiment.txt: loads and stores alone 4.29 ms, arithmetic alone 4.91 ms, together 6.2 ms per 125
+//     frames) the kernel is no longer bound by one of them -- HBM at 62 % of what streams, vector issue at 53 %, LDS at about half.
 // Needs 4-byte aligned output rows (level images of the batched path have a padded row pitch).
 #define RESIZE_MAXS 22
 // per output row of a resize stage, computed once on the host with the oracle's double arithmetic (y = r * y_scale; top = floor(y);
@@ -43,7 +48,6 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
                                                      size_t out_stride, int out_rb, int oh, int ow, double x_scale,
                                                      const RowTab* __restrict__ rows)
 {
-    static_assert(NSTRIP == 1, "one strip of RS rows per wave (more strips per wave were measured no faster: DESIGN.md section 3)");
     constexpr int MAXS = RESIZE_MAXS;
     __shared__ uint32_t s_rows[4][MAXS][64];                     // a wave's source rows: 256-byte windows, dword per lane
     __shared__ uint32_t s_out[4][64];                            // a wave's output row: 64 pixels x 3 bytes = 48 dwords
@@ -67,20 +71,23 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     const unsigned delta = (unsigned)((uintptr_t)in & 3u);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((uintptr_t)in - delta), 0, (int)(delta + (unsigned)ih * (unsigned)in_rb), 0x00020000);
     const int lane4 = 4 * lane;
-    const int r0 = blockIdx.y * RS, r_end = min(r0 + RS, oh);
-    const int s_first = rows[r0].top, nrows = rows[r_end - 1].bottom - s_first + 1;
-    const unsigned win0 = delta + (unsigned)s_first * (unsigned)in_rb + 3u * (unsigned)left0;          // byte offset of row s_first's first needed byte
-    {
-        uint32_t t[MAXS];
+    // a wave writes NSTRIP strips of RS output rows, one below the other; the next strip's source rows are requested (into registers)
+    // before the current strip's arithmetic starts and go to LDS when it is done: the wave's memory phase lies under its compute phase
+    int r0 = blockIdx.y * (RS * NSTRIP), r_end = 0, s_first = 0;
+    unsigned win0 = 0;                                                       // byte offset of row s_first's first needed byte
+    uint32_t t[MAXS];
+    auto request = [&](int q0, int& sf, unsigned& w0) {
+        const int qe = min(q0 + RS, oh);
+        sf = rows[q0].top;
+        const int nr = rows[qe - 1].bottom - sf + 1;
+        w0 = delta + (unsigned)sf * (unsigned)in_rb + 3u * (unsigned)left0;
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) {
             t[k] = 0;
-            if (k < nrows) t[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, (int)((win0 + (unsigned)k * (unsigned)in_rb) & ~3u), 0);     // wave-uniform test and offset
+            if (k < nr) t[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, (int)((w0 + (unsigned)k * (unsigned)in_rb) & ~3u), 0);     // wave-uniform test and offset
         }
-#pragma unroll
-        for (int k = 0; k < MAXS; ++k) s_rows[wave][k][lane] = t[k];
-    }
-    __builtin_amdgcn_wave_barrier();
+    };
+    request(r0, s_first, win0);
     // this lane's two source pixels inside a window, in bytes from the window's first NEEDED byte (the row's alignment offset is added
     // per row); a lane without a right neighbour blends its own pixel with itself (oracle/pvo_image.c)
     const uint8_t* wl = reinterpret_cast<const uint8_t*>(&s_rows[wave][0][0]) + 3 * (left - left0);
@@ -99,6 +106,10 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
         hh[1] = lr1 * (double)l1 + lr * (double)q1;
         hh[2] = lr1 * (double)l2 + lr * (double)q2;
     };
+    // the output image behind a descriptor too: the row's offset is a scalar operand of the store (no 64-bit address arithmetic per row)
+    // and a lane past the segment's end stores out of range, which the descriptor drops (no exec-mask branch per row)
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)ob, 0, (int)((unsigned)oh * (unsigned)out_rb - 3u * (unsigned)c0), 0x00020000);
+    const int st_off = stores ? lane4 : 0x7fffff00;
     auto emit = [&](int r, double tb, double tb1, const double* ht, const double* hb) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -108,35 +119,65 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
         __builtin_amdgcn_wave_barrier();                               // (LDS serves a wave's accesses in order; this only pins the compiler's order)
         const uint32_t dw = *sd;
         __builtin_amdgcn_wave_barrier();
-        if (stores) *reinterpret_cast<uint32_t*>(ob + (size_t)r * out_rb + lane4) = dw;
+        __builtin_amdgcn_raw_buffer_store_b32(dw, ro, st_off, r * out_rb, 0);
     };
     // The walk goes down the SOURCE rows: with H of row s at hand the row below it (s + 1, or s itself on the image's last row: the table's
     // `bottom`) is blended into the other register triple and every output row whose `top` is s is written; then the two triples swap
     // ROLES -- the loop body exists twice, once per role, so no value is ever copied (round 3: a two-entry cache keyed by the output
     // row's (top, bottom), 3 doubles moved and 6 selects per output row).  Every H is evaluated once, in row order, as before.
-    int r = r0, srow = s_first;
+    int r = 0, srow = 0;
     double hA[3], hB[3];
+    // Table entries come through the scalar cache (constant address space: this kernel's stores cannot touch the table).  A source row's
+    // walk step asks for the entries of the next TWO output rows before it blends (their latency hides behind that arithmetic) and
+    // uses them as they are: the two weights stay in scalar registers and are read from there by the products.  (Carried from one
+    // output row to the next -- round 4's prefetch -- the compiler keeps them in vector registers: two 64-bit moves per output row on
+    // the pipe this kernel is bound by.)  The pyramid never writes more than two rows per source row (2x up: two; 6/5 down: one or
+    // none); a third and later row fetch their entries on the spot.
     const __attribute__((address_space(4))) RowTab* crows = (const __attribute__((address_space(4))) RowTab*)rows;
-    // table entries come through the scalar cache (constant address space: this kernel's stores cannot touch the table), the next
-    // row's entry requested before the current row's arithmetic so that its latency hides behind it
-    struct RowVals { int top; double tb, tb1; };
-    auto row_of = [&](int rr) { RowVals v; v.top = crows[rr].top; v.tb = crows[rr].tb; v.tb1 = crows[rr].tb1; return v; };
-    RowVals rt = row_of(r);
+    int top_r = 0;                                                              // `top` of output row r, the next one to write
     auto step = [&](const double* hc, double* hn) {
+        const int ra = min(r, oh - 1), rb = min(r + 1, oh - 1), rc = min(r + 2, oh - 1);
+        const double tbA = crows[ra].tb, tb1A = crows[ra].tb1, tbB = crows[rb].tb, tb1B = crows[rb].tb1;
+        const int topB = crows[rb].top, topC = crows[rc].top;
         hblend(min(srow + 1, ih - 1), hn);
-        while (r < r_end && rt.top == srow) {
-            const RowVals nx = row_of(min(r + 1, oh - 1));
-            emit(r, rt.tb, rt.tb1, hc, hn);
-            rt = nx;
+        if (top_r == srow) {                                                    // (r < r_end here: the walk's loop tests it)
+            emit(r, tbA, tb1A, hc, hn);
             ++r;
+            top_r = topB;
+            if (r < r_end && top_r == srow) {
+                emit(r, tbB, tb1B, hc, hn);
+                ++r;
+                top_r = topC;
+                while (r < r_end && top_r == srow) {
+                    emit(r, crows[r].tb, crows[r].tb1, hc, hn);
+                    ++r;
+                    top_r = crows[min(r, oh - 1)].top;
+                }
+            }
         }
         ++srow;
     };
-    hblend(srow, hA);
-    while (r < r_end) {
-        step(hA, hB);
-        if (r >= r_end) break;
-        step(hB, hA);
+#pragma unroll 1
+    for (int strip = 0; strip < NSTRIP; ++strip) {
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) s_rows[wave][k][lane] = t[k];
+        __builtin_amdgcn_wave_barrier();
+        r_end = min(r0 + RS, oh);
+        const int q0 = r0 + RS;
+        const bool more = (strip + 1 < NSTRIP) && (q0 < oh);
+        int n_first = 0;
+        unsigned n_win0 = 0;
+        if (more) request(q0, n_first, n_win0);
+        r = r0; srow = s_first; top_r = s_first;
+        hblend(srow, hA);
+        while (r < r_end) {
+            step(hA, hB);
+            if (r >= r_end) break;
+            step(hB, hA);
+        }
+        if (!more) break;
+        __builtin_amdgcn_wave_barrier();                               // this strip's LDS reads stay before the next strip's writes
+        r0 = q0; s_first = n_first; win0 = n_win0;
     }
 }
 
@@ -164,10 +205,11 @@ static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint
     constexpr int RS = 16;
     PVF_REQUIRE(x_scale <= 1.25 && (RS - 1) * y_scale + 3 <= RESIZE_MAXS, "resize_rows: scale outside the pyramid's range (2x up, 6/5 down)");
     PVF_REQUIRE(out_rb % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)out & 3) == 0 && out_rb >= (ow * 3 + 3) / 4 * 4, "resize: output rows must be 4-byte aligned");
-    // one strip of RS rows per wave: walking 2 / 4 strips with the next strip's source rows in flight behind the current one's arithmetic was
-    // measured no faster (65 / 66 / 78 us per 1080p frame for 1 / 2 / 4 strips): the kernel is not waiting for its loads
-    dim3 grid((ow + 255) / 256, (oh + RS - 1) / RS, batch);
-    hipLaunchKernelGGL((resize_rows_k<RS, 1>), grid, dim3(256), 0, c->det_stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
+    // two strips per wave, the second one's source rows in flight behind the first one's arithmetic: 6.20 -> 6.02 ms per 125 frames of 1080p
+    // (4 strips 6.14, 8 strips 6.40: the grid of the small levels gets too coarse).  profiles/r05_resize_bounds_experiment.txt
+    constexpr int NSTRIP = 2;
+    dim3 grid((ow + 255) / 256, (oh + RS * NSTRIP - 1) / (RS * NSTRIP), batch);
+    hipLaunchKernelGGL((resize_rows_k<RS, NSTRIP>), grid, dim3(256), 0, c->det_stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
 }
 
 static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
