@@ -217,6 +217,22 @@ class ExtractStream(object):
             self.face_boxes = [self.face_boxes[i] for i in perm]
         rows_file = self.rows_file
         self.rows = [rows_file[i] for i in formats.pandas_sort_order(self.file_T).tolist()]
+        self._early = None
+        if self._perm is not None:
+            # the rows computed so far move to their places in file order now, beside the GPU's last batch: finish() then only places
+            # that batch (a quarter of the 8.4 MB of a configs[1] step; the whole move used to sit at the step's very end, GPU idle).
+            # The GPU thread may be appending: `emb` is appended after `pts`, so its length counts the complete batches.
+            k0 = len(self.emb)
+            perm = np.asarray(self._perm, np.int64)
+            n = len(perm)
+            m0 = sum(len(e) for e in self.emb[:k0])
+            fp, fe = np.empty((n, 68, 2), np.int32), np.empty((n, 128), np.float32)
+            early = perm < m0
+            if m0:
+                src = perm[early]
+                fp[early] = np.concatenate(self.pts[:k0])[src]
+                fe[early] = np.concatenate(self.emb[:k0])[src]
+            self._early = (k0, m0, perm, early, fp, fe)
         self._planned = True
 
     def finish(self, drop_last=True, reorder=True, computed=False):
@@ -227,6 +243,14 @@ class ExtractStream(object):
             self.plan_finish(drop_last, reorder)
         if not computed:
             self.compute(self._final_work)
+        if getattr(self, "_early", None) is not None:
+            k0, m0, perm, early, fp, fe = self._early
+            if len(self.pts) > k0:
+                late = ~early
+                src = perm[late] - m0
+                fp[late] = (np.concatenate(self.pts[k0:]) if len(self.pts) > k0 + 1 else self.pts[k0])[src]
+                fe[late] = (np.concatenate(self.emb[k0:]) if len(self.emb) > k0 + 1 else self.emb[k0])[src]
+            return fp, fe
         pts = np.concatenate(self.pts) if self.pts else np.zeros((0, 68, 2), np.int32)
         emb = np.concatenate(self.emb) if self.emb else np.zeros((0, 128), np.float32)
         if self._perm is not None:
