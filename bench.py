@@ -972,35 +972,52 @@ def oracle_cluster_check(pipe, res, t_end):
 
 
 def merge_order_verdict(logg, logr, tol=1e-10):
-    """the product's merge log (a, b, distance, new size) against the oracle's: "exact" when the same pairs merge in the same order.
-    The long video replays its clips: a track and its replay have the same descriptors, so D(A, B) = D(A', B) = D(A, B') = D(A', B') in
-    exact arithmetic -- the oracle breaks such ties by position (first minimum in row-major order), the product's tiled sums break them
-    by their last bits, and WHICH of the tied pairs merges first (even which copies pair up) is then not defined by the algorithm.  What is
-    defined, and compared here group by group of merges at equal distance (`tol` relative): the distances themselves and the sizes of
-    the clusters that come out -- together with the final labels (compared by the caller) the dendrogram up to its ties."""
+    """the product's merge log (a, b, distance, new size: cluster b joins cluster a) against the oracle's: "exact" when the same pairs
+    merge in the same order.  The long video replays its clips: a track and its replay have the same descriptors, so D(A, B) = D(A', B) =
+    D(A, B') = D(A', B') in exact arithmetic -- the oracle breaks such ties by position (first minimum in row-major order), the product's
+    tiled sums break them by their last bits (the two tables agree to 6e-14 relative), and WHICH of the tied pairs merges first -- even which
+    copies pair up, and with it the sizes of the clusters inside the tie -- is not defined by the algorithm.  What is defined, and compared
+    here group by group of merges at equal distance (`tol` relative): the merge distances, and the PARTITION of the tracks once the group's
+    merges are done (singleton groups: the same two clusters merged) -- together with the final labels (compared by the caller) the dendrogram
+    up to its ties."""
     import numpy as np
     if len(logg) != len(logr):
         return "MISMATCH (%d vs %d merges)" % (len(logg), len(logr))
     if len(logg) == 0:
         return "exact"
     same_pairs = np.array_equal(logg[:, :2], logr[:, :2])
-    i, groups, n = 0, 0, len(logr)
+    if same_pairs and np.array_equal(logg[:, 3], logr[:, 3]) and np.allclose(logg[:, 2], logr[:, 2], rtol=tol, atol=0):
+        return "exact"
+    m = int(max(logg[:, :2].max(), logr[:, :2].max())) + 1
+    lab_g, lab_r = np.arange(m), np.arange(m)
+    i, groups, widest, n = 0, 0, 1, len(logr)
     while i < n:
         j = i + 1
         while j < n and abs(logr[j, 2] - logr[i, 2]) <= tol * max(abs(logr[i, 2]), 1e-300):
             j += 1
         scale = max(abs(logr[i, 2]), 1e-300)
-        if np.max(np.abs(np.sort(logg[i:j, 2]) - np.sort(logr[i:j, 2]))) > tol * scale or sorted(logg[i:j, 3].tolist()) != sorted(logr[i:j, 3].tolist()):
-            return "MISMATCH at merge %d" % i
+        if np.max(np.abs(np.sort(logg[i:j, 2]) - np.sort(logr[i:j, 2]))) > tol * scale:
+            return "MISMATCH at merge %d (distances)" % i
+        for lab, log in ((lab_g, logg), (lab_r, logr)):
+            for a, b in log[i:j, :2].astype(np.int64).tolist():
+                lab[lab == lab[b]] = lab[a]
+        # the same partition: every cluster named by its smallest member
+        cg = np.zeros(m, np.int64); cr = np.zeros(m, np.int64)
+        for lab, canon in ((lab_g, cg), (lab_r, cr)):
+            order = np.argsort(lab, kind="stable")
+            first = np.ones(m, bool); first[1:] = lab[order][1:] != lab[order][:-1]
+            start = np.maximum.accumulate(np.where(first, np.arange(m), 0))       # where in `order` a member's cluster begins ...
+            canon[order] = order[start]                                            # ... with its smallest member (stable argsort)
+        if not np.array_equal(cg, cr):
+            return "MISMATCH at merge %d (the partitions after the %d merge(s) at distance %.9g differ)" % (i, j - i, logr[i, 2])
         if j - i > 1:
             groups += 1
+            widest = max(widest, j - i)
         i = j
-    if same_pairs:
-        return "exact"
-    first = int(np.nonzero((logg[:, :2] != logr[:, :2]).any(axis=1))[0][0])
-    return ("equal up to ties: the same merge distances (%.0e relative) and cluster sizes in the same order over all %d merges; %d group(s) of merges at equal "
-            "distance (replayed clips tie exactly), the pair ids differ from merge %d on (which copies pair up inside a tie names the later clusters differently)"
-            % (tol, n, groups, first))
+    first = int(np.nonzero((logg[:, :2] != logr[:, :2]).any(axis=1) | (logg[:, 3] != logr[:, 3]))[0][0])
+    return ("equal up to ties: the same merge distances (%.0e relative) over all %d merges and the same partition of the tracks after every group of merges "
+            "at one distance; %d such group(s) of more than one merge (replayed clips tie exactly; the widest has %d), inside which the order -- from merge %d on -- differs"
+            % (tol, n, groups, widest, first))
 
 
 def host_ingest_pass(ctx, pipe, frames_t, times, video, shots, args):

@@ -94,3 +94,46 @@ def test_pmc_summary_to_json(tmp_path):
     assert k["fhog"]["traffic_bytes_per_launch"] == (2 * 5000 + 6000) * 1024
     assert k["score_screened"]["batches_in_pass"] == 4 and k["score_screened"]["traffic_bytes_per_launch"] == (2 * 4100 + 10) * 1024
     assert k["score"]["batches_in_pass"] == 4 and d["detector_sha256_16"] == bench.detector_hash()
+
+
+def _avg_linkage_log(D, choose):
+    """average-linkage agglomeration of a distance matrix; `choose(candidates)` picks among the pairs at the minimum distance"""
+    import numpy as np
+    D = np.array(D, np.float64)
+    n = len(D)
+    alive, size, log = list(range(n)), [1] * n, []
+    while len(alive) > 1:
+        best = min(D[a, b] for i, a in enumerate(alive) for b in alive[i + 1:])
+        cand = [(a, b) for i, a in enumerate(alive) for b in alive[i + 1:] if abs(D[a, b] - best) <= 1e-12]
+        a, b = choose(cand)
+        for k in alive:
+            if k not in (a, b):
+                D[a, k] = D[k, a] = (size[a] * D[a, k] + size[b] * D[b, k]) / (size[a] + size[b])
+        size[a] += size[b]
+        alive.remove(b)
+        log.append((a, b, best, size[a]))
+    return np.array(log, np.float64)
+
+
+def test_merge_order_verdict_up_to_ties():
+    import numpy as np
+    rng = np.random.default_rng(3)
+    P = rng.normal(size=(6, 4))
+    P = np.concatenate([P, P, P[:2]])                    # replayed points: exact ties, some three deep
+    D = np.sqrt(((P[:, None] - P[None]) ** 2).sum(-1))
+    first = _avg_linkage_log(D, lambda c: c[0])
+    last = _avg_linkage_log(D, lambda c: c[-1])
+    assert bench.merge_order_verdict(first, first.copy()) == "exact"
+    assert not np.array_equal(first[:, :2], last[:, :2])
+    v = bench.merge_order_verdict(last, first)
+    assert v.startswith("equal up to ties"), v
+    wobble = last.copy(); wobble[:, 2] *= 1 + 3e-14     # the product's table agrees with the oracle's to a few 1e-14
+    assert bench.merge_order_verdict(wobble, first).startswith("equal up to ties")
+    # a different dendrogram is not excused: another distance, or another partition at an untied merge
+    wrong = first.copy(); wrong[-1, 2] *= 1.001
+    assert bench.merge_order_verdict(wrong, first).startswith("MISMATCH")
+    k = int(np.nonzero(np.diff(first[:, 2]) > 1e-9)[0][0]) + 1             # the first untied merge: another cluster joins instead
+    other = [c for c in first[k + 1:, 1].tolist() if c not in (first[k, 0], first[k, 1])][0]
+    wrong = first.copy(); wrong[k, 1] = other
+    assert bench.merge_order_verdict(wrong, first).startswith("MISMATCH")
+    assert bench.merge_order_verdict(first[:-1], first).startswith("MISMATCH")
