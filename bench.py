@@ -965,6 +965,8 @@ def oracle_cluster_check(pipe, res, t_end):
     D = ctx.pair_mean_dist(X, row_start)
     lg, logg = ctx.cluster_tracks_f32(E, order, row_start, pipe.clustering.threshold)
     rel = float(np.max(np.abs(D - Dr) / np.maximum(Dr, 1e-300))) if len(tids) > 1 else 0.0
+    if os.environ.get("PVF_DUMP_MERGE_LOGS"):                 # the two merge logs, for a look at a verdict off line
+        np.savez(os.environ["PVF_DUMP_MERGE_LOGS"], product=logg, oracle=logr)
     return {"tracks": int(len(tids)), "rows": int(row_start[-1]), "oracle_seconds": round(dt, 2),
             "labels": "exact" if np.array_equal(lg, lr) else "MISMATCH",
             "merge_order": merge_order_verdict(logg, logr),
@@ -973,51 +975,56 @@ def oracle_cluster_check(pipe, res, t_end):
 
 def merge_order_verdict(logg, logr, tol=1e-10):
     """the product's merge log (a, b, distance, new size: cluster b joins cluster a) against the oracle's: "exact" when the same pairs
-    merge in the same order.  The long video replays its clips: a track and its replay have the same descriptors, so D(A, B) = D(A', B) =
-    D(A, B') = D(A', B') in exact arithmetic -- the oracle breaks such ties by position (first minimum in row-major order), the product's
-    tiled sums break them by their last bits (the two tables agree to 6e-14 relative), and WHICH of the tied pairs merges first -- even which
-    copies pair up, and with it the sizes of the clusters inside the tie -- is not defined by the algorithm.  What is defined, and compared
-    here group by group of merges at equal distance (`tol` relative): the merge distances, and the PARTITION of the tracks once the group's
-    merges are done (singleton groups: the same two clusters merged) -- together with the final labels (compared by the caller) the dendrogram
-    up to its ties."""
+    merge in the same order.  The long video replays its clips: a track and its replays have the same descriptors, so they are at exactly
+    the same distance from everything else -- the oracle breaks such ties by position (first minimum in row-major order), the product's
+    tiled sums break them by their last bits (the two tables agree to 6e-14 relative), and the ORDER in which interchangeable tracks join a
+    cluster -- and with it the pair ids, even the sizes on the way (four replicas pair up two and two, or one after the other) -- is not
+    defined by the algorithm.  What is defined, and compared here: the merge distance at every step (`tol` relative), the partition of the
+    tracks wherever the two orders have caught up with each other (a stretch of steps inside which the partitions differ must end in
+    the SAME partition), the sizes outside such stretches, and (by the caller) the final labels: the dendrogram up to its ties."""
     import numpy as np
     if len(logg) != len(logr):
         return "MISMATCH (%d vs %d merges)" % (len(logg), len(logr))
-    if len(logg) == 0:
+    n = len(logr)
+    if n == 0:
         return "exact"
-    same_pairs = np.array_equal(logg[:, :2], logr[:, :2])
-    if same_pairs and np.array_equal(logg[:, 3], logr[:, 3]) and np.allclose(logg[:, 2], logr[:, 2], rtol=tol, atol=0):
+    close = np.abs(logg[:, 2] - logr[:, 2]) <= tol * np.maximum(np.abs(logr[:, 2]), 1e-300)
+    if not close.all():
+        return "MISMATCH at merge %d (distance %.12g against the oracle's %.12g)" % (int(np.argmin(close)), logg[np.argmin(close), 2], logr[np.argmin(close), 2])
+    if np.array_equal(logg[:, :2], logr[:, :2]) and np.array_equal(logg[:, 3], logr[:, 3]):
         return "exact"
     m = int(max(logg[:, :2].max(), logr[:, :2].max())) + 1
+
+    def canon(lab):                                        # every cluster named by its smallest member
+        order = np.argsort(lab, kind="stable")
+        first = np.ones(m, bool); first[1:] = lab[order][1:] != lab[order][:-1]
+        out = np.zeros(m, np.int64)
+        out[order] = order[np.maximum.accumulate(np.where(first, np.arange(m), 0))]
+        return out
+
     lab_g, lab_r = np.arange(m), np.arange(m)
-    i, groups, widest, n = 0, 0, 1, len(logr)
-    while i < n:
-        j = i + 1
-        while j < n and abs(logr[j, 2] - logr[i, 2]) <= tol * max(abs(logr[i, 2]), 1e-300):
-            j += 1
-        scale = max(abs(logr[i, 2]), 1e-300)
-        if np.max(np.abs(np.sort(logg[i:j, 2]) - np.sort(logr[i:j, 2]))) > tol * scale:
-            return "MISMATCH at merge %d (distances)" % i
+    stretches, longest, run, agree_before = 0, 0, 0, True
+    for i in range(n):
         for lab, log in ((lab_g, logg), (lab_r, logr)):
-            for a, b in log[i:j, :2].astype(np.int64).tolist():
-                lab[lab == lab[b]] = lab[a]
-        # the same partition: every cluster named by its smallest member
-        cg = np.zeros(m, np.int64); cr = np.zeros(m, np.int64)
-        for lab, canon in ((lab_g, cg), (lab_r, cr)):
-            order = np.argsort(lab, kind="stable")
-            first = np.ones(m, bool); first[1:] = lab[order][1:] != lab[order][:-1]
-            start = np.maximum.accumulate(np.where(first, np.arange(m), 0))       # where in `order` a member's cluster begins ...
-            canon[order] = order[start]                                            # ... with its smallest member (stable argsort)
-        if not np.array_equal(cg, cr):
-            return "MISMATCH at merge %d (the partitions after the %d merge(s) at distance %.9g differ)" % (i, j - i, logr[i, 2])
-        if j - i > 1:
-            groups += 1
-            widest = max(widest, j - i)
-        i = j
-    first = int(np.nonzero((logg[:, :2] != logr[:, :2]).any(axis=1) | (logg[:, 3] != logr[:, 3]))[0][0])
-    return ("equal up to ties: the same merge distances (%.0e relative) over all %d merges and the same partition of the tracks after every group of merges "
-            "at one distance; %d such group(s) of more than one merge (replayed clips tie exactly; the widest has %d), inside which the order -- from merge %d on -- differs"
-            % (tol, n, groups, widest, first))
+            a, b = int(log[i, 0]), int(log[i, 1])
+            lab[lab == lab[b]] = lab[a]
+        agree = np.array_equal(canon(lab_g), canon(lab_r))
+        if agree and agree_before and logg[i, 3] != logr[i, 3]:
+            return "MISMATCH at merge %d (cluster size %d against the oracle's %d)" % (i, int(logg[i, 3]), int(logr[i, 3]))
+        if not agree:
+            run += 1
+            if agree_before:
+                stretches += 1
+            longest = max(longest, run)
+        else:
+            run = 0
+        agree_before = agree
+    if not agree_before:
+        return "MISMATCH: the partitions differ from merge %d to the end" % (n - run)
+    first = int(np.nonzero((logg[:, :2] != logr[:, :2]).any(axis=1))[0][0]) if not np.array_equal(logg[:, :2], logr[:, :2]) else -1
+    return ("equal up to ties: the same merge distance (%.0e relative) at every one of the %d merges; the partitions of the tracks coincide except inside %d "
+            "stretch(es) of at most %d merges in which interchangeable tracks (replayed clips: identical descriptors) join a cluster in another order, "
+            "each ending in the same partition; first differing pair at merge %d" % (tol, n, stretches, longest, first))
 
 
 def host_ingest_pass(ctx, pipe, frames_t, times, video, shots, args):
