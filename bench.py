@@ -390,6 +390,27 @@ def main():
                  "note": "pvf_detector_screening(ctx, 0): score_roll_k evaluates the exact chain of 3100 fmaf for every window on the fp32 matrix cores; the timed steps "
                          "screen every window on the f16 matrix cores first and run that chain for the listed ones only (csrc/screen.hip) -- same candidates, bit for bit"}
 
+    # the same clip four times through ONE engine run (FacePipeline.run_many, what configs[3] is timed on): a step above ends with its
+    # pipeline draining -- the last shots' tracker and extraction work alone on the GPU, then the clustering, then the host's result
+    # assembly before the next step's first kernel -- and a deployment that has the next video waiting does not pay that drain.  NOT
+    # `value` (whose steps run one after the other, each complete before the next starts); outside the timed region.
+    back_to_back = None
+    if world == 1 and not args.dense_scoring and not args.no_dense_leg and args.detect_every == 0.0 and args.config == "c2":
+        clips = [dict(frames=frames, times=times, frame_rate=video.frame_rate, shots=shots) for _ in range(4)]
+        pipe.run_many(clips)
+        barrier()
+        t0 = time.perf_counter()
+        many = pipe.run_many(clips)
+        barrier()
+        b_elapsed = time.perf_counter() - t0
+        same = all(labels_digest(r["labels"]) == labels_digest(labels) and len(r["tracks"]) == len(res["tracks"])
+                   and np.array_equal(np.asarray(r["face_boxes"]), np.asarray(res["face_boxes"]))
+                   and np.array_equal(np.asarray(r["face_T"]), np.asarray(res["face_T"])) for r in many)
+        back_to_back = {"value": round(len(clips) * n_local / b_elapsed, 2), "unit": "frames/s", "clips": len(clips), "ms_per_clip": round(1000.0 * b_elapsed / len(clips), 2),
+                        "same_tracks_faces_and_labels_as_the_timed_steps": bool(same),
+                        "note": "FacePipeline.run_many: four copies of the clip as four jobs of one engine run -- the detector of clip i + 1 runs beside the tracker, "
+                                "extraction and clustering tail of clip i; every clip clustered on its own, as in a timed step"}
+
     # ---- the WHOLE clip against the CPU oracle: the timed steps' own result (tracks, faces, landmarks, descriptors, labels) and the
     # detector's raw candidates of every frame against the fixture the oracle flow wrote for all 1000 frames (tests/golden/c2_full.npz,
     # made by tests/golden/make_full_clip.py: minutes of CPU, so it is frozen, not recomputed here); the dense leg the same way
@@ -431,6 +452,7 @@ def main():
         "roofline": roofline,
         "roofline_other": roofline_other,
         "dense_scoring": dense,
+        "back_to_back": back_to_back,
         "e2e": e2e_object(flop_per_frame if args.detect_every == 0.0 else flop_per_frame * n_score_frames / max(n_local * args.steps, 1),
                           int(len(res["face_T"])) * args.steps, n_local * args.steps, elapsed,
                           bytes_per_frame=frame_bytes(args.height, args.width, len(res["face_T"]) / float(max(n_local, 1))) if args.detect_every == 0.0 else None),
