@@ -168,6 +168,7 @@ static void load_embedder(Ctx* c, const char* path)
     const float* p = blob.f32();
     const float* end = p + blob.numel();
     e.convs.clear();
+    if (e.d_stem) { (void)hipFree(e.d_stem); e.d_stem = nullptr; }     // (fragment-ordered copy of the first layer's weights: rebuilt on the next forward)
     auto add_conv = [&](int cin, int cout, int k, int stride, int pad) {
         ConvLayer L{cin, cout, k, stride, pad, nullptr, nullptr, nullptr, nullptr};
         const size_t nw = (size_t)cout * cin * k * k;

@@ -169,6 +169,7 @@ struct EmbedModel {
     std::vector<ConvLayer> convs;  // 29
     float* d_fc = nullptr;         // [256][128]
     float* d_blob = nullptr;
+    float* d_stem = nullptr;       // the first layer's weights in MFMA fragment order [98 k-pairs][64 lanes] (resnet.hip: stem_frag_k)
 };
 
 struct TrackerTables {

@@ -47,16 +47,6 @@ void face_chip_details(const EmbedModel& m, const int32_t* pts, ChipDetails* out
     out->rows = m.chip_size; out->cols = m.chip_size;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// chips u8 [n][3] -> network input f32 [n][4] (fourth channel 0, see the weight layout in ctx.hip)
-__global__ void __launch_bounds__(256) prep_input_k(const uint8_t* __restrict__ chips, float4* __restrict__ out, size_t n_px)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_px) return;
-    const uint8_t* q = chips + 3 * i;
-    out[i] = make_float4(((float)q[0] - 122.782f) / 256.0f, ((float)q[1] - 117.001f) / 256.0f, ((float)q[2] - 104.298f) / 256.0f, 0.0f);
-}
-
 struct ConvArgs {
     const float* in; int B, H, W, Cin;
     const float* w; int K;             // K = ksz*ksz*Cin (k = (r*ksz + s)*Cin + c), weights transposed: [Cout][K padded to 32]
@@ -163,7 +153,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, float* smem, co
         }
 }
 
-template <int WM, int WN, bool RGB4>        // RGB4: the first layer (4 stored input channels, every float4 of a chunk is a tap of its own)
+template <int WM, int WN>
 __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
 {
     constexpr int BM = 64 * WM, BN = 32 * WN, KC = 32, PITCH = 36;
@@ -224,20 +214,13 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
     float4 vb[B_F4];
     // Three stages per chunk, one chunk apart: its byte offsets are worked out (plain VALU work, spread between the MFMAs of an earlier
     // chunk), its loads are issued right after the barrier of the chunk before it, and it is parked in LDS one barrier later.
-    // Chunk walk of the 32-or-more-channel layers: (tap row, tap column, first channel) advance with scalar adds, no division in the loop.
+    // Chunk walk: (tap row, tap column, first channel) advance with scalar adds, no division in the loop (input channels: a multiple of 32).
     int f_r = 0, f_s = 0, f_c = 0, f_k = 0;             // the chunk whose offsets are computed next
     int voff[A_F4], woff = 0;
     auto offsets = [&]() {
         const int kq = f_k + 4 * j4;
-        int r, sft, delta;
-        if (RGB4) {
-            const int tap = kq >> 2;                    // 4 stored channels per tap
-            r = small_div(tap, a.ksz, 1.0f / (float)a.ksz); sft = tap - r * a.ksz;
-            delta = (r * a.W + sft) * 4;
-        } else {
-            r = f_r; sft = f_s;                         // wave-uniform
-            delta = (r * a.W + sft) * a.Cin + f_c + 4 * j4;
-        }
+        const int r = f_r, sft = f_s;                   // wave-uniform
+        const int delta = (r * a.W + sft) * a.Cin + f_c + 4 * j4;
         const int k_ok = (kq < a.K) ? -1 : 0;
 #pragma unroll
         for (int q = 0; q < A_F4; ++q) {
@@ -249,10 +232,8 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
         woff = f_k;
         if (f_k + KC < Kpad) {                          // (past the last chunk: stay on it; those loads are issued but never parked)
             f_k += KC;
-            if (!RGB4) {
-                f_c += KC;
-                if (f_c >= a.Cin) { f_c = 0; if (++f_s == a.ksz) { f_s = 0; ++f_r; } }
-            }
+            f_c += KC;
+            if (f_c >= a.Cin) { f_c = 0; if (++f_s == a.ksz) { f_s = 0; ++f_r; } }
         }
     };
     auto issue = [&]() {
@@ -310,6 +291,90 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
 // round 5 -- profiles/r05_conv_band_experiment.txt: a layer's MFMAs and its unavoidable HBM traffic are of the same size and run one
 // after the other inside a block; the staging of the A operand is not what the matrix pipe waits for.)
 
+// ---------------------------------------------------------------------------------------------------
+// The first layer (7 x 7, stride 2, 3 -> 32 channels on the 150 x 150 chip) straight from the uint8 chips.  Through the generic kernel it
+// cost three passes over HBM (an input pass: bytes -> 4-channel floats, 270 KB per face written and read back; the result, 663 KB per
+// face) and a seventh K chunk of nothing but zero padding (K = 7 * 7 * 4 = 196 in chunks of 32); its A tile was gathered tap by tap
+// from global memory although a block's whole input is 6 KB.  Here a block owns FOUR output rows of one face (288 pixels = nine 32-row
+// MFMA tiles, three per wave, three waves): the 13 chip rows under them are parked in LDS as bytes (one contiguous, 4-byte aligned
+// range of the chip), the layer's weights next to them in fragment order (stem_frag_k, once per model), and the K loop is unrolled over
+// the 98 k-pairs: per MFMA a lane reads ONE byte at a constant offset from its pixel's base (ds_read_u8 with an immediate), converts it
+// ((q - mean) / 256, as the input pass did) and feeds it with the pair's weight fragment to its three tiles.
+// The products, their pairing ((c0, c1) and (c2, 0) of a tap in one MFMA) and the order of the chain are those of the generic kernel this
+// layer used to run through (conv_mfma_k on the chip expanded to four float channels): the layer's output is bit-identical -- the fourth
+// channel's weights are zero, so what the lane of that k reads (the next pixel's first byte) does not matter, and the generic kernel's
+// k = 196 .. 223 added exact zeros.  Measured: 4096 faces 24.1 -> 22.9 ms for the whole network, the same descriptors bit for bit
+// (tools/bench_embed.py prints their checksum); the layer itself runs at about 0.9 of the fp32 matrix peak counted on K = 196.
+#define STEM_ROWS 4
+#define STEM_IN_DW 1464                                   // 13 rows x 450 bytes = 5850 bytes
+__global__ void __launch_bounds__(64) stem_frag_k(const float* __restrict__ w, float* __restrict__ frag)
+{
+    const int s = blockIdx.x, l = threadIdx.x;            // frag[s][lane] = w[channel lane & 31][k = 2 s + (lane >> 5)]
+    frag[s * 64 + l] = w[(size_t)(l & 31) * 224 + 2 * s + (l >> 5)];
+}
+
+__global__ void __launch_bounds__(192) stem_conv_k(const uint8_t* __restrict__ chips, int B, const float* __restrict__ frag, const float* __restrict__ bias,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out)
+{
+    constexpr int S = 150, OW = 72;
+    __shared__ uint32_t s_in[STEM_IN_DW];
+    __shared__ __attribute__((aligned(16))) float s_b[98 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int face = blockIdx.y, oy0 = blockIdx.x * STEM_ROWS;
+    {
+        // the chips behind a descriptor (a dword past the last chip's end reads as zero); a block's range starts on a multiple of 4:
+        // a chip is 67500 bytes, two chip rows 900
+        const size_t total = (size_t)B * S * S * 3;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(chips + (size_t)face * S * S * 3), 0,
+                                                                             (int)std::min<size_t>(total - (size_t)face * S * S * 3, 0x7ffffff0u), 0x00020000);
+        const int first = 2 * oy0 * S * 3;
+        for (int i = tid; i < STEM_IN_DW; i += 192) s_in[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * i, first, 0);
+        const float4* f4 = reinterpret_cast<const float4*>(frag);
+        float4* b4 = reinterpret_cast<float4*>(s_b);
+        for (int i = tid; i < 98 * 16; i += 192) b4[i] = f4[i];
+    }
+    __syncthreads();
+    const int li = lane & 31, kh = lane >> 5;
+    const uint8_t* px = reinterpret_cast<const uint8_t*>(s_in);
+    const uint8_t* base[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int m = (wave * 3 + t) * 32 + li;           // pixel of the block: row m / 72, column m % 72
+        const int oy = m / OW, ox = m - oy * OW;
+        base[t] = px + ((2 * oy) * S + 2 * ox) * 3 + kh;
+    }
+    // channel of this lane's k: kh in the pair (c0, c1), 2 + kh in the pair (c2, zero channel)
+    const float mean_e = kh ? 117.001f : 122.782f, mean_o = kh ? 0.0f : 104.298f;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 98; ++s) {
+        const int tap = s >> 1, r = tap / 7, q = tap - r * 7;
+        const int off = (r * S + q) * 3 + 2 * (s & 1);
+        const float b = s_b[s * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const float a = ((float)base[t][off] - ((s & 1) ? mean_o : mean_e)) / 256.0f;
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    // C layout of the 32 x 32 MFMA: column (channel) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const float bs = bias[li], g = gamma[li], bt = beta[li];
+    float* o = out + ((size_t)face * OW + oy0) * OW * 32 + li;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = (wave * 3 + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+            float v = (acc[t][reg] + bs) * g + bt;
+            v = v < 0.0f ? 0.0f : v;
+            o[(size_t)m * 32] = v;
+        }
+}
+
 __global__ void __launch_bounds__(256) maxpool3s2_k(const float* __restrict__ in, int B, int H, int W, int C, float* __restrict__ out, int OH, int OW)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,19 +413,15 @@ __global__ void __launch_bounds__(256) head_k(const float* __restrict__ x, int H
 static void launch_conv(Ctx* c, const ConvArgs& a)
 {
     const long M = (long)a.B * a.OH * a.OW;
-    PVF_REQUIRE(a.Cin % 32 == 0 || a.Cin == 4, "conv: input channels must be 4 (padded RGB) or a multiple of 32");
+    PVF_REQUIRE(a.Cin % 32 == 0, "conv: input channels must be a multiple of 32 (the 3-channel first layer has a kernel of its own: stem_conv_k)");
     PVF_REQUIRE(a.OH * a.OW < (1 << 21) && a.Cout % 32 == 0, "conv: output map too large for the kernel's index arithmetic / Cout not a multiple of 32");
-    if (a.Cin == 4) {
-        PVF_REQUIRE(a.Cout == 32, "conv: the RGB layer has 32 output channels");
+    if (a.Cout == 32) {
         const dim3 grid((unsigned)((M + 255) / 256), 1);
-        hipLaunchKernelGGL((conv_mfma_k<4, 1, true>), grid, dim3(256), 0, c->stream, a);
-    } else if (a.Cout == 32) {
-        const dim3 grid((unsigned)((M + 255) / 256), 1);
-        hipLaunchKernelGGL((conv_mfma_k<4, 1, false>), grid, dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((conv_mfma_k<4, 1>), grid, dim3(256), 0, c->stream, a);
     } else {
         PVF_REQUIRE(a.Cout % 64 == 0, "conv: Cout must be 32 or a multiple of 64");
         const dim3 grid((unsigned)((M + 127) / 128), a.Cout / 64);
-        hipLaunchKernelGGL((conv_mfma_k<2, 2, false>), grid, dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((conv_mfma_k<2, 2>), grid, dim3(256), 0, c->stream, a);
     }
 }
 
@@ -385,16 +446,16 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
         float* x = c->s_act0.as<float>();
         float* y = c->s_act1.as<float>();
         float* z = c->s_act2.as<float>();
-        const size_t nin = (size_t)B * S * S;
-        hipLaunchKernelGGL(prep_input_k, dim3((unsigned)((nin + 255) / 256)), dim3(256), 0, c->stream, d_chips + (size_t)b0 * S * S * 3,
-                           reinterpret_cast<float4*>(x), nin);
-        // conv1 -> y ; maxpool -> z
-        ConvArgs a;
-        memset(&a, 0, sizeof a);
+        // conv1 (straight from the uint8 chips) -> y ; maxpool -> z
         const ConvLayer& L0 = e.convs[0];
-        a.in = x; a.B = B; a.H = S; a.W = S; a.Cin = 4; a.w = L0.d_w; a.K = 7 * 7 * 4; a.bias = L0.d_bias; a.gamma = L0.d_gamma; a.beta = L0.d_beta;
-        a.out = y; a.OH = h1; a.OW = h1; a.Cout = 32; a.AH = h1; a.AW = h1; a.ksz = 7; a.stride = 2; a.pad = 0; a.relu = 1; a.skip_mode = 0;
-        launch_conv(c, a);
+        PVF_REQUIRE(S == 150 && L0.cout == 32 && L0.k == 7 && h1 == 72, "stem kernel: 150 x 150 chips, 7 x 7 stride 2, 32 channels");
+        if (!c->emb.d_stem) {
+            HIP_CHECK(hipMalloc(&c->emb.d_stem, 98 * 64 * sizeof(float)));
+            hipLaunchKernelGGL(stem_frag_k, dim3(98), dim3(64), 0, c->stream, L0.d_w, c->emb.d_stem);
+        }
+        hipLaunchKernelGGL(stem_conv_k, dim3(h1 / STEM_ROWS, B), dim3(192), 0, c->stream, d_chips + (size_t)b0 * S * S * 3, B, c->emb.d_stem,
+                           L0.d_bias, L0.d_gamma, L0.d_beta, y);
+        ConvArgs a;
         const size_t npool = (size_t)B * hp * hp * 32;
         hipLaunchKernelGGL(maxpool3s2_k, dim3((unsigned)((npool + 255) / 256)), dim3(256), 0, c->stream, y, B, h1, h1, 32, z, hp, hp);
         // rotate buffers: cur = z (unit input), t1/t2 scratch
