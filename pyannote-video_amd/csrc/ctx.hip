@@ -167,10 +167,11 @@ static void load_embedder(Ctx* c, const char* path)
     const Tensor& blob = need(m, "emb.blob");
     const float* p = blob.f32();
     const float* end = p + blob.numel();
+    for (ConvLayer& L : e.convs) if (L.d_frag) { (void)hipFree(L.d_frag); L.d_frag = nullptr; }
     e.convs.clear();
     if (e.d_stem) { (void)hipFree(e.d_stem); e.d_stem = nullptr; }     // (fragment-ordered copy of the first layer's weights: rebuilt on the next forward)
     auto add_conv = [&](int cin, int cout, int k, int stride, int pad) {
-        ConvLayer L{cin, cout, k, stride, pad, nullptr, nullptr, nullptr, nullptr};
+        ConvLayer L{cin, cout, k, stride, pad, nullptr, nullptr, nullptr, nullptr, nullptr};
         const size_t nw = (size_t)cout * cin * k * k;
         PVF_REQUIRE(p + nw + 3 * (size_t)cout <= end, "emb.blob too short");
         // [cout][cin][r][s] -> [cout][kk], kk = (r*k+s)*cp + c, rows zero-padded to a multiple of 32 (the conv kernel's K chunk); the

@@ -159,6 +159,7 @@ struct ConvLayer {
     float* d_bias;  // [cout]
     float* d_gamma; // [cout]
     float* d_beta;  // [cout]
+    float* d_frag = nullptr;   // 32 -> 32 layers: d_w in MFMA fragment order [k-pairs][64 lanes] (resnet.hip: conv_frag_k), made on first use
 };
 
 struct EmbedModel {

@@ -50,6 +50,7 @@ void face_chip_details(const EmbedModel& m, const int32_t* pts, ChipDetails* out
 struct ConvArgs {
     const float* in; int B, H, W, Cin;
     const float* w; int K;             // K = ksz*ksz*Cin (k = (r*ksz + s)*Cin + c), weights transposed: [Cout][K padded to 32]
+    const float* frag;                 // the same weights in MFMA fragment order (conv_frag_k), for the layers that have a kernel of their own; or null
     const float* bias; const float* gamma; const float* beta;
     float* out; int OH, OW, Cout;      // output tensor dims
     int AH, AW;                        // conv-valid dims (<= OH, OW)
@@ -375,6 +376,142 @@ __global__ void __launch_bounds__(192) stem_conv_k(const uint8_t* __restrict__ c
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The six 3 x 3 layers of the 35 x 35 x 32 stage (a quarter of the network's arithmetic, and through the generic kernel its least efficient
+// part: 32 output channels are ONE MFMA column tile, so every A element staged through LDS feeds a single MFMA) in the first layer's
+// form.  A work item is a band of SEVEN output rows of one face (245 pixels: eight 32-row tiles, two per wave); the nine input rows
+// under it sit in LDS with their zero border, [row][column][33 floats] (the odd pitch spreads a tile's pixels over the banks), the
+// layer's weights next to them in fragment order (81 KB together: two blocks per CU); the K loop is unrolled over the 144 k-pairs, and
+// per MFMA a lane reads ONE float at a constant offset from its pixel's base.  Products, pairing and chain order are the generic
+// kernel's (k = (tap, channel), channel pairs (2 j, 2 j + 1)), so is the epilogue's arithmetic: bit-identical results.
+// How it got here (4096 faces, per layer; the generic kernel: 1.03-1.17 ms; the layer's MFMAs alone at the clock they run at: 0.8 ms --
+// measured with the loads and the stores compiled out): one block per band with the tile loaded slot by slot 1.58 ms (eleven round
+// trips to HBM in a row), with all of a thread's slots requested before the first is parked 1.1-1.3 ms, resident blocks that request the
+// NEXT band's rows before the current band's MFMAs 0.95-1.12 ms.  What is left beside the MFMAs is parking the rows (44 LDS writes per
+// thread), two barriers and the stores, at two waves per SIMD.
+#define C32_ROWS 7
+#define C32_TILE_FLOATS (9 * 37 * 33)
+__global__ void __launch_bounds__(64) conv_frag_k(const float* __restrict__ w, int Kpad, float* __restrict__ frag)
+{
+    const int s = blockIdx.x, l = threadIdx.x;            // frag[s][lane] = w[channel lane & 31][k = 2 s + (lane >> 5)]
+    frag[s * 64 + l] = w[(size_t)(l & 31) * Kpad + 2 * s + (l >> 5)];
+}
+
+__global__ void __launch_bounds__(256) conv3x3_c32_k(const float* __restrict__ in, const float* __restrict__ frag, const float* __restrict__ bias,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ skip,
+                                                     float* __restrict__ out, int n_items)
+{
+    constexpr int HW = 35, TW = 37, PITCH = 33, NP = 144;
+    constexpr int NSLOT = 9 * TW * 8, PER = (NSLOT + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem_c32[];
+    float* T = smem_c32;                                  // [9][37][33]
+    float* Bf = smem_c32 + C32_TILE_FLOATS;               // [144][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    // A block is resident for the whole layer and takes every gridDim.x-th band (item = face * 5 + band): the weight fragments are parked
+    // once, and the NEXT band's input rows (and this band's skip values) are requested before the current band's MFMAs start, so that
+    // what a band costs beside its MFMAs is parking 11 float4 per thread and issuing its stores.
+    {
+        const float4* f4 = reinterpret_cast<const float4*>(frag);
+        float4* b4 = reinterpret_cast<float4*>(Bf);
+        for (int i = tid; i < NP * 16; i += 256) b4[i] = f4[i];
+    }
+    const float bs = bias[li], g = gamma[li], bt = beta[li];
+    const float* base[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        int m = (wave * 2 + t) * 32 + li;                 // pixel of the band: row m / 35, column m % 35 (rows past the band: computed on pixel 0, never stored)
+        if (m >= C32_ROWS * HW) m = 0;
+        const int oy = m / HW, ox = m - oy * HW;
+        base[t] = T + (oy * TW + ox) * PITCH + kh;
+    }
+    const float* bl = Bf + lane;
+    // a thread's slots of the tile (four channels of one tile pixel each): where they come from relative to the band's first input row;
+    // which of them lie in a border column (always zero), in the tile's first / last row (zero for a face's first / last band)
+    int s_off[PER];
+    unsigned m_col = 0, m_row0 = 0, m_row8 = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = tid + j * 256;
+        const int c4 = i & 7, px = i >> 3;
+        const int ry = px / TW, cx = px - ry * TW;
+        if ((i < NSLOT) && ((unsigned)(cx - 1) < (unsigned)HW)) m_col |= 1u << j;
+        if (ry == 0) m_row0 |= 1u << j;
+        if (ry == 8) m_row8 |= 1u << j;
+        s_off[j] = (ry * HW + (cx - 1)) * 32 + 4 * c4;
+    }
+    float4 v[PER];
+    float sk[2][16];
+    auto request = [&](int item) {                        // the band's nine input rows, zero outside the image
+        const int face = item / 5, band = item - face * 5;
+        const float* src = in + ((size_t)face * HW + (band * C32_ROWS - 1)) * HW * 32;
+        const unsigned ok = m_col & ~(band == 0 ? m_row0 : 0u) & ~(band == 4 ? m_row8 : 0u);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            v[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if ((ok >> j) & 1u) v[j] = *reinterpret_cast<const float4*>(src + s_off[j]);
+        }
+    };
+    auto request_skip = [&](int item) {                   // the band's skip values: in flight during its own MFMAs
+        const int face = item / 5, oy0 = (item - face * 5) * C32_ROWS;
+        const size_t p0 = ((size_t)face * HW + oy0) * HW;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = (wave * 2 + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                sk[t][reg] = (m < C32_ROWS * HW) ? skip[(p0 + m) * 32 + li] : 0.0f;
+            }
+    };
+    int item = blockIdx.x;
+    if (item < n_items) request(item);
+    while (item < n_items) {
+        // park the band that was requested during the previous one's MFMAs
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int i = tid + j * 256;
+            if (i < NSLOT) {
+                float* d = T + (i >> 3) * PITCH + 4 * (i & 7);
+                d[0] = v[j].x; d[1] = v[j].y; d[2] = v[j].z; d[3] = v[j].w;
+            }
+        }
+        __syncthreads();
+        const int next = item + gridDim.x;
+        if (next < n_items) request(next);
+        if (skip) request_skip(item);
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+            const int tap = s >> 4, r = tap / 3, q = tap - r * 3;
+            const int off = (r * TW + q) * PITCH + 2 * (s & 15);
+            const float b = bl[s * 64];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(base[t][off], b, acc[t], 0, 0, 0);
+        }
+        // C layout of the 32 x 32 MFMA: column (channel) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); a band's pixels are
+        // contiguous in the output tensor
+        const int face = item / 5, oy0 = (item - face * 5) * C32_ROWS;
+        const size_t p0 = ((size_t)face * HW + oy0) * HW;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int m = (wave * 2 + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
+                if (m >= C32_ROWS * HW) continue;
+                float x = (acc[t][reg] + bs) * g + bt;
+                if (skip) x += sk[t][reg];
+                x = x < 0.0f ? 0.0f : x;
+                out[(p0 + m) * 32 + li] = x;
+            }
+        __syncthreads();                                  // every wave is done with the tile before the next band is parked
+        item = next;
+    }
+}
+
 __global__ void __launch_bounds__(256) maxpool3s2_k(const float* __restrict__ in, int B, int H, int W, int C, float* __restrict__ out, int OH, int OW)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -415,7 +552,15 @@ static void launch_conv(Ctx* c, const ConvArgs& a)
     const long M = (long)a.B * a.OH * a.OW;
     PVF_REQUIRE(a.Cin % 32 == 0, "conv: input channels must be a multiple of 32 (the 3-channel first layer has a kernel of its own: stem_conv_k)");
     PVF_REQUIRE(a.OH * a.OW < (1 << 21) && a.Cout % 32 == 0, "conv: output map too large for the kernel's index arithmetic / Cout not a multiple of 32");
-    if (a.Cout == 32) {
+    if (a.frag && a.Cin == 32 && a.Cout == 32 && a.H == 35 && a.W == 35 && a.OH == 35 && a.OW == 35 && a.AH == 35 && a.AW == 35 && a.ksz == 3 &&
+        a.stride == 1 && a.pad == 1 && a.relu && a.skip_mode != 2) {
+        static bool attr = false;
+        const size_t lds = (size_t)(C32_TILE_FLOATS + 144 * 64) * sizeof(float);
+        if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        const int items = a.B * (35 / C32_ROWS);
+        hipLaunchKernelGGL(conv3x3_c32_k, dim3((unsigned)std::min(items, 2 * c->n_cu)), dim3(256), lds, c->stream, a.in, a.frag, a.bias, a.gamma, a.beta,
+                           a.skip_mode == 1 ? a.skip : nullptr, a.out, items);
+    } else if (a.Cout == 32) {
         const dim3 grid((unsigned)((M + 255) / 256), 1);
         hipLaunchKernelGGL((conv_mfma_k<4, 1>), grid, dim3(256), 0, c->stream, a);
     } else {
@@ -463,6 +608,16 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
         int H = hp, W = hp;
         static const int UN[14][3] = {{32, 32, 0}, {32, 32, 0}, {32, 32, 0}, {32, 64, 1}, {64, 64, 0}, {64, 64, 0}, {64, 64, 0},
                                       {64, 128, 1}, {128, 128, 0}, {128, 128, 0}, {128, 256, 1}, {256, 256, 0}, {256, 256, 0}, {256, 256, 1}};
+        // fragment-ordered weights of the 32 -> 32 layers, made on first use
+        auto frag_of = [&](int layer) -> const float* {
+            ConvLayer& L = c->emb.convs[layer];
+            if (L.cin != 32 || L.cout != 32 || L.k != 3) return nullptr;
+            if (!L.d_frag) {
+                HIP_CHECK(hipMalloc(&L.d_frag, 144 * 64 * sizeof(float)));
+                hipLaunchKernelGGL(conv_frag_k, dim3(144), dim3(64), 0, c->stream, L.d_w, 288, L.d_frag);
+            }
+            return L.d_frag;
+        };
         for (int u = 0; u < 14; ++u) {
             const int cin = UN[u][0], nn = UN[u][1], down = UN[u][2];
             const ConvLayer& La = e.convs[1 + 2 * u];
@@ -472,6 +627,7 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
             memset(&a, 0, sizeof a);
             a.in = cur; a.B = B; a.H = H; a.W = W; a.Cin = cin; a.w = La.d_w; a.K = 9 * cin; a.bias = La.d_bias; a.gamma = La.d_gamma; a.beta = La.d_beta;
             a.out = t1; a.OH = ah; a.OW = aw; a.Cout = nn; a.AH = ah; a.AW = aw; a.ksz = 3; a.stride = stride; a.pad = pad; a.relu = 1; a.skip_mode = 0;
+            a.frag = frag_of(1 + 2 * u);
             launch_conv(c, a);
             int sh = H, sw = W;
             if (down) { sh = 1 + (H - 2) / 2; sw = 1 + (W - 2) / 2; }
@@ -480,6 +636,7 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
             a.in = t1; a.B = B; a.H = ah; a.W = aw; a.Cin = nn; a.w = Lb.d_w; a.K = 9 * nn; a.bias = Lb.d_bias; a.gamma = Lb.d_gamma; a.beta = Lb.d_beta;
             a.out = t2; a.OH = oh; a.OW = ow; a.Cout = nn; a.AH = ah; a.AW = aw; a.ksz = 3; a.stride = 1; a.pad = 1; a.relu = 1;
             a.skip_mode = down ? 2 : 1; a.skip = cur; a.XH = H; a.XW = W; a.XC = cin; a.SH = sh; a.SW = sw;
+            a.frag = frag_of(2 + 2 * u);
             launch_conv(c, a);
             float* old = cur; cur = t2; t2 = old;
             H = oh; W = ow;
