@@ -295,23 +295,28 @@ __global__ void __launch_bounds__(256) conv_mfma_k(ConvArgs a)
 // ---------------------------------------------------------------------------------------------------
 // The first layer (7 x 7, stride 2, 3 -> 32 channels on the 150 x 150 chip) straight from the uint8 chips.  Through the generic kernel it
 // cost three passes over HBM (an input pass: bytes -> 4-channel floats, 270 KB per face written and read back; the result, 663 KB per
-// face) and a seventh K chunk of nothing but zero padding (K = 7 * 7 * 4 = 196 in chunks of 32); its A tile was gathered tap by tap
-// from global memory although a block's whole input is 6 KB.  Here a block owns FOUR output rows of one face (288 pixels = nine 32-row
-// MFMA tiles, three per wave, three waves): the 13 chip rows under them are parked in LDS as bytes (one contiguous, 4-byte aligned
-// range of the chip), the layer's weights next to them in fragment order (stem_frag_k, once per model), and the K loop is unrolled over
-// the 98 k-pairs: per MFMA a lane reads ONE byte at a constant offset from its pixel's base (ds_read_u8 with an immediate), converts it
-// ((q - mean) / 256, as the input pass did) and feeds it with the pair's weight fragment to its three tiles.
-// The products, their pairing ((c0, c1) and (c2, 0) of a tap in one MFMA) and the order of the chain are those of the generic kernel this
-// layer used to run through (conv_mfma_k on the chip expanded to four float channels): the layer's output is bit-identical -- the fourth
-// channel's weights are zero, so what the lane of that k reads (the next pixel's first byte) does not matter, and the generic kernel's
-// k = 196 .. 223 added exact zeros.  Measured: 4096 faces 24.1 -> 22.9 ms for the whole network, the same descriptors bit for bit
-// (tools/bench_embed.py prints their checksum); the layer itself runs at about 0.9 of the fp32 matrix peak counted on K = 196.
+// face) and a K of 7 * 7 * 4 = 196 padded to 224 for 147 real products; its A tile was gathered tap by tap from global memory although
+// a block's whole input is 6 KB.  Here a block owns FOUR output rows of one face (288 pixels = nine 32-row MFMA tiles, three per wave,
+// three waves): the 13 chip rows under them are parked in LDS as bytes (one contiguous, 4-byte aligned range of the chip), the layer's
+// weights next to them in fragment order (stem_frag_k, once per model), and the K loop is unrolled over 77 k-pairs -- the 21 values
+// under a tap ROW (7 taps x 3 colours) are 21 consecutive bytes of a chip row, so k runs along them in pairs, eleven per tap row, the
+// last pair padded with a zero weight.  Per MFMA a lane reads ONE byte at a constant offset from its pixel's base (ds_read_u8 with an
+// immediate), converts it ((q - mean) / 256, as the input pass did) and feeds it with the pair's weight fragment to its three tiles.
+// The chain runs over the same products in the same order as the generic kernel's did (taps row-major, colour fastest; that one's
+// fourth channel and its k = 196 .. 223 added exact zeros); the pairing inside an MFMA differs ((c0, c1), (c2, next tap's c0) ...
+// instead of (c0, c1), (c2, 0)) -- and the descriptors are the same bit for bit (tools/bench_embed.py prints their checksum): the
+// 32 x 32 x 2 MFMA adds its two products to the accumulator one after the other.  Measured on 4096 faces: 24.1 -> 22.9 ms for the
+// whole network with 98 pairs (the generic pairing), 22.4 -> 21.8 with 77.
 #define STEM_ROWS 4
 #define STEM_IN_DW 1464                                   // 13 rows x 450 bytes = 5850 bytes
+#define STEM_NP 77                                        // k-pairs: 7 tap rows x 11 pairs (21 values of a row + one zero-weight pad)
 __global__ void __launch_bounds__(64) stem_frag_k(const float* __restrict__ w, float* __restrict__ frag)
 {
-    const int s = blockIdx.x, l = threadIdx.x;            // frag[s][lane] = w[channel lane & 31][k = 2 s + (lane >> 5)]
-    frag[s * 64 + l] = w[(size_t)(l & 31) * 224 + 2 * s + (l >> 5)];
+    // frag[pair][lane] = weight of channel lane & 31 for the pair's k of this half-wave: tap row r, position t = 2 pp + (lane >> 5) in the
+    // row's 21 values (t = 3 q + c: tap column q, colour c; t = 21: the pad); w is the generic layout [cout][224], k = (r * 7 + q) * 4 + c
+    const int p = blockIdx.x, l = threadIdx.x;
+    const int r = p / 11, t = 2 * (p - r * 11) + (l >> 5);
+    frag[p * 64 + l] = (t < 21) ? w[(size_t)(l & 31) * 224 + (r * 7 + t / 3) * 4 + t % 3] : 0.0f;
 }
 
 __global__ void __launch_bounds__(192) stem_conv_k(const uint8_t* __restrict__ chips, int B, const float* __restrict__ frag, const float* __restrict__ bias,
@@ -319,7 +324,7 @@ __global__ void __launch_bounds__(192) stem_conv_k(const uint8_t* __restrict__ c
 {
     constexpr int S = 150, OW = 72;
     __shared__ uint32_t s_in[STEM_IN_DW];
-    __shared__ __attribute__((aligned(16))) float s_b[98 * 64];
+    __shared__ __attribute__((aligned(16))) float s_b[STEM_NP * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int face = blockIdx.y, oy0 = blockIdx.x * STEM_ROWS;
     {
@@ -332,7 +337,7 @@ __global__ void __launch_bounds__(192) stem_conv_k(const uint8_t* __restrict__ c
         for (int i = tid; i < STEM_IN_DW; i += 192) s_in[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, 4 * i, first, 0);
         const float4* f4 = reinterpret_cast<const float4*>(frag);
         float4* b4 = reinterpret_cast<float4*>(s_b);
-        for (int i = tid; i < 98 * 16; i += 192) b4[i] = f4[i];
+        for (int i = tid; i < STEM_NP * 16; i += 192) b4[i] = f4[i];
     }
     __syncthreads();
     const int li = lane & 31, kh = lane >> 5;
@@ -344,21 +349,22 @@ __global__ void __launch_bounds__(192) stem_conv_k(const uint8_t* __restrict__ c
         const int oy = m / OW, ox = m - oy * OW;
         base[t] = px + ((2 * oy) * S + 2 * ox) * 3 + kh;
     }
-    // channel of this lane's k: kh in the pair (c0, c1), 2 + kh in the pair (c2, zero channel)
-    const float mean_e = kh ? 117.001f : 122.782f, mean_o = kh ? 0.0f : 104.298f;
+    // colour of this lane's k in pair pp of a row: (2 pp + kh) % 3 -- three cases by pp % 3
+    const float M0 = 122.782f, M1 = 117.001f, M2 = 104.298f;
+    const float mean3[3] = {kh ? M1 : M0, kh ? M0 : M2, kh ? M2 : M1};
     f32x16 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
 #pragma unroll
-    for (int s = 0; s < 98; ++s) {
-        const int tap = s >> 1, r = tap / 7, q = tap - r * 7;
-        const int off = (r * S + q) * 3 + 2 * (s & 1);
+    for (int s = 0; s < STEM_NP; ++s) {
+        const int r = s / 11, pp = s - r * 11;
+        const int off = r * S * 3 + 2 * pp;               // + kh (in the base): the row's 21 bytes under the tap row are consecutive
         const float b = s_b[s * 64 + lane];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const float a = ((float)base[t][off] - ((s & 1) ? mean_o : mean_e)) / 256.0f;
+            const float a = ((float)base[t][off] - mean3[pp % 3]) / 256.0f;
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
         }
     }
@@ -595,8 +601,8 @@ void resnet_forward(Ctx* c, const uint8_t* d_chips, int n, float* h_out)
         const ConvLayer& L0 = e.convs[0];
         PVF_REQUIRE(S == 150 && L0.cout == 32 && L0.k == 7 && h1 == 72, "stem kernel: 150 x 150 chips, 7 x 7 stride 2, 32 channels");
         if (!c->emb.d_stem) {
-            HIP_CHECK(hipMalloc(&c->emb.d_stem, 98 * 64 * sizeof(float)));
-            hipLaunchKernelGGL(stem_frag_k, dim3(98), dim3(64), 0, c->stream, L0.d_w, c->emb.d_stem);
+            HIP_CHECK(hipMalloc(&c->emb.d_stem, STEM_NP * 64 * sizeof(float)));
+            hipLaunchKernelGGL(stem_frag_k, dim3(STEM_NP), dim3(64), 0, c->stream, L0.d_w, c->emb.d_stem);
         }
         hipLaunchKernelGGL(stem_conv_k, dim3(h1 / STEM_ROWS, B), dim3(192), 0, c->stream, d_chips + (size_t)b0 * S * S * 3, B, c->emb.d_stem,
                            L0.d_bias, L0.d_gamma, L0.d_beta, y);
