@@ -864,12 +864,13 @@ int hac_dev(Ctx* c, double* d_D, const int32_t* row_start, int T, double thresho
     double hbest[4];
     if (T <= HAC_PERSIST_MAX_T) {
         const size_t lds = hac_persist_lds(T);           // rmin f64, rarg i32, re-scan list u16, alive bits
-        static bool attr_set = false;
-        if (!attr_set) {
+        static std::atomic<uint64_t> attr_on{0};          // per device (a function attribute belongs to the device it was set on)
+        const uint64_t dev_bit = 1ull << (c->device & 63);
+        if (!(attr_on.load() & dev_bit)) {
             HIP_CHECK(hipFuncSetAttribute((const void*)hac_persist_k<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hac_persist_lds(1024)));
             HIP_CHECK(hipFuncSetAttribute((const void*)hac_persist_k<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hac_persist_lds(3072)));
             HIP_CHECK(hipFuncSetAttribute((const void*)hac_persist_k<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hac_persist_lds(HAC_PERSIST_MAX_T)));
-            attr_set = true;
+            attr_on.fetch_or(dev_bit);
         }
         if (T <= 1024) hipLaunchKernelGGL(hac_persist_k<1>, dim3(1), dim3(1024), lds, c->stream, h);
         else if (T <= 3072) hipLaunchKernelGGL(hac_persist_k<3>, dim3(1), dim3(1024), lds, c->stream, h);

@@ -1023,22 +1023,23 @@ static void scale_features(Ctx* c, const DsstBuffers& b, int n)
     hipLaunchKernelGGL(scale_fft_k, dim3(SDIM / 128, n), dim3(128), 0, c->stream, feat, c->ttab.d_mask_scale, c->ttab.d_tw32, b.Fs);
 }
 
-static void ensure_fft_lds()
+static void ensure_fft_lds(int device)
 {
-    static bool done = false;
-    if (done) return;
+    static std::atomic<uint64_t> done_on{0};               // per device (a function attribute belongs to the device it was set on)
+    const uint64_t bit = 1ull << (device & 63);
+    if (done_on.load() & bit) return;
     HIP_CHECK(hipFuncSetAttribute((const void*)trans_planes_fft_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)peak_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)start_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
     HIP_CHECK(hipFuncSetAttribute((const void*)update_fused_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_FFT));
-    done = true;
+    done_on.fetch_or(bit);
 }
 
 void dsst_start_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<Frame>& f, const double* boxes)
 {
     const int n = (int)t.size();
     if (n == 0) return;
-    ensure_fft_lds();
+    ensure_fft_lds(c->device);
     for (int i = 0; i < n; ++i) {
         own_state(c, t[i], false);
         if (!t[i]->d_state) t[i]->d_state = tracker_state_alloc(c);
@@ -1072,7 +1073,7 @@ void dsst_update_many(Ctx* c, const std::vector<Tracker*>& t, const std::vector<
 {
     const int n = (int)t.size();
     if (n == 0) return;
-    ensure_fft_lds();
+    ensure_fft_lds(c->device);
     for (int i = 0; i < n; ++i) {
         PVF_REQUIRE(t[i]->started, "tracker.update before start_track");
         if (mode == 2) {

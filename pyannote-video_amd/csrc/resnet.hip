@@ -560,9 +560,13 @@ static void launch_conv(Ctx* c, const ConvArgs& a)
     PVF_REQUIRE(a.OH * a.OW < (1 << 21) && a.Cout % 32 == 0, "conv: output map too large for the kernel's index arithmetic / Cout not a multiple of 32");
     if (a.frag && a.Cin == 32 && a.Cout == 32 && a.H == 35 && a.W == 35 && a.OH == 35 && a.OW == 35 && a.AH == 35 && a.AW == 35 && a.ksz == 3 &&
         a.stride == 1 && a.pad == 1 && a.relu && a.skip_mode != 2) {
-        static bool attr = false;
+        static std::atomic<uint64_t> attr_set{0};             // per device (a function attribute belongs to the device it was set on)
         const size_t lds = (size_t)(C32_TILE_FLOATS + 144 * 64) * sizeof(float);
-        if (!attr) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        const uint64_t bit = 1ull << (c->device & 63);
+        if (!(attr_set.load() & bit)) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set.fetch_or(bit);
+        }
         const int items = a.B * (35 / C32_ROWS);
         hipLaunchKernelGGL(conv3x3_c32_k, dim3((unsigned)std::min(items, 2 * c->n_cu)), dim3(256), lds, c->stream, a.in, a.frag, a.bias, a.gamma, a.beta,
                            a.skip_mode == 1 ? a.skip : nullptr, a.out, items);
