@@ -458,16 +458,21 @@ __global__ void __launch_bounds__(256) conv3x3_c32_k(const float* __restrict__ i
             if ((ok >> j) & 1u) v[j] = *reinterpret_cast<const float4*>(src + s_off[j]);
         }
     };
+    // the band's output (and skip) rows behind buffer descriptors: 245 pixels x 32 channels; the tile rows past the band (the last tile's
+    // rows 21 .. 31) fall outside and are dropped / read as zero -- no lane-dependent branch around any access
+    constexpr int BAND_BYTES = C32_ROWS * HW * 32 * 4;
+    int e_off[2][16];                                     // byte offset of (this lane's channel, accumulator row) inside the band
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) e_off[t][reg] = (((wave * 2 + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh) * 32 + li) * 4;
     auto request_skip = [&](int item) {                   // the band's skip values: in flight during its own MFMAs
         const int face = item / 5, oy0 = (item - face * 5) * C32_ROWS;
-        const size_t p0 = ((size_t)face * HW + oy0) * HW;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(skip + ((size_t)face * HW + oy0) * HW * 32), 0, BAND_BYTES, 0x00020000);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = (wave * 2 + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                sk[t][reg] = (m < C32_ROWS * HW) ? skip[(p0 + m) * 32 + li] : 0.0f;
-            }
+            for (int reg = 0; reg < 16; ++reg) sk[t][reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, e_off[t][reg], 0, 0));
     };
     int item = blockIdx.x;
     if (item < n_items) request(item);
@@ -499,20 +504,34 @@ __global__ void __launch_bounds__(256) conv3x3_c32_k(const float* __restrict__ i
             for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(base[t][off], b, acc[t], 0, 0, 0);
         }
         // C layout of the 32 x 32 MFMA: column (channel) = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); a band's pixels are
-        // contiguous in the output tensor
+        // contiguous in the output tensor.  All 32 results are finished first (ONE wait for the skip values), then the 32 stores go out
+        // back to back: written value by value the compiler waits before every store for everything in flight -- the next band's rows
+        // included -- because the skip value it is about to add might still be on its way.
         const int face = item / 5, oy0 = (item - face * 5) * C32_ROWS;
-        const size_t p0 = ((size_t)face * HW + oy0) * HW;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + ((size_t)face * HW + oy0) * HW * 32), 0, BAND_BYTES, 0x00020000);
+        float x[2][16];
+        if (skip) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float y = ((acc[t][reg] + bs) * g + bt) + sk[t][reg];
+                    x[t][reg] = y < 0.0f ? 0.0f : y;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const float y = (acc[t][reg] + bs) * g + bt;
+                    x[t][reg] = y < 0.0f ? 0.0f : y;
+                }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int m = (wave * 2 + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kh;
-                if (m >= C32_ROWS * HW) continue;
-                float x = (acc[t][reg] + bs) * g + bt;
-                if (skip) x += sk[t][reg];
-                x = x < 0.0f ? 0.0f : x;
-                out[(p0 + m) * 32 + li] = x;
-            }
+            for (int reg = 0; reg < 16; ++reg)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, x[t][reg]), ro, e_off[t][reg], 0, 0);
         __syncthreads();                                  // every wave is done with the tile before the next band is parked
         item = next;
     }
