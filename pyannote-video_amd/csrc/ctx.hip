@@ -351,6 +351,7 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
     }
     if (c->d_orient_lut) (void)hipFree(c->d_orient_lut);
     if (c->d_grad_lut) (void)hipFree(c->d_grad_lut);
+    if (c->d_wrap_lut) (void)hipFree(c->d_wrap_lut);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->det_stream);
     std::lock_guard<std::mutex> lk(g_ctx_mu);

@@ -480,9 +480,9 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
             if (lane >= 1 && lane <= FUSED_OUT && x < d.hog_nc) {
                 float o[32];
                 cell_features(hprev, n, o);
-                float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)(yh + oy) * d.fw + (x + ox)) * PVF_FHOG_STRIDE);
+                float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + feat_at(yh + oy, 0, x + ox, d.fwp));
 #pragma unroll
-                for (int k = 0; k < 8; ++k) dst[k] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+                for (int k = 0; k < 8; ++k) dst[(size_t)k * d.fwp] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
             }
         }
         // the finished cell row becomes the centre of the next feature row: its bins move to registers, the LDS words are cleared
@@ -494,6 +494,265 @@ __global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc
         else band(gb, accE, accO);
     }
 #undef BYTE_OF
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K2 with the two halves of the work in waves of their own (round 6).  fhog_fused_ml_k above holds the image rows, two rows' worth of
+// gradients, the previous cell row's bins and the feature epilogue in ONE wave: 236 registers, two waves per SIMD, and those two spend
+// their time differently -- 8 x ~35 vector instructions per pixel row for the gradients against a chain of 16 dependent LDS
+// read-add-writes for the votes -- so whenever both sit in their chains the vector pipe idles (SQ_INSTS_VALU 79 % of the issue slots).
+// Here a block of 8 waves works on 4 strips; each strip has
+//   a GRADIENT wave (role 0): image rows in registers, per pixel the channel with the largest |g|^2, its orientation bin from the
+//     table and the exact root -- (magnitude, bin) of its 8 pixels per row go into a two-slot ring in LDS;
+//   a VOTE wave (role 1): reads its own and its right neighbour's 8 pairs from the ring (the neighbour's come from LDS, not from 16 DPP
+//     moves), casts the 16 votes into the two cell rows in the SAME order as before (a cell's bins receive their terms in row-major
+//     order of its 16 x 16 window: bit-identical by construction), keeps the finished rows' bins and energies and writes the features.
+// Neither role needs more than 128 registers => 4 waves per SIMD, two of each kind when the hardware deals a block's waves out to the
+// SIMDs round robin (waves 0-3 gradient, 4-7 vote): the vote waves' LDS waits are filled by the gradient waves' arithmetic.
+// Hand-over without block barriers: per strip two flags per slot in LDS, ready (row + 1, written by the gradient wave after the row's
+// pairs) and done (row + 1, written by the vote wave once its reads are issued).  LDS executes one wave's instructions in order, so a
+// wave that sees the flag sees the data written before it; a vote wave reads flag and data in one go and repeats the lot if the flag
+// was not up yet (the gradient wave runs ahead: rare).
+// The gradient itself is shorter too: the two differences of a channel are formed into the halves of ONE register (SDWA byte selects,
+// the second one written into the upper word), |g|^2 is one v_dot2 of that register with itself, and the register of the winning
+// channel IS the table index after a bit permutation (the table is laid out for it: 9-bit wrapped differences, 8 x 8 tiles).
+#define FS_PAIRS 4
+#define FS_COLS 65                                   // lanes of a ring row: 64 + the column lane 63 reads as its right neighbour (zeros)
+#define FS_SLOT_DW (8 * FS_COLS * 2)                 // dwords of a slot: [pixel][lane](magnitude bits, bin)
+#define FS_BINS_DW (2 * 18 * 64)                     // a vote wave's bins: [parity of the cell row][bin][lane]
+#define FS_FLAG_DW (4 * 64)                          // a strip's flags, a word per lane: ready[2 slots][64], done[2 slots][64]
+#define FS_LDS_BYTES (FS_PAIRS * (FS_BINS_DW + 2 * FS_SLOT_DW + FS_FLAG_DW) * 4)
+static_assert(FS_COLS * 8 == 520, "the ring's column pitch is written into the instruction strings below");
+typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_u32)p; }
+
+// a gradient wave's hand-over: the 8 pairs of a row, then the row's flag.  One statement: LDS executes a wave's instructions in order,
+// the compiler must not move or split them.
+__device__ __forceinline__ void ring_write(uint32_t data_at, uint32_t flag_at, const u32x2* v, uint32_t row1)
+{
+    asm volatile("ds_write_b64 %0, %2\n\tds_write_b64 %0, %3 offset:520\n\tds_write_b64 %0, %4 offset:1040\n\tds_write_b64 %0, %5 offset:1560\n\t"
+                 "ds_write_b64 %0, %6 offset:2080\n\tds_write_b64 %0, %7 offset:2600\n\tds_write_b64 %0, %8 offset:3120\n\t"
+                 "ds_write_b64 %0, %9 offset:3640\n\tds_write_b32 %1, %10"
+                 :: "v"(data_at), "v"(flag_at), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(row1) : "memory");
+}
+// a vote wave's: the row's flag and, behind it, its own and its right neighbour's 8 pairs
+__device__ __forceinline__ uint32_t ring_read(uint32_t data_at, uint32_t flag_at, u32x2* own, u32x2* nb)
+{
+    uint32_t ready;
+    asm volatile("ds_read_b32 %0, %18\n\t"
+                 "ds_read_b64 %1, %17\n\tds_read_b64 %9, %17 offset:8\n\tds_read_b64 %2, %17 offset:520\n\tds_read_b64 %10, %17 offset:528\n\t"
+                 "ds_read_b64 %3, %17 offset:1040\n\tds_read_b64 %11, %17 offset:1048\n\tds_read_b64 %4, %17 offset:1560\n\tds_read_b64 %12, %17 offset:1568\n\t"
+                 "ds_read_b64 %5, %17 offset:2080\n\tds_read_b64 %13, %17 offset:2088\n\tds_read_b64 %6, %17 offset:2600\n\tds_read_b64 %14, %17 offset:2608\n\t"
+                 "ds_read_b64 %7, %17 offset:3120\n\tds_read_b64 %15, %17 offset:3128\n\tds_read_b64 %8, %17 offset:3640\n\tds_read_b64 %16, %17 offset:3648\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(ready), "=&v"(own[0]), "=&v"(own[1]), "=&v"(own[2]), "=&v"(own[3]), "=&v"(own[4]), "=&v"(own[5]), "=&v"(own[6]), "=&v"(own[7]),
+                   "=&v"(nb[0]), "=&v"(nb[1]), "=&v"(nb[2]), "=&v"(nb[3]), "=&v"(nb[4]), "=&v"(nb[5]), "=&v"(nb[6]), "=&v"(nb[7])
+                 : "v"(data_at), "v"(flag_at) : "memory");
+    return ready;
+}
+__device__ __forceinline__ void flag_write(uint32_t flag_at, uint32_t v)
+{
+    asm volatile("ds_write_b32 %0, %1" :: "v"(flag_at), "v"(v) : "memory");
+}
+
+template <int A, int B> __device__ __forceinline__ uint32_t sub_into_upper(uint32_t acc, uint32_t x, uint32_t y);
+// acc[31:16] = byte A of x - byte B of y (low 16 bits of the difference), acc[15:0] kept.  (The wait state after it: a VALU that writes
+// part of a register needs one before the register is read on this family, and the compiler cannot see into the statement.)
+#define PVF_SUBW1(A, B)                                                                                                                  \
+    template <> __device__ __forceinline__ uint32_t sub_into_upper<A, B>(uint32_t acc, uint32_t x, uint32_t y)                           \
+    {                                                                                                                                    \
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #A " src1_sel:BYTE_" #B "\n\ts_nop 0"   \
+            : "+v"(acc) : "v"(x), "v"(y));                                                                                               \
+        return acc;                                                                                                                      \
+    }
+PVF_SUBW1(0, 0) PVF_SUBW1(1, 1) PVF_SUBW1(2, 2) PVF_SUBW1(3, 3)
+#undef PVF_SUBW1
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// (magnitude bits, bin) of pixel P of the centre row from the lane's three 32-byte row windows
+template <int P>
+__device__ __forceinline__ u32x2 split_grad_px(const uint32_t* up, const uint32_t* ce, const uint32_t* dn, const __amdgpu_buffer_rsrc_t& lut_rs,
+                                               bool valid)
+{
+    uint32_t pk[3];
+    int cv[3];
+#define PVF_CH(K)                                                                                                                         \
+    {                                                                                                                                     \
+        constexpr int IU = 4 + 3 * P + K, IL = 1 + 3 * P + K, IR = 7 + 3 * P + K;                                                         \
+        const uint32_t cx = ((ce[IR >> 2] >> (8 * (IR & 3))) & 0xffu) - ((ce[IL >> 2] >> (8 * (IL & 3))) & 0xffu);                          \
+        pk[K] = sub_into_upper<(IU & 3), (IU & 3)>(cx, dn[IU >> 2], up[IU >> 2]);                                                          \
+        const s16x2 v = __builtin_bit_cast(s16x2, pk[K]);                                                                                 \
+        cv[K] = __builtin_amdgcn_sdot2(v, v, 0, false);                                                                                   \
+    }
+    PVF_CH(0) PVF_CH(1) PVF_CH(2)
+#undef PVF_CH
+    const int bv = max(cv[0], max(cv[1], cv[2]));
+    const uint32_t pb = (cv[0] == bv) ? pk[0] : ((cv[1] == bv) ? pk[1] : pk[2]);         // first channel with the largest |g|^2
+    // table offset: X = cx mod 512 (bits 0-8 of pb), Y = cy mod 512 (bits 16-24): (X & 7) | Y << 3 | (X >> 3) << 12
+    const uint32_t off = (pb & 7u) | ((pb >> 13) & 0xff8u) | ((pb << 9) & 0x3f000u);
+    u32x2 r;
+    r.y = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(lut_rs, off, 0, 0);
+    const float m = sqrt_exact_small((float)bv);
+    r.x = valid ? __float_as_uint(m) : 0u;
+    return r;
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+fhog_split_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base, float* __restrict__ feat_base,
+                const uint8_t* __restrict__ lutw, int oy, int ox)
+{
+    constexpr int RSRC_FLAGS = 0x00020000;
+    extern __shared__ __attribute__((aligned(16))) uint32_t fs_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave & 3, role = wave >> 2;
+    // rings (the column lane 63 reads beyond its strip must hold zeros: a bin offset from there is an LDS address) and flags
+    for (int i = threadIdx.x; i < FS_PAIRS * (2 * FS_SLOT_DW + FS_FLAG_DW); i += 512) fs_lds[FS_PAIRS * FS_BINS_DW + i] = 0u;
+    __syncthreads();
+    const int g = ml_block(st);
+    if (g >= st.b0[st.nl]) return;
+    const int l = ml_level(st, g);
+    const LvDesc d = lv[l];
+    const int task = (g - st.b0[l]) * FS_PAIRS + pair;
+    if (task >= d.fused_tasks) return;                             // wave-uniform, the same for both waves of a strip
+    const int sx = task % d.strips;
+    const int t2 = task / d.strips;
+    const int cy = t2 % d.chunks;
+    const int b = t2 / d.chunks;
+    const int y0 = cy * d.chunk_rows;                              // first feature (hog) row of this chunk
+    const int R = min(d.chunk_rows, d.hog_nr - y0);
+    const int g_first = y0 + 1, g_last = y0 + R + 3;               // bands (= cell rows whose upper half they hold)
+    const int y_begin = 8 * g_first - 12;
+    // byte addresses in LDS: this lane's column of the strip's ring (slot s: + s * 4 * FS_SLOT_DW) and its word of the flags
+    const uint32_t ring_at = lds_addr(fs_lds + FS_PAIRS * FS_BINS_DW + pair * 2 * FS_SLOT_DW) + 8u * lane;
+    uint32_t* const flags = fs_lds + FS_PAIRS * (FS_BINS_DW + 2 * FS_SLOT_DW) + pair * FS_FLAG_DW + lane;      // ready: [64 * s], done: [128 + 64 * s]
+    const uint32_t flag_at = lds_addr(flags);
+
+    if (role == 0) {
+        // ---------------- gradient wave ----------------
+        const int hx = FUSED_OUT * sx + 1 + lane;                  // histogram column of this lane
+        const int x_first = 8 * hx - 12;                           // image column of its first pixel
+        const uint8_t* im = img_base + d.img_off + (size_t)b * d.img_stride;
+        const int rb = d.rb;
+        unsigned xmask = 0;                                        // gradients exist for 1 <= x < visible_nc (oracle/pvo_fhog.c)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) if (x_first + p >= 1 && x_first + p < d.visible_nc) xmask |= 1u << p;
+        const int voff = 3 * x_first - 4, voff2 = voff + 16;       // (see fhog_fused_ml_k)
+        const __amdgpu_buffer_rsrc_t lut_rs = __builtin_amdgcn_make_buffer_rsrc((void*)lutw, 0, 1 << 18, RSRC_FLAGS);
+        // Image rows as 8 dwords per lane: the three around the row whose gradients are formed and one on its way.  (Eight buffers, rows
+        // requested six steps ahead, measured the same 7.8 ms per 125 frames: the rows' latency is not what this wave waits for.)
+        uint32_t rw[4][8];
+        auto load_row = [&](int yi, uint32_t* dst) {
+            const int bytes = (yi >= 0 && yi < d.h) ? rb : 0;       // wave-uniform
+            const int yc = min(max(yi, 0), d.h - 1);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(im + (size_t)yc * rb), 0, bytes, RSRC_FLAGS);
+            const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+            const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, voff2, 0, 0);
+            dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = c.x; dst[5] = c.y; dst[6] = c.z; dst[7] = c.w;
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_row(y_begin - 1 + q, rw[q]);
+        const int nrows = 8 * (g_last - g_first + 1);
+        for (int k0 = 0; k0 < nrows; k0 += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + i, y = y_begin + k;
+                // rows y - 1, y, y + 1 in rw[i], rw[i + 1], rw[i + 2] (mod 4); rw[i + 3] holds row y + 2, requested two steps ago
+                const uint32_t* up = rw[i & 3];
+                const uint32_t* ce = rw[(i + 1) & 3];
+                const uint32_t* dn = rw[(i + 2) & 3];
+                // asked for early: the slot's previous row (k - 2) must have been read before the slot is written again
+                const int freed = (int)__hip_atomic_load(flags + 128 + 64 * (i & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool ok = (y >= 1 && y < d.visible_nr);
+                u32x2 mb[8];
+                mb[0] = split_grad_px<0>(up, ce, dn, lut_rs, ok && (xmask & 1u));
+                mb[1] = split_grad_px<1>(up, ce, dn, lut_rs, ok && (xmask & 2u));
+                mb[2] = split_grad_px<2>(up, ce, dn, lut_rs, ok && (xmask & 4u));
+                mb[3] = split_grad_px<3>(up, ce, dn, lut_rs, ok && (xmask & 8u));
+                mb[4] = split_grad_px<4>(up, ce, dn, lut_rs, ok && (xmask & 16u));
+                mb[5] = split_grad_px<5>(up, ce, dn, lut_rs, ok && (xmask & 32u));
+                mb[6] = split_grad_px<6>(up, ce, dn, lut_rs, ok && (xmask & 64u));
+                mb[7] = split_grad_px<7>(up, ce, dn, lut_rs, ok && (xmask & 128u));
+                load_row(y + 3, rw[i & 3]);                          // row y - 1 is done with
+                int fr = freed;
+                while (fr < k - 1) {
+                    __builtin_amdgcn_s_sleep(1);
+                    fr = (int)__hip_atomic_load(flags + 128 + 64 * (i & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                ring_write(ring_at + (i & 1) * 4 * FS_SLOT_DW, flag_at + 256 * (i & 1), mb, (uint32_t)(k + 1));
+            }
+        }
+        return;
+    }
+
+    // ---------------- vote wave ----------------
+    float* accE = reinterpret_cast<float*>(fs_lds) + pair * FS_BINS_DW + lane;      // bin k of this lane: accE[64 * k]
+    float* accO = accE + 18 * 64;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accO[64 * k] = 0.0f; }
+    float hprev[18];
+    float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) hprev[k] = 0.f;
+    int krow = 0;                                                  // rows of this task read so far
+    auto band = [&](int gb, float* accU, float* accL) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // the row's pairs: own 8 pixels and the right neighbour's 8
+            u32x2 own[8], nb[8];
+            for (;;) {
+                const int ready = (int)ring_read(ring_at + (i & 1) * 4 * FS_SLOT_DW, flag_at + 256 * (i & 1), own, nb);
+                if (__builtin_amdgcn_readfirstlane(ready) > krow) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ++krow;
+            flag_write(flag_at + 512 + 256 * (i & 1), (uint32_t)krow);
+            const float fy = ((float)i + 0.5f) / 8.0f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int p = j & 7;
+                const u32x2 v = (j < 8) ? own[p] : nb[p];
+                const float mv = __uint_as_float(v.x);
+                const int bv = (int)(v.y << 8);                    // BYTE offset of the bin's row of 64 lanes
+                const float fx = ((float)p + 0.5f) / 8.0f;
+                const float wx = (j < 8) ? fx : 1.0f - fx;
+                float* const pl = reinterpret_cast<float*>(reinterpret_cast<char*>(accL) + bv);
+                float* const pu = reinterpret_cast<float*>(reinterpret_cast<char*>(accU) + bv);
+                const float vl = *pl, vu = *pu;
+                *pl = vl + ((1.0f - fy) * wx) * mv;
+                *pu = vu + (fy * wx) * mv;
+            }
+        }
+        const int c = gb - 1;                                       // this cell row is complete (see fhog_fused_ml_k)
+        float e = 0.0f;
+#pragma unroll
+        for (int o = 0; o < 9; ++o) { const float s2 = accL[64 * o] + accL[64 * (o + 9)]; e = e + s2 * s2; }
+        e2 = e1; e1 = e0; e0 = e;
+        if (c >= y0 + 3) {
+            // features of the centre cell row c - 1 (histograms in hprev), hog row yh = c - 3; norms: rows c-2, c-1, c x lanes L-1, L, L+1
+            float n[9];
+            n[1] = e2; n[4] = e1; n[7] = e0;
+            n[0] = __uint_as_float(from_prev_lane(__float_as_uint(e2))); n[2] = __uint_as_float(from_next_lane(__float_as_uint(e2)));
+            n[3] = __uint_as_float(from_prev_lane(__float_as_uint(e1))); n[5] = __uint_as_float(from_next_lane(__float_as_uint(e1)));
+            n[6] = __uint_as_float(from_prev_lane(__float_as_uint(e0))); n[8] = __uint_as_float(from_next_lane(__float_as_uint(e0)));
+            const int x = FUSED_OUT * sx + lane - 1, yh = c - 3;
+            if (lane >= 1 && lane <= FUSED_OUT && x < d.hog_nc) {
+                float o[32];
+                cell_features(hprev, n, o);
+                // plane group k of the strip's 61 cells is one run of memory (detect_ml.h: feat_at): every store writes whole lines
+                float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + feat_at(yh + oy, 0, x + ox, d.fwp));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dst[(size_t)k * d.fwp] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+            }
+        }
+        // the finished cell row becomes the centre of the next feature row: its bins move to registers, the LDS words are cleared
+#pragma unroll
+        for (int k = 0; k < 18; ++k) { hprev[k] = accL[64 * k]; accL[64 * k] = 0.0f; }
+    };
+    for (int gb = g_first; gb <= g_last; ++gb) {
+        if (gb & 1) band(gb, accO, accE);                           // upper half -> the odd cell row gb, lower half -> the even row gb - 1
+        else band(gb, accE, accO);
+    }
 }
 
 // writes the zero border of the feature maps (the padding ring around the hog cells: (frows-1)/2 cells above / left, the rest below / right).
@@ -509,12 +768,12 @@ __global__ void __launch_bounds__(256) feat_ring_zero_k(MlStarts st, const LvDes
     const int py = (local / d.feat_bx) % d.fh;
     const int b = local / (d.feat_bx * d.fh);
     const int px = xb * 256 + threadIdx.x;
-    if (px >= d.fw) return;
+    if (px >= d.fwp) return;                                       // (the zero columns behind the map's last one included)
     const int x = px - ox, y = py - oy;
     if (x >= 0 && y >= 0 && x < d.hog_nc && y < d.hog_nr) return;
-    float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)py * d.fw + px) * PVF_FHOG_STRIDE);
+    float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + feat_at(py, 0, px, d.fwp));
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dst[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 8; ++k) dst[(size_t)k * d.fwp] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -560,7 +819,8 @@ score_roll_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __r
     const int r_base = sg * d.roll_rows;
     const int out_rows = min(d.roll_rows, d.fh - (FR - 1) - r_base);
     const int fh = out_rows + FR - 1;
-    const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride + ((size_t)r_base * fw + c_base) * PVF_FHOG_STRIDE;
+    const int fwp = d.fwp;
+    const float* fb = feat_base + d.feat_off + (size_t)b * d.feat_stride + feat_at(r_base, 0, c_base, fwp);
     const int seg_cells = (fw - c_base < SEG) ? fw - c_base : SEG;
     const int i = lane & 15, kq = lane >> 4;
     const int lane16 = lane * 16;
@@ -571,25 +831,29 @@ score_roll_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const float* __r
     for (int q = 0; q < R; ++q)
 #pragma unroll
         for (int tt = 0; tt < MT; ++tt) acc[q][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // this thread's share of a feature row: the 16-byte pieces tid + 128 u of the segment's seg_cells * 128 bytes (beyond: zeros), fetched
-    // and parked in two halves (u < NH, then the rest) so that only NH pieces are held in registers at a time
-    constexpr int NH = (NSTW + 1) / 2;
+    // this thread's share of a feature row: cell `tid` of the segment (threads 107 .. 127: none), its eight 16-byte pieces -- one per
+    // plane group, each group a run of memory of its own (detect_ml.h: feat_at) -- fetched and parked in two halves so that only four
+    // pieces are held in registers at a time.  The range of a plane group's descriptor is the segment's cells: cells past the segment (or
+    // any cell of a row past the piece's last) come back as zeros.
+    constexpr int NH = 4;
+    static_assert(NSTW <= 8 && SEG <= 128, "one cell per thread");
     u32x4 sv[NH];
     const int tid16 = (int)threadIdx.x * 16;
     auto load_part = [&](int fr, int half) {
-        const int bytes = (fr < fh) ? seg_cells * PVF_FHOG_STRIDE * 4 : 0;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + (size_t)fr * fw * PVF_FHOG_STRIDE), 0, bytes, RSRC_FLAGS);
-#pragma unroll
-        for (int u = 0; u < NH; ++u)
-            if (half * NH + u < NSTW) sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid16, (half * NH + u) * 2048, 0);
-    };
-    auto fill_part = [&](float* seg, int half) {
+        const int bytes = (fr < fh) ? seg_cells * 16 : 0;
 #pragma unroll
         for (int u = 0; u < NH; ++u) {
-            const int idx = (int)threadIdx.x + 128 * (half * NH + u);
-            if (half * NH + u < NSTW && idx < SEG * 8) {
-                const int cell = idx >> 3, q = idx & 7;
-                uint32_t* dd = reinterpret_cast<uint32_t*>(seg + cell * PITCH + 4 * q);
+            // a descriptor per plane group (its base is scalar arithmetic): a scalar OFFSET would count against the range
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + ((size_t)fr * 8 + half * NH + u) * fwp * 4), 0, bytes, RSRC_FLAGS);
+            sv[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, tid16, 0, 0);
+        }
+    };
+    auto fill_part = [&](float* seg, int half) {
+        if ((int)threadIdx.x < SEG) {
+#pragma unroll
+            for (int u = 0; u < NH; ++u) {
+                const int q = half * NH + u;
+                uint32_t* dd = reinterpret_cast<uint32_t*>(seg + (int)threadIdx.x * PITCH + 4 * q);
                 dd[0] = sv[u].x; dd[1] = sv[u].y; dd[2] = sv[u].z;
                 if (q != 7) dd[3] = sv[u].w;            // (plane 31 is padding; its slot belongs to the next cell)
             }
@@ -783,9 +1047,10 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         d.rb = (int)al((size_t)d.w * 3, 64);
         d.img_off = (long long)p.img_bytes; d.img_stride = (long long)d.h * d.rb;
         p.img_bytes += (size_t)d.img_stride * B;
-        d.feat_off = (long long)p.feat_floats; d.feat_stride = (long long)d.fh * d.fw * PVF_FHOG_STRIDE;
+        d.fwp = feat_ok ? d.fw + FEAT_PAD_COLS : 0;
+        d.feat_off = (long long)p.feat_floats; d.feat_stride = (long long)d.fh * d.fwp * PVF_FHOG_STRIDE;
         p.feat_floats += (size_t)d.feat_stride * B;
-        d.feat_bx = std::max((d.fw + 255) / 256, 0);
+        d.feat_bx = feat_ok ? (d.fwp + 255) / 256 : 0;
         const int out_c = d.fw - 9;
         d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0;        // column strips of 96 output columns (K3)
         // fused FHOG tasks: strips of 61 feature columns x chunks of feature rows (smaller chunks for the small levels: more tasks)
@@ -935,6 +1200,18 @@ static MlPlan* ml_features(Ctx* c, const std::vector<Frame>& frames, int upsampl
         hipLaunchKernelGGL(feat_ring_zero_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->det_stream, p->feat, p->d_lv, B, c->s_feat.as<float>(), oy, ox);
         c->feat_ring_owner = (const void*)p;
     }
+    static const int split = getenv("PVF_FHOG_SPLIT") ? atoi(getenv("PVF_FHOG_SPLIT")) : 1;
+    if (split) {
+        static std::atomic<uint64_t> attr_set{0};             // per device (a function attribute belongs to the device it was set on)
+        const uint64_t bit = 1ull << (c->device & 63);
+        if (!(attr_set.load() & bit)) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fhog_split_ml_k), hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS_BYTES));
+            attr_set.fetch_or(bit);
+        }
+        hipLaunchKernelGGL(fhog_split_ml_k, dim3(ml_grid(p->fused_blocks)), dim3(512), FS_LDS_BYTES, c->det_stream, p->fused, p->d_lv, B,
+                           c->s_pyr.as<uint8_t>(), c->s_feat.as<float>(), orientation_lut_wrapped(c), oy, ox);
+        return p;
+    }
     hipLaunchKernelGGL(fhog_fused_ml_k, dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->det_stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
                        c->s_feat.as<float>(), lut2, oy, ox);
     return p;
@@ -987,9 +1264,16 @@ void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::ve
     const LvDesc& d = p->lv[level];
     *fh = d.fh; *fw = d.fw;
     if (out) {
+        // the caller's view is [row][column][32 planes]; the device's is [row][plane group][column][4] with padded rows (feat_at)
         out->resize((size_t)d.fh * d.fw * PVF_FHOG_STRIDE);
-        if (!out->empty())
-            HIP_CHECK(hipMemcpyAsync(out->data(), c->s_feat.as<float>() + d.feat_off, out->size() * sizeof(float), hipMemcpyDeviceToHost, c->det_stream));
+        std::vector<float> dev((size_t)d.feat_stride);
+        if (!dev.empty())
+            HIP_CHECK(hipMemcpyAsync(dev.data(), c->s_feat.as<float>() + d.feat_off, dev.size() * sizeof(float), hipMemcpyDeviceToHost, c->det_stream));
+        HIP_CHECK(hipStreamSynchronize(c->det_stream));
+        for (int y = 0; y < d.fh; ++y)
+            for (int j = 0; j < 8; ++j)
+                for (int x = 0; x < d.fw; ++x)
+                    memcpy(out->data() + ((size_t)y * d.fw + x) * PVF_FHOG_STRIDE + 4 * j, dev.data() + feat_at(y, j, x, d.fwp), 4 * sizeof(float));
     }
     HIP_CHECK(hipStreamSynchronize(c->det_stream));
 }

@@ -9,6 +9,7 @@ struct LvDesc {
     int h, w, rb;                               // level image, row pitch in bytes (multiple of 64)
     int cells_nr, cells_nc, visible_nr, visible_nc;
     int fh, fw, hog_nr, hog_nc;                 // feature map (with its zero border) and the cells that carry features
+    int fwp;                                    // cells per stored row of a plane group (fw + FEAT_PAD_COLS zero columns): see feat_at()
     int feat_bx, score_bx;
     int valid_score;
     int roll_nseg, roll_rows;                   // K3 v5: a column strip is walked in roll_nseg pieces of roll_rows output rows
@@ -17,6 +18,16 @@ struct LvDesc {
     long long feat_off, feat_stride;            // floats
 };
 struct MlStarts { int nl; int b0[ML_MAX + 1]; };
+
+// Layout of a level's feature map (round 6): [row][plane group j = plane / 4][column][4 planes] -- a row of the map is 8 runs of fwp
+// 16-byte pieces, one per plane group.  The FHOG kernel's lanes own one cell each, so store j of a wave writes the pieces of 61 neighbouring
+// cells: ONE run of 976 bytes (with the cell-major [row][column][32 planes] of rounds 1-5 every store touched 64 lines with 16 bytes each:
+// 3.0 of the kernel's 7.8 ms per 125 frames, tools/probes/store_pattern_probe.hip: 3.65 against 5.7 TB/s for the same bytes).  The readers
+// fetch 16-byte pieces anyway (a slab of cells for the matrix cores); they address piece (row, j, column) instead of (row, column, j).
+// A stored row is FEAT_PAD_COLS columns longer than the map and those columns hold zeros (written with the zero border): the screening
+// pass reads up to 49 cells past the last column of a level's last strip and relies on finding zeros there.
+#define FEAT_PAD_COLS 52
+__host__ __device__ __forceinline__ size_t feat_at(int row, int j, int col, int fwp) { return (((size_t)row * 8 + j) * fwp + col) * 4; }   // in floats
 
 struct ScoreParams { float thresh[8]; int n_filters; int level; int cap; };
 struct CandRec { float score; int32_t filter, level, r, c; };

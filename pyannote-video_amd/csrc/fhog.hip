@@ -60,6 +60,27 @@ const uint8_t* orientation_lut_tiled(Ctx* c)
     return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
 }
 
+// The table of the detector's gradient waves (detect.hip: fhog_split_ml_k): the winning channel's two differences sit in the halves of one
+// register as 16-bit two's complement, and the entry's place is made of bits of THAT register -- X = bx mod 512, Y = by mod 512 (no bias
+// add), entry at (X & 7) | Y << 3 | (X >> 3) << 12: a 64-byte line is again an 8 x 8 tile of neighbouring gradients.
+const uint8_t* orientation_lut_wrapped(Ctx* c)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_lut_mu);
+    if (c->d_wrap_lut) return c->d_wrap_lut;
+    orientation_lut(c);
+    std::vector<uint8_t> ol((size_t)511 * 511);
+    HIP_CHECK(hipMemcpy(ol.data(), c->d_orient_lut, ol.size(), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> lut((size_t)1 << 18, 0);
+    for (int by = -255; by <= 255; ++by)
+        for (int bx = -255; bx <= 255; ++bx) {
+            const unsigned X = (unsigned)bx & 511u, Y = (unsigned)by & 511u;
+            lut[(X & 7u) | (Y << 3) | ((X >> 3) << 12)] = ol[(size_t)(by + 255) * 511 + (bx + 255)];
+        }
+    HIP_CHECK(hipMalloc((void**)&c->d_wrap_lut, lut.size()));
+    HIP_CHECK(hipMemcpy(c->d_wrap_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
+    return c->d_wrap_lut;
+}
+
 // The per-image FHOG kernels below run on 1-D grids over (image, row, column): the images they see in production are the
 // trackers' chips (23 x 23 scale samples, 64 x 64 translation windows), whose rows would fill 2-25 % of a 256-lane block each.
 __device__ __forceinline__ bool flat_index(int nx, int ny, int nb, int* x, int* y, int* b)

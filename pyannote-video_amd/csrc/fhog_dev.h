@@ -11,6 +11,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // orientation-bin tables (fhog.hip): row-major 511 x 511, and the same in 8 x 8 tiles (one 64-byte line each)
 const uint8_t* orientation_lut(Ctx* c);
 const uint8_t* orientation_lut_tiled(Ctx* c);
+// ... and addressed by the two differences mod 512 (X = bx & 511, Y = by & 511): (X & 7) | Y << 3 | (X >> 3) << 12 -- 8 x 8 tiles again
+const uint8_t* orientation_lut_wrapped(Ctx* c);
 
 // gradient of the colour channel with the largest |g|^2 (first wins): squared magnitude and orientation bin (row-major table)
 __device__ __forceinline__ void pixel_grad(const uint8_t* __restrict__ row_u, const uint8_t* __restrict__ row_c,

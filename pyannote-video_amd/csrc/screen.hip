@@ -70,11 +70,19 @@ __device__ __forceinline__ void screen_walk(const ScreenItem t, const LvDesc* __
     const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
     const int fw = lv[t.lv].fw;
     const long long feat_off = lv[t.lv].feat_off, feat_stride = lv[t.lv].feat_stride;
-    const float* fb = feat_base + feat_off + (size_t)t.b * feat_stride + ((size_t)t.r_base * fw + t.c_base) * PVF_FHOG_STRIDE;
-    const int row_bytes = (fw - t.c_base) * PVF_FHOG_STRIDE * 4;
+    // feature maps are [row][plane group][column][4 planes] with FEAT_PAD_COLS zero columns behind every run (detect_ml.h: feat_at): a
+    // lane's planes 8 kq .. 8 kq + 7 of a cell are the pieces of the plane groups 2 kq and 2 kq + 1, fwp * 16 bytes apart, and a cell
+    // past the level's last column (the last strip's overhang: < 48 + 3 cells) reads zeros
+    const int fwp = lv[t.lv].fwp;
+    const float* fb = feat_base + feat_off + (size_t)t.b * feat_stride + feat_at(t.r_base, 0, t.c_base, fwp);
+    const int row_bytes = (8 * fwp - t.c_base) * 16;
     const int fh_in = t.out_rows + FR - 1;
     const int c1 = fw - (FC - FC / 2 - 1);
-    const int voff = i * 384 + kq * 32;           // cell 3 i, planes 8 kq .. 8 kq + 7 (bytes within the strip's row)
+    const int voff = i * 48 + kq * 2 * fwp * 16;  // cell 3 i, plane group 2 kq (bytes within the strip's row)
+    const int voff2 = voff + fwp * 16;            // plane group 2 kq + 1
+    // the tail group holds bases 16 NG .. 16 NG + 2 only: its other lanes would read up to 86 cells past the level's last column, past the
+    // zero columns -- they are sent out of the descriptor's range instead (zeros, as the cell-major layout's row range gave them)
+    const int voff_t = i < 3 ? voff : 0x40000000, voff2_t = i < 3 ? voff2 : 0x40000000;
     f32x4 acc[10][NG];
 #pragma unroll
     for (int q = 0; q < 10; ++q)
@@ -86,13 +94,13 @@ __device__ __forceinline__ void screen_walk(const ScreenItem t, const LvDesc* __
     const uint8_t* b_hi = s_b + lane * 16 + 5 * SCR_M_STRIDE;
     // phase `cls` (cells 3 i + cls) of feature row `row`: two 16-byte loads per group; group NG is the tail (bases 16 NG .. 16 NG + 2)
     auto load_cls = [&](int row, int cls, u32x4 (&raw)[NG + 1][2]) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + (size_t)row * fw * PVF_FHOG_STRIDE), 0,
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(fb + (size_t)row * 8 * fwp * 4), 0,
                                                                             row < fh_in ? row_bytes : 0, RSRC_FLAGS);
 #pragma unroll
         for (int g = 0; g <= NG; ++g) {
-            // (everything in the VGPR offset: the scalar offset of a raw buffer access takes no part in the range check)
-            raw[g][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + cls * 128 + g * 6144, 0, 0);
-            raw[g][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + cls * 128 + g * 6144 + 16, 0, 0);
+            // (everything in the VGPR offset)
+            raw[g][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (g < NG ? voff : voff_t) + cls * 16 + g * 768, 0, 0);
+            raw[g][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, (g < NG ? voff2 : voff2_t) + cls * 16 + g * 768, 0, 0);
         }
     };
     auto cvt_frag = [&](const u32x4 (&r)[2]) -> u32x4 {
@@ -253,17 +261,17 @@ __global__ void __launch_bounds__(256) score_list_k(const uint2* __restrict__ li
         const uint2 q = list[e];
         const int b = (int)q.x;
         const int l = (int)(q.y >> 27), f = (int)((q.y >> 24) & 7), r = (int)((q.y >> 12) & 4095), cc = (int)(q.y & 4095);
-        const int fw = lv[l].fw;
-        const float* fp = feat_base + lv[l].feat_off + (size_t)b * lv[l].feat_stride + ((size_t)(r - FR / 2) * fw + (cc - FC / 2)) * PVF_FHOG_STRIDE;
+        const int fwp = lv[l].fwp;
+        const float* fp = feat_base + lv[l].feat_off + (size_t)b * lv[l].feat_stride + feat_at(r - FR / 2, 0, cc - FC / 2, fwp);
         const float* wp = W + (size_t)f * FR * FC * PVF_FHOG_STRIDE;
         float acc = 0.0f;
         for (int m = 0; m < FR; ++m)
             for (int nn = 0; nn < FC; ++nn) {
-                const f32x4* fv = reinterpret_cast<const f32x4*>(fp + ((size_t)m * fw + nn) * PVF_FHOG_STRIDE);
+                const f32x4* fv = reinterpret_cast<const f32x4*>(fp + feat_at(m, 0, nn, fwp));
                 const f32x4* wv = reinterpret_cast<const f32x4*>(wp + ((size_t)m * FC + nn) * PVF_FHOG_STRIDE);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const f32x4 a = fv[k], w = wv[k];
+                    const f32x4 a = fv[(size_t)k * fwp], w = wv[k];
                     acc = fmaf(a[0], w[0], acc); acc = fmaf(a[1], w[1], acc); acc = fmaf(a[2], w[2], acc);
                     if (k < 7) acc = fmaf(a[3], w[3], acc);          // (plane 31 is padding)
                 }
