@@ -92,7 +92,7 @@ def detector_rooflines(fam, height, width, frames_scored, detect_batch):
     the most time -- the step's dominant kernel (the other families are several kernels each, none of them as long).  Algorithmic work
     per frame from the level schedule:
       resize_rows_k   (20 launches per batch)  HBM: the frame read, every level written once and read once by the next stage
-      fhog_fused_ml_k (1 launch per batch)     HBM: every level image read once, 31 feature planes of every cell written once
+      fhog_split_ml_k (1 launch per batch)     HBM: every level image read once, 31 feature planes of every cell written once
       score_roll_k    (dense scoring)          fp32 MFMA: positions x 3100 MAC x 5 filters
       score_screen_k  (+ score_list_k)         f16 MFMA: the same sums (every window is scored), against the f16 peak"""
     from pyannote_video_amd import pipeline
@@ -105,7 +105,7 @@ def detector_rooflines(fam, height, width, frames_scored, detect_batch):
         return int(round(frames_scored / float(n))) if n > 0 else detect_batch       # frames of one launch as launched (a 250-frame shot runs as 125 + 125, not 128 + 122)
     work = {"pyramid": ("resize_rows_k (every pyramid level of a %d-frame batch from the level above it, 20 launches)" % per_launch("pyramid"), "hbm",
                         height * width * 3.0 + img[0] + sum(img[l - 1] + img[l] for l in range(1, len(img)))),
-            "fhog": ("fhog_fused_ml_k (gradients, cell histograms and 31-plane features of every pyramid level of a %d-frame batch in one pass)" % per_launch("fhog"), "hbm",
+            "fhog": ("fhog_split_ml_k (gradients, cell histograms and 31-plane features of every pyramid level of a %d-frame batch in one pass)" % per_launch("fhog"), "hbm",
                      sum(img) + sum(cells) * 31 * 4.0),
             "score": ("score_roll_k (HOG filter scoring of every pyramid level of a %d-frame batch, 5 filters x 3100 MAC per position)" % per_launch("score"), "mfma", flop),
             "score_screened": ("score_screen_k + score_list_k (every window of a %d-frame batch scored on the f16 matrix cores, the exact fp32 chain for the windows "

@@ -229,7 +229,9 @@ int32_t pvf_round_decimals(const double* in, int64_t n, int32_t decimals, double
 /* The two halves of pvf_cluster_tracks for several GPUs sharing one global clustering (dist.py).
  * pvf_pair_mean_dist_rows: the COMPLETE rows [track0, track1) of the T x T matrix of pvf_pair_mean_dist (D: T x T, row-major; other
  *   rows are left untouched) -- entries j > i computed, entries j < i the mirror of D[j][i] (clustering.py:111-112), diagonal 0; what
- *   this entry has returned since round 2 (round 4 silently left the part below the diagonal zero: restored in round 5).
+ *   this entry has returned since round 2 (round 4 silently left the part below the diagonal zero: restored in round 5).  COST: the
+ *   mirrored part of row i is column i of the rows above it, so the rows [0, track1) are computed, not only [track0, track1) -- for the
+ *   last share of a split that is the whole matrix, O(T^2): a job that splits the work calls pvf_pair_upper_rows (dist.py does).
  * pvf_pair_upper_rows: only the UPPER-TRIANGLE entries D[i][j], i < j, of those rows (entries j <= i written as zeros): the share a
  *   rank contributes when the ranks split the pairs by triangle area -- nothing is computed twice.
  * Then the agglomeration of a complete D (pvf_cluster_dist) or of the assembled upper triangle (pvf_cluster_upper mirrors it first).

@@ -14,21 +14,35 @@
 static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int imax(int a, int b) { return a > b ? a : b; }
 
+/* source coordinates of a resize stage: i * scale (the restatement), or carried from index to index when PVO_RESIZE_COORDS=accumulate
+ * (v = -scale; v += scale per step): the two ways dlib's loop may generate them -- oracle/EXT_REGISTER.md E1.  The HIP path has the
+ * same switch (PVF_RESIZE_COORDS, csrc/detect.hip: resize_coords); tests/test_gpu_parity.py runs the pyramid under both. */
+static double* resize_coords(int n_in, int n_out)
+{
+    const double scale = (n_in - 1) / (double)imax(n_out - 1, 1);
+    const char* mode = getenv("PVO_RESIZE_COORDS");
+    const int accumulate = mode && strcmp(mode, "accumulate") == 0;
+    double* v = (double*)malloc(sizeof(double) * (size_t)imax(n_out, 1));
+    double a = -scale;
+    for (int i = 0; i < n_out; ++i) { a += scale; v[i] = accumulate ? a : i * scale; }
+    return v;
+}
+
 /* [EXT dlib/image_transforms/interpolation.h resize_image(in,out,interpolate_bilinear)], RGB branch.
  * Coordinates and blend in double; result = (uint8)(v + 0.5). */
 void pvo_resize_bilinear_rgb(const uint8_t* in, int ih, int iw, uint8_t* out, int oh, int ow)
 {
-    const double x_scale = (iw - 1) / (double)imax(ow - 1, 1);
-    const double y_scale = (ih - 1) / (double)imax(oh - 1, 1);
+    double* ys = resize_coords(ih, oh);
+    double* xs = resize_coords(iw, ow);
     /* rows are independent: OpenMP over rows for the all-core CPU baseline (pvo_set_threads); same bytes for any thread count */
     #pragma omp parallel for schedule(static) if (oh * ow > 65536)
     for (int r = 0; r < oh; ++r) {
-        const double y = r * y_scale;
+        const double y = ys[r];
         const int top = (int)floor(y);
         const int bottom = imin(top + 1, ih - 1);
         const double tb = y - top;
         for (int c = 0; c < ow; ++c) {
-            const double x = c * x_scale;
+            const double x = xs[c];
             const int left = (int)floor(x);
             const int right = imin(left + 1, iw - 1);
             const double lr = x - left;
@@ -44,6 +58,7 @@ void pvo_resize_bilinear_rgb(const uint8_t* in, int ih, int iw, uint8_t* out, in
             }
         }
     }
+    free(ys); free(xs);
 }
 
 /* [EXT OpenCV resize.cpp, INTER_LINEAR, 8-bit, 3 channels] -- cv2.resize(frame, (ow, oh)) as the reference's Video applies it to

@@ -719,7 +719,10 @@ extern "C" int32_t pvf_pair_upper_rows(pvf_handle h, const double* X, int32_t N,
 }
 
 // complete rows: the entries below the diagonal of rows [track0, track1) are D[j][i] of the rows j < i, so the upper-triangle rows
-// [0, track1) are computed on the device, mirrored there, and the asked-for rows copied out
+// [0, track1) are computed on the device, mirrored there, and the asked-for rows copied out.  That is O(T^2) work for the last share of
+// a split (include/pvface.h says so; a split job uses pvf_pair_upper_rows).  The mirror runs over the whole T x T scratch matrix: the
+// rows >= track1 were not computed in this call and hold whatever the scratch held, so only the rows copied out below mean anything
+// -- the device matrix (dD) is not kept past this call.
 extern "C" int32_t pvf_pair_mean_dist_rows(pvf_handle h, const double* X, int32_t N, int32_t dim, const int32_t* row_start, int32_t T,
                                            int32_t track0, int32_t track1, double* D)
 {

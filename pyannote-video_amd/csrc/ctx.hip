@@ -350,7 +350,6 @@ extern "C" int32_t pvf_ctx_destroy(pvf_handle h)
         (void)hipFree(q.p);
     }
     if (c->d_orient_lut) (void)hipFree(c->d_orient_lut);
-    if (c->d_grad_lut) (void)hipFree(c->d_grad_lut);
     if (c->d_wrap_lut) (void)hipFree(c->d_wrap_lut);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->det_stream);

@@ -41,12 +41,16 @@
 // bottom = min(top + 1, ih - 1); tb = y - top; tb1 = 1 - tb): the row loop reads it through the scalar cache instead of redoing
 // wave-uniform double arithmetic in every lane.  32 bytes = one aligned s_load_dwordx8.
 struct RowTab { int32_t top, bottom; double tb, tb1, pad; };
+// ... and per output column (round 6): left source column and the two horizontal weights, likewise host data.  HOW the source coordinates
+// are generated (c * x_scale as restated in oracle/pvo_image.c, or by accumulation as dlib's loop may do it: oracle/EXT_REGISTER.md E1)
+// is therefore decided in ONE place on the host (resize_coords) for rows and columns alike, and the kernel does not change with it.
+struct ColTab { int32_t left, pad; double lr, lr1, pad2; };
 
 template <int RS, int NSTRIP>
 __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __restrict__ in_ptrs, const uint8_t* __restrict__ in_base,
                                                      size_t in_stride, int in_rb, int ih, int iw, uint8_t* __restrict__ out,
-                                                     size_t out_stride, int out_rb, int oh, int ow, double x_scale,
-                                                     const RowTab* __restrict__ rows)
+                                                     size_t out_stride, int out_rb, int oh, int ow,
+                                                     const RowTab* __restrict__ rows, const ColTab* __restrict__ cols)
 {
     constexpr int MAXS = RESIZE_MAXS;
     __shared__ uint32_t s_rows[4][MAXS][64];                     // a wave's source rows: 256-byte windows, dword per lane
@@ -59,11 +63,11 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     const int c = min(c0 + lane, ow - 1);                      // lanes past the row end recompute the last column (never stored)
     const uint8_t* in = in_ptrs ? in_ptrs[b] : in_base + (size_t)b * in_stride;
     uint8_t* ob = out + (size_t)b * out_stride + (size_t)c0 * 3;
-    const double x = c * x_scale;
-    const int left = (int)floor(x);
+    const ColTab ct = cols[c];                                 // (once per wave and segment: 32 bytes per lane, coalesced)
+    const int left = ct.left;
     const int left0 = __builtin_amdgcn_readfirstlane(left);    // lane 0 holds column c0: the smallest source column of the wave
     const bool has_right = (left + 1 <= iw - 1);
-    const double lr = x - left, lr1 = 1 - lr;
+    const double lr = ct.lr, lr1 = ct.lr1;
     const int seg_bytes = min(ow - c0, 64) * 3;
     const bool stores = (4 * lane < seg_bytes);
     // the frame behind a buffer descriptor whose base is 4-byte aligned (`delta` = what the alignment cut off): a row's window starts at
@@ -181,13 +185,29 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
     }
 }
 
+// source coordinate of output index i of a resize stage, i = 0 .. n_out - 1, scale = (n_in - 1) / max(n_out - 1, 1).
+// PVF_RESIZE_COORDS=accumulate: the coordinate is carried from index to index (v = -scale; v += scale per step) instead of formed as
+// i * scale -- the other way dlib's resize_image may generate it (oracle/EXT_REGISTER.md E1; the oracle has the same switch,
+// PVO_RESIZE_COORDS, and tests/test_gpu_parity.py runs the pyramid under both).  Read per plan: a context's plans are built once.
+static std::vector<double> resize_coords(int n_in, int n_out)
+{
+    const double scale = (n_in - 1) / (double)std::max(n_out - 1, 1);
+    const char* mode = getenv("PVF_RESIZE_COORDS");
+    const bool accumulate = mode && strcmp(mode, "accumulate") == 0;
+    PVF_REQUIRE(!mode || accumulate || strcmp(mode, "mul") == 0, "PVF_RESIZE_COORDS must be mul or accumulate");
+    std::vector<double> v((size_t)n_out);
+    double a = -scale;
+    for (int i = 0; i < n_out; ++i) { a += scale; v[i] = accumulate ? a : i * scale; }
+    return v;
+}
+
 static void fill_row_table(std::vector<RowTab>& t, int ih, int oh)
 {
-    const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
+    const std::vector<double> ys = resize_coords(ih, oh);
     const size_t base = t.size();
     t.resize(base + oh);
     for (int r = 0; r < oh; ++r) {
-        const double y = r * y_scale;
+        const double y = ys[r];
         RowTab& e = t[base + r];
         e.top = (int)std::floor(y);
         e.bottom = std::min(e.top + 1, ih - 1);
@@ -197,8 +217,22 @@ static void fill_row_table(std::vector<RowTab>& t, int ih, int oh)
     }
 }
 
+static void fill_col_table(std::vector<ColTab>& t, int iw, int ow)
+{
+    const std::vector<double> xs = resize_coords(iw, ow);
+    const size_t base = t.size();
+    t.resize(base + ow);
+    for (int c = 0; c < ow; ++c) {
+        ColTab& e = t[base + c];
+        e.left = (int)std::floor(xs[c]);
+        e.lr = xs[c] - e.left;
+        e.lr1 = 1 - e.lr;
+        e.pad = 0; e.pad2 = 0;
+    }
+}
+
 static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint8_t* in_base, size_t in_stride, int in_rb, int ih, int iw,
-                               uint8_t* out, size_t out_stride, int out_rb, int oh, int ow, int batch, const RowTab* d_rows)
+                               uint8_t* out, size_t out_stride, int out_rb, int oh, int ow, int batch, const RowTab* d_rows, const ColTab* d_cols)
 {
     const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
     const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
@@ -209,7 +243,7 @@ static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint
     // (4 strips 6.14, 8 strips 6.40: the grid of the small levels gets too coarse).  profiles/r05_resize_bounds_experiment.txt
     constexpr int NSTRIP = 2;
     dim3 grid((ow + 255) / 256, (oh + RS * NSTRIP - 1) / (RS * NSTRIP), batch);
-    hipLaunchKernelGGL((resize_rows_k<RS, NSTRIP>), grid, dim3(256), 0, c->det_stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, x_scale, d_rows);
+    hipLaunchKernelGGL((resize_rows_k<RS, NSTRIP>), grid, dim3(256), 0, c->det_stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, d_rows, d_cols);
 }
 
 static void pyramid_up_dims(int ih, int iw, int* oh, int* ow)
@@ -305,25 +339,24 @@ __device__ __forceinline__ int ml_level(const MlStarts& st, int g)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2 fused: image rows -> 31-plane features in ONE pass; gradients and cell histograms never leave the chip.
+// K2: image rows -> 31-plane features in ONE pass; gradients and cell histograms never leave the chip.
 //
-// A wave owns a strip of 64 histogram columns (lane L <-> histogram column hx0 + L) and walks a chunk of the level top to bottom,
-// one pixel row at a time.  Per row a lane
-//   - holds the image rows y-1, y, y+1 of its own 8 pixel columns in registers (each row is loaded once, 32 bytes per lane, a
-//     further row is in flight) and turns them into 8 (magnitude, bin) pairs;
-//   - fetches the 8 pairs of the lane to its right (DPP wave shift): together they are the 16 columns of its cell's window;
-//   - adds the 16 votes to the bins of the cell whose UPPER half the row lies in and of the cell whose LOWER half it lies in.
+// A strip is 64 histogram columns wide (lane L <-> histogram column hx0 + L) and a chunk of the level high; it is walked top to bottom,
+// one pixel row at a time.  Per row and lane
+//   - the image rows y-1, y, y+1 of the lane's own 8 pixel columns (each row loaded once, 32 bytes per lane) become 8 (magnitude, bin)
+//     pairs: the colour channel with the largest |g|^2, its orientation bin from a table, the exact root;
+//   - the lane's own 8 pairs and the 8 of the lane to its right are the 16 columns of its cell's window: their votes go to the bins of
+//     the cell whose UPPER half the row lies in and of the cell whose LOWER half it lies in.
 // A cell therefore receives its votes in row-major order of its own 16 x 16 window -- the order dlib's scatter loop produces
 // (oracle/pvo_fhog.c) -- while every pixel's gradient is computed exactly once.  The bins live in LDS, [bin][lane] (conflict-free), the
 // even and the odd cell rows' in two halves of ONE array a constant distance apart: a vote reads, adds to and writes the lane's own word
-// in both cells with one ds_read2st64 / ds_write2st64 pair off one address (round 4; two arrays before: two addresses, four LDS
-// instructions), the chains of the two cells a row votes into are independent, and LDS executes a wave's accesses in order, so no wait
-// sits between one vote's write and the next vote's read.  Bin offsets are kept in bytes (no shift per vote).  (ds_add_f32 gives the same sums -- it is an IEEE add -- but the LDS atomic unit retires so few lanes per
-// clock that the kernel ran 5 x slower with it: measured 713 us per 1080p frame.)  When a cell is complete its 18 bins move into registers;
-// a finished cell row's features (4-way block normalisation over the 3 x 3 neighbourhood of cell energies: rows from the two
-// previous cell rows kept in registers, columns from the neighbouring lanes) are written straight to the feature map.
-// HBM traffic: the level images once (83 MB per 1080p frame) + the features once (58 MB), against 472 MB for the three-pass
-// form (109 MB/frame gradient plane written and read 1.25 x, 33 MB histogram round trip).
+// in both cells with one ds_read2st64 / ds_write2st64 pair off one address, the chains of the two cells a row votes into are
+// independent, and LDS executes a wave's accesses in order, so no wait sits between one vote's write and the next vote's read.
+// (ds_add_f32 gives the same sums -- it is an IEEE add -- but the LDS atomic unit retires so few lanes per clock that the kernel ran 5 x
+// slower with it.)  When a cell is complete its 18 bins move into registers; a finished cell row's features (4-way block normalisation
+// over the 3 x 3 neighbourhood of cell energies: rows from the two previous cell rows kept in registers, columns from the neighbouring
+// lanes) are written straight to the feature map.
+// HBM traffic: the level images once (83 MB per 1080p frame) + the features once (58 MB).
 //
 // Strip geometry: feature column x needs the histograms x+1 .. x+3, so a strip of 64 lanes yields 61 feature columns
 // (lane 63 only supplies gradients to lane 62; lanes 0 and 62 only supply cell energies).  Row chunks of `chunk_rows` feature
@@ -335,172 +368,11 @@ __device__ __forceinline__ int ml_level(const MlStarts& st, int g)
 __device__ __forceinline__ uint32_t from_next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 
-
-__global__ void __launch_bounds__(256) fhog_fused_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t* __restrict__ img_base,
-                                                       float* __restrict__ feat_base, const uint8_t* __restrict__ lut2, int oy, int ox)
-{
-    constexpr int RSRC_FLAGS = 0x00020000;
-    // the bins of the two cell rows a pixel row votes into
-    __shared__ float s_bins[2][4][18][64];                         // [parity of the cell row][wave][bin][lane]: the two parities a constant distance apart
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int g = ml_block(st);
-    if (g >= st.b0[st.nl]) return;
-    const int l = ml_level(st, g);
-    const LvDesc d = lv[l];
-    const int task = (g - st.b0[l]) * 4 + wave;
-    if (task >= d.fused_tasks) return;                             // wave-uniform
-    const int sx = task % d.strips;
-    const int t2 = task / d.strips;
-    const int cy = t2 % d.chunks;
-    const int b = t2 / d.chunks;
-    const int y0 = cy * d.chunk_rows;                              // first feature (hog) row of this chunk
-    const int R = min(d.chunk_rows, d.hog_nr - y0);
-    const int hx = FUSED_OUT * sx + 1 + lane;                      // histogram column of this lane
-    const int x_first = 8 * hx - 12;                               // image column of its first pixel
-    const uint8_t* im = img_base + d.img_off + (size_t)b * d.img_stride;
-    const int rb = d.rb;
-    // validity of the lane's 8 pixel columns: gradients exist for 1 <= x < visible_nc (oracle/pvo_fhog.c)
-    unsigned xmask = 0;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) if (x_first + p >= 1 && x_first + p < d.visible_nc) xmask |= 1u << p;
-    // byte offsets of the two 16-byte halves of the lane's 32-byte window in an image row (8-aligned).  Columns left of the image
-    // give negative offsets, which are huge as unsigned: out of range for the row's buffer descriptor => zeros.  Both offsets go
-    // through the VGPR: the range check does not see an SGPR offset, so -16 + an SGPR 16 would be rejected although it is byte 0.
-    const int voff = 3 * x_first - 4, voff2 = voff + 16;
-    float* accE = &s_bins[0][wave][0][lane];                       // bin k of this lane: accE[64 * k]
-    float* accO = &s_bins[1][wave][0][lane];
-#pragma unroll
-    for (int k = 0; k < 18; ++k) { accE[64 * k] = 0.0f; accO[64 * k] = 0.0f; }
-
-    // image rows as 8 dwords per lane: bytes [3 x_first - 4, 3 x_first + 28) -- pixel p, channel k at byte 4 + 3 p + k;
-    // a row outside the image, or bytes outside a row, read as 0 (such pixels are never valid)
-    uint32_t rw[4][8];
-    auto load_row = [&](int yi, uint32_t* dst) {
-        const int bytes = (yi >= 0 && yi < d.h) ? rb : 0;           // wave-uniform
-        const int yc = min(max(yi, 0), d.h - 1);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(im + (size_t)yc * rb), 0, bytes, RSRC_FLAGS);
-        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-        const u32x4 c = __builtin_amdgcn_raw_buffer_load_b128(rs, voff2, 0, 0);
-        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = c.x; dst[5] = c.y; dst[6] = c.z; dst[7] = c.w;
-    };
-    const int g_first = y0 + 1, g_last = y0 + R + 3;               // bands (= cell rows whose upper half they hold)
-    const int y_begin = 8 * g_first - 12;
-    load_row(y_begin - 1, rw[0]);
-    load_row(y_begin, rw[1]);
-    load_row(y_begin + 1, rw[2]);
-    load_row(y_begin + 2, rw[3]);
-
-    float hprev[18];
-    float e0 = 0.f, e1 = 0.f, e2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 18; ++k) hprev[k] = 0.f;
-
-#define BYTE_OF(w, i) (int)(((w)[(i) >> 2] >> (8 * ((i) & 3))) & 0xffu)
-    // (magnitude, bin offset) of pixel p of image row y from the three row buffers; rows / columns without a gradient give magnitude 0
-    auto grad_px = [&](const uint32_t* up, const uint32_t* ce, const uint32_t* dn, int p, bool row_ok, float* mo, int* bof) {
-        int u3[3], d3[3], l3[3], r3[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            u3[k] = BYTE_OF(up, 4 + 3 * p + k); d3[k] = BYTE_OF(dn, 4 + 3 * p + k);
-            l3[k] = BYTE_OF(ce, 1 + 3 * p + k); r3[k] = BYTE_OF(ce, 7 + 3 * p + k);
-        }
-        float v; int o;
-        grad_lookup(u3, d3, l3, r3, lut2, &v, &o);
-        *mo = (row_ok && ((xmask >> p) & 1u)) ? v : 0.0f;
-        *bof = o << 8;                                             // BYTE offset of the bin's row of 64 lanes (no shift left per vote)
-    };
-    // the votes of a row are a chain of LDS read-add-writes (latency bound); the gradients of the NEXT row are pure VALU work plus a table
-    // look-up: they are computed in between, one pixel per two votes, so that a wave fills its own LDS waits and the look-ups of a row are
-    // back long before its votes start
-    float mc[8];
-    int bc[8];
-    {
-        const bool ok0 = (y_begin >= 1 && y_begin < d.visible_nr);
-#pragma unroll
-        for (int p = 0; p < 8; ++p) grad_px(rw[0], rw[1], rw[2], p, ok0, &mc[p], &bc[p]);
-    }
-    // One band = 8 pixel rows: the upper half of cell row gb (bins in accU) and the lower half of cell row gb - 1 (bins in accL).
-    // The first band's lower half (cell row y0) and the last band's upper half (cell row y0 + R + 3) belong to cells this chunk
-    // does not need; they are accumulated all the same (no branches in the vote loop): the first is read and dropped, the last
-    // is never read.  Rows without gradients vote with magnitude 0 (x + 0 = x: nothing changes).
-    auto band = [&](int gb, float* accU, float* accL) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int y = 8 * gb + i - 12;                         // the row whose votes are cast in this step (gradients in mc / bc)
-            // buffers: rows y, y + 1, y + 2 in rw[(i+1)&3], rw[(i+2)&3], rw[(i+3)&3]; rw[i & 3] held row y - 1 (done with) and takes
-            // row y + 3, which is needed one step from now: a full step to arrive
-            load_row(y + 3, rw[i & 3]);
-            const uint32_t* nu = rw[(i + 1) & 3];                  // rows around y + 1, whose gradients are formed meanwhile
-            const uint32_t* nc = rw[(i + 2) & 3];
-            const uint32_t* nd = rw[(i + 3) & 3];
-            const bool nok = (y + 1 >= 1 && y + 1 < d.visible_nr);
-            float mn[8];
-            int bn[8];
-            const float fy = ((float)i + 0.5f) / 8.0f;
-            // the 16 columns of the window, left to right: own 8 (weights rising), then the right neighbour's 8 (falling).
-            // Each vote is a read-add-write on the lane's own bin in LDS; the two cells' chains are independent.
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int p = j & 7;
-                float mv; int bv;
-                if (j < 8) { mv = mc[p]; bv = bc[p]; }
-                else {
-                    mv = __uint_as_float(from_next_lane(__float_as_uint(mc[p])));
-                    bv = (int)from_next_lane((uint32_t)bc[p]);
-                }
-                const float fx = ((float)p + 0.5f) / 8.0f;
-                const float wx = (j < 8) ? fx : 1.0f - fx;
-                float* const pl = reinterpret_cast<float*>(reinterpret_cast<char*>(accL) + bv);
-                float* const pu = reinterpret_cast<float*>(reinterpret_cast<char*>(accU) + bv);
-                const float vl = *pl, vu = *pu;
-                if ((j & 1) == 0) grad_px(nu, nc, nd, j >> 1, nok, &mn[j >> 1], &bn[j >> 1]);
-                *pl = vl + ((1.0f - fy) * wx) * mv;
-                *pu = vu + (fy * wx) * mv;
-            }
-#pragma unroll
-            for (int p = 0; p < 8; ++p) { mc[p] = mn[p]; bc[p] = bn[p]; }
-        }
-        // cell row c = gb - 1 is complete (for c = y0: a half-filled cell that only has to be cleared; its energy is shifted out of
-        // e0..e2 before the first feature row is formed): energy in the oracle's order (straight from LDS: the new bins and the
-        // previous row's never sit in registers together)
-        const int c = gb - 1;
-        float e = 0.0f;
-#pragma unroll
-        for (int o = 0; o < 9; ++o) { const float s2 = accL[64 * o] + accL[64 * (o + 9)]; e = e + s2 * s2; }
-        e2 = e1; e1 = e0; e0 = e;
-        if (c >= y0 + 3) {
-            // features of the centre cell row c - 1 (histograms in hprev), hog row y = c - 3; norms: rows c-2, c-1, c x lanes L-1, L, L+1
-            float n[9];
-            n[1] = e2; n[4] = e1; n[7] = e0;
-            n[0] = __uint_as_float(from_prev_lane(__float_as_uint(e2))); n[2] = __uint_as_float(from_next_lane(__float_as_uint(e2)));
-            n[3] = __uint_as_float(from_prev_lane(__float_as_uint(e1))); n[5] = __uint_as_float(from_next_lane(__float_as_uint(e1)));
-            n[6] = __uint_as_float(from_prev_lane(__float_as_uint(e0))); n[8] = __uint_as_float(from_next_lane(__float_as_uint(e0)));
-            const int x = FUSED_OUT * sx + lane - 1, yh = c - 3;
-            if (lane >= 1 && lane <= FUSED_OUT && x < d.hog_nc) {
-                float o[32];
-                cell_features(hprev, n, o);
-                float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + feat_at(yh + oy, 0, x + ox, d.fwp));
-#pragma unroll
-                for (int k = 0; k < 8; ++k) dst[(size_t)k * d.fwp] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-            }
-        }
-        // the finished cell row becomes the centre of the next feature row: its bins move to registers, the LDS words are cleared
-#pragma unroll
-        for (int k = 0; k < 18; ++k) { hprev[k] = accL[64 * k]; accL[64 * k] = 0.0f; }
-    };
-    for (int gb = g_first; gb <= g_last; ++gb) {
-        if (gb & 1) band(gb, accO, accE);                           // upper half -> the odd cell row gb, lower half -> the even row gb - 1
-        else band(gb, accE, accO);
-    }
-#undef BYTE_OF
-}
-
 // ---------------------------------------------------------------------------------------------------
-// K2 with the two halves of the work in waves of their own (round 6).  fhog_fused_ml_k above holds the image rows, two rows' worth of
-// gradients, the previous cell row's bins and the feature epilogue in ONE wave: 236 registers, two waves per SIMD, and those two spend
+// The two halves of that work run in waves of their own (round 6).  Rounds 2-5 held the image rows, two rows' worth of gradients, the
+// previous cell row's bins and the feature epilogue in ONE wave (fhog_fused_ml_k: 236 registers, two waves per SIMD), and those two spent
 // their time differently -- 8 x ~35 vector instructions per pixel row for the gradients against a chain of 16 dependent LDS
-// read-add-writes for the votes -- so whenever both sit in their chains the vector pipe idles (SQ_INSTS_VALU 79 % of the issue slots).
+// read-add-writes for the votes -- so whenever both sat in their chains the vector pipe idled.
 // Here a block of 8 waves works on 4 strips; each strip has
 //   a GRADIENT wave (role 0): image rows in registers, per pixel the channel with the largest |g|^2, its orientation bin from the
 //     table and the exact root -- (magnitude, bin) of its 8 pixels per row go into a two-slot ring in LDS;
@@ -637,7 +509,10 @@ fhog_split_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t
         unsigned xmask = 0;                                        // gradients exist for 1 <= x < visible_nc (oracle/pvo_fhog.c)
 #pragma unroll
         for (int p = 0; p < 8; ++p) if (x_first + p >= 1 && x_first + p < d.visible_nc) xmask |= 1u << p;
-        const int voff = 3 * x_first - 4, voff2 = voff + 16;       // (see fhog_fused_ml_k)
+        // byte offsets of the two 16-byte halves of the lane's 32-byte window in an image row (8-aligned): bytes [3 x_first - 4, 3 x_first + 28),
+        // pixel p, channel k at byte 4 + 3 p + k.  Columns left of the image give negative offsets, which are huge as unsigned: out of range
+        // for the row's buffer descriptor => zeros (such pixels are never valid); a row outside the image gets an empty descriptor.
+        const int voff = 3 * x_first - 4, voff2 = voff + 16;
         const __amdgpu_buffer_rsrc_t lut_rs = __builtin_amdgcn_make_buffer_rsrc((void*)lutw, 0, 1 << 18, RSRC_FLAGS);
         // Image rows as 8 dwords per lane: the three around the row whose gradients are formed and one on its way.  (Eight buffers, rows
         // requested six steps ahead, measured the same 7.8 ms per 125 frames: the rows' latency is not what this wave waits for.)
@@ -695,6 +570,10 @@ fhog_split_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t
 #pragma unroll
     for (int k = 0; k < 18; ++k) hprev[k] = 0.f;
     int krow = 0;                                                  // rows of this task read so far
+    // One band = 8 pixel rows: the upper half of cell row gb (bins in accU) and the lower half of cell row gb - 1 (bins in accL).
+    // The first band's lower half (cell row y0) and the last band's upper half (cell row y0 + R + 3) belong to cells this chunk
+    // does not need; they are accumulated all the same (no branches in the vote loop): the first is read and dropped, the last
+    // is never read.  Rows without gradients vote with magnitude 0 (x + 0 = x: nothing changes).
     auto band = [&](int gb, float* accU, float* accL) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -723,7 +602,9 @@ fhog_split_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t
                 *pu = vu + (fy * wx) * mv;
             }
         }
-        const int c = gb - 1;                                       // this cell row is complete (see fhog_fused_ml_k)
+        // cell row c = gb - 1 is complete (for c = y0: a half-filled cell that only has to be cleared; its energy is shifted out of
+        // e0..e2 before the first feature row is formed): energy in the oracle's order, straight from LDS
+        const int c = gb - 1;
         float e = 0.0f;
 #pragma unroll
         for (int o = 0; o < 9; ++o) { const float s2 = accL[64 * o] + accL[64 * (o + 9)]; e = e + s2 * s2; }
@@ -996,11 +877,13 @@ struct MlPlan {
     size_t img_bytes = 0, feat_floats = 0, up_bytes = 0;
     LvDesc* d_lv = nullptr;
     RowTab* d_rowtab = nullptr;                // row tables of every resize stage: upsampling stages first, then level l from level l - 1
+    ColTab* d_coltab = nullptr;                // column tables, the same stages
     std::vector<size_t> up_tab, lv_tab;        // offsets (entries) into d_rowtab
+    std::vector<size_t> up_ctab, lv_ctab;      // ... into d_coltab
     const void* ring_valid_for = nullptr;      // feature buffer whose zero border was written for this plan (fused FHOG)
     ScreenPlan screen;                         // work items of the screening pass (screen.hip), built when it is first used
     bool screen_built = false;
-    ~MlPlan() { if (d_lv) (void)hipFree(d_lv); if (d_rowtab) (void)hipFree(d_rowtab); }
+    ~MlPlan() { if (d_lv) (void)hipFree(d_lv); if (d_rowtab) (void)hipFree(d_rowtab); if (d_coltab) (void)hipFree(d_coltab); }
     MlPlan() = default;
     MlPlan(const MlPlan&) = delete;
     MlPlan& operator=(const MlPlan&) = delete;
@@ -1033,7 +916,20 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
     auto al = [](size_t v, size_t a) { return (v + a - 1) / a * a; };
     for (size_t u = 0; u + 1 < p.ups.size(); ++u) p.up_bytes = std::max(p.up_bytes, (size_t)p.ups[u].h * al((size_t)p.ups[u].w * 3, 64) * B);
     p.feat.nl = p.fused.nl = p.walk.nl = (int)dims.size();
-    const int chunk_big = 32;                  // feature rows per fused-FHOG task on the large levels
+    // Feature rows per FHOG task.  A task re-walks 3 cell rows above its first feature row, so tasks are as tall as the batch allows: the
+    // tallest that still leave two tasks per strip slot of the device (n_cu x 2 blocks x 4 strips).  Measured on 125 1080p frames, detector
+    // alone, ms per batch: 16 rows 7.39, 32 rows 6.84, 64 rows 6.59, 96 rows 6.54, 160 rows 6.50, whole levels 6.52
+    // (profiles/r06_fhog_split_experiment.txt).
+    int chunk_big = 8;
+    for (int cand : {160, 128, 96, 64, 48, 32, 24, 16}) {
+        long long tasks = 0;
+        for (const LevelDims& ld : dims) {
+            const int hog_nr = (int)((double)ld.h / 8.0 + 0.5) - 2, hog_nc = (int)((double)ld.w / 8.0 + 0.5) - 2;
+            if (hog_nr > 0 && hog_nc > 0) tasks += (long long)((hog_nc + FUSED_OUT - 1) / FUSED_OUT) * std::max(2, (hog_nr + cand - 1) / cand) * B;
+        }
+        if (tasks >= 2LL * c->n_cu * 2 * 4) { chunk_big = cand; break; }
+    }
+    if (getenv("PVF_FHOG_CHUNK") && atoi(getenv("PVF_FHOG_CHUNK")) > 0) chunk_big = atoi(getenv("PVF_FHOG_CHUNK"));
     for (size_t l = 0; l < dims.size(); ++l) {
         LvDesc d;
         memset(&d, 0, sizeof d);
@@ -1055,7 +951,11 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         d.score_bx = d.valid_score ? (out_c + 95) / 96 : 0;        // column strips of 96 output columns (K3)
         // fused FHOG tasks: strips of 61 feature columns x chunks of feature rows (smaller chunks for the small levels: more tasks)
         d.strips = feat_ok ? (d.hog_nc + FUSED_OUT - 1) / FUSED_OUT : 0;
-        d.chunk_rows = (d.hog_nr >= 2 * chunk_big) ? chunk_big : std::max((d.hog_nr + 1) / 2, 1);
+        {
+            // chunks of about chunk_big feature rows, all of a level's the same height (a level lower than two chunks: two halves)
+            const int nch = std::max(2, (d.hog_nr + chunk_big - 1) / chunk_big);
+            d.chunk_rows = std::max((d.hog_nr + nch - 1) / nch, 1);
+        }
         d.chunks = feat_ok ? (d.hog_nr + d.chunk_rows - 1) / d.chunk_rows : 0;
         d.fused_tasks = d.strips * d.chunks * B;
         p.feat.b0[l] = p.feat_blocks; p.feat_blocks += d.feat_bx * d.fh * B;
@@ -1094,6 +994,13 @@ static MlPlan* ml_plan(Ctx* c, int h, int w, int upsample, int B)
         for (int l = 1; l < nl; ++l) { p.lv_tab.push_back(tab.size()); fill_row_table(tab, p.lv[l - 1].h, p.lv[l].h); }
         HIP_CHECK(hipMalloc((void**)&p.d_rowtab, sizeof(RowTab) * std::max<size_t>(tab.size(), 1)));
         if (!tab.empty()) HIP_CHECK(hipMemcpy(p.d_rowtab, tab.data(), sizeof(RowTab) * tab.size(), hipMemcpyHostToDevice));
+        std::vector<ColTab> ctab;
+        int cw2 = w;
+        for (size_t u = 0; u < p.ups.size(); ++u) { p.up_ctab.push_back(ctab.size()); fill_col_table(ctab, cw2, p.ups[u].w); cw2 = p.ups[u].w; }
+        p.lv_ctab.push_back(0);
+        for (int l = 1; l < nl; ++l) { p.lv_ctab.push_back(ctab.size()); fill_col_table(ctab, p.lv[l - 1].w, p.lv[l].w); }
+        HIP_CHECK(hipMalloc((void**)&p.d_coltab, sizeof(ColTab) * std::max<size_t>(ctab.size(), 1)));
+        if (!ctab.empty()) HIP_CHECK(hipMemcpy(p.d_coltab, ctab.data(), sizeof(ColTab) * ctab.size(), hipMemcpyHostToDevice));
     }
     MlPlan* raw = pp.get();
     c->ml_plans->plans[key] = std::move(pp);
@@ -1122,7 +1029,7 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
         uint8_t* dst = last ? base + p->lv[0].img_off : up_tmp;
         const int drb = (int)al((size_t)p->ups[u].w * 3, 64);
         const size_t dstride = (size_t)p->ups[u].h * drb;
-        launch_resize_rows(c, cur ? nullptr : d_ptrs, cur, cstride, crb, ch, cw, dst, dstride, drb, p->ups[u].h, p->ups[u].w, B, p->d_rowtab + p->up_tab[u]);
+        launch_resize_rows(c, cur ? nullptr : d_ptrs, cur, cstride, crb, ch, cw, dst, dstride, drb, p->ups[u].h, p->ups[u].w, B, p->d_rowtab + p->up_tab[u], p->d_coltab + p->up_ctab[u]);
         cur = dst; cstride = dstride; crb = drb; ch = p->ups[u].h; cw = p->ups[u].w;
     }
     if (!cur) {
@@ -1132,7 +1039,7 @@ static MlPlan* ml_build_pyramid(Ctx* c, const std::vector<Frame>& frames, int up
     }
     for (size_t l = 1; l < p->lv.size(); ++l)
         launch_resize_rows(c, nullptr, base + p->lv[l - 1].img_off, (size_t)p->lv[l - 1].img_stride, p->lv[l - 1].rb, p->lv[l - 1].h, p->lv[l - 1].w,
-                           base + p->lv[l].img_off, (size_t)p->lv[l].img_stride, p->lv[l].rb, p->lv[l].h, p->lv[l].w, B, p->d_rowtab + p->lv_tab[l]);
+                           base + p->lv[l].img_off, (size_t)p->lv[l].img_stride, p->lv[l].rb, p->lv[l].h, p->lv[l].w, B, p->d_rowtab + p->lv_tab[l], p->d_coltab + p->lv_ctab[l]);
     return p;
 }
 
@@ -1187,7 +1094,6 @@ static MlPlan* ml_features(Ctx* c, const std::vector<Frame>& frames, int upsampl
     const DetectorModel& m = c->det;
     const int B = (int)frames.size();
     MlPlan* p = ml_build_pyramid(c, frames, upsample);
-    const uint8_t* lut2 = orientation_lut_tiled(c);
     const int oy = (m.frows - 1) / 2, ox = (m.fcols - 1) / 2;
     const void* feat_before = c->s_feat.p;
     c->s_feat.ensure(p->feat_floats * sizeof(float) + 64);
@@ -1200,20 +1106,14 @@ static MlPlan* ml_features(Ctx* c, const std::vector<Frame>& frames, int upsampl
         hipLaunchKernelGGL(feat_ring_zero_k, dim3(ml_grid(p->feat_blocks)), dim3(256), 0, c->det_stream, p->feat, p->d_lv, B, c->s_feat.as<float>(), oy, ox);
         c->feat_ring_owner = (const void*)p;
     }
-    static const int split = getenv("PVF_FHOG_SPLIT") ? atoi(getenv("PVF_FHOG_SPLIT")) : 1;
-    if (split) {
-        static std::atomic<uint64_t> attr_set{0};             // per device (a function attribute belongs to the device it was set on)
-        const uint64_t bit = 1ull << (c->device & 63);
-        if (!(attr_set.load() & bit)) {
-            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fhog_split_ml_k), hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS_BYTES));
-            attr_set.fetch_or(bit);
-        }
-        hipLaunchKernelGGL(fhog_split_ml_k, dim3(ml_grid(p->fused_blocks)), dim3(512), FS_LDS_BYTES, c->det_stream, p->fused, p->d_lv, B,
-                           c->s_pyr.as<uint8_t>(), c->s_feat.as<float>(), orientation_lut_wrapped(c), oy, ox);
-        return p;
+    static std::atomic<uint64_t> attr_set{0};             // per device (a function attribute belongs to the device it was set on)
+    const uint64_t bit = 1ull << (c->device & 63);
+    if (!(attr_set.load() & bit)) {
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fhog_split_ml_k), hipFuncAttributeMaxDynamicSharedMemorySize, FS_LDS_BYTES));
+        attr_set.fetch_or(bit);
     }
-    hipLaunchKernelGGL(fhog_fused_ml_k, dim3(ml_grid(p->fused_blocks)), dim3(256), 0, c->det_stream, p->fused, p->d_lv, B, c->s_pyr.as<uint8_t>(),
-                       c->s_feat.as<float>(), lut2, oy, ox);
+    hipLaunchKernelGGL(fhog_split_ml_k, dim3(ml_grid(p->fused_blocks)), dim3(512), FS_LDS_BYTES, c->det_stream, p->fused, p->d_lv, B,
+                       c->s_pyr.as<uint8_t>(), c->s_feat.as<float>(), orientation_lut_wrapped(c), oy, ox);
     return p;
 }
 

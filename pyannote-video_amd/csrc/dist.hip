@@ -27,6 +27,7 @@ struct Comm {
     hipStream_t stream = nullptr;
     void* d_send = nullptr; size_t send_cap = 0;
     void* d_recv = nullptr; size_t recv_cap = 0;
+    int64_t* h_counts = nullptr;          // pinned, world + 1 entries: the counts land HERE and reach the caller's array only on success
     void grow(void** p, size_t* cap, size_t need)
     {
         if (need <= *cap) return;
@@ -52,6 +53,17 @@ Comm* get(pvfd_handle h)
 // A collective that never completes (a rank that died, went a different way through its shots, or posted other sizes) must not hang the
 // job silently: the stream is POLLED -- the communicator's asynchronous error state beside it -- and after PVF_DIST_TIMEOUT_S seconds
 // (default 120) the communicator is aborted and the call fails with an error that names this rank and what it was waiting for.
+// After an abort the collective's kernel ends, but what was queued BEHIND it on the stream (the copy of the counts, the next call's use of
+// d_send / d_recv) still runs: the stream is drained -- bounded, the device may be beyond help -- before the error leaves this library, so
+// nothing of this call touches memory after the caller has been told it failed.
+void abort_and_drain(Comm* c)
+{
+    (void)ncclCommAbort(c->comm); c->comm = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(c->stream) == hipErrorNotReady && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 10.0)
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+}
+
 void wait_collective(Comm* c, const char* what, const std::string& detail)
 {
     double limit = 120.0;
@@ -63,12 +75,12 @@ void wait_collective(Comm* c, const char* what, const std::string& detail)
         if (q != hipErrorNotReady) throw Err(std::string(what) + ": " + hipGetErrorString(q));
         ncclResult_t async = ncclSuccess;
         if (ncclCommGetAsyncError(c->comm, &async) == ncclSuccess && async != ncclSuccess && async != ncclInProgress) {
-            (void)ncclCommAbort(c->comm); c->comm = nullptr;
+            abort_and_drain(c);
             throw Err(std::string(what) + ": rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) + ": communicator error: " + ncclGetErrorString(async) + " (" + detail + ")");
         }
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (waited > limit) {
-            (void)ncclCommAbort(c->comm); c->comm = nullptr;
+            abort_and_drain(c);
             throw Err(std::string(what) + ": rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) + " gave up after " + std::to_string((int)waited) +
                       " s (PVF_DIST_TIMEOUT_S): a peer never joined this collective (" + detail + "); the communicator was aborted");
         }
@@ -83,8 +95,11 @@ void gather_counts(Comm* c, int64_t n_rows, int64_t* counts)
     c->grow(&c->d_recv, &c->recv_cap, sizeof(int64_t) * c->world);
     HIPC(hipMemcpyAsync(c->d_send, &n_rows, sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
     NCCLC(ncclAllGather(c->d_send, c->d_recv, 1, ncclInt64, c->comm, c->stream));
-    HIPC(hipMemcpyAsync(counts, c->d_recv, sizeof(int64_t) * c->world, hipMemcpyDeviceToHost, c->stream));
+    // into the communicator's own pinned buffer: should the collective fail, no copy into the CALLER's array is left on the stream
+    if (!c->h_counts) HIPC(hipHostMalloc((void**)&c->h_counts, sizeof(int64_t) * (c->world + 1), hipHostMallocDefault));
+    HIPC(hipMemcpyAsync(c->h_counts, c->d_recv, sizeof(int64_t) * c->world, hipMemcpyDeviceToHost, c->stream));
     wait_collective(c, "pvfd_allgather_counts", "all-gather of one int64 per rank: mine = " + std::to_string(n_rows));
+    memcpy(counts, c->h_counts, sizeof(int64_t) * c->world);
 }
 } // namespace
 
@@ -131,6 +146,7 @@ extern "C" int32_t pvfd_comm_destroy(pvfd_handle h)
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->d_send) (void)hipFree(c->d_send);
     if (c->d_recv) (void)hipFree(c->d_recv);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
     (void)hipStreamDestroy(c->stream);
     std::lock_guard<std::mutex> lk(g_mu);
     g_comms.erase(h);

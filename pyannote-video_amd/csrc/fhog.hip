@@ -40,29 +40,10 @@ const uint8_t* orientation_lut(Ctx* c)
     return c->d_orient_lut;
 }
 
-// The same table in 8 x 8 tiles (one 64-byte line each): with Y = by + 255, X = bx + 255 the entry sits at
-// (Y >> 3) << 12 | (X >> 3) << 6 | (Y & 7) << 3 | (X & 7).  Neighbouring pixels mostly have small, similar gradients, so a
-// wave's 64 look-ups touch a handful of lines instead of one line per table row (the row-major form cost ~50 L1 accesses
-// per gather and made the gradient pass texture-addresser bound).
-const uint8_t* orientation_lut_tiled(Ctx* c)
-{
-    std::lock_guard<std::recursive_mutex> lk(g_lut_mu);
-    if (c->d_grad_lut) return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
-    orientation_lut(c);
-    std::vector<uint8_t> ol((size_t)511 * 511);
-    HIP_CHECK(hipMemcpy(ol.data(), c->d_orient_lut, ol.size(), hipMemcpyDeviceToHost));
-    std::vector<uint8_t> lut((size_t)64 * 64 * 64, 0);
-    for (int Y = 0; Y < 511; ++Y)
-        for (int X = 0; X < 511; ++X)
-            lut[((size_t)(Y >> 3) << 12) | ((size_t)(X >> 3) << 6) | ((Y & 7) << 3) | (X & 7)] = ol[(size_t)Y * 511 + X];
-    HIP_CHECK(hipMalloc((void**)&c->d_grad_lut, lut.size()));
-    HIP_CHECK(hipMemcpy(c->d_grad_lut, lut.data(), lut.size(), hipMemcpyHostToDevice));
-    return reinterpret_cast<const uint8_t*>(c->d_grad_lut);
-}
-
 // The table of the detector's gradient waves (detect.hip: fhog_split_ml_k): the winning channel's two differences sit in the halves of one
 // register as 16-bit two's complement, and the entry's place is made of bits of THAT register -- X = bx mod 512, Y = by mod 512 (no bias
-// add), entry at (X & 7) | Y << 3 | (X >> 3) << 12: a 64-byte line is again an 8 x 8 tile of neighbouring gradients.
+// add), entry at (X & 7) | Y << 3 | (X >> 3) << 12: a 64-byte line is an 8 x 8 tile of neighbouring gradients.  (Neighbouring pixels mostly
+// have small, similar gradients, so a wave's 64 look-ups touch a handful of lines; the row-major table cost ~50 L1 accesses per gather.)
 const uint8_t* orientation_lut_wrapped(Ctx* c)
 {
     std::lock_guard<std::recursive_mutex> lk(g_lut_mu);

@@ -8,9 +8,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4u __attribute__((aligned(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// orientation-bin tables (fhog.hip): row-major 511 x 511, and the same in 8 x 8 tiles (one 64-byte line each)
+// orientation-bin tables (fhog.hip): row-major 511 x 511 ...
 const uint8_t* orientation_lut(Ctx* c);
-const uint8_t* orientation_lut_tiled(Ctx* c);
 // ... and addressed by the two differences mod 512 (X = bx & 511, Y = by & 511): (X & 7) | Y << 3 | (X >> 3) << 12 -- 8 x 8 tiles again
 const uint8_t* orientation_lut_wrapped(Ctx* c);
 
@@ -41,26 +40,6 @@ __device__ __forceinline__ float sqrt_exact_small(float x)
     const float s = __builtin_amdgcn_sqrtf(x);
     const float sp = __uint_as_float(__float_as_uint(s) + 1u);
     return fmaf(-sp, s, x) > 0.0f ? sp : s;
-}
-
-// colour channel with the largest |g|^2 (first wins); magnitude by arithmetic, orientation bin from the tiled table
-__device__ __forceinline__ void grad_lookup(const int u[3], const int d[3], const int l[3], const int r[3],
-                                            const uint8_t* __restrict__ lut_t, float* v, int* o)
-{
-    int cv[3], ci[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int cx = r[k] - l[k], cy = d[k] - u[k];
-        cv[k] = cx * cx + cy * cy;
-        ci[k] = cy * 512 + cx;
-    }
-    const int bv = max(cv[0], max(cv[1], cv[2]));                  // v_max3_i32
-    const int bi = (cv[0] == bv) ? ci[0] : ((cv[1] == bv) ? ci[1] : ci[2]);
-    const unsigned P = (unsigned)(bi + 255 * 512 + 255);           // Y << 9 | X
-    const unsigned off = (P & 0x3F007u) | ((P & 0x1F8u) << 3) | ((P >> 6) & 0x38u);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)lut_t, 0, 64 * 64 * 64, 0x00020000);
-    *o = (int)__builtin_amdgcn_raw_buffer_load_b8(rs, off, 0, 0);
-    *v = sqrt_exact_small((float)bv);
 }
 
 __device__ __forceinline__ void cell_features(const float* h, const float* n, float* o)

@@ -270,7 +270,6 @@ struct Ctx {
     std::map<std::vector<int>, std::unique_ptr<DevBuf>> resize_tabs;   // pvf_frame_resize coefficient tables by (in_w, in_h, out_w, out_h)
     const void* feat_ring_owner = nullptr;    // plan whose zero padding ring s_feat currently holds
     uint8_t* d_orient_lut = nullptr; // 511x511 orientation bins (fhog.hip)
-    void* d_grad_lut = nullptr;          // orientation bins in 8 x 8 tiles (64^3 bytes): orientation_lut_tiled()
     uint8_t* d_wrap_lut = nullptr;       // the same, indexed by the differences mod 512 (2^18 bytes): orientation_lut_wrapped()
 
     // a copy of the frame record (the table may be re-hashed by another thread as soon as the lock is gone)

@@ -8,7 +8,36 @@ Usage contract kept (clustering.py:130-134):
 The N x N `pdist` matrix (clustering.py:100-101), the T x T block means (:104-112) and the agglomeration loop of
 pyannote.algorithms' HierarchicalAgglomerativeClustering run on the GPU (pvf_cluster_tracks)."""
 import numpy as np
-from ._core import Segment, Annotation
+try:                                    # the reference's result types where they are installed (clustering.py:38,57,76) ...
+    from pyannote.core import Segment, Annotation
+except ImportError:                     # ... and stand-ins with the methods the face path touches where they are not
+    from ._core import Segment, Annotation
+try:                                    # the base class whose hooks pyannote.algorithms' agglomeration loop calls (clustering.py:40-43,49)
+    from pyannote.algorithms.clustering.hac.model import HACModel as _HACModelBase
+except ImportError:
+    class _HACModelBase(object):
+        """[EXT pyannote.algorithms HACModel, absent here] what the reference's `_Model` uses of it: the per-cluster models, kept by
+        cluster name and read back with `model[cluster]` (clustering.py:90,107,109,117-118)"""
+
+        def __init__(self, is_symmetric=False):
+            self.is_symmetric = is_symmetric
+            self._models = {}
+
+        def __getitem__(self, cluster):
+            return self._models[cluster]
+try:
+    from sortedcollections import ValueSortedDict
+except ImportError:
+    class ValueSortedDict(dict):
+        """[EXT sortedcollections, absent here] a dict whose iteration order is by value; the two calls an agglomeration loop makes on
+        the similarity matrix are kept: peekitem(-1) (the most similar pair) and plain item access / deletion"""
+
+        def peekitem(self, index=-1):
+            items = sorted(self.items(), key=lambda kv: kv[1])
+            return items[index]
+
+        def __iter__(self):
+            return iter(k for k, _ in sorted(self.items(), key=lambda kv: kv[1]))
 from . import runtime
 from . import formats
 
@@ -26,9 +55,32 @@ class Features(object):
     def __len__(self):
         return len(self.time)
 
+    def __getitem__(self, column):
+        """`features['track']` / `features['time']` as the reference's DataFrame gives them (clustering.py:87)"""
+        if column == "track":
+            return self.track
+        if column == "time":
+            return self.time
+        raise KeyError(column)
 
-class _Model(object):
-    """Average Euclidean distance between face embeddings (reference _Model, clustering.py:49-119)"""
+
+def _columns(features):
+    """(track column, X) of what `preprocess` returned: this module's Features, or the reference's DataFrame (time, track, d0..d127)"""
+    if isinstance(features, Features):
+        return features.track, features.X
+    return np.asarray(features["track"]), np.ascontiguousarray(np.asarray(features[features.columns[2:]]), np.float64)
+
+
+class _Model(_HACModelBase):
+    """Average Euclidean distance between face embeddings (reference _Model, clustering.py:49-119): the hook methods an
+    agglomeration driver calls -- `compute_model`, `compute_merged_model`, `compute_similarity_matrix`, `compute_similarity` -- with the
+    reference's arguments and return types.  The T x T block means come from the GPU (pvf_pair_mean_dist: K10) instead of an N x N
+    `pdist` matrix on the host (clustering.py:100-101); a merged cluster's similarity is the size-weighted mean of its tracks' block
+    means, which is the mean of the union block the reference takes (clustering.py:116-119)."""
+
+    def __init__(self, ctx=None):
+        super(_Model, self).__init__(is_symmetric=True)
+        self.ctx = ctx
 
     def preprocess(self, embedding):
         """embedding: path of embedding.txt, or a (time, track, X) triple already in memory"""
@@ -50,6 +102,43 @@ class _Model(object):
             starting_point[segment, int(trk)] = int(trk)
         return starting_point, data
 
+    # ---- the hooks (clustering.py:84-119) -------------------------------------------------------------------------------------------
+    def compute_model(self, cluster, parent=None):
+        """a cluster's model = the indices of its rows in parent.features (clustering.py:84-87)"""
+        return np.where(_columns(parent.features)[0] == cluster)[0]
+
+    def compute_merged_model(self, clusters, parent=None):
+        """clustering.py:89-90 (a list, not a generator: numpy >= 2 refuses np.hstack of a generator -- SURVEY.md section 8 a9)"""
+        return np.hstack([self[cluster] for cluster in clusters])
+
+    def compute_similarity_matrix(self, parent=None):
+        """{(cluster_i, cluster_j): - mean Euclidean distance of the |i| x |j| block}, both orders (clustering.py:92-114)"""
+        clusters = list(self._models)
+        _, X = _columns(parent.features)
+        rows = [np.asarray(self[c], np.int64) for c in clusters]
+        counts = np.array([len(r) for r in rows], np.int64)
+        row_start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        order = np.concatenate(rows) if rows else np.zeros(0, np.int64)
+        ctx = self.ctx or runtime.default_context()
+        D = ctx.pair_mean_dist(np.ascontiguousarray(X[order], np.float64), row_start)
+        # what compute_similarity needs later on: the block means, which initial cluster a row belongs to, the clusters' sizes
+        self._block_mean = D
+        self._cluster_of_row = np.full(len(X), -1, np.int64)
+        self._cluster_of_row[order] = np.repeat(np.arange(len(clusters)), counts)
+        matrix = ValueSortedDict()
+        for i in range(len(clusters)):
+            for j in range(i + 1, len(clusters)):
+                similarity = -float(D[i, j])
+                matrix[clusters[i], clusters[j]] = similarity
+                matrix[clusters[j], clusters[i]] = similarity
+        return matrix
+
+    def compute_similarity(self, cluster1, cluster2, parent=None):
+        """- mean distance between the rows of two (possibly merged) clusters (clustering.py:116-119)"""
+        w1 = np.bincount(self._cluster_of_row[np.asarray(self[cluster1], np.int64)], minlength=len(self._block_mean)).astype(np.float64)
+        w2 = np.bincount(self._cluster_of_row[np.asarray(self[cluster2], np.int64)], minlength=len(self._block_mean)).astype(np.float64)
+        return -float(w1 @ self._block_mean @ w2) / (w1.sum() * w2.sum())
+
 
 class FaceClustering(object):
     """Face clustering
@@ -70,7 +159,7 @@ class FaceClustering(object):
         self.force = bool(force)
         self.metric = metric
         self.threshold = threshold
-        self.model = _Model()
+        self.model = _Model(ctx)
         self.ctx = ctx
         self.logger = logger
         self.history = None

@@ -245,6 +245,11 @@ class ExtractStream(object):
             self.compute(self._final_work)
         if getattr(self, "_early", None) is not None:
             k0, m0, perm, early, fp, fe = self._early
+            # every row of fp / fe must have a source: the rows placed early plus the batches appended since (a final batch that was
+            # skipped or failed would leave np.empty rows behind -- ADVICE r5)
+            if sum(len(e) for e in self.emb) != len(perm) or len(self.pts) != len(self.emb):
+                raise RuntimeError("extraction store: %d descriptor rows computed for %d faces planned (the final batch did not run?)"
+                                   % (sum(len(e) for e in self.emb), len(perm)))
             if len(self.pts) > k0:
                 late = ~early
                 src = perm[late] - m0
@@ -639,8 +644,20 @@ class Engine(object):
                 # video.py:402-403) already delivers detection-size frames and gets no second copy; native frames are resized here
                 tw, th = si.resize
                 if any((int(f.shape[1]), int(f.shape[0])) != (tw, th) for _, f in si.cache):
-                    si.natives = [f for _, f in si.cache]
-                    si.cache = [(t, ctx.resize(f, tw, th)) for t, f in si.cache]
+                    # built aside and put in place only when every copy exists: should a resize fail half way, the copies made so far go
+                    # back here and `natives` / `cache` still say what they said before (release_shot_frames reads them) -- ADVICE r5
+                    resized = []
+                    try:
+                        for t, f in si.cache:
+                            resized.append((t, ctx.resize(f, tw, th)))
+                    except BaseException:
+                        for _, f in resized:
+                            try:
+                                f.release()
+                            except Exception:       # noqa: BLE001 -- the first error is the one to report
+                                pass
+                        raise
+                    si.natives, si.cache = [f for _, f in si.cache], resized
                 si.resize = None
         cache, flags = si.cache, si.flags
         idx = [i for i, f in enumerate(flags) if f]

@@ -342,7 +342,13 @@ def shot_tracks_native(lane_forward, lane_backward, times, max_gap):
     """tracks of a shot from its two finished native passes: (rows int32 [m, 6] = frame, l, t, r, b, status code; track_start int32 [T + 1])"""
     import ctypes as C
     times = np.ascontiguousarray(times, np.float64)
-    cap = 2 * max(lane_forward.total, 1) + 16
+    # room known beforehand: a row is a graph node, a node is a detection or the far end of an edge of one of the two passes (with
+    # detections every N frames or long tracker bridges a shot has many times more rows than detections: sized from the detections
+    # alone the whole union-find / _fix / _fill_gaps pass ran twice -- ADVICE r5).  pvf_lane_edges with no room reports the count.
+    n_f, n_b = C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.lib().pvf_lane_edges(lane_forward.handle, C.byref(n_f), None, None, None, None, None, 0))
+    _lib.check(_lib.lib().pvf_lane_edges(lane_backward.handle, C.byref(n_b), None, None, None, None, None, 0))
+    cap = max(lane_forward.total, 1) + n_f.value + n_b.value + 16
     while True:
         rows = np.zeros((cap, 6), np.int32)
         starts = np.zeros(cap + 1, np.int32)

@@ -23,13 +23,13 @@ def _fam(**ms):
 def test_algorithmic_work_of_the_detector_kernels_at_1080p():
     fam = _fam(pyramid=(400.0, 40), fhog=(450.0, 40), score_screened=(90.0, 40))
     rl = bench.detector_rooflines(fam, 1080, 1920, 5000, 128)
-    assert [o["kernel"].split(" ")[0] for o in rl] == ["fhog_fused_ml_k", "resize_rows_k", "score_screen_k"]      # most time first
+    assert [o["kernel"].split(" ")[0] for o in rl] == ["fhog_split_ml_k", "resize_rows_k", "score_screen_k"]      # most time first
     by = {o["kernel"].split(" ")[0]: o for o in rl}
     per_launch = 5000 / 40
-    assert by["fhog_fused_ml_k"]["algorithmic_bytes_per_launch"] / per_launch == pytest.approx(132.75e6, rel=2e-3)
+    assert by["fhog_split_ml_k"]["algorithmic_bytes_per_launch"] / per_launch == pytest.approx(132.75e6, rel=2e-3)
     assert by["resize_rows_k"]["algorithmic_bytes_per_launch"] / per_launch == pytest.approx(168.9e6, rel=2e-3)      # K1
     assert by["score_screen_k"]["flop_per_launch"] / per_launch == pytest.approx(414725 * 3100 * 5 * 2.0, rel=1e-9)  # K3 / K3s
-    o = by["fhog_fused_ml_k"]
+    o = by["fhog_split_ml_k"]
     assert o["bound"] == "hbm" and o["unit"] == "GB/s" and o["peak"] == 8000.0
     assert o["achieved"] == pytest.approx(o["algorithmic_bytes_per_launch"] / (o["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-3)
     assert o["frac"] == pytest.approx(o["achieved"] / 8000.0, abs=1e-4)
@@ -46,7 +46,7 @@ def test_traffic_is_attached_only_for_the_measured_sources(monkeypatch, tmp_path
     rl = bench.detector_rooflines(fam, 1080, 1920, 5000, 128)
     current = pm["detector_sha256_16"] == bench.detector_hash()
     for o in rl:
-        key = {"fhog_fused_ml_k": "fhog", "resize_rows_k": "pyramid", "score_screen_k": "score_screened"}[o["kernel"].split(" ")[0]]
+        key = {"fhog_split_ml_k": "fhog", "resize_rows_k": "pyramid", "score_screen_k": "score_screened"}[o["kernel"].split(" ")[0]]
         if current:
             assert o["traffic"] == pm["kernels"][key]["traffic_bytes_per_launch"]
             assert "traffic_attached_from_profiles_not_measured_in_this_run" in o
@@ -72,12 +72,12 @@ def test_detector_hash_ignores_comments():
 def test_pmc_summary_to_json(tmp_path):
     fetch = tmp_path / "f.txt"; write = tmp_path / "w.txt"
     fetch.write_text("void resize_rows_k<16, 1>                 n=160   FETCH_SIZE=1000\n"
-                     "fhog_fused_ml_k                           n=8     FETCH_SIZE=5000\n"
+                     "fhog_split_ml_k                           n=8     FETCH_SIZE=5000\n"
                      "score_screen_k                            n=4     FETCH_SIZE=4000\n"
                      "score_list_k                              n=4     FETCH_SIZE=100\n"
                      "score_roll_k                              n=4     FETCH_SIZE=3900\n")
     write.write_text("void resize_rows_k<16, 1>                 n=160   WRITE_SIZE=500\n"
-                     "fhog_fused_ml_k                           n=8     WRITE_SIZE=6000\n"
+                     "fhog_split_ml_k                           n=8     WRITE_SIZE=6000\n"
                      "score_screen_k                            n=4     WRITE_SIZE=10\n")
     os.makedirs(os.path.join(ROOT, "gpurun_out", "zz_test"), exist_ok=True)
     try:

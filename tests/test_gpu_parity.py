@@ -34,6 +34,28 @@ def test_pyramid_levels_bit_exact(ctx, oracle, small_video):
         assert bad == 0, "level %d: %d differing bytes" % (l, bad)
 
 
+@pytest.mark.parametrize("mode", ["mul", "accumulate"])
+def test_pyramid_bit_exact_under_both_coordinate_generations(oracle, small_video, monkeypatch, mode):
+    """oracle/EXT_REGISTER.md E1: whether dlib's resize_image forms a source coordinate as i * scale or carries it from index to index is
+    recalled, not read.  Both the oracle (PVO_RESIZE_COORDS) and the HIP path (PVF_RESIZE_COORDS: host-built row and column tables, the
+    kernel is the same) can do either; the pyramid bytes must agree under each."""
+    from pyannote_video_amd import models
+    from pyannote_video_amd.runtime import Context
+    monkeypatch.setenv("PVO_RESIZE_COORDS", mode)
+    monkeypatch.setenv("PVF_RESIZE_COORDS", mode)
+    det = _detector(oracle)
+    c = Context(device=0, detector=models.DEFAULT_DETECTOR)          # (a context of its own: the tables belong to a context's plans)
+    try:
+        f = small_video.frame(5)
+        up = oracle.Detector.pyramid_level(det, f, 1, 0)
+        n = det.levels(up.shape[0], up.shape[1])
+        for l in range(n):
+            a, b = c.pyramid_level(f, 1, l), det.pyramid_level(f, 1, l)
+            assert a.shape == b.shape and int((a != b).sum()) == 0, "mode %s, level %d: %d differing bytes" % (mode, l, int((a != b).sum()))
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("cell,pad,shape", [(8, 10, (200, 264)), (8, 10, (97, 131)), (4, 1, (23, 23)), (1, 3, (64, 64)), (4, 1, (40, 52))])
 def test_fhog_bit_exact(ctx, oracle, small_video, cell, pad, shape):
     f = small_video.frame(1)[40:40 + shape[0], 100:100 + shape[1]]

@@ -79,3 +79,57 @@ def test_reference_model_similarities_equal_oracle_and_product_host(tmp_path, se
     n0, n1 = row_start[1] - row_start[0], row_start[2] - row_start[1]
     want = (n0 * D[0, 2] + n1 * D[1, 2]) / (n0 + n1)
     assert abs(-sim_merged - want) <= 1e-12
+
+
+class _OracleContext(object):
+    """stands where the GPU context stands on the CPU suite: the block means from the CPU oracle (checker, not product)"""
+
+    def pair_mean_dist(self, X, row_start, metric=0):
+        from oracle import oracle
+        return oracle.pair_mean_dist(X, row_start)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_product_hooks_drive_the_same_agglomeration_as_the_reference_hooks(tmp_path, seed):
+    """seam S5: the reference's `_Model` (executed verbatim) and the product's, each driven through the SAME average-linkage loop over
+    compute_model / compute_merged_model / compute_similarity_matrix / compute_similarity -- same models, same matrix (to 1e-12), same
+    merges, same labels, same return types."""
+    import hac_driver
+    from pyannote_video_amd import clustering as mine
+    from pyannote_video_amd._core import Segment, Annotation
+    path = _embedding_file(tmp_path, 100 + seed, n_tracks=18, n_ident=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with refhost.reference_clustering_module(Segment, Annotation) as ref:
+            model_r = ref._Model()
+            sp_r, data_r = model_r.preprocess(path)
+            tracks = sorted(int(t) for _, _, t in sp_r.itertracks(yield_label=True))
+            first_model = model_r.compute_model(tracks[0], parent=hac_driver._Parent(data_r))
+            labels_r, log_r = hac_driver.agglomerate(model_r, data_r, tracks, 0.6)
+            matrix_type = type(ref.ValueSortedDict()).__mro__[1]
+    model_p = mine._Model(ctx=_OracleContext())
+    sp_p, data_p = model_p.preprocess(path)
+    assert tracks == sorted(int(t) for _, _, t in sp_p.itertracks(yield_label=True))
+    got = model_p.compute_model(tracks[0], parent=hac_driver._Parent(data_p))
+    assert isinstance(got, np.ndarray) and np.array_equal(got, first_model)
+    # the product's hooks accept the reference's DataFrame as parent.features too (a site that keeps its own preprocess)
+    assert np.array_equal(mine._Model().compute_model(tracks[0], parent=hac_driver._Parent(data_r)), first_model)
+    labels_p, log_p = hac_driver.agglomerate(model_p, data_p, tracks, 0.6)
+    assert labels_p == labels_r
+    assert [(a, b) for a, b, _ in log_p] == [(a, b) for a, b, _ in log_r] and len(log_r) > 0
+    assert np.allclose([d for _, _, d in log_p], [d for _, _, d in log_r], rtol=0, atol=1e-12)
+    m = mine._Model(ctx=_OracleContext())
+    for c in tracks:
+        m._models[c] = m.compute_model(c, parent=hac_driver._Parent(data_p))
+    matrix = m.compute_similarity_matrix(parent=hac_driver._Parent(data_p))
+    assert isinstance(matrix, dict) and isinstance(matrix, mine.ValueSortedDict) and matrix_type is dict
+    assert set(matrix) == set((a, b) for a in tracks for b in tracks if a != b)
+    assert isinstance(m.compute_similarity(tracks[0], tracks[1]), float)
+    # the whole-replacement path agrees with the hook-driven one: FaceClustering.__call__ on the oracle-backed context's GPU twin is a
+    # -m gpu test (tests/test_gpu_s5_hooks.py); here the oracle's own agglomeration
+    from oracle import oracle
+    rows = [np.where(data_p.track == t)[0] for t in tracks]
+    row_start = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    D = oracle.pair_mean_dist(data_p.X[np.concatenate(rows)], row_start)
+    lab, _ = oracle.hac(D, np.diff(row_start), 0.6)
+    assert [tracks[int(l)] for l in lab] == [labels_p[t] for t in tracks]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""CPU emulation (numpy, float32, lane by lane) of the index logic of csrc/detect.hip:fhog_fused_ml_k -- strips of 64 lanes,
+"""CPU emulation (numpy, float32, lane by lane) of the index logic of csrc/detect.hip:fhog_split_ml_k (the strip / band geometry the gradient and the vote waves share) -- strips of 64 lanes,
 chunks of feature rows, bands, the right-neighbour hand-over, the two alternating accumulator sets, the three-row energy window
 -- checked against the oracle's FHOG on random images.  Development aid: it validates everything about the kernel except the
 hardware-specific pieces (DPP lane shifts, ds_add_f32), which the GPU parity tests cover.

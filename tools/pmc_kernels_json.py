@@ -2,7 +2,7 @@
 launch of the detector's kernel families, which bench.py attaches as roofline.traffic while the detector's sources still hash the same.
 usage: python tools/pmc_kernels_json.py <fetch.txt> <write.txt> <tag>
 Bytes = FETCH_SIZE x 2 (MI355X_MICROARCH.md, section HBM: on gfx950 the counter reports half the bytes of wide coalesced reads) + WRITE_SIZE
-as reported (the guide calls it uncalibrated; for fhog_fused_ml_k it comes to 0.92 of the bytes the kernel is known to write), KB -> bytes.
+as reported (the guide calls it uncalibrated; for fhog_split_ml_k it comes to 0.92 of the bytes the kernel is known to write), KB -> bytes.
 A family's "launch" is what bench.py's HIP events bracket: one kernel for fhog / score, the 20 resize launches of a batch for pyramid,
 score_screen_k + score_list_k for score_screened."""
 import json, os, re, sys
@@ -26,7 +26,7 @@ def main():
         return sum(n for name, (n, kb) in table.items() if key in name)
     # batches of the pass that ran a family: the launches of the one kernel it launches once per batch (the pass holds bench.py's
     # dense-scoring leg as well: score_roll_k and score_screen_k each see a part of the batches, the pyramid and FHOG kernels all of them)
-    fam = {"pyramid": (["resize_rows_k"], "fhog_fused_ml_k"), "fhog": (["fhog_fused_ml_k"], "fhog_fused_ml_k"), "score": (["score_roll_k"], "score_roll_k"),
+    fam = {"pyramid": (["resize_rows_k"], "fhog_split_ml_k"), "fhog": (["fhog_split_ml_k"], "fhog_split_ml_k"), "score": (["score_roll_k"], "score_roll_k"),
            "score_screened": (["score_screen_k", "score_list_k"], "score_screen_k")}
     kernels = {}
     for name, (keys, per_batch) in fam.items():
