@@ -172,6 +172,10 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=100, help="frames of the all-core CPU-oracle sample, centred on the first shot cut (0 = skip)")
     ap.add_argument("--cpu-frames-1t", type=int, default=16, help="frames of the single-thread CPU-oracle sample (same centre)")
     ap.add_argument("--no-host-ingest", action="store_true", help="skip the extra pass whose frames start in pinned host memory")
+    ap.add_argument("--preflight", action="store_true", help="--gpus N: before any frame is rendered every rank brings the communicator up, exchanges counts and "
+                    "gathers 1 MB in uneven shares with every byte checked, each step under a 30 s watchdog and reported on stderr (dist.preflight)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json configs[2], [3], [4] the default line carries as `other_configs`")
+    ap.add_argument("--other-configs-budget", type=float, default=240.0, help="seconds the `other_configs` runs may take together (each is a process of its own)")
     ap.add_argument("--no-overlap", action="store_true", help="no GPU-feeding thread: every stage runs in the caller's thread, shot after shot")
     ap.add_argument("--small-models", action="store_true", help="debug only: reduced landmark model")
     ap.add_argument("--parity-seed", type=int, default=None, help="seed of the extra 8-frame parity window placed at random in the clip (default: from the clock; printed in the line)")
@@ -225,6 +229,10 @@ def main():
 
     from pyannote_video_amd import synth, models, pipeline, dist as pdist
     from pyannote_video_amd.runtime import Context
+    if args.preflight or world > 1:
+        # the first thing a multi-GPU run does (N > 1 has never run on hardware the builder could see): if the exchange step cannot work
+        # the job says so here, per rank, within seconds -- not after the frames were rendered and a step ran into a silent collective
+        pdist.preflight()
 
     model_dir = os.path.join(tempfile.gettempdir(), "pvface_models_rank%d" % rank)
     lp, ep = models.ensure_synthetic_models(model_dir, small=args.small_models)
@@ -434,6 +442,11 @@ def main():
     if world == 1 and not args.no_dropin and args.config == "c2" and args.detect_every == 0.0:
         dropin = dropin_cli_pass(ctx, frames, video, lp, ep, fps, res, labels)
 
+    other = None
+    if (world == 1 and args.config == "c2" and not args.no_other_configs and not args.dense_scoring and not args.small_models and args.detect_every == 0.0
+            and args.frames == 1000 and args.cpu_frames > 0):
+        other = other_configs_pass(args)
+
     n_clusters = len(set(labels.values()))
     label = "1080p@25fps" if args.config == "c2" else "%dx%d@%gfps (BASELINE.json configs[4])" % (args.width, args.height, args.fps)
     out = {
@@ -460,6 +473,7 @@ def main():
         "parity": parity,
         "host_ingest": host,
         "dropin_cli": dropin,
+        "other_configs": other,
         "hbm": hbm.report(frames_bytes=int(frames_t.numel()), engine=timed_engine),
         "stage_seconds_last_step": {k: round(v, 3) for k, v in tm.items()},
         "per_rank": per_rank,
@@ -484,7 +498,46 @@ def main():
         out["roofline"]["screening_listed_pairs_per_frame"] = out.get("listed_per_frame")
     # last key of the line (the driver keeps the line's tail verbatim): the whole-clip verdict in one short string
     out["full_clip_parity"] = full_clip_summary(full_clip)
+    if other is not None:
+        out["full_clip_parity"] += " || other configs: " + "; ".join("%s %s frames/s, %s" % (k, v.get("frames_per_s"), v.get("verdict")) for k, v in other.items() if isinstance(v, dict))
     print(json.dumps(out))
+
+
+def other_configs_pass(args):
+    """BASELINE.json configs[2], [3], [4] at a size that fits a default run, each as a process of its own (`python bench.py --config ...`,
+    this file), each ending with the whole-clip comparison against its committed CPU-oracle fixture (tests/golden/c3_clip0.npz,
+    c4_clip0.npz, c5_shot0.npz):
+      c5_shot0   the 4K 50 fps 40-face clip (500 frames, two steps); the fixture covers its first shot (250 frames) -- configs[4]
+      c4_8clips  8 of the 64 independent 720p clips through one engine run                -- configs[3]
+      c3_clip0   the long video's first 1000-frame clip, STREAMED (frames copied into fresh library buffers as a decoder would) -- configs[2]
+    Not `value`; outside the timed region; the GPU is otherwise idle while they run (this process only waits)."""
+    import subprocess
+    runs = [("c5_shot0", ["--config", "c5", "--steps", "2", "--warmup", "1"]),
+            ("c4_8clips", ["--config", "c4", "--clips", "8", "--steps", "2", "--warmup", "1"]),
+            ("c3_clip0", ["--config", "c3", "--frames", "1000", "--distinct-clips", "1", "--steps", "1", "--warmup", "1", "--cluster-check-frames", "0"])]
+    common = ["--gpus", "1", "--cpu-frames", "0", "--no-host-ingest", "--no-dropin", "--no-dense-leg", "--no-other-configs"]
+    out = {}
+    t_all = time.perf_counter()
+    for name, extra in runs:
+        left = args.other_configs_budget - (time.perf_counter() - t_all)
+        if left < 20.0:
+            out[name] = {"frames_per_s": None, "verdict": "skipped: the budget of %g s was used up" % args.other_configs_budget}
+            continue
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
+            line = [l for l in p.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                out[name] = {"frames_per_s": None, "verdict": "failed (rc %d): %s" % (p.returncode, p.stderr.decode("utf-8", "replace")[-300:])}
+                continue
+            d = json.loads(line[-1])
+            fc = ((d.get("parity") or {}).get("full_clip") or {})
+            out[name] = {"frames_per_s": d.get("value"), "ms_per_step": d.get("ms_per_step"), "steps": d.get("steps"), "workload": (d.get("config") or {}).get("workload"),
+                         "fixture": fc.get("fixture"), "exact": fc.get("all_exact"), "verdict": d.get("full_clip_parity"),
+                         "results": d.get("results"), "wall_s": round(time.perf_counter() - t0, 1)}
+        except subprocess.TimeoutExpired:
+            out[name] = {"frames_per_s": None, "verdict": "timed out after %.0f s" % left}
+    return out
 
 
 def full_clip_parity(ctx, frames, res, labels, args, d_res=None, d_labels=None, name="c2_full", seed=20260925, identities=12, n_frames=None):

@@ -33,6 +33,13 @@ int32_t pvfd_allgather_counts(pvfd_handle comm, int64_t n, int64_t* counts /* [w
  * must have finished; consumers of d_recv may start afterwards).  What travels in a run: 528 bytes per face (float32[128], float64
  * time, int32 track id) -- 95 MB per rank at configs[2]'s 180 000 faces -- and each rank's rows of the T x T track-pair matrix. */
 int32_t pvfd_allgatherv_dev(pvfd_handle comm, const void* d_send, const int64_t* nbytes /* [world] */, void* d_recv);
+/* Every collective above is WATCHED: its stream is polled, the communicator's asynchronous error state beside it, and after
+ * PVF_DIST_TIMEOUT_S seconds (default 120) the communicator is aborted, the stream drained, and the call fails with a message that names
+ * this rank, the world size, what was being exchanged (the counts / the bytes per rank) and that the communicator was aborted; later calls
+ * on the handle fail at once ("aborted by an earlier failure"), pvfd_comm_destroy still releases it.
+ * pvfd_debug_stall: the watchdog's own test entry (tests/test_gpu_sharded.py) -- a kernel that spins for `milliseconds` is put on the
+ * communicator's stream and waited for exactly as a collective is: a peer that never joins looks like this from the waiting rank's side. */
+int32_t pvfd_debug_stall(pvfd_handle comm, int32_t milliseconds);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,12 @@ void gather_counts(Comm* c, int64_t n_rows, int64_t* counts)
     wait_collective(c, "pvfd_allgather_counts", "all-gather of one int64 per rank: mine = " + std::to_string(n_rows));
     memcpy(counts, c->h_counts, sizeof(int64_t) * c->world);
 }
+// spins for about `ms` milliseconds (s_memtime counts at 100 MHz): stands for a collective whose peer never arrives (pvfd_debug_stall)
+__global__ void stall_k(long long ticks)
+{
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
 } // namespace
 
 #define API_BEGIN try {
@@ -189,5 +195,18 @@ extern "C" int32_t pvfd_allgatherv_dev(pvfd_handle h, const void* d_send, const 
     std::string detail = "grouped broadcasts, bytes per rank =";
     for (int r = 0; r < c->world; ++r) detail += " " + std::to_string((long long)nbytes[r]);
     wait_collective(c, "pvfd_allgatherv_dev", detail);
+    API_END
+}
+
+extern "C" int32_t pvfd_debug_stall(pvfd_handle h, int32_t milliseconds)
+{
+    API_BEGIN
+    Comm* c = get(h);
+    HIPC(hipSetDevice(c->device));
+    if (!c->comm) throw Err("pvfd_debug_stall: the communicator was aborted by an earlier failure");
+    if (milliseconds < 0 || milliseconds > 60000) throw Err("pvfd_debug_stall: 0 .. 60000 ms");
+    hipLaunchKernelGGL(stall_k, dim3(1), dim3(64), 0, c->stream, (long long)milliseconds * 100000LL);
+    HIPC(hipGetLastError());
+    wait_collective(c, "pvfd_debug_stall", "a kernel that spins for " + std::to_string(milliseconds) + " ms in place of a collective");
     API_END
 }

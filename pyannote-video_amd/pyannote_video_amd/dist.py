@@ -27,6 +27,7 @@ _DIST_SIGS = {
     "pvfd_comm_destroy": (C.c_int32, [C.c_uint64]),
     "pvfd_allgather_counts": (C.c_int32, [C.c_uint64, C.c_int64, C.c_void_p]),
     "pvfd_allgatherv_dev": (C.c_int32, [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pvfd_debug_stall": (C.c_int32, [C.c_uint64, C.c_int32]),
 }
 DIST_EXPORTS = sorted(_DIST_SIGS)
 _dist_lib = None
@@ -88,6 +89,10 @@ class RcclRows(object):
         torch.cuda.synchronize(t.device)                  # whoever produced t (another library's stream, torch's) is done
         self._check(self.l.pvfd_allgatherv_dev(self.h, C.c_void_p(t.data_ptr() if n else 0), nbytes.ctypes.data_as(C.c_void_p), C.c_void_p(out.data_ptr())))
         return out[:sum(counts)], counts
+
+    def stall(self, milliseconds):
+        """the watchdog's test entry: a spinning kernel in place of a collective (include/pvface_dist.h: pvfd_debug_stall)"""
+        self._check(self.l.pvfd_debug_stall(self.h, int(milliseconds)))
 
     def close(self):
         if getattr(self, "h", None):
@@ -178,6 +183,66 @@ def exchange():
                            "PVF_DIST_COLLECTIVE=torch selects the torch.distributed collectives explicitly" % (err if err is not None else "another rank failed"))
     _exchange["comm"] = comm
     return comm
+
+
+def preflight(log=None, payload_bytes=1 << 20):
+    """Make the first multi-GPU run diagnose itself BEFORE any video is rendered: the communicator, one exchange of counts, and one
+    all-gather of about `payload_bytes` in UNEVEN shares (rank r sends r + 1 parts of world (world + 1) / 2) whose every byte is checked
+    on arrival -- each step under the collectives' watchdog (PVF_DIST_TIMEOUT_S, 30 s here unless set), each reported per rank through
+    `log` (a callable taking one string; default: stderr).  Returns the report as a dict; raises on the first failure, naming the step."""
+    import sys
+    import time
+    import torch
+    import torch.distributed as dist
+    if log is None:
+        def log(msg):
+            sys.stderr.write(msg + "\n"); sys.stderr.flush()
+    had = os.environ.get("PVF_DIST_TIMEOUT_S")
+    if had is None:
+        os.environ["PVF_DIST_TIMEOUT_S"] = "30"
+    rep = {"world": 1, "rank": 0, "collective": "none"}
+    try:
+        t0 = time.perf_counter()
+        ex = exchange()
+        if ex is None:
+            log("preflight: a single process, no exchange step")
+            return rep
+        rank, world = ex.rank, ex.world
+        rep.update(world=world, rank=rank, collective=ex.name, communicator_s=round(time.perf_counter() - t0, 3))
+        log("preflight rank %d/%d: communicator up (%s) in %.3f s" % (rank, world, ex.name, rep["communicator_s"]))
+        t0 = time.perf_counter()
+        counts = ex.counts(rank + 1)
+        if counts != list(range(1, world + 1)):
+            raise RuntimeError("preflight rank %d: the count exchange returned %r, expected %r" % (rank, counts, list(range(1, world + 1))))
+        rep["counts_s"] = round(time.perf_counter() - t0, 4)
+        log("preflight rank %d/%d: counts exchanged in %.4f s" % (rank, world, rep["counts_s"]))
+        part = max(16, int(payload_bytes) // (world * (world + 1) // 2) // 16 * 16)
+        on_gpu = dist.get_backend() == "nccl"
+        dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+        mine = (torch.arange((rank + 1) * part // 16 * 16, dtype=torch.int64, device=dev) * 37 + rank * 101) % 251
+        t0 = time.perf_counter()
+        got, rows = ex.allgather(mine.to(torch.uint8).reshape(-1, 16))
+        if on_gpu:
+            torch.cuda.synchronize()
+        rep["allgatherv_s"] = round(time.perf_counter() - t0, 4)
+        want_rows = [(r + 1) * part // 16 for r in range(world)]
+        if rows != want_rows:
+            raise RuntimeError("preflight rank %d: share sizes %r arrived, expected %r" % (rank, rows, want_rows))
+        got = got.reshape(-1).to(torch.int64)
+        off = 0
+        for r in range(world):
+            n = want_rows[r] * 16
+            want = (torch.arange(n, dtype=torch.int64, device=got.device) * 37 + r * 101) % 251
+            if not bool(torch.equal(got[off:off + n], want)):
+                bad = int((got[off:off + n] != want).nonzero()[0])
+                raise RuntimeError("preflight rank %d: rank %d's share (%d bytes at offset %d) arrived damaged, first at byte %d" % (rank, r, n, off, bad))
+            off += n
+        rep["allgatherv_bytes"] = int(off)
+        log("preflight rank %d/%d: %d bytes in uneven shares %r gathered and verified in %.4f s" % (rank, world, off, [w * 16 for w in want_rows], rep["allgatherv_s"]))
+        return rep
+    finally:
+        if had is None:
+            os.environ.pop("PVF_DIST_TIMEOUT_S", None)
 
 
 def collective_name():

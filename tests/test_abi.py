@@ -25,7 +25,7 @@ def test_dist_library_exports_every_declared_symbol():
     from pyannote_video_amd import dist
     hdr = open(os.path.join(ROOT, "include", "pvface_dist.h")).read()
     declared = sorted(set(re.findall(r"\b(pvfd_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(declared) == 6
+    assert len(declared) == 7
     l = dist.dist_lib()
     for name in declared:
         assert hasattr(l, name), name

@@ -252,3 +252,33 @@ def test_gather_rows_and_distance_shares_world8_uneven_and_empty(tmp_path):
     assert ranges[0][0] == 0 and ranges[-1][1] == len(row_start) - 1 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
     bounds = pd.DistanceShard(0, 8).bounds(np.array(row_start))
     assert [list(x) for x in zip(bounds, bounds[1:])] == ranges
+
+
+PREFLIGHT_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "pyannote-video_amd"))
+import torch.distributed as dist
+from pyannote_video_amd import dist as pd
+dist.init_process_group("gloo")
+lines = []
+rep = pd.preflight(log=lines.append, payload_bytes=1 << 16)
+open(sys.argv[2] + ".%d" % dist.get_rank(), "w").write(json.dumps({"rep": rep, "lines": lines}))
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_preflight_world2(tmp_path):
+    """dist.preflight (what `bench.py --gpus N` runs before it renders a frame): communicator, counts, an all-gather in uneven shares with
+    every byte verified, each step reported per rank -- here over gloo at world 2 (PVF_DIST_COLLECTIVE=torch)"""
+    import json
+    script = tmp_path / "preflight.py"
+    script.write_text(PREFLIGHT_WORKER)
+    out = str(tmp_path / "out")
+    _run2(script, [ROOT, out], 29641, PVF_DIST_COLLECTIVE="torch")
+    for r in (0, 1):
+        d = json.loads(open(out + ".%d" % r).read())
+        rep = d["rep"]
+        assert rep["world"] == 2 and rep["rank"] == r and rep["collective"] == "torch"
+        part = (1 << 16) // 3 // 16 * 16
+        assert rep["allgatherv_bytes"] == part + 2 * part
+        assert len(d["lines"]) == 3 and all(("rank %d/2" % r) in l for l in d["lines"]) and "verified" in d["lines"][-1]

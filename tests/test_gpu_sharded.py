@@ -205,3 +205,47 @@ def test_cluster_stress_reduced_config5(ctx, oracle):
     lo, _ = oracle.hac(Ds, [R] * sub, 0.6)
     lg, _ = ctx.cluster_tracks(X[:sub * R], rs[:sub + 1], 0.6)
     assert np.array_equal(lo, lg)
+
+
+STALL_WORKER = r'''
+import os, sys, time
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "pyannote-video_amd"))
+import torch
+from pyannote_video_amd import dist
+comm = dist.RcclRows(0, 0, 1, dist.RcclRows.unique_id())
+os.environ["PVF_DIST_TIMEOUT_S"] = "5"
+comm.stall(200)                                  # a collective that takes 0.2 s: well inside the limit
+assert comm.counts(7) == [7]
+os.environ["PVF_DIST_TIMEOUT_S"] = "1"
+t0 = time.time()
+try:
+    comm.stall(4000)                             # "a peer that never joins": 4 s against a limit of 1 s
+    print("NO-ERROR")
+except RuntimeError as e:
+    msg = str(e)
+    print("ERR:", msg)
+    took = time.time() - t0
+    ok = ("rank 0 of 1" in msg and "gave up after" in msg and "PVF_DIST_TIMEOUT_S" in msg and "spins for 4000 ms" in msg and "aborted" in msg)
+    assert ok, msg
+    assert 0.9 < took < 16.0, took                # gave up at the limit, then drained the stream (the spin ends by itself after 4 s)
+    try:
+        comm.counts(1)
+        print("NO-SECOND-ERROR")
+    except RuntimeError as e2:
+        assert "aborted by an earlier failure" in str(e2), str(e2)
+        comm.close()
+        print("WATCHDOG-OK")
+'''
+
+
+def test_watchdog_gives_up_on_a_collective_that_never_completes(tmp_path):
+    """csrc/dist.hip wait_collective: a spinning kernel stands where a collective whose peer never joins would stand (pvfd_debug_stall).
+    Inside the limit the call returns; beyond it the rank gives up after PVF_DIST_TIMEOUT_S, aborts the communicator, drains the stream
+    and fails with a message naming the rank, the world size and what it was waiting for; the handle then refuses further collectives
+    and can still be destroyed."""
+    script = tmp_path / "stall_worker.py"
+    script.write_text(STALL_WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, timeout=300, capture_output=True, text=True)
+    assert p.returncode == 0 and "WATCHDOG-OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
