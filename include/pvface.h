@@ -288,6 +288,8 @@ int32_t pvf_prof_get(pvf_handle ctx, const char* family, double* total_ms, int64
 /* ---- stage access used by the parity tests ------------------------------------------------------------ */
 int32_t pvf_debug_pyramid_level(pvf_handle ctx, pvf_handle frame, int32_t upsample, int32_t level,
                                 uint8_t* out, int32_t* h, int32_t* w);               /* out may be NULL: dims only */
+/* the image pyramids of a batch of frames and nothing else (the detector's resize chain alone, for measurements); returns when they are built */
+int32_t pvf_debug_pyramid_batch(pvf_handle ctx, const pvf_handle* frames, int32_t n, int32_t upsample);
 /* features of one pyramid level exactly as the batched detector computes them (all levels per launch); out [fh][fw][32] or NULL */
 int32_t pvf_debug_level_features(pvf_handle ctx, pvf_handle frame, int32_t upsample, int32_t level,
                                  float* out, int32_t* fh, int32_t* fw);

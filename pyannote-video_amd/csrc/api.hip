@@ -195,6 +195,17 @@ extern "C" int32_t pvf_debug_pyramid_level(pvf_handle h, pvf_handle frame, int32
     API_END
 }
 
+extern "C" int32_t pvf_debug_pyramid_batch(pvf_handle h, const pvf_handle* frames, int32_t n, int32_t upsample)
+{
+    API_BEGIN
+    ENTER_DET(c, h);
+    PVF_REQUIRE(frames && n > 0, "pvf_debug_pyramid_batch: bad arguments");
+    std::vector<Frame> fr;
+    for (int i = 0; i < n; ++i) fr.push_back(c->frame(frames[i]));
+    det_pyramid_batch(c, fr, upsample);
+    API_END
+}
+
 extern "C" int32_t pvf_debug_level_features(pvf_handle h, pvf_handle frame, int32_t upsample, int32_t level, float* out, int32_t* fh, int32_t* fw)
 {
     API_BEGIN

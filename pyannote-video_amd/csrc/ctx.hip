@@ -314,8 +314,9 @@ extern "C" int32_t pvf_ctx_create_prio(int32_t device, int32_t priority_class, p
         // the detector's stream at the lowest priority, the latency-bound side above it (class < 0: both at the lowest)
         int prio = priority_class < 0 ? lo : hi;
         if (const char* e = getenv("PVF_MAIN_STREAM_PRIO")) prio = (strcmp(e, "low") == 0) ? lo : hi;     // (measurement switch)
-        HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio));
-        HIP_CHECK(hipStreamCreateWithPriority(&c->det_stream, hipStreamNonBlocking, lo));
+        // (class 2, measurements only: the other way round -- the detector's stream above the main one; tools/probes/coissue_probe.py)
+        HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, priority_class == 2 ? lo : prio));
+        HIP_CHECK(hipStreamCreateWithPriority(&c->det_stream, hipStreamNonBlocking, priority_class == 2 ? hi : lo));
     }
     if (const char* e = getenv("PVF_DETECTOR_SCREENING")) c->det_screen = atoi(e) != 0;     // (what pvf_detector_screening sets: 0 = dense scoring only)
     std::lock_guard<std::mutex> lk(g_ctx_mu);

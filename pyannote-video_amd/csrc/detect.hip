@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) resize_rows_k(const uint8_t* const* __res
                                                      size_t out_stride, int out_rb, int oh, int ow,
                                                      const RowTab* __restrict__ rows, const ColTab* __restrict__ cols)
 {
-    constexpr int MAXS = RESIZE_MAXS;
+    constexpr int MAXS = (RS == 16) ? RESIZE_MAXS : (RS * 5) / 4 + 3;     // source rows of a strip at the pyramid's largest step (6/5 down)
     __shared__ uint32_t s_rows[4][MAXS][64];                     // a wave's source rows: 256-byte windows, dword per lane
     __shared__ uint32_t s_out[4][64];                            // a wave's output row: 64 pixels x 3 bytes = 48 dwords
     const int lane = threadIdx.x & 63;
@@ -237,11 +237,19 @@ static void launch_resize_rows(Ctx* c, const uint8_t* const* in_ptrs, const uint
     const double x_scale = (iw - 1) / (double)std::max(ow - 1, 1);
     const double y_scale = (ih - 1) / (double)std::max(oh - 1, 1);
     constexpr int RS = 16;
-    PVF_REQUIRE(x_scale <= 1.25 && (RS - 1) * y_scale + 3 <= RESIZE_MAXS, "resize_rows: scale outside the pyramid's range (2x up, 6/5 down)");
+    PVF_REQUIRE(x_scale <= 1.25 && y_scale <= 1.25 && (RS - 1) * y_scale + 3 <= RESIZE_MAXS, "resize_rows: scale outside the pyramid's range (2x up, 6/5 down)");
     PVF_REQUIRE(out_rb % 4 == 0 && out_stride % 4 == 0 && ((uintptr_t)out & 3) == 0 && out_rb >= (ow * 3 + 3) / 4 * 4, "resize: output rows must be 4-byte aligned");
     // two strips per wave, the second one's source rows in flight behind the first one's arithmetic: 6.20 -> 6.02 ms per 125 frames of 1080p
     // (4 strips 6.14, 8 strips 6.40: the grid of the small levels gets too coarse).  profiles/r05_resize_bounds_experiment.txt
     constexpr int NSTRIP = 2;
+    static const int thin = getenv("PVF_RESIZE_THIN") ? atoi(getenv("PVF_RESIZE_THIN")) : 0;
+    if (thin) {
+        // strips of 8 output rows: 13 source rows of LDS per wave instead of 22 (13.3 KB per block instead of 23.5) -- room for a block of
+        // the embedder beside six of these on a CU (profiles/r06_coissue_experiment.txt)
+        dim3 grid8((ow + 255) / 256, (oh + 8 * NSTRIP - 1) / (8 * NSTRIP), batch);
+        hipLaunchKernelGGL((resize_rows_k<8, NSTRIP>), grid8, dim3(256), 0, c->det_stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, d_rows, d_cols);
+        return;
+    }
     dim3 grid((ow + 255) / 256, (oh + RS * NSTRIP - 1) / (RS * NSTRIP), batch);
     hipLaunchKernelGGL((resize_rows_k<RS, NSTRIP>), grid, dim3(256), 0, c->det_stream, in_ptrs, in_base, in_stride, in_rb, ih, iw, out, out_stride, out_rb, oh, ow, d_rows, d_cols);
 }
@@ -1151,6 +1159,15 @@ void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vec
         HIP_CHECK(hipMemcpy2DAsync(out->data(), (size_t)(*ow) * 3, c->s_pyr.as<uint8_t>() + p->lv[level].img_off, (size_t)p->lv[level].rb,
                                    (size_t)(*ow) * 3, (size_t)(*oh), hipMemcpyDeviceToHost, c->det_stream));
     }
+    HIP_CHECK(hipStreamSynchronize(c->det_stream));
+}
+
+// the resize chain of a whole batch and nothing else (measurement: tools/probes/coissue_probe.py runs it beside the embedder)
+void det_pyramid_batch(Ctx* c, const std::vector<Frame>& frames, int upsample)
+{
+    PVF_REQUIRE(c->det.loaded, "detector not loaded");
+    PVF_REQUIRE(!frames.empty(), "pyramid batch: no frames");
+    (void)ml_build_pyramid(c, frames, upsample);
     HIP_CHECK(hipStreamSynchronize(c->det_stream));
 }
 

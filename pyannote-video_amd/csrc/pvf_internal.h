@@ -358,6 +358,7 @@ void ingest_free_all(Ctx* c);
 void det_nms(const DetectorModel& m, const std::vector<RawDet>& sorted, std::vector<RawDet>& out);
 void det_pyramid_level(Ctx* c, const Frame& f, int upsample, int level, std::vector<uint8_t>* out, int* h, int* w);
 void det_level_features(Ctx* c, const Frame& f, int upsample, int level, std::vector<float>* out, int* fh, int* fw);
+void det_pyramid_batch(Ctx* c, const std::vector<Frame>& frames, int upsample);
 void fhog_debug(Ctx* c, const uint8_t* himg, int h, int w, int cell, int pad_r, int pad_c, std::vector<float>& out, int* fh, int* fw);
 // generic device fhog (cell 4 / 8; stage access): img u8 [n][h][w][3] -> feat [n][fh][fw][32]
 void fhog_device(Ctx* c, const uint8_t* d_img, int n, int h, int w, int cell, int pad_r, int pad_c, float* d_feat,

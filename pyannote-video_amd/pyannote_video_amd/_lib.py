@@ -97,6 +97,7 @@ _SIGS = {
     "pvf_prof_reset": (C.c_int32, [H]),
     "pvf_prof_get": (C.c_int32, [H, C.c_char_p, P, P]),
     "pvf_debug_pyramid_level": (C.c_int32, [H, H, C.c_int32, C.c_int32, P, P, P]),
+    "pvf_debug_pyramid_batch": (C.c_int32, [H, P, C.c_int32, C.c_int32]),
     "pvf_debug_level_features": (C.c_int32, [H, H, C.c_int32, C.c_int32, P, P, P]),
     "pvf_debug_fhog": (C.c_int32, [H, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
     "pvf_debug_detect_raw": (C.c_int32, [H, H, C.c_int32, C.c_double, P, P, C.c_int32, P]),

@@ -368,6 +368,12 @@ class Context(object):
         off = np.concatenate([[0], np.cumsum(counts)])
         return [rows[off[i]:off[i + 1]] for i in range(n)]
 
+    def pyramid_batch(self, frames, upsample=1):
+        """the image pyramids of a batch and nothing else (measurement: the detector's resize chain alone)"""
+        with self._staging():
+            hs = self._handles(frames)
+            check(self._l.pvf_debug_pyramid_batch(self._h, ptr(hs), len(frames), int(upsample)))
+
     def pyramid_level(self, frame, upsample, level):
         f = self.stage(frame)
         oh, ow = C.c_int32(0), C.c_int32(0)
