@@ -626,12 +626,55 @@ fhog_split_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t
             n[6] = __uint_as_float(from_prev_lane(__float_as_uint(e0))); n[8] = __uint_as_float(from_next_lane(__float_as_uint(e0)));
             const int x = FUSED_OUT * sx + lane - 1, yh = c - 3;
             if (lane >= 1 && lane <= FUSED_OUT && x < d.hog_nc) {
-                float o[32];
-                cell_features(hprev, n, o);
-                // plane group k of the strip's 61 cells is one run of memory (detect_ml.h: feat_at): every store writes whole lines
+                // fhog_dev.h: cell_features, statement for statement, but every plane group leaves as soon as its four values exist and the
+                // scheduler may not pull later groups' arithmetic in front of it (sched_barrier): with all 32 outputs alive at once the
+                // kernel does not fit its 128 registers, the allocator spills around the stores, and a reload (scratch_load -> vmcnt(0))
+                // waits for every store issued before it.  Plane group k of the strip's 61 cells is one run of memory (detect_ml.h:
+                // feat_at): every store writes whole lines.
                 float4* dst = reinterpret_cast<float4*>(feat_base + d.feat_off + (size_t)b * d.feat_stride + feat_at(yh + oy, 0, x + ox, d.fwp));
+                const size_t step = (size_t)d.fwp;
+                const float eps = 0.0001f;
+                const float z1[4] = {n[4], n[1], n[3], n[0]}, z2[4] = {n[5], n[2], n[4], n[1]}, z3[4] = {n[7], n[4], n[6], n[3]}, z4[4] = {n[8], n[5], n[7], n[4]};
+                float nn[4], nv[4], t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 8; ++k) dst[(size_t)k * d.fwp] = make_float4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+                for (int k = 0; k < 4; ++k) {
+                    nn[k] = 0.2f * sqrtf((((z1[k] + z2[k]) + z3[k]) + z4[k]) + eps);
+                    nv[k] = 0.1f / nn[k];
+                }
+                float o[20];                                          // the contrast-sensitive planes 0 .. 17, then 18, 19 of the next part
+#pragma unroll
+                for (int g = 0; g < 18; g += 3) {
+                    float hh[3][4];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) hh[j][k] = fminf(hprev[g + j], nn[k]) * nv[k];
+                        o[g + j] = (hh[j][0] + hh[j][1]) + (hh[j][2] + hh[j][3]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[k] = t[k] + ((hh[0][k] + hh[1][k]) + hh[2][k]);
+                    // planes 0..3 are complete after g = 3, 4..7 after g = 6, 8..11 after g = 9, 12..15 after g = 15
+                    if (g == 3) { *dst = make_float4(o[0], o[1], o[2], o[3]); dst += step; __builtin_amdgcn_sched_barrier(0); }
+                    if (g == 6) { *dst = make_float4(o[4], o[5], o[6], o[7]); dst += step; __builtin_amdgcn_sched_barrier(0); }
+                    if (g == 9) { *dst = make_float4(o[8], o[9], o[10], o[11]); dst += step; __builtin_amdgcn_sched_barrier(0); }
+                    if (g == 15) { *dst = make_float4(o[12], o[13], o[14], o[15]); dst += step; __builtin_amdgcn_sched_barrier(0); }
+                }
+                float ci[9];                                          // the contrast-insensitive planes 18 .. 26
+#pragma unroll
+                for (int g = 0; g < 9; ++g) {
+                    const float s2 = hprev[g] + hprev[g + 9];
+                    float hh[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hh[k] = fminf(s2, nn[k]) * nv[k];
+                    ci[g] = (hh[0] + hh[1]) + (hh[2] + hh[3]);
+                    if (g == 1) { *dst = make_float4(o[16], o[17], ci[0], ci[1]); dst += step; __builtin_amdgcn_sched_barrier(0); }
+                    if (g == 5) { *dst = make_float4(ci[2], ci[3], ci[4], ci[5]); dst += step; __builtin_amdgcn_sched_barrier(0); }
+                }
+                const float tscale = (float)(2 * 0.2357);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = t[k] * tscale;
+                *dst = make_float4(ci[6], ci[7], ci[8], t[0]); dst += step;
+                *dst = make_float4(t[1], t[2], t[3], 0.0f);
             }
         }
         // the finished cell row becomes the centre of the next feature row: its bins move to registers, the LDS words are cleared
