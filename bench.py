@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "pyannote-video_amd"))
 FP32_PEAK_TFLOPS = 157.3   # dense fp32 (vector == f32 MFMA) peak, MI355X_MICROARCH.md chip table
 F16_PEAK_TFLOPS = 2500.0    # dense f16 / bf16 MFMA peak, same table (the 5 PF headline figure includes 2:1 sparsity)
 HBM_PEAK_GBS = 8000.0       # HBM3E, same table
-PMC_KERNELS_FILE = "r05_pmc_kernels.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the detector kernels, keyed on the hash of csrc/detect.hip + screen.hip
+PMC_KERNELS_FILE = "r06_pmc_kernels.json"  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the detector kernels, keyed on the hash of csrc/detect.hip + screen.hip
 DTYPE_NOTE_DENSE = "f32 (detector, embedder) / f64 (tracker, clustering) / u8 frames"
 DTYPE_NOTE = ("f32 (detector scores, embedder) / f64 (tracker, clustering) / u8 frames; an f16 screening pass with a proven error bound decides which windows the "
               "detector's exact f32 chain is evaluated for -- results identical to dense f32 scoring (`dense_scoring`)")

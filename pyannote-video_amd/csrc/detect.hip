@@ -517,6 +517,7 @@ fhog_split_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t
         unsigned xmask = 0;                                        // gradients exist for 1 <= x < visible_nc (oracle/pvo_fhog.c)
 #pragma unroll
         for (int p = 0; p < 8; ++p) if (x_first + p >= 1 && x_first + p < d.visible_nc) xmask |= 1u << p;
+        const bool strip_inside = __builtin_amdgcn_ballot_w64(xmask != 0xffu) == 0;      // wave-uniform
         // byte offsets of the two 16-byte halves of the lane's 32-byte window in an image row (8-aligned): bytes [3 x_first - 4, 3 x_first + 28),
         // pixel p, channel k at byte 4 + 3 p + k.  Columns left of the image give negative offsets, which are huge as unsigned: out of range
         // for the row's buffer descriptor => zeros (such pixels are never valid); a row outside the image gets an empty descriptor.
@@ -548,14 +549,22 @@ fhog_split_ml_k(MlStarts st, const LvDesc* __restrict__ lv, int B, const uint8_t
                 const int freed = (int)__hip_atomic_load(flags + 128 + 64 * (i & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const bool ok = (y >= 1 && y < d.visible_nr);
                 u32x2 mb[8];
-                mb[0] = split_grad_px<0>(up, ce, dn, lut_rs, ok && (xmask & 1u));
-                mb[1] = split_grad_px<1>(up, ce, dn, lut_rs, ok && (xmask & 2u));
-                mb[2] = split_grad_px<2>(up, ce, dn, lut_rs, ok && (xmask & 4u));
-                mb[3] = split_grad_px<3>(up, ce, dn, lut_rs, ok && (xmask & 8u));
-                mb[4] = split_grad_px<4>(up, ce, dn, lut_rs, ok && (xmask & 16u));
-                mb[5] = split_grad_px<5>(up, ce, dn, lut_rs, ok && (xmask & 32u));
-                mb[6] = split_grad_px<6>(up, ce, dn, lut_rs, ok && (xmask & 64u));
-                mb[7] = split_grad_px<7>(up, ce, dn, lut_rs, ok && (xmask & 128u));
+                if (strip_inside && ok) {
+                    // every pixel of the row has a gradient (a strip that touches neither side of the image, a row inside it: most of them): no select per pixel
+                    mb[0] = split_grad_px<0>(up, ce, dn, lut_rs, true); mb[1] = split_grad_px<1>(up, ce, dn, lut_rs, true);
+                    mb[2] = split_grad_px<2>(up, ce, dn, lut_rs, true); mb[3] = split_grad_px<3>(up, ce, dn, lut_rs, true);
+                    mb[4] = split_grad_px<4>(up, ce, dn, lut_rs, true); mb[5] = split_grad_px<5>(up, ce, dn, lut_rs, true);
+                    mb[6] = split_grad_px<6>(up, ce, dn, lut_rs, true); mb[7] = split_grad_px<7>(up, ce, dn, lut_rs, true);
+                } else {
+                    mb[0] = split_grad_px<0>(up, ce, dn, lut_rs, ok && (xmask & 1u));
+                    mb[1] = split_grad_px<1>(up, ce, dn, lut_rs, ok && (xmask & 2u));
+                    mb[2] = split_grad_px<2>(up, ce, dn, lut_rs, ok && (xmask & 4u));
+                    mb[3] = split_grad_px<3>(up, ce, dn, lut_rs, ok && (xmask & 8u));
+                    mb[4] = split_grad_px<4>(up, ce, dn, lut_rs, ok && (xmask & 16u));
+                    mb[5] = split_grad_px<5>(up, ce, dn, lut_rs, ok && (xmask & 32u));
+                    mb[6] = split_grad_px<6>(up, ce, dn, lut_rs, ok && (xmask & 64u));
+                    mb[7] = split_grad_px<7>(up, ce, dn, lut_rs, ok && (xmask & 128u));
+                }
                 load_row(y + 3, rw[i & 3]);                          // row y - 1 is done with
                 int fr = freed;
                 while (fr < k - 1) {

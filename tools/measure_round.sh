@@ -4,7 +4,7 @@
 #   attaches it as roofline.traffic when the hash of the detector's sources matches); the default bench line (cpu_baseline / parity / host_ingest / dropin_cli);
 #   the other BASELINE.json configurations (c3 streamed long video, c4 clip farm, c5 4K crowd); a rocprofv3 kernel-trace summary of the default
 #   workload; WRITE_SIZE, matrix-pipe and SQ counter passes (every --pmc pass on its own, with --kernel-trace only); the C5 clustering stressor.
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=gpurun_out/$TAG; mkdir -p $O
 t() { name=$1; lim=$2; shift; shift; echo "=== $name" >> $O/summary.log; s=$(date +%s); ( timeout $lim "$@" ) > $O/$name.log 2>&1; echo "rc=$? $(( $(date +%s) - s ))s" >> $O/summary.log; tail -3 $O/$name.log | cut -c1-600 >> $O/summary.log; }
