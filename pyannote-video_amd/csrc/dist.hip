@@ -101,11 +101,12 @@ void gather_counts(Comm* c, int64_t n_rows, int64_t* counts)
     wait_collective(c, "pvfd_allgather_counts", "all-gather of one int64 per rank: mine = " + std::to_string(n_rows));
     memcpy(counts, c->h_counts, sizeof(int64_t) * c->world);
 }
-// spins for about `ms` milliseconds (s_memtime counts at 100 MHz): stands for a collective whose peer never arrives (pvfd_debug_stall)
+// spins for about `ms` milliseconds (s_memrealtime: the constant 100 MHz reference clock -- s_memtime follows the shader clock): stands
+// for a collective whose peer never arrives (pvfd_debug_stall)
 __global__ void stall_k(long long ticks)
 {
-    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-    while ((long long)__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
 }
 } // namespace
 

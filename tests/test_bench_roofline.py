@@ -50,7 +50,9 @@ def test_traffic_is_attached_only_for_the_measured_sources(monkeypatch, tmp_path
         if current:
             assert o["traffic"] == pm["kernels"][key]["traffic_bytes_per_launch"]
             assert "traffic_attached_from_profiles_not_measured_in_this_run" in o
-            assert 1.0 < o["traffic"] / (o["algorithmic_bytes_per_launch"]) < 1.3          # what the kernels fetch beyond their algorithmic bytes
+            # what the kernels fetch beyond their algorithmic bytes (the screening pass since round 6: its 16-byte pieces of the
+            # plane-group layout sit 48 bytes apart, 1.34 x -- the price of the FHOG kernel's whole-line stores)
+            assert 1.0 < o["traffic"] / (o["algorithmic_bytes_per_launch"]) < (1.45 if key == "score_screened" else 1.3)
         else:
             assert o["traffic"] is None
     # another configuration, or changed sources: the figure is dropped, not carried

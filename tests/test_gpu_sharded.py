@@ -248,4 +248,5 @@ def test_watchdog_gives_up_on_a_collective_that_never_completes(tmp_path):
     script.write_text(STALL_WORKER)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, timeout=300, capture_output=True, text=True)
-    assert p.returncode == 0 and "WATCHDOG-OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+    marks = [l for l in p.stdout.splitlines() if l.startswith(("ERR:", "NO-", "WATCHDOG-OK"))]
+    assert p.returncode == 0 and "WATCHDOG-OK" in marks, (marks, p.stdout[-800:], p.stderr[-2000:])
