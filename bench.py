@@ -501,7 +501,8 @@ def main():
     # last key of the line (the driver keeps the line's tail verbatim): the whole-clip verdict in one short string
     out["full_clip_parity"] = full_clip_summary(full_clip)
     if other is not None:
-        out["full_clip_parity"] += " || other configs: " + "; ".join("%s %s frames/s, %s" % (k, v.get("frames_per_s"), v.get("verdict")) for k, v in other.items() if isinstance(v, dict))
+        out["full_clip_parity"] += " || other configs: " + "; ".join(("%s %s frames/s, %s" % (k, v.get("frames_per_s"), v.get("verdict"))) if v.get("frames_per_s") else ("%s: %s" % (k, v.get("verdict")))
+                                                                        for k, v in other.items() if isinstance(v, dict))
     print(json.dumps(out))
 
 
@@ -539,6 +540,24 @@ def other_configs_pass(args):
                          "results": d.get("results"), "wall_s": round(time.perf_counter() - t0, 1)}
         except subprocess.TimeoutExpired:
             out[name] = {"frames_per_s": None, "verdict": "timed out after %.0f s" % left}
+    # configs[4] names 10 000 tracks: the clustering stressor at that size (tools/c5_cluster.py) against the CPU oracle's frozen labels and
+    # merge list (tests/golden/c5_cluster_T10000.npz)
+    left = args.other_configs_budget - (time.perf_counter() - t_all)
+    if left >= 20.0:
+        try:
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "c5_cluster.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
+            rows = [json.loads(l) for l in p.stdout.decode("utf-8", "replace").splitlines() if l.startswith("{")]
+            r = [x for x in rows if x.get("T") == 10000 and x.get("rows_per_track") == 10]
+            if p.returncode == 0 and r and r[0].get("oracle_fixture"):
+                fx = r[0]["oracle_fixture"]
+                ok = fx["labels_equal_oracle"] and fx["merges_equal_oracle_in_order"] and fx["f32_path_labels_equal_oracle"]
+                out["c5_cluster_T10000"] = {"frames_per_s": None, "pdist_ms": r[0]["pdist_ms"], "hac_ms": r[0]["hac_ms"], "N": r[0]["N"], "merges": r[0]["merges"],
+                                            "oracle_fixture": fx, "fixture": "c5_cluster_T10000", "exact": bool(ok),
+                                            "verdict": "clustering of 10 000 tracks (N = 1e5): labels and all %d merges %s the oracle fixture's" % (r[0]["merges"], "EQUAL" if ok else "DIFFER from")}
+            else:
+                out["c5_cluster_T10000"] = {"frames_per_s": None, "verdict": "failed (rc %d): %s" % (p.returncode, p.stderr.decode("utf-8", "replace")[-300:])}
+        except subprocess.TimeoutExpired:
+            out["c5_cluster_T10000"] = {"frames_per_s": None, "verdict": "timed out"}
     return out
 
 

@@ -466,3 +466,23 @@ def test_detector_border_windows_after_tracker_work(ctx, oracle, small_video):
     assert len(raw_c) > 15000 and min(r[3] for r in raw_c) == 5           # windows of the first scanned row are among them
     assert raw_g == raw_c
     ctx.tracker_destroy_many(trk)
+
+
+def test_cluster_ten_thousand_tracks_equals_the_oracle_fixture(ctx):
+    """BASELINE.json configs[4]'s clustering stressor at FULL size (T = 10 000 tracks x 10 rows, N = 1e5; tools/c5_cluster.py's generator
+    and seed) against the CPU oracle's frozen result (tests/golden/c5_cluster_T10000.npz, made by tests/golden/make_c5_cluster.py in a
+    minute of CPU): labels, every merge in order, merge distances -- through pvf_cluster_tracks and through the float32 in-memory path."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import importlib
+    c5 = importlib.import_module("c5_cluster")
+    g = np.load(os.path.join(root, "tests", "golden", "c5_cluster_T10000.npz"))
+    X, rs, ident = c5.make(10000, 10)
+    labels, log = ctx.cluster_tracks(X, rs, 0.6)
+    assert np.array_equal(labels, g["labels"])
+    assert len(log) == len(g["merge_pairs"]) == 9500 and len(set(labels.tolist())) == 500
+    assert np.array_equal(np.asarray(log)[:, :2].astype(np.int32), g["merge_pairs"])
+    assert np.abs(np.asarray(log)[:, 2] - g["merge_dist"]).max() <= 1e-12
+    lf, _ = ctx.cluster_tracks_f32(X.astype(np.float32), None, rs, 0.6)
+    assert np.array_equal(lf, g["labels"])

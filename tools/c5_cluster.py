@@ -28,7 +28,7 @@ def make(T, rows, K=500, seed=20260925):
     return x, (np.arange(T + 1) * rows).astype(np.int32), ident
 
 
-def main():
+def main():  # noqa: C901
     out = sys.argv[1] if len(sys.argv) > 1 else None
     ctx = Context(device=0, detector=None)
     res = []
@@ -56,7 +56,16 @@ def main():
         lf, logf = ctx.cluster_tracks_f32(E, None, rs, 0.6)
         wall_f32 = time.perf_counter() - t1
         ctx.prof_enable(False)
-        res.append({"T": T, "rows_per_track": rows, "N": N, "pdist_ms": round(pd_ms, 3), "hac_ms": round(hac_ms, 3), "wall_s": round(wall, 3), "wall_s_f32_in_memory_path": round(wall_f32, 3), "f32_path_same_labels": bool(np.array_equal(lf, labels)),
+        # the full-size case against the CPU oracle's frozen result (tests/golden/c5_cluster_T10000.npz, made by tests/golden/make_c5_cluster.py)
+        fixture = None
+        fx = os.path.join(ROOT, "tests", "golden", "c5_cluster_T10000.npz")
+        if (T, rows) == (10000, 10) and os.path.exists(fx):
+            g = np.load(fx)
+            same_pairs = len(log) == len(g["merge_pairs"]) and np.array_equal(np.asarray(log)[:, :2].astype(np.int32), g["merge_pairs"])
+            fixture = {"labels_equal_oracle": bool(np.array_equal(labels, g["labels"])), "merges_equal_oracle_in_order": bool(same_pairs),
+                       "merge_distance_max_abs_diff": float(np.abs(np.asarray(log)[:, 2] - g["merge_dist"]).max()) if len(log) == len(g["merge_dist"]) else None,
+                       "f32_path_labels_equal_oracle": bool(np.array_equal(lf, g["labels"]))}
+        res.append({"T": T, "rows_per_track": rows, "N": N, "oracle_fixture": fixture, "pdist_ms": round(pd_ms, 3), "hac_ms": round(hac_ms, 3), "wall_s": round(wall, 3), "wall_s_f32_in_memory_path": round(wall_f32, 3), "f32_path_same_labels": bool(np.array_equal(lf, labels)),
                     "pdist_fp64_tflops": round(flop / (pd_ms * 1e-3) / 1e12, 2), "pdist_frac_of_fp64_mfma_peak": round(flop / (pd_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, 3),
                     "merges": int(len(log)), "merges_per_s": round(len(log) / max(hac_ms * 1e-3, 1e-9)),
                     "hac_D_bytes": int(T) * int(T) * 8, "clusters": int(len(set(labels.tolist()))), "identities": int(len(set(ident.tolist()))),
