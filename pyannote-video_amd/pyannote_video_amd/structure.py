@@ -9,7 +9,10 @@ median filtering, the threshold on the normalised difference, "first of a run of
 """
 import numpy as np
 
-from ._core import Segment
+try:                                    # the reference's own segment type where it is installed (structure/shot.py:33) ...
+    from pyannote.core import Segment
+except ImportError:                     # ... a stand-in with the same constructor and truthiness where it is not
+    from ._core import Segment
 
 
 def shot_tables(poly_n=5, poly_sigma=1.1):
